@@ -1,0 +1,142 @@
+"""Generate tests/golden/*.npz by running the REAL reference (container-only).
+
+TEST INFRASTRUCTURE.  Run from the repo root in the build container:
+
+    python -m oracle.gen_golden
+
+Imports the reference from /root/reference (oracle/ref_import.py), feeds it
+seeded inputs / deterministic weights (occlusions-4d_amd/configs.py) and stores
+inputs (when small) and the reference's outputs.  The fixtures are data only;
+no reference source travels.  Case definitions live in tests/golden_cases.py so
+that the tests rebuild the identical inputs on any machine.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import golden_cases as gc  # noqa: E402
+import occlusions4d_amd as pk  # noqa: E402
+from oracle import ref_import  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print('%-28s %8.1f KB' % (name, os.path.getsize(path) / 1024))
+
+
+@torch.no_grad()
+def main():
+    ref = ref_import.load()
+    ptl, mods, mdl, imp, geo, inf = (ref.point_transformer_layer, ref.modules, ref.model,
+                                     ref.implicit, ref.geometry, ref.inference)
+    os.makedirs(OUT, exist_ok=True)
+
+    # G1: square_distance + kNN_torch (E4)
+    for case in gc.KNN_CASES:
+        q, d = gc.knn_inputs(case)
+        idx = ptl.kNN_torch(t(q)[None], t(d)[None], case['k'])[0]
+        save('g1_knn_' + case['name'], idx=idx.numpy().astype(np.int32))
+
+    # G2: PointTransformerLayer (E3), self and cross
+    for case in gc.PTL_CASES:
+        x, pos, x2, pos2, sd = gc.ptl_inputs(case)
+        layer = ptl.PointTransformerLayer(case['dim'], num_neighbors=case['k'], dim2=case.get('dim2'))
+        layer.load_state_dict(sd)
+        args = (t(x)[None], t(pos)[None]) + ((t(x2)[None], t(pos2)[None]) if x2 is not None else ())
+        save('g2_ptl_' + case['name'], agg=layer(*args)[0].numpy())
+
+    # G3: PointTransformerBlock (E2)
+    for case in gc.PTB_CASES:
+        x, pos, x2, pos2, sd = gc.ptb_inputs(case)
+        blk = mods.PointTransformerBlock(case['dim'], case['dim'], case['dim'], num_neighbors=case['k'],
+                                         d_hidden_abstract=case.get('dim2'))
+        blk.load_state_dict(sd)
+        args = (t(x)[None], t(pos)[None]) + ((t(x2)[None], t(pos2)[None]) if x2 is not None else ())
+        save('g3_ptb_' + case['name'], z=blk(*args)[0][0].numpy())
+
+    # G4: DownTransition (E6/E7) -- fps/knn come from oracle/cluster.py (parity unpinned)
+    for case in gc.DOWN_CASES:
+        x, pos, sd = gc.down_inputs(case)
+        dt = mods.DownTransition(case['d_in'], case['d_out'], factor=3, knn_k=case['k'],
+                                 norm_type=case['norm'], fps_random_start=False)
+        dt.load_state_dict(sd)
+        z, p_sub = dt(t(x)[None], t(pos)[None])
+        save('g4_down_' + case['name'], z=z[0].numpy(), p_sub=p_sub[0].numpy())
+
+    # G5: PointCompletionNetV3.forward (E1)
+    for case in gc.ENC_CASES:
+        pcl, pa, sd = gc.enc_inputs(case)
+        net = mdl.PointCompletionNetV3(**pa)
+        net.load_state_dict(sd)
+        net.eval()
+        out, xg, _ = net(pcl, False)
+        save('g5_enc_' + case['name'], pcl_out=out[0].numpy(), x_global=xg[0].numpy())
+
+    # G6: my_knn_torch (D2)
+    for case in gc.MYKNN_CASES:
+        q, key = gc.myknn_inputs(case)
+        inds, dists = geo.my_knn_torch(t(q), t(key), case['k'], return_inds=True, return_knn=False,
+                                       return_dists=True)
+        save('g6_myknn_' + case['name'], inds=inds.numpy().astype(np.int32), dists=dists.numpy())
+
+    # G7: positional_encode (D5)
+    pts = gc.posenc_inputs()
+    save('g7_posenc', points=pts, enc=imp.positional_encode(t(pts), 0.1, 8).numpy())
+
+    # G8: LocalPclResnetFC.forward (D1-D7)
+    for case in gc.DEC_CASES:
+        q, abstract, fglob, ia, sd = gc.dec_inputs(case)
+        net = imp.LocalPclResnetFC(**ia)
+        net.load_state_dict(sd)
+        net.eval()
+        out, pen = net(t(q), t(abstract), t(fglob), None)
+        save('g8_dec_' + case['name'], output=out.numpy(), penult=pen.numpy()[:, ::8])
+
+    # G9: sample_implicit_points_blind_numpy grid (D9)
+    g9 = {}
+    for case in gc.GRID_CASES:
+        pts = geo.sample_implicit_points_blind_numpy(case['num_sample'], case['min_z'], case['cube_bounds'],
+                                                     case['time_idx'], case['kind'], 4, 'grid')
+        g9[case['name'] + '_n'] = np.array([pts.shape[0]])
+        g9[case['name'] + '_head'] = pts[:130]
+        g9[case['name'] + '_tail'] = pts[-130:]
+        g9[case['name'] + '_sum'] = pts.astype(np.float64).sum(axis=0)
+    save('g9_grid', **g9)
+
+    # G10: perform_inference end to end, config 1 (D8)
+    for case in gc.INFER_CASES:
+        pcl, pa, ia, ia_inf, esd, dsd = gc.infer_inputs(case)
+        enc = mdl.PointCompletionNetV3(**pa)
+        enc.load_state_dict(esd)
+        dec = imp.LocalPclResnetFC(**ia)
+        dec.load_state_dict(dsd)
+        enc.eval()
+        dec.eval()
+        res = inf.perform_inference(
+            pcl.clone(), None, None, [enc, dec], torch.device('cpu'), 'if', ia_inf['min_z'],
+            ia_inf['cube_bounds'], ia_inf['color_mode'], case['time_idx'], None,
+            sample_implicit=True, num_sample=case['num_sample'], point_sample_mode='grid',
+            batch_size=case['batch_size'], predict_segmentation=ia_inf['predict_segmentation'],
+            track_mode='none', semantic_classes=13, density_threshold=0.5,
+            data_kind=ia_inf['data_kind'], cube_mode=4, compress_air=True)
+        save('g10_infer_' + case['name'], implicit_output=res['implicit_output'],
+             pcl_abstract=res['pcl_abstract'], features_global=res['features_global'],
+             n_solid=np.array([res['output_solid'].shape[0]]), n_air=np.array([res['output_air'].shape[0]]),
+             air_head=res['output_air'][:64], solid_head=res['output_solid'][:64])
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,333 @@
+"""CPU restatement of the reference hot path.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py): plain PyTorch-CPU, fp32, written
+from scratch as free functions over a ``state_dict`` (parameter names are the
+reference's).  Every function cites the reference lines it
+follows (paths relative to /root/reference).  It is checked against golden
+vectors produced by the real reference (tests/golden, oracle/gen_golden.py).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import cluster
+
+
+# ----------------------------------------------------------------------------
+# small helpers
+# ----------------------------------------------------------------------------
+def _lin(sd, name, x):
+    return F.linear(x, sd[name + '.weight'], sd.get(name + '.bias'))
+
+
+def _sub(sd, prefix):
+    n = len(prefix)
+    return {k[n:]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+# ----------------------------------------------------------------------------
+# E4 / E5: kNN_torch, index_points   (model/point_transformer_layer.py:16-113)
+# ----------------------------------------------------------------------------
+def knn_indices(query, dataset, k, chunk=1024):
+    """(B,N0,3),(B,N1,3) -> (B,N0,k) int64.  Follows square_distance (:16-30) and
+    kNN_torch (:76-99): d = sum_c (q_c - p_c)^2 over the broadcast difference,
+    then argsort and keep the first k.  Rows are processed in chunks (same
+    arithmetic per row; the reference materialises the full N0 x N1 matrix)."""
+    assert query.dim() == 3 and dataset.dim() == 3
+    assert query.shape[0] == dataset.shape[0] and query.shape[2] == dataset.shape[2]
+    out = []
+    for lo in range(0, query.shape[1], chunk):
+        q = query[:, lo:lo + chunk]
+        d = torch.sum((q[:, :, None] - dataset[:, None]) ** 2, dim=-1)
+        out.append(d.argsort()[:, :, :k])
+    return torch.cat(out, dim=1)
+
+
+def gather_rows(points, idx):
+    """index_points (:102-113): (B,N,C),(B,S,K) -> (B,S,K,C)."""
+    B = idx.shape[0]
+    flat = idx.reshape(B, -1)
+    res = torch.gather(points, 1, flat[..., None].expand(-1, -1, points.shape[-1]))
+    return res.reshape(*idx.shape, -1)
+
+
+# ----------------------------------------------------------------------------
+# E3: PointTransformerLayer.forward   (model/point_transformer_layer.py:148-183)
+# ----------------------------------------------------------------------------
+def pt_layer(sd, x, pos, x2=None, pos2=None, num_neighbors=16):
+    if x2 is None:
+        x2, pos2 = x, pos
+    idx = knn_indices(pos, pos2, num_neighbors)                 # :167
+    nb_xyz = gather_rows(pos2, idx)                             # :168
+    q = _lin(sd, 'to_q', x)                                     # :170
+    k = gather_rows(_lin(sd, 'to_k', x2), idx)                  # :171
+    v = gather_rows(_lin(sd, 'to_v', x2), idx)                  # :172
+    rel = pos[:, :, None] - nb_xyz
+    pe = _lin(sd, 'pos_mlp.2', F.relu(_lin(sd, 'pos_mlp.0', rel)))           # :174
+    a = _lin(sd, 'attn_mlp.2', F.relu(_lin(sd, 'attn_mlp.0', q[:, :, None] - k + pe)))  # :176
+    a = F.softmax(a / np.sqrt(k.shape[-1]), dim=-2)             # :177 (per channel over K)
+    return torch.einsum('bijd,bijd->bid', a, v + pe)            # :179
+
+
+# ----------------------------------------------------------------------------
+# E2: PointTransformerBlock.forward   (model/modules.py:45-67)
+# ----------------------------------------------------------------------------
+def pt_block(sd, x, p, x2=None, p2=None, num_neighbors=16):
+    assert x.shape[:2] == p.shape[:2]
+    if x2 is not None:
+        assert x2.shape[:2] == p2.shape[:2]
+    y = _lin(sd, 'layer1', x)
+    y = pt_layer(_sub(sd, 'layer2.'), y, p, x2, p2, num_neighbors)
+    y = _lin(sd, 'layer3', y)
+    return x + y, p
+
+
+# ----------------------------------------------------------------------------
+# E6 (+E7): DownTransition.forward   (model/modules.py:113-163)
+# ----------------------------------------------------------------------------
+def down_transition(sd, x, p, factor, knn_k, norm_type='none', return_inds=False):
+    assert x.shape[:2] == p.shape[:2]
+    B, N, d_in = x.shape
+    n_new = int(np.ceil(N / factor))                            # :126
+    p_flat = p.reshape(B * N, 3)
+    batch = torch.arange(B).repeat_interleave(N)
+    inds = cluster.fps(p_flat, batch, ratio=1.0 / factor, random_start=False)  # :133
+    inds = torch.sort(inds)[0]                                  # :135
+    p_sub = p_flat[inds]
+    batch_sub = torch.arange(B).repeat_interleave(n_new)
+    nn = cluster.knn(p_flat, p_sub, knn_k, batch, batch_sub)[1].view(B * n_new, knn_k)  # :142-146
+    y = _lin(sd, 'mlp.0', x.reshape(B * N, d_in))               # :152
+    if norm_type == 'layer':
+        y = F.layer_norm(y, (y.shape[-1],), sd['mlp.1.weight'], sd['mlp.1.bias'], 1e-5)
+    elif norm_type != 'none':
+        raise ValueError(norm_type)   # 'batch' is unused by every published config
+    y = F.relu(y)
+    z = y[nn[:, 0]]                                             # :156-158
+    for i in range(1, knn_k):
+        z = torch.maximum(z, y[nn[:, i]])
+    z = z.view(B, n_new, -1)
+    p_sub = p_sub.view(B, n_new, 3)
+    if return_inds:
+        return z, p_sub, inds, nn
+    return z, p_sub
+
+
+# ----------------------------------------------------------------------------
+# E1: PointCompletionNetV3.forward   (model/model.py:148-233)
+# ----------------------------------------------------------------------------
+def encoder_forward(sd, cfg, pcl):
+    """pcl (B,N,d_in) -> (pcl_out (B,M,3+D), x_global (B,global_dim)).
+    cfg keys: down_blocks, transition_factor, pt_num_neighbors, pt_norm_type,
+    down_neighbors, abstract_levels (model/model.py:18-22)."""
+    nb = cfg['down_blocks']
+    x = _lin(sd, 'pre_mlp.2', F.relu(_lin(sd, 'pre_mlp.0', pcl)))   # :167
+    pos = pcl[..., :3]                                               # :168
+    skips = []
+    x_global = None
+    for i in range(2 * nb + 1):
+        bsd = _sub(sd, 'blocks.%d.' % i)
+        if i % 2 == 0:
+            x, pos = pt_block(bsd, x, pos, num_neighbors=cfg['pt_num_neighbors'])
+        else:
+            x, pos = down_transition(bsd, x, pos, cfg['transition_factor'],
+                                     cfg['down_neighbors'], cfg['pt_norm_type'])
+        if i == 2 * nb:                                              # :188-190
+            x_global = _lin(sd, 'global_mlp.2', F.relu(_lin(sd, 'global_mlp.0', x.mean(dim=1))))
+        if cfg['abstract_levels'] > 1 and i % 2 == 1:                # :202-207
+            j = 0
+            while ('abstract_skip_mlps.%d.weight' % j) in sd:
+                w = sd['abstract_skip_mlps.%d.weight' % j]
+                if w.shape[1] == x.shape[-1]:
+                    y = _lin(sd, 'abstract_skip_mlps.%d' % j, x)
+                    y[..., -1] = j + 1.0
+                    skips.append(torch.cat([pos, y], dim=-1))
+                j += 1
+    out = torch.cat([pos, x], dim=-1)                                # :220
+    if cfg['abstract_levels'] > 1:                                   # :224-228
+        out[..., -1] = cfg['abstract_levels']
+        assert len(skips) == cfg['abstract_levels'] - 1
+        out = torch.cat([torch.cat(skips, dim=1), out], dim=1)
+    return out, x_global
+
+
+# ----------------------------------------------------------------------------
+# D5: positional_encode   (model/implicit.py:20-43)
+# ----------------------------------------------------------------------------
+def positional_encode(points, base_frequency, num_powers):
+    parts = [points]
+    for p in range(num_powers):
+        omega = base_frequency * (2 ** p) * np.pi * 2.0   # python double -> fp32 multiply
+        parts.append(torch.sin(points * omega))
+        parts.append(torch.cos(points * omega))
+    return torch.cat(parts, dim=-1)
+
+
+# ----------------------------------------------------------------------------
+# D2: geometry.my_knn_torch   (utils/geometry.py:458-503)
+# ----------------------------------------------------------------------------
+def knn_with_dists(pcl_query, pcl_key, k, chunk=8192):
+    """(N,>=3),(M,>=3) -> inds (N,k) int64, dists (N,k) fp32 (Euclidean, via
+    linalg.norm of the broadcast difference, then topk(largest=False) along the
+    key axis).  Chunked over queries; per-query arithmetic is unchanged."""
+    inds, dists = [], []
+    for lo in range(0, pcl_query.shape[0], chunk):
+        q = pcl_query[lo:lo + chunk]
+        diffs = q[None, :, :3] - pcl_key[:, None, :3]            # :479  (M,n,3)
+        d = torch.linalg.norm(diffs, axis=-1, ord=2)             # :481
+        dk, ik = d.topk(k, dim=0, largest=False)                 # :484
+        inds.append(ik.permute(1, 0))
+        dists.append(dk.permute(1, 0))
+    return torch.cat(inds), torch.cat(dists)
+
+
+def _act(name, x):
+    if name == 'relu':
+        return F.relu(x)
+    if name == 'swish':                                          # model/implicit.py:46-64
+        return x * torch.sigmoid(x)
+    raise ValueError('Unknown activation: ' + str(name))
+
+
+# ----------------------------------------------------------------------------
+# D1, D3, D4, D6, D7: LocalPclResnetFC.forward / do_forward_attention
+#                      (model/implicit.py:271-445)
+# ----------------------------------------------------------------------------
+def decoder_forward(sd, cfg, points_query, points_abstract, features_global,
+                    features_abstract=None):
+    """points_query (N,4); points_abstract (M,3+E) (or (M,3) with features_abstract
+    (M,E)); features_global (D,) -> (output (N,G), penult (N,H)).
+    cfg keys: n_blocks, pos_encoding_freqs, activation, num_local_features,
+    cross_attn_neighbors, cross_attn_layers, d_latent, d_latent_local."""
+    if features_abstract is None:                                # :286-290
+        features_abstract = points_abstract[..., 3:]
+        points_abstract = points_abstract[..., :3]
+    assert points_query.dim() == 2, 'oracle takes the un-batched (B == 1) form'
+    act = cfg.get('activation', 'relu')
+    nblk = cfg['n_blocks']
+    L = cfg['cross_attn_layers']
+    use_at = {int((i + 1) * nblk / (L + 1)): i for i in range(L)}   # :264-268
+
+    # D2 + D3: local feature interpolation (:328-342)
+    abstract = torch.cat([points_abstract, features_abstract], dim=-1)
+    inds, dists = knn_with_dists(points_query, abstract, cfg['num_local_features'])
+    w = 1.0 / (dists + 1e-4)
+    w = F.normalize(w, p=1, dim=-1)
+    f_local = torch.einsum('ik,ikf->if', w, features_abstract[inds])
+    f_query = torch.cat([features_global[None, :].expand(points_query.shape[0], -1), f_local], dim=-1)
+    assert f_query.shape[-1] == cfg['d_latent']
+
+    # D4 (:380-445)
+    pe = positional_encode(points_query, 0.1, cfg['pos_encoding_freqs']) \
+        if cfg['pos_encoding_freqs'] > 0 else points_query
+    x = _lin(sd, 'lin_in', pe)
+    p = pe[..., :3][None]                                        # :424 (raw xyz come first)
+    for i in range(nblk):
+        x = x + _lin(sd, 'lin_z.%d' % i, f_query)                # :416-417
+        h = _lin(sd, 'blocks.%d.fc_0' % i, _act(act, x))         # D6 (:92-101)
+        x = x + _lin(sd, 'blocks.%d.fc_1' % i, _act(act, h))
+        if i in use_at:                                          # :421-439
+            bsd = _sub(sd, 'pt_blocks.%d.' % use_at[i])
+            x = pt_block(bsd, x[None], p, features_abstract[None], points_abstract[None],
+                         cfg['cross_attn_neighbors'])[0][0]
+    penult = x
+    out = _lin(sd, 'lin_out', _act(act, x))                      # :441-443
+    return out, penult
+
+
+# ----------------------------------------------------------------------------
+# D9: sample_implicit_points_blind_numpy, grid / random modes
+#     (utils/geometry.py:1199-1283)
+# ----------------------------------------------------------------------------
+def query_cuboid(min_z, cube_bounds, data_kind, cube_mode):
+    cb = cube_bounds
+    if data_kind == 'greater':                                   # :1215-1218
+        return (-cb, cb), (-cb, cb), (min_z, cb)
+    if data_kind == 'carla':                                     # :1220-1241
+        table = {1: (2.0, 1.0, 0.5), 2: (2.4, 0.8, 0.4), 3: (2.2, 1.0, 0.4), 4: (2.5, 1.0, 0.4)}
+        fx, fy, fz = table[cube_mode]
+        return (0.0, cb * fx), (-cb * fy, cb * fy), (min_z, cb * fz)
+    raise ValueError(data_kind)
+
+
+def sample_query_points(num_sample, min_z, cube_bounds, time_idx, data_kind, cube_mode,
+                        point_sample_mode):
+    (x0, x1), (y0, y1), (z0, z1) = query_cuboid(min_z, cube_bounds, data_kind, cube_mode)
+    if point_sample_mode == 'random':                            # :1247-1255
+        n = num_sample
+        px = np.random.rand(n).astype(np.float32) * (x1 - x0) + x0
+        py = np.random.rand(n).astype(np.float32) * (y1 - y0) + y0
+        pz = np.random.rand(n).astype(np.float32) * (z1 - z0) + z0
+        xyz = np.stack([px, py, pz], axis=-1)
+    elif point_sample_mode == 'grid':                            # :1257-1275
+        per_unit = np.cbrt(num_sample / ((x1 - x0) * (y1 - y0) * (z1 - z0)))
+        nx = int(np.ceil(per_unit * (x1 - x0)))
+        ny = int(np.ceil(per_unit * (y1 - y0)))
+        nz = int(np.ceil(per_unit * (z1 - z0)))
+        gx = (np.arange(nx, dtype=np.float32) + 0.5) * ((x1 - x0) / nx) + x0
+        gy = (np.arange(ny, dtype=np.float32) + 0.5) * ((y1 - y0) / ny) + y0
+        gz = (np.arange(nz, dtype=np.float32) + 0.5) * ((z1 - z0) / nz) + z0
+        n = nx * ny * nz
+        xyz = np.stack([np.repeat(gx, ny * nz), np.tile(np.repeat(gy, nz), nx),
+                        np.tile(gz, nx * ny)], axis=-1)          # x slowest, z fastest
+    else:
+        raise ValueError(point_sample_mode)
+    t = np.ones((n, 1), dtype=np.float32) * time_idx             # :1281
+    return np.concatenate([xyz, t], axis=-1)
+
+
+# ----------------------------------------------------------------------------
+# D8: perform_inference   (eval/inference.py:83-325), track_mode none/one
+# ----------------------------------------------------------------------------
+def track_channel(color_mode):                                   # utils/utils.py:204-224
+    return {'rgb': 4, 'rgb_nosigmoid': 4, 'hsv': 15, 'bins': 10}[color_mode]
+
+
+def squash_outputs(o, color_mode, predict_segmentation, track_mode, semantic_classes):
+    """In-place post-ops of eval/inference.py:218-243 on an (n,G) tensor."""
+    o[..., 0] = torch.sigmoid(o[..., 0])
+    if color_mode == 'rgb':
+        o[..., 1:4] = torch.sigmoid(o[..., 1:4])
+    elif color_mode == 'rgb_nosigmoid':
+        o[..., 1:4] = torch.clamp(o[..., 1:4].clone(), min=0.0, max=1.0)
+    elif color_mode == 'hsv':
+        o[..., 1:13] = torch.sigmoid(o[..., 1:13])
+        o[..., 13:15] = torch.clamp(o[..., 13:15].clone(), min=0.0, max=1.0)
+    elif color_mode == 'bins':
+        o[..., 1:10] = torch.sigmoid(o[..., 1:10])
+    if predict_segmentation:
+        o[..., -semantic_classes:] = torch.sigmoid(o[..., -semantic_classes:])
+    if track_mode != 'none':
+        ti = track_channel(color_mode)
+        o[..., ti] = torch.sigmoid(o[..., ti])
+    return o
+
+
+def perform_inference(pcl_input, enc_sd, enc_cfg, dec_sd, dec_cfg, min_z, cube_bounds, color_mode,
+                      time_idx, num_sample=16384, point_sample_mode='random', batch_size=1024,
+                      predict_segmentation=False, track_mode='none', semantic_classes=13,
+                      density_threshold=0.5, data_kind='', cube_mode=4, compress_air=False):
+    assert track_mode in ('none', 'one')                         # :140-142 (one rerun)
+    if isinstance(pcl_input, np.ndarray):
+        pcl_input = torch.from_numpy(pcl_input).unsqueeze(0)
+    points_query = sample_query_points(num_sample, min_z, cube_bounds, time_idx, data_kind,
+                                       cube_mode, point_sample_mode)          # :175
+    pcl_abstract, f_global = encoder_forward(enc_sd, enc_cfg, pcl_input)      # :195
+    pcl_abstract, f_global = pcl_abstract[0], f_global[0]
+    outs = []
+    for lo in range(0, points_query.shape[0], batch_size):                    # :204
+        q = torch.from_numpy(points_query[lo:lo + batch_size])
+        o, _ = decoder_forward(dec_sd, dec_cfg, q, pcl_abstract, f_global)    # :211
+        outs.append(squash_outputs(o, color_mode, predict_segmentation, track_mode,
+                                   semantic_classes).numpy())
+    implicit_output = np.concatenate(outs, axis=0)
+    io = np.concatenate([points_query, implicit_output], axis=-1)             # :279
+    solid = io[io[..., 4] >= density_threshold]                               # :283-284
+    air = io[io[..., 4] < density_threshold]
+    if compress_air:                                                          # :299-305
+        seg = air[..., -semantic_classes:].argmax(axis=-1)
+        air = np.concatenate([air[..., :3], air[..., 4:5], seg[..., None]], axis=-1)
+    return dict(output_solid=solid, output_air=air, pcl_abstract=pcl_abstract.numpy(),
+                features_global=f_global.numpy(), implicit_output=implicit_output,
+                points_query=points_query)

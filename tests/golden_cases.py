@@ -1,0 +1,197 @@
+"""Case definitions + seeded input builders shared by oracle/gen_golden.py (which
+ran the real reference on them in the build container) and the parity tests
+(which rebuild the identical inputs anywhere and compare with tests/golden/*.npz).
+
+Inputs come from numpy's PCG64 ``default_rng(seed)`` (stream stable across numpy
+versions) so only outputs need to be stored.
+"""
+import numpy as np
+import torch
+
+import occlusions4d_amd as pk
+
+cfg = pk.configs
+
+
+def _rng(seed):
+    return np.random.default_rng(seed)
+
+
+def _cloud(rng, n, scale=5.0):
+    return rng.uniform(-scale, scale, size=(n, 3)).astype(np.float32)
+
+
+# ---------------------------------------------------------------- G1
+KNN_CASES = [
+    dict(name='self_n700_k16', n0=700, n1=700, k=16, self_=True, seed=11),
+    dict(name='cross_n300_m531_k14', n0=300, n1=531, k=14, self_=False, seed=12),
+    dict(name='cross_n257_m76_k12', n0=257, n1=76, k=12, self_=False, seed=13),
+    dict(name='tiny_n5_m9_k8', n0=5, n1=9, k=8, self_=False, seed=14),
+]
+
+
+def knn_inputs(case):
+    rng = _rng(case['seed'])
+    d = _cloud(rng, case['n1'])
+    q = d if case['self_'] else _cloud(rng, case['n0'])
+    return q, d
+
+
+# ---------------------------------------------------------------- G2 / G3
+PTL_CASES = [
+    dict(name='self_d36_k16', dim=36, k=16, n=200, seed=21),
+    dict(name='self_d72_k16', dim=72, k=16, n=90, seed=22),
+    dict(name='cross_d416_e288_k14', dim=416, dim2=288, k=14, n=64, m=76, seed=23),
+]
+PTB_CASES = [
+    dict(name='self_d36_k16', dim=36, k=16, n=150, seed=31),
+    dict(name='cross_d416_e288_k14', dim=416, dim2=288, k=14, n=48, m=100, seed=32),
+]
+
+
+def _ptl_shapes(dim, dim2):
+    s = {}
+    cfg._ptb_shapes(s, '', dim, dim2)
+    return {k[len('layer2.'):]: v for k, v in s.items() if k.startswith('layer2.')}
+
+
+def ptl_inputs(case):
+    rng = _rng(case['seed'])
+    x = rng.normal(size=(case['n'], case['dim'])).astype(np.float32)
+    pos = _cloud(rng, case['n'])
+    x2 = pos2 = None
+    if 'dim2' in case:
+        x2 = rng.normal(size=(case['m'], case['dim2'])).astype(np.float32)
+        pos2 = _cloud(rng, case['m'])
+    sd = cfg.fill_state_dict(_ptl_shapes(case['dim'], case.get('dim2')), case['seed'] + 1000)
+    return x, pos, x2, pos2, sd
+
+
+def ptb_inputs(case):
+    rng = _rng(case['seed'])
+    x = rng.normal(size=(case['n'], case['dim'])).astype(np.float32)
+    pos = _cloud(rng, case['n'])
+    x2 = pos2 = None
+    if 'dim2' in case:
+        x2 = rng.normal(size=(case['m'], case['dim2'])).astype(np.float32)
+        pos2 = _cloud(rng, case['m'])
+    s = {}
+    cfg._ptb_shapes(s, '', case['dim'], case.get('dim2'))
+    return x, pos, x2, pos2, cfg.fill_state_dict(s, case['seed'] + 1000)
+
+
+# ---------------------------------------------------------------- G4
+DOWN_CASES = [
+    dict(name='none_n301_36to72_k12', n=301, d_in=36, d_out=72, k=12, norm='none', seed=41),
+    dict(name='layer_n200_72to144_k12', n=200, d_in=72, d_out=144, k=12, norm='layer', seed=42),
+]
+
+
+def down_inputs(case):
+    rng = _rng(case['seed'])
+    x = rng.normal(size=(case['n'], case['d_in'])).astype(np.float32)
+    pos = _cloud(rng, case['n'])
+    s = {'mlp.0.weight': (case['d_out'], case['d_in']), 'mlp.0.bias': (case['d_out'],)}
+    if case['norm'] == 'layer':
+        s['mlp.1.weight'] = (case['d_out'],)
+        s['mlp.1.bias'] = (case['d_out'],)
+    return x, pos, cfg.fill_state_dict(s, case['seed'] + 1000)
+
+
+# ---------------------------------------------------------------- G5
+ENC_CASES = [
+    dict(name='greater_n512', kind='greater', n=512, video_len=4, seed=51),
+    dict(name='carla_n512', kind='carla', n=512, video_len=4, seed=52),
+    dict(name='greater_n2048', kind='greater', n=2048, video_len=4, seed=1830),
+    dict(name='carla_n2048', kind='carla', n=2048, video_len=4, seed=1831),
+]
+
+
+def enc_inputs(case):
+    pa, ia, _ = cfg.model_args(case['kind'], case['n'])
+    pcl = cfg.synthetic_pcl(case['kind'], case['n'], case['video_len'], case['seed'])
+    sd = cfg.fill_state_dict(cfg.encoder_param_shapes(pa), case['seed'] + 1000)
+    return pcl, pa, sd
+
+
+# ---------------------------------------------------------------- G6
+MYKNN_CASES = [
+    dict(name='n400_m531_k8', n=400, m=531, k=8, e=5, seed=61),
+    dict(name='n300_m2124_k8', n=300, m=2124, k=8, e=0, seed=62),
+    dict(name='n64_m76_k1', n=64, m=76, k=1, e=2, seed=63),
+]
+
+
+def myknn_inputs(case):
+    rng = _rng(case['seed'])
+    q = np.concatenate([_cloud(rng, case['n']), rng.normal(size=(case['n'], 1)).astype(np.float32)], axis=1)
+    key = np.concatenate([_cloud(rng, case['m']),
+                          rng.normal(size=(case['m'], case['e'])).astype(np.float32)], axis=1)
+    return q, key
+
+
+# ---------------------------------------------------------------- G7
+def posenc_inputs():
+    rng = _rng(71)
+    pts = rng.uniform(-40.0, 40.0, size=(512, 4)).astype(np.float32)
+    pts[:, 3] = rng.integers(0, 12, size=512).astype(np.float32)
+    pts[0] = [40.0, -40.0, 10.0, 11.0]
+    pts[1] = [-40.0, 40.0, -1.0, 0.0]
+    pts[2] = [0.0, 0.0, 0.0, 0.0]
+    pts[3] = [39.869873, -19.83606, 6.103448, 3.0]
+    return pts
+
+
+# ---------------------------------------------------------------- G8
+DEC_CASES = [
+    dict(name='greater_m76_q256', kind='greater', m=76, nq=256, seed=81),
+    dict(name='greater_m531_q256', kind='greater', m=531, nq=256, seed=82),
+    dict(name='carla_m2124_q256', kind='carla', m=2124, nq=256, seed=83),
+    dict(name='greater_m531_q1', kind='greater', m=531, nq=1, seed=84),
+]
+
+
+def dec_inputs(case):
+    """Queries inside the query cuboid, abstract cloud inside the input cuboid with
+    N(0, 0.5) features (the scale the encoder emits), N(0, 0.3) global embedding."""
+    rng = _rng(case['seed'])
+    _, ia, inf = cfg.model_args(case['kind'])
+    (x0, x1), (y0, y1), (z0, z1) = cfg.input_cuboid(case['kind'])
+    lo, hi = np.array([x0, y0, z0]), np.array([x1, y1, z1])
+    xyz = rng.uniform(lo, hi, size=(case['m'], 3)).astype(np.float32)
+    feats = (0.5 * rng.normal(size=(case['m'], ia['d_latent_local']))).astype(np.float32)
+    abstract = np.concatenate([xyz, feats], axis=1)
+    fglob = (0.3 * rng.normal(size=(ia['d_latent'] - ia['d_latent_local'],))).astype(np.float32)
+    q = np.concatenate([rng.uniform(lo, hi, size=(case['nq'], 3)),
+                        rng.integers(0, 12, size=(case['nq'], 1))], axis=1).astype(np.float32)
+    sd = cfg.fill_state_dict(cfg.decoder_param_shapes(ia), case['seed'] + 1000)
+    return q, abstract, fglob, ia, sd
+
+
+# ---------------------------------------------------------------- G9
+GRID_CASES = [
+    dict(name='greater_8192', kind='greater', num_sample=8192, min_z=-1.0, cube_bounds=5.0, time_idx=3),
+    dict(name='greater_524288', kind='greater', num_sample=524288, min_z=-1.0, cube_bounds=5.0, time_idx=3),
+    dict(name='carla_524288', kind='carla', num_sample=524288, min_z=-1.0, cube_bounds=16.0, time_idx=3),
+    dict(name='greater_2097152', kind='greater', num_sample=2097152, min_z=-1.0, cube_bounds=5.0, time_idx=7),
+    dict(name='carla_8192', kind='carla', num_sample=8192, min_z=-1.0, cube_bounds=16.0, time_idx=0),
+]
+
+# ---------------------------------------------------------------- G10
+INFER_CASES = [
+    dict(name='config1_greater', kind='greater', n=2048, video_len=4, num_sample=8192, batch_size=4096,
+         time_idx=3, seed=1830),
+    dict(name='small_carla', kind='carla', n=768, video_len=4, num_sample=2048, batch_size=1024,
+         time_idx=2, seed=1832),
+]
+
+
+def infer_inputs(case):
+    pa, ia, inf = cfg.model_args(case['kind'], case['n'])
+    pcl = cfg.synthetic_pcl(case['kind'], case['n'], case['video_len'], case['seed'])
+    esd, dsd = cfg.synthetic_weights(pa, ia, case['seed'])
+    return pcl, pa, ia, inf, esd, dsd
+
+
+def as_tensor(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
