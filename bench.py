@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""Benchmark of the occlusions-4d hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+One "step" = one perform_inference unit of work: ONE encode of the
+(1, 14336, 8) point-cloud video + decode of every grid query point of one output frame,
+inputs (point cloud, query grid, weights) already resident in HBM, outputs left in HBM.
+
+Workload (BASELINE.json configs[1], "GREATER inference 1xMI355X"): n_points 14336,
+video_len 12, num_sample 524288 -> 534 528 grid queries, implicit_batch_size 32768,
+fp32, synthetic data + seeded random-init weights of the published architecture.
+At N GPUs the grid is num_sample = 524288 * N (N = 4 is configs[3]'s 2 M-query grid),
+rank 0 encodes and broadcasts the abstract cloud, every rank decodes a contiguous 1/N
+slice -> per-GPU work is fixed: "scaling": "weak".  value = total queries of all ranks /
+max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline      the dominant kernel = linear_kernel<13> on the (rows x 832) @ (832 x 416)
+                attention-logit GEMM; achieved = algorithmic FLOP (2 M K N) / HIP-event time
+                of those launches inside the timed region; peak = 157.3 TFLOP/s fp32 MFMA.
+  cpu_baseline  the CPU oracle (oracle/path.py = the reference's PyTorch-CPU op sequence)
+                timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import occlusions4d_amd as pk  # noqa: E402
+
+FP32_MFMA_PEAK = 157.3e12
+N_POINTS, VIDEO_LEN, NUM_SAMPLE, BATCH = 14336, 12, 524288, 32768
+SEED = 1830
+
+
+def as_written_flops(n_queries, n_calls, m_abstract, g_out):
+    """Matmul FLOPs of the reference's op sequence (SURVEY.md §8(d) closed form)."""
+    H, E, P, B, L, K, KL = 416, 288, 68, 6, 2, 14, 8
+    per_query = 2 * (P * H + B * 3 * H * H + L * (3 * H * H + K * (3 * 32 + 32 * H + 2 * H * H + 2 * H * H) + K * H)
+                     + H * g_out + KL * E)
+    per_call = L * 2 * (2 * E * H) * m_abstract
+    return per_query * n_queries + per_call * n_calls + 18.35e9
+
+
+def cpu_baseline(kind, pcl, esd, pa, dsd, ia, queries_np, n_queries_total):
+    """Oracle timed on the host: 1 encode + one 4096-query decode batch, extrapolated linearly in
+    N_q (decode is exactly linear in the number of queries)."""
+    from oracle import path as op
+    torch.set_num_threads(os.cpu_count() or 1)
+    sample = 4096
+    t0 = time.time()
+    with torch.no_grad():
+        ab, fg = op.encoder_forward(esd, pa, pcl)
+        t1 = time.time()
+        op.decoder_forward(dsd, ia, torch.from_numpy(queries_np[:sample]), ab[0], fg[0])
+    t2 = time.time()
+    t_enc, t_dec = t1 - t0, t2 - t1
+    total = t_enc + t_dec * n_queries_total / sample
+    return dict(value=n_queries_total / total, unit='query-points/s', cores=torch.get_num_threads(), kind='port',
+                sample='oracle/path.py on host CPU: 1 encode (n_points=%d) %.1f s + %d-query decode %.1f s, '
+                       'extrapolated to %d queries' % (N_POINTS, t_enc, sample, t_dec, n_queries_total))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--kind', default='greater', choices=['greater', 'carla'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    pa, ia, inf = pk.configs.model_args(args.kind, N_POINTS)
+    esd, dsd = pk.configs.synthetic_weights(pa, ia, SEED)
+    pcl_cpu = pk.configs.synthetic_pcl(args.kind, N_POINTS, VIDEO_LEN, SEED)
+    enc = pk.model.PointCompletionNetV3(**pa).to(device).eval()
+    dec = pk.implicit.LocalPclResnetFC(**ia).to(device).eval()
+    enc.load_state_dict(esd)
+    dec.load_state_dict(dsd)
+    queries_np = pk.geometry.sample_implicit_points_blind_numpy(
+        NUM_SAMPLE * world, inf['min_z'], inf['cube_bounds'], 3, inf['data_kind'], inf['cube_mode'], 'grid')
+    queries = torch.from_numpy(queries_np).to(device)
+    pcl = pcl_cpu.to(device)
+    n_total = queries.shape[0]
+    lo, hi = pk.distributed.shard_bounds(n_total, rank, world)
+
+    def step():
+        return pk.distributed.sharded_inference(pcl, queries, enc, dec, BATCH, inf['color_mode'],
+                                                inf['predict_segmentation'], 'none', 13)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        prof = pk.ops.LinearProfiler(lambda M, K, N: K == 832 and N == 416)
+        pk.ops.set_linear_profiler(prof)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out, _ = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        pk.ops.set_linear_profiler(None)
+        psum = prof.summary()
+        # encode share, measured separately (informational)
+        torch.cuda.synchronize()
+        te = time.perf_counter()
+        enc(pcl, False)
+        torch.cuda.synchronize()
+        t_encode = time.perf_counter() - te
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = n_total * args.steps / elapsed
+
+    if rank == 0:
+        m_abs = pk.distributed.abstract_shape(enc, N_POINTS)[0]
+        calls = -(-(hi - lo) // BATCH)
+        fl = as_written_flops(hi - lo, calls, m_abs, ia['d_out'])
+        achieved = psum['total_flops'] / (psum['total_ms'] * 1e-3) if psum['total_ms'] > 0 else 0.0
+        line = {
+            'metric': '4D query-points/sec (encode+decode) at n_points=14336',
+            'value': value, 'unit': 'query-points/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s inference: n_points=%d video_len=%d num_sample=%d (-> %d grid queries'
+                                   '%s) implicit_batch_size=%d, seeded random-init weights'
+                                   % (args.kind.upper(), N_POINTS, VIDEO_LEN, NUM_SAMPLE * world, n_total,
+                                      ', %d per GPU' % (hi - lo) if world > 1 else '', BATCH),
+                       'abstract_points': m_abs, 'outputs_per_query': ia['d_out'],
+                       'parallelism': 'query-sharded x%d, abstract cloud broadcast' % world},
+            'roofline': {
+                'bound': 'mfma', 'achieved': achieved / 1e12, 'peak': FP32_MFMA_PEAK / 1e12, 'unit': 'TFLOP/s',
+                'frac': achieved / FP32_MFMA_PEAK, 'traffic': None,
+                'kernel': 'linear_kernel<13> (attention-logit GEMM rows x 832 @ 832 x 416)',
+                'launches': psum['launches'], 'avg_launch_ms': psum['total_ms'] / max(1, psum['launches']),
+                'flop_per_launch': psum['total_flops'] / max(1, psum['launches'])},
+            'pipeline': {
+                'as_written_tflop_per_step_per_gpu': fl / 1e12,
+                'as_written_fp32_mfma_frac': fl / (ms_per_step * 1e-3) / FP32_MFMA_PEAK,
+                'encode_ms': 1e3 * t_encode},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args.kind, pcl_cpu, esd, pa, dsd, ia, queries_np, n_total)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,162 @@
+/*
+ * occ4d.h -- C ABI of libocc4d.so: the occlusions-4d hot path (point-transformer
+ * encode + cross-attention implicit decode of 4D query points) as hand-written
+ * HIP kernels for MI355X (gfx950).
+ *
+ * The reference (basilevh/occlusions-4d) has NO FFI / plugin layer of its own:
+ * the hot path sits behind Python nn.Module.forward signatures and all native
+ * work is third-party (ATen, torch_cluster).  Each entry point below therefore
+ * cites the reference call site(s) whose native work it replaces (paths relative
+ * to the reference root).  INTEGRATION.md shows the ctypes binding a maintainer
+ * of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (fp32 row-major unless noted); nothing is
+ *     allocated, freed or synchronised inside the library;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream);
+ *   - row strides (`ld*`, `*_stride`) are in ELEMENTS;
+ *   - return value: OCC4D_OK, or a negative OCC4D_E* code; occ4d_last_error()
+ *     describes the most recent failure on the calling thread;
+ *   - re-entrant: no global mutable state besides that thread-local message.
+ */
+#ifndef OCC4D_H_
+#define OCC4D_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCC4D_OK 0
+#define OCC4D_EINVAL (-1)   /* bad argument (maps to AssertionError / ValueError) */
+#define OCC4D_ELAUNCH (-2)  /* HIP launch failure */
+
+#define OCC4D_ABI_VERSION 1
+
+int occ4d_abi_version(void);
+const char* occ4d_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * K1 / K6 / K8  brute-force exact kNN, streaming top-k (k <= 16), never
+ * materialises the N0 x N1 distance matrix.
+ *   metric 0: d = ((dx*dx + dy*dy) + dz*dz), fp32, no FMA  -- square_distance +
+ *             kNN_torch, model/point_transformer_layer.py:16-30,76-99; also the
+ *             restated torch_cluster.knn of model/modules.py:142-146.
+ *   metric 1: d = sqrt(fma(dz,dz, fma(dy,dy, dx*dx)))  -- torch.linalg.norm +
+ *             topk(largest=False), utils/geometry.py:479-484 (my_knn_torch).
+ * Ties: lowest data index first.  Neighbours are emitted nearest first.
+ * out_idx: (n_query, k) int32, or int64 when idx_is_i64 != 0.
+ * out_dist: (n_query, k) fp32 distances in the chosen metric, or NULL.
+ * Requires 1 <= k <= 16 and n_data >= k.
+ */
+int occ4d_knn_f32(const float* query, int64_t q_stride, int n_query,
+                  const float* data, int64_t d_stride, int n_data,
+                  int k, int metric, void* out_idx, int idx_is_i64,
+                  float* out_dist, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K5  farthest point sampling (restated torch_cluster.fps with
+ * random_start=False, model/modules.py:133-135): start at index 0, then
+ * repeatedly the first argmax of the running min of ((dx*dx+dy*dy)+dz*dz).
+ * One workgroup, register-resident points.  n <= 32768, 1 <= m <= n.
+ * out_sorted: (m) int32 selected indices in ASCENDING order (the reference sorts
+ * them, :135);  out_order: (m) int32 in selection order, or NULL.
+ */
+int occ4d_fps_f32(const float* xyz, int64_t stride, int n, int m,
+                  int32_t* out_sorted, int32_t* out_order, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K3 / K11  torch.nn.Linear on row tiles with fused prologue/epilogue, exact
+ * fp32 on v_mfma_f32_32x32x2_f32:
+ *     t = (relu_in ? relu(x) : x) @ w^T + bias
+ *         + add_rows[row / add_div] - sub_rows[sub_idx[row]]      (each optional)
+ *     t = relu_out ? relu(t) : t
+ *     y = t + residual                                            (optional)
+ * x (M,K) ldx; w (N,K) torch layout, ldw; y (M,N) ldy.  K % 4 == 0, ldx % 4 == 0,
+ * ldw % 4 == 0, x and w 16-byte aligned.  Replaces the ATen addmm calls of
+ * model/implicit.py:92-101,408,416-418,443, model/modules.py:61,64,152,
+ * model/point_transformer_layer.py:170-176, model/model.py:167,189-190,204.
+ */
+typedef struct occ4d_linear_args {
+  const float* x;        int64_t ldx;
+  const float* w;        int64_t ldw;
+  const float* bias;                      /* (N) or NULL */
+  const float* residual; int64_t ldr;     /* (M,N) or NULL */
+  float* y;              int64_t ldy;
+  int32_t M, K, N;
+  int32_t relu_in, relu_out;
+  const float* add_rows; int64_t ld_add; int32_t add_div;        /* or NULL */
+  const float* sub_rows; int64_t ld_sub; const int32_t* sub_idx; /* or NULL */
+} occ4d_linear_args;
+
+int occ4d_linear_f32(const occ4d_linear_args* args, void* stream);
+
+/* ------------------------------------------------------------------------
+ * E3 pieces (model/point_transformer_layer.py:148-183), K2/K4.
+ *
+ * pos_hidden: r[p,:] = relu(P1 @ (pos[i] - pos2[idx[p]]) + c1), p = i*k + j;
+ *   pos (n,3) stride ps; pos2 (m,3) stride p2s; idx (n,k) int32; P1 (h,3), c1 (h);
+ *   out (n*k, h) contiguous.  (:168,174 first Linear + ReLU of pos_mlp)
+ */
+int occ4d_pt_pos_hidden_f32(const float* pos, int64_t ps, const float* pos2, int64_t p2s,
+                            const int32_t* idx, int n, int k, const float* P1, const float* c1,
+                            int h, float* out, void* stream);
+
+/* attn_in[p,:] = q[i,:] - kfeat[idx[p],:] + pe[p,:]   (:176 argument of attn_mlp) */
+int occ4d_pt_attn_in_f32(const float* q, int64_t ldq, const float* kfeat, int64_t ldk,
+                         const float* pe, const int32_t* idx, int n, int k, int d,
+                         float* out, void* stream);
+
+/* agg[i,c] = sum_j softmax_j(logits[i*k+j,c] / divisor) * (v[idx[i*k+j],c] + pe[i*k+j,c])
+ * (:177,179; per-channel softmax over the k <= 16 neighbours, divisor = fp32(sqrt(d))).
+ * pe may be NULL (treated as 0). */
+int occ4d_pt_softmax_agg_f32(const float* logits, const float* v, int64_t ldv, const float* pe,
+                             const int32_t* idx, int n, int k, int d, float divisor,
+                             float* agg, int64_t ld_agg, void* stream);
+
+/* ------------------------------------------------------------------------
+ * E6 pieces (model/modules.py:152-158), K7 / K12.
+ * layernorm: y = LayerNorm(x) * gamma + beta (biased variance, eps as given; torch
+ *   default 1e-5), followed by ReLU when relu_out != 0; in place allowed; gamma and
+ *   beta both NULL => no affine.
+ * maxpool_gather: z[i,c] = max_j y[idx[i*k+j], c].
+ */
+int occ4d_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta,
+                        float eps, int relu_out, float* y, int64_t ldy, int n, int d, void* stream);
+int occ4d_maxpool_gather_f32(const float* y, int64_t ldy, const int32_t* idx, int n_out, int k,
+                             int d, float* z, int64_t ldz, void* stream);
+
+/* gather_rows: out[i,:] = src[idx[i],:]  (index_points, :102-113; p_flat[inds], modules.py:137) */
+int occ4d_gather_rows_f32(const float* src, int64_t lds, const int32_t* idx, int n_out, int d,
+                          float* out, int64_t ldo, void* stream);
+
+/* mean over rows: out[c] = (1/n) sum_i x[i,c]   (model/model.py:188) */
+int occ4d_mean_rows_f32(const float* x, int64_t ldx, int n, int d, float* out, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Decoder pieces (model/implicit.py).
+ *
+ * posenc (D5, :20-43): out (n, c*(2f+1)) = [p, sin(p w0), cos(p w0), ...],
+ *   w_i = fp32(2*pi*base*2^i) computed in double then rounded, full-range sinf/cosf.
+ */
+int occ4d_posenc_f32(const float* pts, int64_t stride, int n, int c, int n_freq, double base_freq,
+                     float* out, int64_t ldo, void* stream);
+
+/* interp weights (D3, :336-337): w = 1/(d + 1e-4); w /= max(sum |w|, 1e-12)  (n,k) in place ok */
+int occ4d_interp_weights_f32(const float* dist, int n, int k, float* w, void* stream);
+
+/* x[i,:] += cvec[:] + sum_j w[i,j] * table[idx[i*k+j], :]
+ * (D3 + lin_z of D4 with the exact-in-R refactoring of DESIGN.md; also plain D3
+ * feature interpolation when x is zero-initialised and cvec is NULL) */
+int occ4d_interp_add_f32(float* x, int64_t ldx, const float* cvec, const float* table, int64_t ldt,
+                         const int32_t* idx, const float* w, int n, int k, int d, void* stream);
+
+/* K13 post-ops (eval/inference.py:218-243): per channel op code in `ops` (G ints):
+ * 0 = identity, 1 = sigmoid, 2 = clamp to [0,1].  In place. */
+int occ4d_squash_f32(float* out, int64_t ld, int n, int g, const int32_t* ops_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCC4D_H_ */

@@ -2,10 +2,15 @@
 decode of 4D query points) as hand-written HIP for MI355X / gfx950.
 
 Host side mirrors the reference's ``model/`` + ``eval/inference.py`` interface
-(same class names, constructor kwargs, parameter names and forward signatures,
-SURVEY.md §8(b)); every forward runs on the C-ABI library ``libocc4d.so``
-(include/occ4d.h) and raises if it is missing -- there is no CPU fallback.
+(same module / class names, constructor kwargs, parameter names and forward
+signatures); every forward runs on the C-ABI library
+``libocc4d.so`` (include/occ4d.h) and raises if it is missing -- there is no CPU
+fallback.  ``configs`` is pure host code (named configurations, synthetic inputs).
 """
-from . import configs  # noqa: F401  (pure host code; no native dependency)
+from . import configs  # noqa: F401
+from . import _lib  # noqa: F401
+from . import ops  # noqa: F401
+from . import point_transformer_layer, modules, model, geometry, implicit, inference, distributed  # noqa: F401
 
-__all__ = ['configs']
+__all__ = ['configs', 'ops', 'point_transformer_layer', 'modules', 'model', 'geometry', 'implicit',
+           'inference', 'distributed']

@@ -1,0 +1,95 @@
+"""ctypes binding of libocc4d.so (include/occ4d.h).  Fails loudly when the library is
+missing or stale: the product has no CPU / PyTorch fallback path."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libocc4d.so')
+ABI_VERSION = 1
+
+OK, EINVAL, ELAUNCH = 0, -1, -2
+
+_f = C.c_void_p      # device float*
+_i = C.c_void_p      # device int32*/int64*
+_s = C.c_void_p      # hipStream_t
+
+
+class LinearArgs(C.Structure):
+    """occ4d_linear_args (include/occ4d.h)."""
+    _fields_ = [
+        ('x', C.c_void_p), ('ldx', C.c_int64),
+        ('w', C.c_void_p), ('ldw', C.c_int64),
+        ('bias', C.c_void_p),
+        ('residual', C.c_void_p), ('ldr', C.c_int64),
+        ('y', C.c_void_p), ('ldy', C.c_int64),
+        ('M', C.c_int32), ('K', C.c_int32), ('N', C.c_int32),
+        ('relu_in', C.c_int32), ('relu_out', C.c_int32),
+        ('add_rows', C.c_void_p), ('ld_add', C.c_int64), ('add_div', C.c_int32),
+        ('sub_rows', C.c_void_p), ('ld_sub', C.c_int64), ('sub_idx', C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes): every symbol include/occ4d.h declares
+SIGNATURES = {
+    'occ4d_abi_version': (C.c_int, []),
+    'occ4d_last_error': (C.c_char_p, []),
+    'occ4d_knn_f32': (C.c_int, [_f, C.c_int64, C.c_int, _f, C.c_int64, C.c_int, C.c_int, C.c_int, _i, C.c_int,
+                                _f, _s]),
+    'occ4d_fps_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, _i, _i, _s]),
+    'occ4d_linear_f32': (C.c_int, [C.POINTER(LinearArgs), _s]),
+    'occ4d_pt_pos_hidden_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _i, C.c_int, C.c_int, _f, _f, C.c_int,
+                                          _f, _s]),
+    'occ4d_pt_attn_in_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, _i, C.c_int, C.c_int, C.c_int, _f, _s]),
+    'occ4d_pt_softmax_agg_f32': (C.c_int, [_f, _f, C.c_int64, _f, _i, C.c_int, C.c_int, C.c_int, C.c_float, _f,
+                                           C.c_int64, _s]),
+    'occ4d_layernorm_f32': (C.c_int, [_f, C.c_int64, _f, _f, C.c_float, C.c_int, _f, C.c_int64, C.c_int, C.c_int,
+                                      _s]),
+    'occ4d_maxpool_gather_f32': (C.c_int, [_f, C.c_int64, _i, C.c_int, C.c_int, C.c_int, _f, C.c_int64, _s]),
+    'occ4d_gather_rows_f32': (C.c_int, [_f, C.c_int64, _i, C.c_int, C.c_int, _f, C.c_int64, _s]),
+    'occ4d_mean_rows_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, _f, _s]),
+    'occ4d_posenc_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, _f, C.c_int64, _s]),
+    'occ4d_interp_weights_f32': (C.c_int, [_f, C.c_int, C.c_int, _f, _s]),
+    'occ4d_interp_add_f32': (C.c_int, [_f, C.c_int64, _f, _f, C.c_int64, _i, _f, C.c_int, C.c_int, C.c_int, _s]),
+    'occ4d_squash_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int32), _s]),
+}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library (cached).  Raises NativeLibraryError if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            'libocc4d.so not found at %s -- build it with `python occlusions-4d_amd/build.py` '
+            '(or __graft_entry__.build()); this package has no CPU/PyTorch fallback.' % LIB_PATH)
+    handle = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError:
+            raise NativeLibraryError('libocc4d.so is stale: symbol %s missing; rebuild it' % name)
+        fn.restype = res
+        fn.argtypes = args
+    if handle.occ4d_abi_version() != ABI_VERSION:
+        raise NativeLibraryError('libocc4d.so ABI version %d != expected %d; rebuild it'
+                                 % (handle.occ4d_abi_version(), ABI_VERSION))
+    _lib = handle
+    return _lib
+
+
+def check(rc):
+    """Map a status code to the exception the reference would have raised
+    (AssertionError for shape/argument violations)."""
+    if rc == OK:
+        return
+    msg = lib().occ4d_last_error().decode('utf-8', 'replace')
+    if rc == EINVAL:
+        raise AssertionError(msg)
+    raise RuntimeError('libocc4d launch failure: ' + msg)

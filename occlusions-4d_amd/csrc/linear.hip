@@ -1,0 +1,169 @@
+// torch.nn.Linear on row tiles, exact fp32 on v_mfma_f32_32x32x2_f32 (K3/K11).
+//
+// Tiling (wave64, one wave per SIMD): a 256-thread workgroup owns BM = 128 rows x
+// BN = 32*NT columns (NT = 13 covers the decoder's 416-wide layers with no padding
+// waste: 416 = 13 * 32).  Wave w owns row tile w and ALL NT column tiles, so one A
+// fragment feeds NT MFMAs and the 16*NT accumulators stay in the unified VGPR/AGPR
+// file.  x and w tiles (BK = 16) are staged global -> registers -> LDS, double
+// buffered, one barrier per k-tile; rows are padded to 20 floats so the
+// ds_read_b128 fragment reads are bank-conflict free (stride 5 x 16 B is odd).
+//
+// Fragment / k mapping: lane l supplies row (l & 31); within an 8-wide k group the
+// lower half-wave reads k = 0..3 and the upper k = 4..7 as one float4 each, and MFMA
+// step i consumes element i of both, i.e. the k order inside a group is
+// (0,4),(1,5),(2,6),(3,7).  A and B use the same map, so the product is exact; only
+// the fp32 summation order differs from a serial dot product.
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128;
+constexpr int BK = 16;
+constexpr int LDT = 20;  // padded LDS row (floats)
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void linear_kernel(const occ4d_linear_args a) {
+  constexpr int BN = 32 * NT;
+  constexpr int WLOADS = (NT * 128 + 255) / 256;  // float4 per thread for the w tile
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDT];
+  float* const As0 = smem;
+  float* const Ws0 = smem + 2 * BM * LDT;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * BM;
+  const int col0 = blockIdx.y * BN;
+  const int M = a.M, K = a.K, N = a.N;
+
+  f32x4 ra[2], rw[WLOADS];
+
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = tid + 256 * i;
+      const int r = row0 + (f >> 2), k = k0 + 4 * (f & 3);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < M && k < K) v = *reinterpret_cast<const f32x4*>(a.x + (int64_t)r * a.ldx + k);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < WLOADS; ++i) {
+      const int f = tid + 256 * i;
+      const int c = col0 + (f >> 2), k = k0 + 4 * (f & 3);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if ((f >> 2) < BN && c < N && k < K) v = *reinterpret_cast<const f32x4*>(a.w + (int64_t)c * a.ldw + k);
+      rw[i] = v;
+    }
+  };
+  auto sstore = [&](int buf) {
+    float* As = As0 + buf * BM * LDT;
+    float* Ws = Ws0 + buf * BN * LDT;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = tid + 256 * i;
+      f32x4 v = ra[i];
+      if (a.relu_in) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      *reinterpret_cast<f32x4*>(As + (f >> 2) * LDT + 4 * (f & 3)) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < WLOADS; ++i) {
+      const int f = tid + 256 * i;
+      if ((f >> 2) < BN) *reinterpret_cast<f32x4*>(Ws + (f >> 2) * LDT + 4 * (f & 3)) = rw[i];
+    }
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int c = 0; c < NT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  const int nk = (K + BK - 1) / BK;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  const int frag_off = (lane & 31) * LDT + 4 * (lane >> 5);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload((kt + 1) * BK);
+    const float* Ab = As0 + buf * BM * LDT + wave * 32 * LDT + frag_off;
+    const float* Wb = Ws0 + buf * BN * LDT + frag_off;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(Ab + 8 * j);
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(Wb + c * 32 * LDT + 8 * j);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[c], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nk) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: C/D map of 32x32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const int half = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (row >= M) continue;
+    const float* addp = a.add_rows ? a.add_rows + (int64_t)(row / a.add_div) * a.ld_add : nullptr;
+    const float* subp = a.sub_rows ? a.sub_rows + (int64_t)a.sub_idx[row] * a.ld_sub : nullptr;
+    const float* resp = a.residual ? a.residual + (int64_t)row * a.ldr : nullptr;
+    float* yp = a.y + (int64_t)row * a.ldy;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+      const int col = col0 + 32 * c + (lane & 31);
+      if (col >= N) continue;
+      float v = acc[c][r];
+      if (a.bias) v += a.bias[col];
+      if (addp) v += addp[col];
+      if (subp) v -= subp[col];
+      if (a.relu_out) v = fmaxf(v, 0.f);
+      if (resp) v += resp[col];
+      yp[col] = v;
+    }
+  }
+}
+
+template <int NT>
+int launch(const occ4d_linear_args& a, hipStream_t st) {
+  dim3 grid(occ4d::cdiv(a.M, BM), occ4d::cdiv(a.N, 32 * NT)), block(256);
+  linear_kernel<NT><<<grid, block, 0, st>>>(a);
+  return occ4d::check_launch("occ4d_linear_f32");
+}
+
+}  // namespace
+
+extern "C" int occ4d_linear_f32(const occ4d_linear_args* args, void* stream) {
+  OCC4D_REQUIRE(args, "occ4d_linear_f32: null args");
+  const occ4d_linear_args& a = *args;
+  OCC4D_REQUIRE(a.x && a.w && a.y, "occ4d_linear_f32: null x/w/y");
+  OCC4D_REQUIRE(a.M >= 0 && a.N >= 1 && a.K >= 4, "occ4d_linear_f32: bad M/N/K = %d/%d/%d", a.M, a.N, a.K);
+  OCC4D_REQUIRE(a.K % 4 == 0 && a.ldx % 4 == 0 && a.ldw % 4 == 0,
+                "occ4d_linear_f32: K, ldx, ldw must be multiples of 4 (K=%d ldx=%lld ldw=%lld)", a.K,
+                (long long)a.ldx, (long long)a.ldw);
+  OCC4D_REQUIRE(((uintptr_t)a.x % 16) == 0 && ((uintptr_t)a.w % 16) == 0,
+                "occ4d_linear_f32: x and w must be 16-byte aligned");
+  OCC4D_REQUIRE(a.ldx >= a.K && a.ldw >= a.K && a.ldy >= a.N, "occ4d_linear_f32: leading dimension too small");
+  OCC4D_REQUIRE(!a.add_rows || a.add_div >= 1, "occ4d_linear_f32: add_div must be >= 1");
+  OCC4D_REQUIRE(!a.sub_rows || a.sub_idx, "occ4d_linear_f32: sub_rows needs sub_idx");
+  if (a.M == 0) return OCC4D_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int n = a.N;
+  if (n <= 32) return launch<1>(a, st);
+  if (n <= 64) return launch<2>(a, st);
+  if (n <= 96) return launch<3>(a, st);
+  if (n <= 128) return launch<4>(a, st);
+  if (n <= 160) return launch<5>(a, st);
+  if (n <= 288) return launch<9>(a, st);
+  return launch<13>(a, st);
+}

@@ -1,0 +1,81 @@
+"""Query-sharded inference over the GPUs of one node (one process per GPU, RCCL).
+
+The reference is single-GPU at inference and nn.DataParallel for training (SURVEY.md
+§2.1); nothing is ported.  Given (pcl_abstract, features_global) every query point is
+independent (no cross-query op in model/implicit.py:271-445), so the path shards with one
+exchange step: rank 0 encodes the clip and broadcasts the abstract cloud (M x 291 fp32,
+0.6-2.5 MB) and the global embedding (512 B); each rank then decodes a contiguous slice of
+the query grid.  Outputs stay sharded unless `gather=True` (all_gather of (N/R) x G fp32).
+All three messages are latency-bound on xGMI; no collective sits inside the decode loop.
+"""
+import torch
+import torch.distributed as dist
+
+from . import inference
+from . import ops
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous slice [lo, hi) of n queries owned by `rank` (ceil split, last ranks may be short)."""
+    per = (n + world - 1) // world
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+def encode_and_share(pcl_input, pcl_net, abstract_shape, global_dim, device, src=0):
+    """Rank `src` runs the encoder; everyone receives (pcl_abstract (M,3+E), features_global (D))."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if rank == src:
+        (pcl_abstract, features_global, _) = pcl_net(pcl_input, False)
+        pcl_abstract = pcl_abstract.squeeze(0).contiguous()
+        features_global = features_global.squeeze(0).contiguous()
+        assert tuple(pcl_abstract.shape) == tuple(abstract_shape)
+    else:
+        pcl_abstract = torch.empty(abstract_shape, dtype=torch.float32, device=device)
+        features_global = torch.empty((global_dim,), dtype=torch.float32, device=device)
+    if world > 1:
+        dist.broadcast(pcl_abstract, src=src)
+        dist.broadcast(features_global, src=src)
+    return pcl_abstract, features_global
+
+
+def abstract_shape(pcl_net, n_points):
+    """(M, 3+E) of the encoder output for an n_points input (ceil(N/factor) per level,
+    model/modules.py:126; multi-level concat, model/model.py:224-228)."""
+    sizes = [n_points]
+    for _ in range(pcl_net.down_blocks):
+        sizes.append(-(-sizes[-1] // pcl_net.transition_factor))
+    m = sum(sizes[len(sizes) - pcl_net.abstract_levels:])
+    return (m, 3 + pcl_net.d_feat * 2 ** pcl_net.down_blocks)
+
+
+def sharded_inference(pcl_input, points_query, pcl_net, implicit_net, batch_size, color_mode,
+                      predict_segmentation=False, track_mode='none', semantic_classes=13, gather=False):
+    """pcl_input (1,N,8) and points_query (Nq,4) are CUDA tensors present on every rank (the query
+    grid is deterministic, every rank builds it).  Returns (local_output (n_local,G), (lo, hi)) or the
+    gathered (Nq,G) tensor when gather=True."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    device = points_query.device
+    shape = abstract_shape(pcl_net, pcl_input.shape[1])
+    pcl_abstract, features_global = encode_and_share(pcl_input, pcl_net, shape, pcl_net.global_dim, device)
+    lo, hi = shard_bounds(points_query.shape[0], rank, world)
+    out = torch.empty((hi - lo, implicit_net.d_out), dtype=torch.float32, device=device)
+    for b in range(lo, hi, batch_size):
+        e = min(hi, b + batch_size)
+        (o, _) = implicit_net(points_query[b:e], pcl_abstract, features_global, None)
+        out[b - lo:e - lo] = o
+    ops.squash(out, inference.squash_codes(implicit_net.d_out, color_mode, predict_segmentation, track_mode,
+                                           semantic_classes))
+    if not gather:
+        return out, (lo, hi)
+    per = (points_query.shape[0] + world - 1) // world
+    padded = torch.zeros((per, implicit_net.d_out), dtype=torch.float32, device=device)
+    padded[:hi - lo] = out
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(parts, padded)
+    else:
+        parts = [padded]
+    return torch.cat(parts)[:points_query.shape[0]]

@@ -1,0 +1,87 @@
+"""Encoder building blocks on the HIP library.
+
+Interface mirror of the reference's model/modules.py: ``PointTransformerBlock``
+(:18-67) and ``DownTransition`` (:70-163) with the reference's constructor
+arguments, parameter names (layer1/layer2/layer3, mlp.0[/mlp.1]) and forward
+signatures.  ``UpTransition`` (:166-289) is not instantiated by any published
+config (enable_decoder=False, train.py:223) and is out of scope.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from . import point_transformer_layer
+from .point_transformer_layer import _no_autograd
+
+
+class PointTransformerBlock(torch.nn.Module):
+    """z = x + layer3(PointTransformerLayer(layer1(x), p[, x2, p2]))."""
+
+    def __init__(self, d_in, d_hidden, d_out, num_neighbors=16, d_hidden_abstract=None):
+        super().__init__()
+        self.d_in, self.d_hidden, self.d_out = d_in, d_hidden, d_out
+        self.num_neighbors = num_neighbors
+        self.layer1 = torch.nn.Linear(d_in, d_hidden)
+        self.layer2 = point_transformer_layer.PointTransformerLayer(
+            d_hidden, pos_mlp_hidden_dim=32, attn_mlp_hidden_mult=2, num_neighbors=num_neighbors,
+            dim2=d_hidden_abstract)
+        self.layer3 = torch.nn.Linear(d_hidden, d_out)
+
+    def forward(self, x, p, x2=None, p2=None, scene_owner=None):
+        """x (B,N,d_in), p (B,N,3) [, x2 (B,M,E), p2 (B,M,3)] -> (z (B,N,d_out), p).
+        `scene_owner` (extension, optional): tensor object identifying the abstract cloud so
+        its key/value tables are computed once per scene instead of once per call."""
+        assert x.shape[:2] == p.shape[:2]
+        if x2 is not None:
+            assert x2.shape[:2] == p2.shape[:2]
+        _no_autograd(x, p, x2, p2)
+        # layer1 is folded into the query-side merged matrix (cross) or applied once (self)
+        agg = self.layer2._forward(x, p, x2, p2, pre=self.layer1, scene_owner=scene_owner)
+        z = torch.stack([ops.linear(agg[b], self.layer3.weight, self.layer3.bias, residual=x[b])
+                         for b in range(x.shape[0])])
+        return (z, p)
+
+
+class DownTransition(torch.nn.Module):
+    """Farthest point sampling + kNN + Linear[/LayerNorm]/ReLU on all points + K-way max pool."""
+
+    def __init__(self, d_in, d_out, factor=2, knn_k=8, norm_type='none', fps_random_start=True):
+        super().__init__()
+        self.d_in, self.d_out, self.factor, self.knn_k = d_in, d_out, factor, knn_k
+        self.norm_type = norm_type
+        self.fps_random_start = fps_random_start
+        if norm_type == 'none':
+            self.mlp = torch.nn.Sequential(torch.nn.Linear(d_in, d_out), torch.nn.ReLU())
+        elif norm_type == 'layer':
+            self.mlp = torch.nn.Sequential(torch.nn.Linear(d_in, d_out), torch.nn.LayerNorm(d_out),
+                                           torch.nn.ReLU())
+        elif norm_type == 'batch':
+            raise NotImplementedError("norm_type 'batch' is unused by every published configuration")
+        else:
+            raise ValueError()
+
+    def forward(self, x, p):
+        """x (B,N,d_in), p (B,N,3) -> (z (B,ceil(N/factor),d_out), p_sub (B,ceil(N/factor),3))."""
+        assert x.shape[:2] == p.shape[:2]
+        _no_autograd(x, p)
+        if self.fps_random_start:
+            raise NotImplementedError('fps_random_start=True (training-time randomness) is not part of the '
+                                      'inference path; the reference forces False at test time '
+                                      '(eval/inference.py:59)')
+        (B, N, d_in) = x.shape
+        n_new = int(np.ceil(N / self.factor))
+        lin = self.mlp[0]
+        zs, ps = [], []
+        for b in range(B):
+            inds = ops.fps(p[b], n_new)                                   # ascending int32
+            p_sub = ops.gather_rows(p[b], inds)                            # (n_new,3)
+            nn_idx = ops.knn(p_sub, p[b], self.knn_k, metric=0)            # (n_new,k)
+            if self.norm_type == 'layer':
+                y = ops.linear(x[b], lin.weight, lin.bias)
+                ln = self.mlp[1]
+                ops.layernorm(y, ln.weight, ln.bias, eps=ln.eps, relu=True, out=y)
+            else:
+                y = ops.linear(x[b], lin.weight, lin.bias, relu_out=True)
+            zs.append(ops.maxpool_gather(y, nn_idx))
+            ps.append(p_sub)
+        return (torch.stack(zs), torch.stack(ps))

@@ -1,0 +1,278 @@
+"""Tensor-level wrappers over the C ABI (include/occ4d.h): each takes CUDA fp32 /
+int32 torch tensors, launches on torch's current stream and returns torch tensors.
+torch is plumbing here (device memory + streams); all arithmetic happens in
+libocc4d.so.  CPU tensors are rejected -- there is no fallback path."""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+
+
+class LinearProfiler:
+    """Times selected occ4d_linear_f32 launches with HIP events on the launch stream
+    (bench.py's roofline leg).  `match(M, K, N)` picks the launches; durations are read
+    after a synchronise via `summary()`."""
+
+    def __init__(self, match):
+        self.match = match
+        self.events = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b, _ in self.events]
+        flops = [f for _, _, f in self.events]
+        return dict(launches=len(ms), total_ms=sum(ms), total_flops=float(sum(flops)))
+
+
+_linear_profiler = None
+
+
+def set_linear_profiler(p):
+    global _linear_profiler
+    _linear_profiler = p
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, dtype=torch.float32, name='tensor'):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError('%s must be a CUDA tensor: occlusions4d_amd runs only on the HIP library '
+                           '(no CPU fallback)' % name)
+    assert t.dtype == dtype, '%s must be %s, got %s' % (name, dtype, t.dtype)
+    return t
+
+
+def _rows(t, name='tensor'):
+    """2-D view whose last dim is contiguous; returns (tensor, row stride in elements)."""
+    assert t.dim() == 2, '%s must be 2-D, got %s' % (name, tuple(t.shape))
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    return t, (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0)))
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _aligned_rows(t, name):
+    """2-D fp32 tensor with 16-byte aligned base and row stride % 4 == 0 (copies if needed)."""
+    t, ld = _rows(t, name)
+    if t.data_ptr() % 16 or ld % 4:
+        t = t.contiguous()
+        if t.shape[1] % 4:
+            pad = 4 - t.shape[1] % 4
+            t = torch.nn.functional.pad(t, (0, pad))
+        ld = t.stride(0) if t.shape[0] > 1 else t.shape[1]
+        if t.data_ptr() % 16:
+            t = t.clone()
+    return t, ld
+
+
+# --------------------------------------------------------------------------------------
+def knn(query, data, k, metric=0, return_dist=False, int64=False):
+    """query (N0,>=3), data (N1,>=3) -> idx (N0,k) [, dist (N0,k)].  metric 0 = squared
+    sum (kNN_torch arithmetic), 1 = Euclidean norm (my_knn_torch arithmetic)."""
+    q, qs = _rows(_dev(query, name='query'), 'query')
+    d, ds = _rows(_dev(data, name='data'), 'data')
+    assert q.shape[1] >= 3 and d.shape[1] >= 3
+    n0 = q.shape[0]
+    idx = torch.empty((n0, k), dtype=torch.int64 if int64 else torch.int32, device=q.device)
+    dist = torch.empty((n0, k), dtype=torch.float32, device=q.device) if return_dist else None
+    _lib.check(_lib.lib().occ4d_knn_f32(_ptr(q), qs, n0, _ptr(d), ds, d.shape[0], k, metric, _ptr(idx),
+                                        1 if int64 else 0, _ptr(dist), _stream()))
+    return (idx, dist) if return_dist else idx
+
+
+def fps(xyz, m, return_order=False):
+    """xyz (N,>=3) -> ascending int32 indices (m) of the farthest-point sample."""
+    p, ps = _rows(_dev(xyz, name='xyz'), 'xyz')
+    out = torch.empty((m,), dtype=torch.int32, device=p.device)
+    order = torch.empty((m,), dtype=torch.int32, device=p.device) if return_order else None
+    _lib.check(_lib.lib().occ4d_fps_f32(_ptr(p), ps, p.shape[0], m, _ptr(out), _ptr(order), _stream()))
+    return (out, order) if return_order else out
+
+
+def linear(x, w, b=None, relu_in=False, relu_out=False, residual=None, out=None,
+           add_rows=None, add_div=1, sub_rows=None, sub_idx=None):
+    """y = [relu]( [relu](x) @ w.T + b + add_rows[row // add_div] - sub_rows[sub_idx[row]] ) + residual."""
+    x, ldx = _aligned_rows(_dev(x, name='x'), 'x')
+    w, ldw = _aligned_rows(_dev(w, name='w'), 'w')
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K, 'linear: x is (%d,%d) but w is %s' % (M, K, tuple(w.shape))
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    y, ldy = _rows(_dev(out, name='out'), 'out')
+    assert y is out and y.shape == (M, N)
+    a = _lib.LinearArgs()
+    a.x, a.ldx, a.w, a.ldw = x.data_ptr(), ldx, w.data_ptr(), ldw
+    a.bias = _dev(b, name='bias').data_ptr() if b is not None else None
+    if b is not None:
+        assert b.is_contiguous() and b.numel() == N
+    if residual is not None:
+        r, ldr = _rows(_dev(residual, name='residual'), 'residual')
+        assert r.shape == (M, N)
+        a.residual, a.ldr = r.data_ptr(), ldr
+    a.y, a.ldy = y.data_ptr(), ldy
+    a.M, a.K, a.N = M, K, N
+    a.relu_in, a.relu_out = int(relu_in), int(relu_out)
+    if add_rows is not None:
+        ar, lda = _rows(_dev(add_rows, name='add_rows'), 'add_rows')
+        assert ar.shape[1] == N and ar.shape[0] * add_div >= M
+        a.add_rows, a.ld_add, a.add_div = ar.data_ptr(), lda, add_div
+    if sub_rows is not None:
+        sr, lds = _rows(_dev(sub_rows, name='sub_rows'), 'sub_rows')
+        si = _dev(sub_idx, torch.int32, 'sub_idx')
+        assert sr.shape[1] == N and si.is_contiguous() and si.numel() == M
+        a.sub_rows, a.ld_sub, a.sub_idx = sr.data_ptr(), lds, si.data_ptr()
+    prof = _linear_profiler
+    if prof is not None and prof.match(M, K, N):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(_lib.lib().occ4d_linear_f32(C.byref(a), _stream()))
+        e1.record()
+        prof.events.append((e0, e1, 2.0 * M * K * N))
+        return out
+    _lib.check(_lib.lib().occ4d_linear_f32(C.byref(a), _stream()))
+    return out
+
+
+def pt_pos_hidden(pos, pos2, idx, P1, c1):
+    p, ps = _rows(_dev(pos, name='pos'), 'pos')
+    p2, p2s = _rows(_dev(pos2, name='pos2'), 'pos2')
+    idx = _dev(idx, torch.int32, 'idx')
+    assert idx.is_contiguous() and idx.shape[0] == p.shape[0]
+    n, k = idx.shape
+    P1 = _dev(P1).contiguous()
+    c1 = _dev(c1).contiguous()
+    h = P1.shape[0]
+    assert P1.shape == (h, 3) and c1.shape == (h,)
+    out = torch.empty((n * k, h), dtype=torch.float32, device=p.device)
+    _lib.check(_lib.lib().occ4d_pt_pos_hidden_f32(_ptr(p), ps, _ptr(p2), p2s, _ptr(idx), n, k, _ptr(P1), _ptr(c1),
+                                                  h, _ptr(out), _stream()))
+    return out
+
+
+def pt_attn_in(q, kfeat, pe, idx):
+    q, ldq = _rows(_dev(q, name='q'), 'q')
+    kf, ldk = _rows(_dev(kfeat, name='kfeat'), 'kfeat')
+    n, k = idx.shape
+    d = q.shape[1]
+    pe = _dev(pe, name='pe')
+    assert pe.is_contiguous() and pe.shape == (n * k, d) and kf.shape[1] == d and idx.is_contiguous()
+    out = torch.empty((n * k, d), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.lib().occ4d_pt_attn_in_f32(_ptr(q), ldq, _ptr(kf), ldk, _ptr(pe), _ptr(_dev(idx, torch.int32)),
+                                               n, k, d, _ptr(out), _stream()))
+    return out
+
+
+def pt_softmax_agg(logits, v, pe, idx, out=None):
+    """agg (n,d) from logits (n*k,d), v (m,d), pe (n*k,d) or None, idx (n,k) int32."""
+    n, k = idx.shape
+    logits = _dev(logits, name='logits')
+    d = logits.shape[1]
+    assert logits.is_contiguous() and logits.shape == (n * k, d) and idx.is_contiguous()
+    v, ldv = _rows(_dev(v, name='v'), 'v')
+    if pe is not None:
+        assert pe.is_contiguous() and pe.shape == (n * k, d)
+    if out is None:
+        out = torch.empty((n, d), dtype=torch.float32, device=logits.device)
+    o, ldo = _rows(out, 'out')
+    assert o is out
+    divisor = float(torch.tensor(math.sqrt(d), dtype=torch.float32))
+    _lib.check(_lib.lib().occ4d_pt_softmax_agg_f32(_ptr(logits), _ptr(v), ldv, _ptr(pe),
+                                                   _ptr(_dev(idx, torch.int32)), n, k, d, divisor, _ptr(o), ldo,
+                                                   _stream()))
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, relu=False, out=None):
+    x, ldx = _rows(_dev(x, name='x'), 'x')
+    n, d = x.shape
+    if out is None:
+        out = torch.empty((n, d), dtype=torch.float32, device=x.device)
+    o, ldo = _rows(out, 'out')
+    assert o is out
+    g = _dev(gamma).contiguous() if gamma is not None else None
+    b = _dev(beta).contiguous() if beta is not None else None
+    _lib.check(_lib.lib().occ4d_layernorm_f32(_ptr(x), ldx, _ptr(g), _ptr(b), eps, int(relu), _ptr(o), ldo, n, d,
+                                              _stream()))
+    return out
+
+
+def maxpool_gather(y, idx):
+    y, ldy = _rows(_dev(y, name='y'), 'y')
+    idx = _dev(idx, torch.int32, 'idx')
+    assert idx.is_contiguous() and idx.dim() == 2
+    n_out, k = idx.shape
+    d = y.shape[1]
+    z = torch.empty((n_out, d), dtype=torch.float32, device=y.device)
+    _lib.check(_lib.lib().occ4d_maxpool_gather_f32(_ptr(y), ldy, _ptr(idx), n_out, k, d, _ptr(z), d, _stream()))
+    return z
+
+
+def gather_rows(src, idx):
+    src, lds = _rows(_dev(src, name='src'), 'src')
+    idx = _dev(idx, torch.int32, 'idx').contiguous()
+    n_out = idx.numel()
+    d = src.shape[1]
+    out = torch.empty((n_out, d), dtype=torch.float32, device=src.device)
+    _lib.check(_lib.lib().occ4d_gather_rows_f32(_ptr(src), lds, _ptr(idx), n_out, d, _ptr(out), d, _stream()))
+    return out
+
+
+def mean_rows(x):
+    x, ldx = _rows(_dev(x, name='x'), 'x')
+    out = torch.empty((x.shape[1],), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().occ4d_mean_rows_f32(_ptr(x), ldx, x.shape[0], x.shape[1], _ptr(out), _stream()))
+    return out
+
+
+def posenc(points, n_freq, base_freq=0.1):
+    p, ps = _rows(_dev(points, name='points'), 'points')
+    n, c = p.shape
+    width = c * (2 * n_freq + 1)
+    # row stride padded to a multiple of 4 floats so the Linear that follows can vector-load
+    ld = (width + 3) // 4 * 4
+    buf = torch.zeros((n, ld), dtype=torch.float32, device=p.device) if ld != width else \
+        torch.empty((n, ld), dtype=torch.float32, device=p.device)
+    _lib.check(_lib.lib().occ4d_posenc_f32(_ptr(p), ps, n, c, n_freq, float(base_freq), _ptr(buf), ld, _stream()))
+    return buf[:, :width]
+
+
+def interp_weights(dist):
+    dist = _dev(dist, name='dist')
+    assert dist.is_contiguous() and dist.dim() == 2
+    w = torch.empty_like(dist)
+    _lib.check(_lib.lib().occ4d_interp_weights_f32(_ptr(dist), dist.shape[0], dist.shape[1], _ptr(w), _stream()))
+    return w
+
+
+def interp_add(x, cvec, table, idx, w):
+    """x (n,d) += cvec + sum_j w[:,j] * table[idx[:,j]]   (in place)."""
+    xx, ldx = _rows(_dev(x, name='x'), 'x')
+    assert xx is x
+    t, ldt = _rows(_dev(table, name='table'), 'table')
+    idx = _dev(idx, torch.int32, 'idx')
+    w = _dev(w, name='w')
+    n, k = idx.shape
+    d = x.shape[1]
+    assert idx.is_contiguous() and w.is_contiguous() and w.shape == (n, k) and x.shape[0] == n and t.shape[1] == d
+    cv = _dev(cvec).contiguous() if cvec is not None else None
+    _lib.check(_lib.lib().occ4d_interp_add_f32(_ptr(x), ldx, _ptr(cv), _ptr(t), ldt, _ptr(idx), _ptr(w), n, k, d,
+                                               _stream()))
+    return x
+
+
+def squash(out, ops):
+    """In-place per-channel post-op; ops: list of G codes (0 identity, 1 sigmoid, 2 clamp[0,1])."""
+    o, ld = _rows(_dev(out, name='out'), 'out')
+    assert o is out
+    n, g = out.shape
+    arr = (C.c_int32 * g)(*[int(v) for v in ops])
+    _lib.check(_lib.lib().occ4d_squash_f32(_ptr(out), ld, n, g, arr, _stream()))
+    return out

@@ -14,6 +14,27 @@ import torch.nn.functional as F
 
 from . import cluster
 
+# Tie handling.  The reference orders equal distances with an UNSTABLE sort
+# (argsort(), model/point_transformer_layer.py:97) / topk (utils/geometry.py:484): which of
+# two equidistant points it keeps at the k-th rank is implementation-defined (and differs
+# between its CPU and CUDA runs).  CARLA's two-level abstract cloud contains every coarse
+# point twice (same xyz, different features, model/model.py:202-228), so such ties are
+# systematic there.  False (default): restate the reference literally (what the golden
+# vectors pin).  True: the product's documented rule -- lowest index first.
+STABLE_TIES = False
+
+
+class stable_ties:
+    """with stable_ties(): ... -> neighbour lists use the lowest-index-first rule."""
+
+    def __enter__(self):
+        global STABLE_TIES
+        self._old, STABLE_TIES = STABLE_TIES, True
+
+    def __exit__(self, *exc):
+        global STABLE_TIES
+        STABLE_TIES = self._old
+
 
 # ----------------------------------------------------------------------------
 # small helpers
@@ -41,7 +62,7 @@ def knn_indices(query, dataset, k, chunk=1024):
     for lo in range(0, query.shape[1], chunk):
         q = query[:, lo:lo + chunk]
         d = torch.sum((q[:, :, None] - dataset[:, None]) ** 2, dim=-1)
-        out.append(d.argsort()[:, :, :k])
+        out.append(d.argsort(stable=True)[:, :, :k] if STABLE_TIES else d.argsort()[:, :, :k])
     return torch.cat(out, dim=1)
 
 
@@ -176,10 +197,33 @@ def knn_with_dists(pcl_query, pcl_key, k, chunk=8192):
         q = pcl_query[lo:lo + chunk]
         diffs = q[None, :, :3] - pcl_key[:, None, :3]            # :479  (M,n,3)
         d = torch.linalg.norm(diffs, axis=-1, ord=2)             # :481
-        dk, ik = d.topk(k, dim=0, largest=False)                 # :484
+        if STABLE_TIES:
+            dk, ik = torch.sort(d, dim=0, stable=True)
+            dk, ik = dk[:k], ik[:k]
+        else:
+            dk, ik = d.topk(k, dim=0, largest=False)             # :484
         inds.append(ik.permute(1, 0))
         dists.append(dk.permute(1, 0))
     return torch.cat(inds), torch.cat(dists)
+
+
+def tie_ambiguous(points_query, points_abstract, k_interp, k_attn):
+    """(N,) bool: queries whose k-th and (k+1)-th nearest abstract points are equidistant for
+    the interpolation kNN (Euclidean norm, k_interp) or the attention kNN (squared sum,
+    k_attn) -- for these the reference's own result is implementation-defined."""
+    q, a = points_query[:, :3], points_abstract[:, :3]
+    amb = torch.zeros(q.shape[0], dtype=torch.bool)
+    for lo in range(0, q.shape[0], 4096):
+        qq = q[lo:lo + 4096]
+        dn = torch.linalg.norm(qq[None] - a[:, None], axis=-1, ord=2).T.sort(dim=1)[0]
+        ds = torch.sum((qq[:, None] - a[None]) ** 2, dim=-1).sort(dim=1)[0]
+        t = torch.zeros(qq.shape[0], dtype=torch.bool)
+        if a.shape[0] > k_interp:
+            t |= dn[:, k_interp - 1] == dn[:, k_interp]
+        if a.shape[0] > k_attn:
+            t |= ds[:, k_attn - 1] == ds[:, k_attn]
+        amb[lo:lo + 4096] = t
+    return amb
 
 
 def _act(name, x):

@@ -1,0 +1,251 @@
+"""GPU parity: the HIP path (through the C ABI) against (a) the golden vectors the real
+reference produced and (b) the CPU oracle on the same seeded inputs.  Bit-exact for
+indices and kNN distances; 1e-4 absolute for floating-point outputs (BASELINE.json
+north_star tolerance) -- most checks are far tighter."""
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+T = gc.as_tensor
+
+
+@pytest.fixture(scope='module')
+def pk():
+    import occlusions4d_amd
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    occlusions4d_amd._lib.lib()   # fail loudly if the native library is missing
+    return occlusions4d_amd
+
+
+def dev(a):
+    return T(a).cuda()
+
+
+def close(a, b, tol=TOL):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b).max() if a.size else 0.0
+    assert err <= tol, 'max abs err %.3g > %.3g' % (err, tol)
+
+
+# ------------------------------------------------------------------ kNN (E4, K1/K6/K8)
+@pytest.mark.parametrize('case', gc.KNN_CASES, ids=lambda c: c['name'])
+def test_knn_matches_reference_indices(pk, case):
+    q, d = gc.knn_inputs(case)
+    idx = pk.point_transformer_layer.kNN_torch(dev(q)[None], dev(d)[None], case['k'])[0]
+    assert idx.dtype == torch.int64
+    assert np.array_equal(idx.cpu().numpy(), load_golden('g1_knn_' + case['name'])['idx'])
+
+
+def test_knn_strided_xyz_and_large(pk):
+    from oracle import path as op
+    rng = np.random.default_rng(5)
+    pcl = rng.uniform(-5, 5, size=(3000, 8)).astype(np.float32)
+    idx = pk.point_transformer_layer.kNN_torch(dev(pcl)[None, :, :3], dev(pcl)[None, :, :3], 16)[0].cpu()
+    ref = op.knn_indices(T(pcl)[None, :, :3], T(pcl)[None, :, :3], 16)[0]
+    assert torch.equal(idx, ref)
+    assert torch.equal(idx[:, 0], torch.arange(3000))      # a point is its own nearest neighbour
+
+
+def test_knn_rejects_bad_k(pk):
+    x = torch.zeros(1, 4, 3).cuda()
+    with pytest.raises(AssertionError):
+        pk.point_transformer_layer.kNN_torch(x, x, 17)
+    with pytest.raises(AssertionError):
+        pk.point_transformer_layer.kNN_torch(x, x, 5)       # n_data < k
+
+
+@pytest.mark.parametrize('case', gc.MYKNN_CASES, ids=lambda c: c['name'])
+def test_my_knn_torch_bit_exact(pk, case):
+    q, key = gc.myknn_inputs(case)
+    inds, knn, dists = pk.geometry.my_knn_torch(dev(q), dev(key), case['k'], return_inds=True, return_knn=True,
+                                                return_dists=True)
+    g = load_golden('g6_myknn_' + case['name'])
+    assert np.array_equal(inds.cpu().numpy(), g['inds'])
+    assert np.array_equal(dists.cpu().numpy(), g['dists'])          # sqrt(fma chain), bit for bit
+    assert np.array_equal(knn.cpu().numpy(), key[g['inds']])
+
+
+# ------------------------------------------------------------------ FPS (E7, K5)
+@pytest.mark.parametrize('n', [1, 2, 63, 76, 531, 1024, 1593, 2048, 4779, 14336])
+def test_fps_matches_restated_torch_cluster(pk, n):
+    from oracle import cluster
+    rng = np.random.default_rng(100 + n)
+    p = rng.uniform(-5, 5, size=(n, 3)).astype(np.float32)
+    m = int(np.ceil(n / 3))
+    got, order = pk.ops.fps(dev(p), m, return_order=True)
+    ref_order = cluster.fps(T(p), None, ratio=1.0 / 3, random_start=False)
+    assert ref_order.numel() == m
+    assert np.array_equal(order.cpu().numpy(), ref_order.numpy().astype(np.int32))
+    assert np.array_equal(got.cpu().numpy(), np.sort(ref_order.numpy()).astype(np.int32))
+
+
+# ------------------------------------------------------------------ Linear (K3/K11)
+@pytest.mark.parametrize('shape', [(1, 8, 36), (37, 36, 36), (300, 68, 416), (129, 416, 416), (515, 832, 416),
+                                   (64, 32, 832), (200, 416, 5), (200, 416, 18), (100, 288, 128), (77, 144, 288),
+                                   (50, 72, 144)])
+def test_linear_against_torch_fp32(pk, shape):
+    M, K, N = shape
+    rng = np.random.default_rng(M * 1000 + K + N)
+    x = rng.normal(size=(M, K)).astype(np.float32)
+    w = (rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.normal(size=(N,)).astype(np.float32)
+    r = rng.normal(size=(M, N)).astype(np.float32)
+    ref = torch.nn.functional.linear(torch.relu(T(x)).double(), T(w).double(), T(b).double())
+    ref = torch.relu(ref) + T(r).double()
+    got = pk.ops.linear(dev(x), dev(w), dev(b), relu_in=True, relu_out=True, residual=dev(r))
+    close(got, ref.float(), 2e-5)
+    # asymmetric check without epilogue (catches row/col transposition)
+    close(pk.ops.linear(dev(x), dev(w)), (T(x).double() @ T(w).double().T).float(), 2e-5)
+
+
+def test_linear_gather_epilogue(pk):
+    rng = np.random.default_rng(7)
+    M, K, N, k = 280, 32, 832, 14
+    x = rng.normal(size=(M, K)).astype(np.float32)
+    w = rng.normal(size=(N, K)).astype(np.float32)
+    add = rng.normal(size=(M // k, N)).astype(np.float32)
+    sub = rng.normal(size=(50, N)).astype(np.float32)
+    si = rng.integers(0, 50, size=M).astype(np.int32)
+    ref = T(x).double() @ T(w).double().T + T(add).double().repeat_interleave(k, 0) - T(sub).double()[si.astype(np.int64)]
+    got = pk.ops.linear(dev(x), dev(w), add_rows=dev(add), add_div=k, sub_rows=dev(sub), sub_idx=dev(si))
+    close(got, ref.float(), 2e-5)
+
+
+# ------------------------------------------------------------------ PT layer / block (E2/E3)
+@pytest.mark.parametrize('case', gc.PTL_CASES, ids=lambda c: c['name'])
+def test_pt_layer(pk, case):
+    x, pos, x2, pos2, sd = gc.ptl_inputs(case)
+    layer = pk.point_transformer_layer.PointTransformerLayer(case['dim'], num_neighbors=case['k'],
+                                                             dim2=case.get('dim2')).cuda()
+    layer.load_state_dict(sd)
+    args = (dev(x)[None], dev(pos)[None]) + ((dev(x2)[None], dev(pos2)[None]) if x2 is not None else ())
+    with torch.no_grad():
+        close(layer(*args)[0], load_golden('g2_ptl_' + case['name'])['agg'])
+
+
+@pytest.mark.parametrize('case', gc.PTB_CASES, ids=lambda c: c['name'])
+def test_pt_block(pk, case):
+    x, pos, x2, pos2, sd = gc.ptb_inputs(case)
+    blk = pk.modules.PointTransformerBlock(case['dim'], case['dim'], case['dim'], num_neighbors=case['k'],
+                                           d_hidden_abstract=case.get('dim2')).cuda()
+    blk.load_state_dict(sd)
+    args = (dev(x)[None], dev(pos)[None]) + ((dev(x2)[None], dev(pos2)[None]) if x2 is not None else ())
+    with torch.no_grad():
+        z, p = blk(*args)
+    close(z[0], load_golden('g3_ptb_' + case['name'])['z'])
+
+
+@pytest.mark.parametrize('case', gc.DOWN_CASES, ids=lambda c: c['name'])
+def test_down_transition(pk, case):
+    x, pos, sd = gc.down_inputs(case)
+    dt = pk.modules.DownTransition(case['d_in'], case['d_out'], factor=3, knn_k=case['k'], norm_type=case['norm'],
+                                   fps_random_start=False).cuda()
+    dt.load_state_dict(sd)
+    with torch.no_grad():
+        z, p_sub = dt(dev(x)[None], dev(pos)[None])
+    g = load_golden('g4_down_' + case['name'])
+    assert np.array_equal(p_sub[0].cpu().numpy(), g['p_sub'])
+    close(z[0], g['z'])
+
+
+# ------------------------------------------------------------------ encoder (E1)
+@pytest.mark.parametrize('case', gc.ENC_CASES, ids=lambda c: c['name'])
+def test_encoder(pk, case):
+    pcl, pa, sd = gc.enc_inputs(case)
+    net = pk.model.PointCompletionNetV3(**pa).cuda().eval()
+    net.load_state_dict(sd)
+    with torch.no_grad():
+        out, xg, lc = net(pcl.cuda(), False)
+    g = load_golden('g5_enc_' + case['name'])
+    assert lc is None
+    assert np.array_equal(out[0, :, :3].cpu().numpy(), g['pcl_out'][:, :3])     # FPS subset, bit exact
+    close(out[0], g['pcl_out'])
+    close(xg[0], g['x_global'])
+
+
+# ------------------------------------------------------------------ decoder (D1-D7)
+def test_posenc(pk):
+    g = load_golden('g7_posenc')
+    enc = pk.implicit.positional_encode(dev(g['points']), 0.1, 8)
+    assert enc.shape == (512, 68)
+    close(enc, g['enc'], 2e-6)
+    assert np.array_equal(enc[:, :4].cpu().numpy(), g['points'])
+
+
+@pytest.mark.parametrize('case', gc.DEC_CASES, ids=lambda c: c['name'])
+def test_decoder(pk, case):
+    q, abstract, fglob, ia, sd = gc.dec_inputs(case)
+    net = pk.implicit.LocalPclResnetFC(**ia).cuda().eval()
+    net.load_state_dict(sd)
+    with torch.no_grad():
+        out, pen = net(dev(q), dev(abstract), dev(fglob), None)
+        out_b, pen_b = net(dev(q)[None], dev(abstract)[None], dev(fglob)[None], None)   # batched form
+    g = load_golden('g8_dec_' + case['name'])
+    close(out, g['output'])
+    close(pen[:, ::8], g['penult'])
+    assert out_b.shape == (1,) + tuple(out.shape) and torch.equal(out_b[0], out)
+
+
+def test_decoder_batch_split_invariance(pk):
+    """A query's result must not depend on which mini-batch it travels in."""
+    case = gc.DEC_CASES[1]
+    q, abstract, fglob, ia, sd = gc.dec_inputs(case)
+    net = pk.implicit.LocalPclResnetFC(**ia).cuda().eval()
+    net.load_state_dict(sd)
+    a, g = dev(abstract), dev(fglob)
+    with torch.no_grad():
+        full, _ = net(dev(q), a, g, None)
+        parts = torch.cat([net(dev(q[lo:lo + 100]), a, g, None)[0] for lo in range(0, q.shape[0], 100)])
+    assert torch.equal(full, parts)
+
+
+# ------------------------------------------------------------------ perform_inference (D8)
+@pytest.mark.parametrize('case', gc.INFER_CASES, ids=lambda c: c['name'])
+def test_perform_inference(pk, case):
+    pcl, pa, ia, inf, esd, dsd = gc.infer_inputs(case)
+    enc = pk.model.PointCompletionNetV3(**pa).cuda().eval()
+    enc.load_state_dict(esd)
+    dec = pk.implicit.LocalPclResnetFC(**ia).cuda().eval()
+    dec.load_state_dict(dsd)
+    res = pk.inference.perform_inference(
+        pcl.clone(), None, None, [enc, dec], torch.device('cuda:0'), 'if', inf['min_z'], inf['cube_bounds'],
+        inf['color_mode'], case['time_idx'], None, sample_implicit=True, num_sample=case['num_sample'],
+        point_sample_mode='grid', batch_size=case['batch_size'],
+        predict_segmentation=inf['predict_segmentation'], track_mode='none', semantic_classes=13,
+        density_threshold=0.5, data_kind=inf['data_kind'], cube_mode=4, compress_air=True)
+    g = load_golden('g10_infer_' + case['name'])
+    close(res['pcl_abstract'], g['pcl_abstract'])
+    close(res['features_global'], g['features_global'])
+    # Queries whose k-th / (k+1)-th abstract neighbours are equidistant (systematic for CARLA's
+    # two-level abstract cloud) are implementation-defined in the reference (unstable sort);
+    # everywhere else the reference's output is matched, and on ALL rows the product's
+    # documented rule (lowest index first) is matched against the oracle run with that rule.
+    from oracle import path as op
+    amb = op.tie_ambiguous(T(res['points_query']), T(g['pcl_abstract']), ia['num_local_features'],
+                           ia['cross_attn_neighbors']).numpy()
+    if inf['data_kind'] == 'greater':
+        assert not amb.any()
+    assert (~amb).sum() > 0.5 * amb.size
+    close(res['implicit_output'][~amb], g['implicit_output'][~amb])
+    with op.stable_ties():
+        ref = op.perform_inference(
+            pcl.clone(), esd, pa, dsd, ia, inf['min_z'], inf['cube_bounds'], inf['color_mode'],
+            case['time_idx'], num_sample=case['num_sample'], point_sample_mode='grid',
+            batch_size=case['batch_size'], predict_segmentation=inf['predict_segmentation'],
+            track_mode='none', semantic_classes=13, density_threshold=0.5, data_kind=inf['data_kind'],
+            cube_mode=4, compress_air=True)
+    close(res['implicit_output'], ref['implicit_output'])
+    dens = ref['implicit_output'][:, 0]
+    slack = int((np.abs(dens - 0.5) < TOL).sum())
+    assert abs(res['output_solid'].shape[0] - ref['output_solid'].shape[0]) <= slack
+    assert res['output_solid'].shape[0] + res['output_air'].shape[0] == dens.shape[0]
+    assert res['output_air'].shape[1] == g['air_head'].shape[1]
+    assert all(v.dtype == np.float32 for k, v in res.items() if k not in ('output_air',))
