@@ -55,8 +55,10 @@ def cpu_baseline(kind, pcl, esd, pa, dsd, ia, queries_np, n_queries_total):
     """Oracle timed on the host: 1 encode + one 4096-query decode batch, extrapolated linearly in
     N_q (decode is exactly linear in the number of queries)."""
     from oracle import path as op
-    torch.set_num_threads(os.cpu_count() or 1)
-    sample = 4096
+    # many-core hosts thrash on the oracle's small ops (measured: 256 threads -> 100x slower
+    # than 16); the baseline uses at most 16 threads and says so in `cores`
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 16)))
+    sample = 2048
     t0 = time.time()
     with torch.no_grad():
         ab, fg = op.encoder_forward(esd, pa, pcl)

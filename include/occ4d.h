@@ -115,6 +115,22 @@ int occ4d_pt_softmax_agg_f32(const float* logits, const float* v, int64_t ldv, c
                              const int32_t* idx, int n, int k, int d, float divisor,
                              float* agg, int64_t ld_agg, void* stream);
 
+/* Fused vector attention for d in {288, 416} (model/point_transformer_layer.py:168-179 in one
+ * kernel; the (n*k, 2d) hidden, (n*k, d) logits and (n*k, d) positional encodings never
+ * reach HBM).  With r_p = relu(P1 (qpos_i - apos_j) + c1), j = idx[i,s], p = (i,s):
+ *   h_p      = relu(aq[i,:] - kt[j,:] + wp @ r_p)                (2d)   [aq, kt: see DESIGN.md
+ *   logit_p  = w2 @ h_p + b2                                     (d)     refactoring (i)]
+ *   agg[i,c] = sum_s softmax_s(logit_p[c] / divisor) * (vt[j,c] + (p2 @ r_p + c2)[c])
+ * aq (n,2d), kt (m,2d), vt (m,d), wp (2d,32), w2 (d,2d), p2 (d,32), P1 (32,3); k <= 16.
+ * aq, kt, w2, wp, p2 16-byte aligned, ld_aq % 4 == 0, ld_kt % 4 == 0. */
+int occ4d_pt_cross_attn_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t qs,
+                            const float* apos, int64_t as, const int32_t* idx,
+                            const float* kt, int64_t ld_kt, const float* vt, int64_t ld_vt,
+                            const float* P1, const float* c1, const float* wp,
+                            const float* w2, const float* b2, const float* p2, const float* c2,
+                            float* agg, int64_t ld_agg, int n, int m, int k, int d,
+                            float divisor, void* stream);
+
 /* ------------------------------------------------------------------------
  * E6 pieces (model/modules.py:152-158), K7 / K12.
  * layernorm: y = LayerNorm(x) * gamma + beta (biased variance, eps as given; torch

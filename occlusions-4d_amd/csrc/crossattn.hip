@@ -1,0 +1,247 @@
+// Fused vector attention over K <= 16 neighbours (E3 of SURVEY.md §8(a); K2-K4 of §2.1):
+// for a tile of queries, everything between the per-point projections and the aggregated
+// output stays on chip -- the (N*K, 2D) hidden activations, the (N*K, D) logits and the
+// (N*K, D) positional encodings of the reference (1.5 GB + 0.76 GB + 0.76 GB per 32768
+// queries at D = 416) are never written to HBM.
+//
+// Work decomposition (wave64, one wave per SIMD, 4 waves per workgroup):
+//   wave  = 32 "pair rows" = 2 queries x 16 neighbour slots (slots >= K are masked),
+//           ALL D = 32*NT output channels -> 16*NT fp32 accumulators per lane.
+//   block = 8 queries; the weight stream (W2: D x 2D, Wp: 2D x 32) is shared by the 4
+//           waves through LDS, one 32-wide hidden block at a time, double buffered,
+//           one barrier per block.
+// Chained MFMAs, no data movement between the two GEMMs of attn_mlp:
+//   GEMM1 (transposed form)  Hpre^T[hid][pair] = Wp[hid][:] . r[pair][:]   (K = 32)
+//          accumulator initialised with Aq[query][hid] - Kt[neighbour][hid];
+//          its C/D registers (lane: column = pair, 16 hidden rows) ARE the A operand of
+//   GEMM2  logits[pair][ch] += relu(Hpre)[pair][hid] * W2[ch][hid]         (K = 2D)
+//          because the k order of a dot product is free: MFMA step s of a hidden block
+//          consumes hid = (s&3) + 8*(s>>2) + 4*(lane>>5), and the W2 fragment is read
+//          from LDS with the same map.
+//   GEMM3  pe[pair][ch] = r[pair][:] . P2[ch][:]  reuses the r registers as A operand.
+// Per-channel softmax over the 16 slots: 8 live in a lane's registers, the other 8 in
+// lane ^ 32 -> one cross-half exchange per reduction.
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HB = 32;        // hidden block (k-tile of GEMM2)
+constexpr int LDW = 36;       // padded LDS row (floats): stride 9 x 16 B -> conflict-free ds_read_b128
+constexpr int QPB = 8;        // queries per block (4 waves x 2)
+
+struct CrossAttnArgs {
+  const float* aq; int64_t ld_aq;
+  const float* qpos; int64_t qs;
+  const float* apos; int64_t as;
+  const int32_t* idx;
+  const float* kt; int64_t ld_kt;
+  const float* vt; int64_t ld_vt;
+  const float* P1; const float* c1;
+  const float* wp;
+  const float* w2; const float* b2;
+  const float* p2; const float* c2;
+  float* agg; int64_t ld_agg;
+  int N, M, K;
+  float divisor;
+};
+
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void cross_attn_kernel(const CrossAttnArgs a) {
+  constexpr int D = 32 * NT;
+  constexpr int H2 = 2 * D;
+  constexpr int NHB = H2 / HB;
+  constexpr int W2_LOADS = (D * 8) / 256;          // float4 per thread per hidden block (NT)
+  constexpr int BUF = (D + HB) * LDW;              // floats per LDS buffer: W2 block + Wp block
+  __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+  __shared__ int s_idx[QPB * 16];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, prow = lane & 31;
+  const int q0 = blockIdx.x * QPB;
+
+  // ---- neighbour indices of the block's 8 queries -> LDS (invalid slots/queries repeat a valid one)
+  if (tid < QPB * 16) {
+    const int q = min(q0 + (tid >> 4), a.N - 1);
+    const int s = min(tid & 15, a.K - 1);
+    s_idx[tid] = a.idx[(int64_t)q * a.K + s];
+  }
+  // ---- this lane's pair: query, neighbour, r = relu(P1 d + c1) for its 16 k-slots
+  const int my_q = min(q0 + wave * 2 + (prow >> 4), a.N - 1);
+  const int my_slot = prow & 15;
+  const bool my_valid = my_slot < a.K;
+  const int my_j = a.idx[(int64_t)my_q * a.K + min(my_slot, a.K - 1)];
+  float r[16];
+  {
+    const float* qp = a.qpos + (int64_t)my_q * a.qs;
+    const float* ap = a.apos + (int64_t)my_j * a.as;
+    const float dx = qp[0] - ap[0], dy = qp[1] - ap[1], dz = qp[2] - ap[2];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int m = 8 * (s >> 2) + 4 * half + (s & 3);
+      const float* w = a.P1 + 3 * m;
+      const float v = fmaf(dz, w[2], fmaf(dy, w[1], dx * w[0])) + a.c1[m];
+      r[s] = my_valid ? fmaxf(v, 0.f) : 0.f;
+    }
+  }
+  const float* aq_row = a.aq + (int64_t)my_q * a.ld_aq + 4 * half;
+  const float* kt_row = a.kt + (int64_t)my_j * a.ld_kt + 4 * half;
+
+  f32x4 pw[W2_LOADS], pp;
+  auto gload = [&](int hb) {
+#pragma unroll
+    for (int i = 0; i < W2_LOADS; ++i) {
+      const int f = tid + 256 * i;
+      pw[i] = *reinterpret_cast<const f32x4*>(a.w2 + (int64_t)(f >> 3) * H2 + hb * HB + 4 * (f & 7));
+    }
+    pp = *reinterpret_cast<const f32x4*>(a.wp + (int64_t)(hb * HB + (tid >> 3)) * 32 + 4 * (tid & 7));
+  };
+  auto sstore = [&](int buf) {
+    float* W = smem + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < W2_LOADS; ++i) {
+      const int f = tid + 256 * i;
+      *reinterpret_cast<f32x4*>(W + (f >> 3) * LDW + 4 * (f & 7)) = pw[i];
+    }
+    *reinterpret_cast<f32x4*>(W + D * LDW + (tid >> 3) * LDW + 4 * (tid & 7)) = pp;
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int c = 0; c < NT; ++c)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  const int frag_off = prow * LDW + 4 * half;
+
+  for (int hb = 0; hb < NHB; ++hb) {
+    const int buf = hb & 1;
+    if (hb + 1 < NHB) gload(hb + 1);
+    const float* W = smem + buf * BUF;
+    // GEMM1 accumulator init: Aq[q][hid] - Kt[j][hid], hid = 32 hb + 8 g + 4 half + i  (reg = 4 g + i)
+    f32x16 hacc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(aq_row + hb * HB + 8 * g);
+      const f32x4 kv = *reinterpret_cast<const f32x4*>(kt_row + hb * HB + 8 * g);
+      hacc[4 * g + 0] = av.x - kv.x; hacc[4 * g + 1] = av.y - kv.y;
+      hacc[4 * g + 2] = av.z - kv.z; hacc[4 * g + 3] = av.w - kv.w;
+    }
+    const float* Wp = W + D * LDW + frag_off;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(Wp + 8 * g);
+      hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, r[4 * g + 0], hacc, 0, 0, 0);
+      hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, r[4 * g + 1], hacc, 0, 0, 0);
+      hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, r[4 * g + 2], hacc, 0, 0, 0);
+      hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, r[4 * g + 3], hacc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) hacc[i] = fmaxf(hacc[i], 0.f);
+    // GEMM2
+    const float* W2 = W + frag_off;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(W2 + c * 32 * LDW + 8 * g);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(hacc[4 * g + 0], bv.x, acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(hacc[4 * g + 1], bv.y, acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(hacc[4 * g + 2], bv.z, acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(hacc[4 * g + 3], bv.w, acc[c], 0, 0, 0);
+      }
+    }
+    if (hb + 1 < NHB) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: positional-encoding GEMM, per-channel softmax over the slots, weighted sum
+  // C/D rows of this lane: row(reg) = (reg&3) + 8*(reg>>2) + 4*half ; regs 0-7 -> query A, 8-15 -> query B
+  int jrow[16];
+  bool vrow[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
+    jrow[i] = s_idx[wave * 32 + row];
+    vrow[i] = (row & 15) < a.K;
+  }
+  const int qa = q0 + wave * 2, qb = qa + 1;
+#pragma unroll
+  for (int c = 0; c < NT; ++c) {
+    const int ch = 32 * c + prow;
+    f32x16 pe;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) pe[i] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 pv = *reinterpret_cast<const f32x4*>(a.p2 + (int64_t)ch * 32 + 8 * g + 4 * half);
+      pe = __builtin_amdgcn_mfma_f32_32x32x2f32(r[4 * g + 0], pv.x, pe, 0, 0, 0);
+      pe = __builtin_amdgcn_mfma_f32_32x32x2f32(r[4 * g + 1], pv.y, pe, 0, 0, 0);
+      pe = __builtin_amdgcn_mfma_f32_32x32x2f32(r[4 * g + 2], pv.z, pe, 0, 0, 0);
+      pe = __builtin_amdgcn_mfma_f32_32x32x2f32(r[4 * g + 3], pv.w, pe, 0, 0, 0);
+    }
+    const float b2c = a.b2[ch], c2c = a.c2[ch];
+    float out2[2];
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+      float lg[8];
+      float mx = -__builtin_inff();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int reg = 8 * qq + i;
+        lg[i] = vrow[reg] ? (acc[c][reg] + b2c) / a.divisor : -__builtin_inff();
+        mx = fmaxf(mx, lg[i]);
+      }
+      mx = fmaxf(mx, xhalf(mx));
+      float den = 0.f, num = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int reg = 8 * qq + i;
+        const float e = vrow[reg] ? expf(lg[i] - mx) : 0.f;
+        const float val = (pe[reg] + c2c) + a.vt[(int64_t)jrow[reg] * a.ld_vt + ch];
+        den += e;
+        num += e * val;
+      }
+      den += xhalf(den);
+      num += xhalf(num);
+      out2[qq] = num / den;
+    }
+    // half 0 stores query A, half 1 stores query B (128 B coalesced each)
+    const int qs = half ? qb : qa;
+    if (qs < a.N) a.agg[(int64_t)qs * a.ld_agg + ch] = half ? out2[1] : out2[0];
+  }
+}
+
+}  // namespace
+
+extern "C" int occ4d_pt_cross_attn_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t qs,
+                                       const float* apos, int64_t as, const int32_t* idx, const float* kt,
+                                       int64_t ld_kt, const float* vt, int64_t ld_vt, const float* P1,
+                                       const float* c1, const float* wp, const float* w2, const float* b2,
+                                       const float* p2, const float* c2, float* agg, int64_t ld_agg, int n, int m,
+                                       int k, int d, float divisor, void* stream) {
+  OCC4D_REQUIRE(aq && qpos && apos && idx && kt && vt && P1 && c1 && wp && w2 && b2 && p2 && c2 && agg,
+                "occ4d_pt_cross_attn_f32: null pointer");
+  OCC4D_REQUIRE(d == 416 || d == 288, "occ4d_pt_cross_attn_f32: fused kernel is built for d in {288, 416}, got %d", d);
+  OCC4D_REQUIRE(k >= 1 && k <= 16 && m >= 1 && n >= 0, "occ4d_pt_cross_attn_f32: bad n/m/k");
+  OCC4D_REQUIRE(ld_aq >= 2 * d && ld_kt >= 2 * d && ld_vt >= d && ld_agg >= d && qs >= 3 && as >= 3,
+                "occ4d_pt_cross_attn_f32: leading dimension too small");
+  OCC4D_REQUIRE(ld_aq % 4 == 0 && ld_kt % 4 == 0 && ((uintptr_t)aq % 16) == 0 && ((uintptr_t)kt % 16) == 0 &&
+                    ((uintptr_t)w2 % 16) == 0 && ((uintptr_t)wp % 16) == 0 && ((uintptr_t)p2 % 16) == 0,
+                "occ4d_pt_cross_attn_f32: aq/kt/w2/wp/p2 must be 16-byte aligned with ld %% 4 == 0");
+  OCC4D_REQUIRE(divisor > 0.f, "occ4d_pt_cross_attn_f32: divisor must be > 0");
+  if (n == 0) return OCC4D_OK;
+  CrossAttnArgs a{aq, ld_aq, qpos, qs, apos, as, idx, kt, ld_kt, vt, ld_vt, P1, c1, wp, w2, b2, p2, c2,
+                  agg, ld_agg, n, m, k, divisor};
+  dim3 grid(occ4d::cdiv(n, QPB)), block(256);
+  if (d == 416) cross_attn_kernel<13><<<grid, block, 0, (hipStream_t)stream>>>(a);
+  else cross_attn_kernel<9><<<grid, block, 0, (hipStream_t)stream>>>(a);
+  return occ4d::check_launch("occ4d_pt_cross_attn_f32");
+}

@@ -190,6 +190,34 @@ def pt_softmax_agg(logits, v, pe, idx, out=None):
     return out
 
 
+FUSED_ATTN_DIMS = (288, 416)
+
+
+def pt_cross_attn(aq, qpos, apos, idx, kt, vt, P1, c1, wp, w2, b2, p2, c2, out=None):
+    """Fused vector attention (occ4d_pt_cross_attn_f32): agg (n,d)."""
+    aq, ld_aq = _aligned_rows(_dev(aq, name='aq'), 'aq')
+    kt, ld_kt = _aligned_rows(_dev(kt, name='kt'), 'kt')
+    vt, ld_vt = _rows(_dev(vt, name='vt'), 'vt')
+    qp, qs = _rows(_dev(qpos, name='qpos'), 'qpos')
+    ap, as_ = _rows(_dev(apos, name='apos'), 'apos')
+    idx = _dev(idx, torch.int32, 'idx')
+    n, k = idx.shape
+    d = vt.shape[1]
+    assert idx.is_contiguous() and aq.shape == (n, 2 * d) and kt.shape[1] == 2 * d and qp.shape[0] == n
+    ws = [_dev(t).contiguous() for t in (P1, c1, wp, w2, b2, p2, c2)]
+    assert ws[2].shape == (2 * d, 32) and ws[3].shape == (d, 2 * d) and ws[5].shape == (d, 32)
+    if out is None:
+        out = torch.empty((n, d), dtype=torch.float32, device=aq.device)
+    o, ldo = _rows(out, 'out')
+    assert o is out and o.shape == (n, d)
+    divisor = float(torch.tensor(math.sqrt(d), dtype=torch.float32))
+    _lib.check(_lib.lib().occ4d_pt_cross_attn_f32(
+        _ptr(aq), ld_aq, _ptr(qp), qs, _ptr(ap), as_, _ptr(idx), _ptr(kt), ld_kt, _ptr(vt), ld_vt,
+        _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(ws[3]), _ptr(ws[4]), _ptr(ws[5]), _ptr(ws[6]),
+        _ptr(o), ldo, n, kt.shape[0], k, d, divisor, _stream()))
+    return out
+
+
 def layernorm(x, gamma, beta, eps=1e-5, relu=False, out=None):
     x, ldx = _rows(_dev(x, name='x'), 'x')
     n, d = x.shape

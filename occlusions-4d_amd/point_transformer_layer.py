@@ -21,6 +21,7 @@ from torch import nn
 from . import ops
 
 _PAIR_CHUNK = 32768      # query rows per pass (bounds the (rows*K, 2D) workspace)
+USE_FUSED_ATTENTION = True   # tests flip this to cover the unfused kernel chain as well
 
 
 def _no_autograd(*tensors):
@@ -147,6 +148,10 @@ class PointTransformerLayer(nn.Module):
             hi = min(n, lo + _PAIR_CHUNK)
             idx = ops.knn(pos[lo:hi], pos2, K, metric=0)                        # (c,K) int32
             aq = aq_all[lo:hi] if aq_all is not None else ops.linear(x[lo:hi], m['wq'], m['bq'])
+            if self.dim in ops.FUSED_ATTN_DIMS and self.pos_mlp[0].out_features == 32 and USE_FUSED_ATTENTION:
+                ops.pt_cross_attn(aq, pos[lo:hi], pos2, idx, kt, vt, P1, c1, m['wp'], W2, b2, P2, c2,
+                                  out=agg[lo:hi])
+                continue
             r = ops.pt_pos_hidden(pos[lo:hi], pos2, idx, P1, c1)                # (c*K,32)
             h = ops.linear(r, m['wp'], relu_out=True, add_rows=aq, add_div=K,
                            sub_rows=kt, sub_idx=idx.view(-1))                   # (c*K,2D)

@@ -249,3 +249,26 @@ def test_perform_inference(pk, case):
     assert res['output_solid'].shape[0] + res['output_air'].shape[0] == dens.shape[0]
     assert res['output_air'].shape[1] == g['air_head'].shape[1]
     assert all(v.dtype == np.float32 for k, v in res.items() if k not in ('output_air',))
+
+
+# ------------------------------------------------------------------ fused vs unfused attention
+def test_fused_attention_matches_unfused_chain(pk):
+    case = gc.PTL_CASES[2]          # cross, d = 416, e = 288, k = 14
+    x, pos, x2, pos2, sd = gc.ptl_inputs(case)
+    rng = np.random.default_rng(9)
+    n = 1003                        # not a multiple of the 8-query block
+    x = rng.normal(size=(n, case['dim'])).astype(np.float32)
+    pos = rng.uniform(-5, 5, size=(n, 3)).astype(np.float32)
+    layer = pk.point_transformer_layer.PointTransformerLayer(case['dim'], num_neighbors=case['k'],
+                                                             dim2=case['dim2']).cuda()
+    layer.load_state_dict(sd)
+    args = (dev(x)[None], dev(pos)[None], dev(x2)[None], dev(pos2)[None])
+    ptl = pk.point_transformer_layer
+    with torch.no_grad():
+        fused = layer(*args)[0]
+        ptl.USE_FUSED_ATTENTION = False
+        try:
+            chain = layer(*args)[0]
+        finally:
+            ptl.USE_FUSED_ATTENTION = True
+    close(fused, chain, 2e-5)
