@@ -116,23 +116,39 @@ __global__ __launch_bounds__(256, 1) void cross_attn_kernel(const CrossAttnArgs 
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
 
+  // Software pipeline, pinned with sched_barrier so hipcc cannot sink the prefetches next to
+  // their use (it did: both global latencies were exposed once per hidden block):
+  //   top of block hb : issue weight loads (W2/Wp block hb+1) and the Aq/Kt slices of hb+1
+  //   body            : GEMM1 -> relu -> GEMM2 on LDS buffer hb&1
+  //   bottom          : registers -> LDS buffer (hb+1)&1, one barrier
+  f32x4 av[4], kv[4], nav[4], nkv[4];
+  auto iload = [&](int hb, f32x4* A, f32x4* Kk) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      A[g] = *reinterpret_cast<const f32x4*>(aq_row + hb * HB + 8 * g);
+      Kk[g] = *reinterpret_cast<const f32x4*>(kt_row + hb * HB + 8 * g);
+    }
+  };
   gload(0);
+  iload(0, av, kv);
   sstore(0);
   __syncthreads();
   const int frag_off = prow * LDW + 4 * half;
 
   for (int hb = 0; hb < NHB; ++hb) {
     const int buf = hb & 1;
-    if (hb + 1 < NHB) gload(hb + 1);
+    if (hb + 1 < NHB) {
+      gload(hb + 1);
+      iload(hb + 1, nav, nkv);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     const float* W = smem + buf * BUF;
     // GEMM1 accumulator init: Aq[q][hid] - Kt[j][hid], hid = 32 hb + 8 g + 4 half + i  (reg = 4 g + i)
     f32x16 hacc;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 av = *reinterpret_cast<const f32x4*>(aq_row + hb * HB + 8 * g);
-      const f32x4 kv = *reinterpret_cast<const f32x4*>(kt_row + hb * HB + 8 * g);
-      hacc[4 * g + 0] = av.x - kv.x; hacc[4 * g + 1] = av.y - kv.y;
-      hacc[4 * g + 2] = av.z - kv.z; hacc[4 * g + 3] = av.w - kv.w;
+      hacc[4 * g + 0] = av[g].x - kv[g].x; hacc[4 * g + 1] = av[g].y - kv[g].y;
+      hacc[4 * g + 2] = av[g].z - kv[g].z; hacc[4 * g + 3] = av[g].w - kv[g].w;
     }
     const float* Wp = W + D * LDW + frag_off;
 #pragma unroll
@@ -158,7 +174,12 @@ __global__ __launch_bounds__(256, 1) void cross_attn_kernel(const CrossAttnArgs 
         acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(hacc[4 * g + 3], bv.w, acc[c], 0, 0, 0);
       }
     }
-    if (hb + 1 < NHB) sstore(buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (hb + 1 < NHB) {
+      sstore(buf ^ 1);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { av[g] = nav[g]; kv[g] = nkv[g]; }
+    }
     __syncthreads();
   }
 
@@ -173,19 +194,33 @@ __global__ __launch_bounds__(256, 1) void cross_attn_kernel(const CrossAttnArgs 
     vrow[i] = (row & 15) < a.K;
   }
   const int qa = q0 + wave * 2, qb = qa + 1;
+  // P2 fragments and gathered V rows are fetched one channel tile ahead (single wave per
+  // SIMD: nothing else hides their latency)
+  f32x4 pv[4], npv[4];
+  float vv[16], nvv[16];
+  auto eload = [&](int c, f32x4* P, float* V) {
+    const int ch = 32 * c + prow;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      P[g] = *reinterpret_cast<const f32x4*>(a.p2 + (int64_t)ch * 32 + 8 * g + 4 * half);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) V[i] = a.vt[(int64_t)jrow[i] * a.ld_vt + ch];
+  };
+  eload(0, pv, vv);
 #pragma unroll
   for (int c = 0; c < NT; ++c) {
     const int ch = 32 * c + prow;
+    if (c + 1 < NT) eload(c + 1, npv, nvv);
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 pe;
 #pragma unroll
     for (int i = 0; i < 16; ++i) pe[i] = 0.f;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 pv = *reinterpret_cast<const f32x4*>(a.p2 + (int64_t)ch * 32 + 8 * g + 4 * half);
-      pe = __builtin_amdgcn_mfma_f32_32x32x2f32(r[4 * g + 0], pv.x, pe, 0, 0, 0);
-      pe = __builtin_amdgcn_mfma_f32_32x32x2f32(r[4 * g + 1], pv.y, pe, 0, 0, 0);
-      pe = __builtin_amdgcn_mfma_f32_32x32x2f32(r[4 * g + 2], pv.z, pe, 0, 0, 0);
-      pe = __builtin_amdgcn_mfma_f32_32x32x2f32(r[4 * g + 3], pv.w, pe, 0, 0, 0);
+      pe = __builtin_amdgcn_mfma_f32_32x32x2f32(r[4 * g + 0], pv[g].x, pe, 0, 0, 0);
+      pe = __builtin_amdgcn_mfma_f32_32x32x2f32(r[4 * g + 1], pv[g].y, pe, 0, 0, 0);
+      pe = __builtin_amdgcn_mfma_f32_32x32x2f32(r[4 * g + 2], pv[g].z, pe, 0, 0, 0);
+      pe = __builtin_amdgcn_mfma_f32_32x32x2f32(r[4 * g + 3], pv[g].w, pe, 0, 0, 0);
     }
     const float b2c = a.b2[ch], c2c = a.c2[ch];
     float out2[2];
@@ -205,7 +240,7 @@ __global__ __launch_bounds__(256, 1) void cross_attn_kernel(const CrossAttnArgs 
       for (int i = 0; i < 8; ++i) {
         const int reg = 8 * qq + i;
         const float e = vrow[reg] ? expf(lg[i] - mx) : 0.f;
-        const float val = (pe[reg] + c2c) + a.vt[(int64_t)jrow[reg] * a.ld_vt + ch];
+        const float val = (pe[reg] + c2c) + vv[reg];
         den += e;
         num += e * val;
       }
@@ -216,6 +251,13 @@ __global__ __launch_bounds__(256, 1) void cross_attn_kernel(const CrossAttnArgs 
     // half 0 stores query A, half 1 stores query B (128 B coalesced each)
     const int qs = half ? qb : qa;
     if (qs < a.N) a.agg[(int64_t)qs * a.ld_agg + ch] = half ? out2[1] : out2[0];
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 1 < NT) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) pv[g] = npv[g];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) vv[i] = nvv[i];
+    }
   }
 }
 

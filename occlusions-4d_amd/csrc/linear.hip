@@ -24,7 +24,7 @@ constexpr int BM = 128;
 constexpr int BK = 16;
 constexpr int LDT = 20;  // padded LDS row (floats)
 
-template <int NT>
+template <int NT, bool VEC>
 __global__ __launch_bounds__(256, 1) void linear_kernel(const occ4d_linear_args a) {
   constexpr int BN = 32 * NT;
   constexpr int WLOADS = (NT * 128 + 255) / 256;  // float4 per thread for the w tile
@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256, 1) void linear_kernel(const occ4d_linear_args 
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) gload((kt + 1) * BK);
+    __builtin_amdgcn_sched_barrier(0);   // keep the prefetch at the top (hipcc sinks it next to sstore)
     const float* Ab = As0 + buf * BM * LDT + wave * 32 * LDT + frag_off;
     const float* Wb = Ws0 + buf * BN * LDT + frag_off;
 #pragma unroll
@@ -105,12 +106,72 @@ __global__ __launch_bounds__(256, 1) void linear_kernel(const occ4d_linear_args 
         acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[c], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (kt + 1 < nk) sstore(buf ^ 1);
     __syncthreads();
   }
 
   // epilogue: C/D map of 32x32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const int half = lane >> 5;
+  if (VEC) {
+    // Through LDS (free after the k-loop's last barrier) so that every global access is a
+    // 16-byte, row-contiguous one: per-lane 4-byte stores at a row stride were latency/issue
+    // bound (the K = 32 pair GEMM ran at 0.6 TB/s).  Each wave transposes its own 32 x (32*CT)
+    // chunk in a private LDS region: write conflict-free ds_write_b32, read ds_read_b128.
+    constexpr int REGION = (2 * (BM + BN) * LDT) / 4;                       // floats per wave
+    constexpr int CT_FIT = (REGION / 32 - 4) / 32;
+    constexpr int CT = CT_FIT < 1 ? 1 : (CT_FIT > NT ? NT : (CT_FIT > 4 ? 4 : CT_FIT));
+    constexpr int LDE = 32 * CT + 4;
+    static_assert(32 * LDE <= REGION, "epilogue staging does not fit the wave's LDS region");
+    float* E = smem + wave * REGION;
+    constexpr int F4_PER_ROW = 8 * CT;                  // float4 per staged row
+    constexpr int ROWS_PER_PASS = 64 / F4_PER_ROW > 0 ? 64 / F4_PER_ROW : 1;
+#pragma unroll
+    for (int c0 = 0; c0 < NT; c0 += CT) {
+#pragma unroll
+      for (int cc = 0; cc < CT; ++cc) {
+        if (c0 + cc < NT) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            E[((r & 3) + 8 * (r >> 2) + 4 * half) * LDE + 32 * cc + (lane & 31)] = acc[c0 + cc][r];
+        }
+      }
+      // (same wave wrote and reads: program order + lgkmcnt is enough, no barrier)
+      const int ncol4 = 8 * ((NT - c0) < CT ? (NT - c0) : CT);     // live float4 per row in this chunk
+      if (F4_PER_ROW <= 64) {
+        const int c4 = lane % F4_PER_ROW, rsub = lane / F4_PER_ROW;
+        for (int rp = 0; rp < 32; rp += ROWS_PER_PASS) {
+          const int rl = rp + rsub;
+          const int row = row0 + wave * 32 + rl;
+          const int col = col0 + 32 * c0 + 4 * c4;
+          if (rl < 32 && c4 < ncol4 && row < M && col < N) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(E + rl * LDE + 4 * c4);
+            if (a.bias) {
+              const f32x4 t = *reinterpret_cast<const f32x4*>(a.bias + col);
+              v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            if (a.add_rows) {
+              const f32x4 t = *reinterpret_cast<const f32x4*>(a.add_rows + (int64_t)(row / a.add_div) * a.ld_add + col);
+              v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            if (a.sub_rows) {
+              const f32x4 t = *reinterpret_cast<const f32x4*>(a.sub_rows + (int64_t)a.sub_idx[row] * a.ld_sub + col);
+              v.x -= t.x; v.y -= t.y; v.z -= t.z; v.w -= t.w;
+            }
+            if (a.relu_out) {
+              v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            if (a.residual) {
+              const f32x4 t = *reinterpret_cast<const f32x4*>(a.residual + (int64_t)row * a.ldr + col);
+              v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            *reinterpret_cast<f32x4*>(a.y + (int64_t)row * a.ldy + col) = v;
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -137,7 +198,13 @@ __global__ __launch_bounds__(256, 1) void linear_kernel(const occ4d_linear_args 
 template <int NT>
 int launch(const occ4d_linear_args& a, hipStream_t st) {
   dim3 grid(occ4d::cdiv(a.M, BM), occ4d::cdiv(a.N, 32 * NT)), block(256);
-  linear_kernel<NT><<<grid, block, 0, st>>>(a);
+  auto al16 = [](const void* p) { return ((uintptr_t)p % 16) == 0; };
+  const bool vec = a.N % 4 == 0 && a.ldy % 4 == 0 && al16(a.y) && (!a.bias || al16(a.bias)) &&
+                   (!a.residual || (al16(a.residual) && a.ldr % 4 == 0)) &&
+                   (!a.add_rows || (al16(a.add_rows) && a.ld_add % 4 == 0)) &&
+                   (!a.sub_rows || (al16(a.sub_rows) && a.ld_sub % 4 == 0));
+  if (vec) linear_kernel<NT, true><<<grid, block, 0, st>>>(a);
+  else linear_kernel<NT, false><<<grid, block, 0, st>>>(a);
   return occ4d::check_launch("occ4d_linear_f32");
 }
 

@@ -199,6 +199,33 @@ __global__ __launch_bounds__(TPB) void interp_add_kernel(float* __restrict__ x, 
   x[i * ldx + c] += s;
 }
 
+// float4 variant: one lane owns 4 consecutive channels -> 16-byte gathers from the L2-resident table
+__global__ __launch_bounds__(TPB) void interp_add4_kernel(float* __restrict__ x, int64_t ldx,
+                                                          const float* __restrict__ cvec,
+                                                          const float* __restrict__ table, int64_t ldt,
+                                                          const int32_t* __restrict__ idx, const float* __restrict__ w,
+                                                          int64_t total, int k, int d4) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (e >= total) return;
+  const int c = 4 * (int)(e % d4);
+  const int64_t i = e / d4;
+  f4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < k; ++j) {
+    const float wj = w[i * k + j];
+    const f4 t = *reinterpret_cast<const f4*>(table + (int64_t)idx[i * k + j] * ldt + c);
+    s.x += wj * t.x; s.y += wj * t.y; s.z += wj * t.z; s.w += wj * t.w;
+  }
+  if (cvec) {
+    const f4 cv = *reinterpret_cast<const f4*>(cvec + c);
+    s.x += cv.x; s.y += cv.y; s.z += cv.z; s.w += cv.w;
+  }
+  f4* xp = reinterpret_cast<f4*>(x + i * ldx + c);
+  f4 xv = *xp;
+  xv.x += s.x; xv.y += s.y; xv.z += s.z; xv.w += s.w;
+  *xp = xv;
+}
+
 struct SquashOps { int32_t op[32]; };
 
 __global__ __launch_bounds__(TPB) void squash_kernel(float* __restrict__ out, int64_t ld, int64_t total, int g,
@@ -318,7 +345,14 @@ int occ4d_interp_add_f32(float* x, int64_t ldx, const float* cvec, const float* 
   OCC4D_REQUIRE(n >= 0 && k >= 1 && d >= 1 && ldx >= d && ldt >= d, "occ4d_interp_add_f32: bad sizes");
   const int64_t total = (int64_t)n * d;
   if (!total) return OCC4D_OK;
-  interp_add_kernel<<<grid1d(total), TPB, 0, (hipStream_t)stream>>>(x, ldx, cvec, table, ldt, idx, w, total, k, d);
+  const bool vec = d % 4 == 0 && ldx % 4 == 0 && ldt % 4 == 0 && ((uintptr_t)x % 16) == 0 &&
+                   ((uintptr_t)table % 16) == 0 && (!cvec || ((uintptr_t)cvec % 16) == 0);
+  if (vec) {
+    const int64_t total4 = (int64_t)n * (d / 4);
+    interp_add4_kernel<<<grid1d(total4), TPB, 0, (hipStream_t)stream>>>(x, ldx, cvec, table, ldt, idx, w, total4, k, d / 4);
+  } else {
+    interp_add_kernel<<<grid1d(total), TPB, 0, (hipStream_t)stream>>>(x, ldx, cvec, table, ldt, idx, w, total, k, d);
+  }
   return occ4d::check_launch("occ4d_interp_add_f32");
 }
 
