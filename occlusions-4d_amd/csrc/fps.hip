@@ -31,10 +31,16 @@ __device__ __forceinline__ unsigned wave_reduce_u32(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// PPT (even) points per thread, held as PPT/2 float2 pairs so that the distance update maps to
+// packed fp32 VALU ops (v_pk_add_f32 / v_pk_mul_f32: two points per instruction).
 template <int PPT>
 __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restrict__ xyz, int64_t stride, int n,
                                                           int m, int32_t* __restrict__ out_sorted,
                                                           int32_t* __restrict__ out_order) {
+  static_assert(PPT % 2 == 0, "PPT must be even");
+  constexpr int PP = PPT / 2;
   __shared__ unsigned s_d[2][FPS_WAVES];
   __shared__ unsigned s_i[2][FPS_WAVES];
   __shared__ float s_p[2][FPS_WAVES][4];
@@ -42,18 +48,20 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
   __shared__ int s_scan[FPS_THREADS];
 
   const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
-  float px[PPT], py[PPT], pz[PPT], md[PPT];
+  const int wave = t >> 6;
+  f32x2 px[PP], py[PP], pz[PP], md[PP];
 #pragma unroll
-  for (int s = 0; s < PPT; ++s) {
-    const int i = t + FPS_THREADS * s;
-    if (i < n) {
-      const float* p = xyz + (int64_t)i * stride;
-      px[s] = p[0]; py[s] = p[1]; pz[s] = p[2];
-      md[s] = __builtin_inff();
-    } else {
-      px[s] = py[s] = pz[s] = 0.f;
-      md[s] = -1.f;  // never wins: every live running min is >= 0
+  for (int u = 0; u < PP; ++u) {
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int i = t + FPS_THREADS * (2 * u + v);
+      float x = 0.f, y = 0.f, z = 0.f, d0 = -1.f;   // d0 = -1: never wins (live running mins are >= 0)
+      if (i < n) {
+        const float* p = xyz + (int64_t)i * stride;
+        x = p[0]; y = p[1]; z = p[2];
+        d0 = __builtin_inff();
+      }
+      px[u][v] = x; py[u][v] = y; pz[u][v] = z; md[u][v] = d0;
     }
   }
   s_flags[t] = 0u;
@@ -68,15 +76,20 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
   for (int it = 1; it < m; ++it) {
     float bd = -1.f, bx = 0.f, by = 0.f, bz = 0.f;
     unsigned bi = 0xffffffffu;
+    const f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
 #pragma unroll
-    for (int s = 0; s < PPT; ++s) {
-      const float dx = px[s] - cx, dy = py[s] - cy, dz = pz[s] - cz;
-      const float d = (dx * dx + dy * dy) + dz * dz;
-      const float v = fminf(md[s], d);
-      md[s] = v;
-      if (v > bd) {  // strict: slots ascend in index, so the lowest index wins ties
-        bd = v; bi = (unsigned)(t + FPS_THREADS * s);
-        bx = px[s]; by = py[s]; bz = pz[s];
+    for (int u = 0; u < PP; ++u) {
+      const f32x2 dx = px[u] - c2x, dy = py[u] - c2y, dz = pz[u] - c2z;
+      const f32x2 d = (dx * dx + dy * dy) + dz * dz;          // -ffp-contract=off: no FMA
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const float old = md[u][v];
+        const float nv = d[v] < old ? d[v] : old;              // dead slots: old = -1 stays
+        md[u][v] = nv;
+        if (nv > bd) {  // strict: slots ascend in index, so the lowest index wins ties
+          bd = nv; bi = (unsigned)(t + FPS_THREADS * (2 * u + v));
+          bx = px[u][v]; by = py[u][v]; bz = pz[u][v];
+        }
       }
     }
     // bd >= 0 for live candidates, so its bit pattern orders like the float; dead lanes map to 0.
@@ -102,7 +115,6 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
       if (out_order) out_order[it] = (int)gi;
     }
     par ^= 1;
-    (void)lane;
   }
   __syncthreads();
 
@@ -137,12 +149,13 @@ extern "C" int occ4d_fps_f32(const float* xyz, int64_t stride, int n, int m, int
   OCC4D_REQUIRE(stride >= 3, "occ4d_fps_f32: stride=%lld < 3", (long long)stride);
   hipStream_t st = (hipStream_t)stream;
   const int ppt = occ4d::cdiv(n, FPS_THREADS);
-  if (ppt <= 1) fps_kernel<1><<<1, FPS_THREADS, 0, st>>>(xyz, stride, n, m, out_sorted, out_order);
-  else if (ppt <= 2) fps_kernel<2><<<1, FPS_THREADS, 0, st>>>(xyz, stride, n, m, out_sorted, out_order);
-  else if (ppt <= 5) fps_kernel<5><<<1, FPS_THREADS, 0, st>>>(xyz, stride, n, m, out_sorted, out_order);
-  else if (ppt <= 10) fps_kernel<10><<<1, FPS_THREADS, 0, st>>>(xyz, stride, n, m, out_sorted, out_order);
-  else if (ppt <= 14) fps_kernel<14><<<1, FPS_THREADS, 0, st>>>(xyz, stride, n, m, out_sorted, out_order);
-  else if (ppt <= 28) fps_kernel<28><<<1, FPS_THREADS, 0, st>>>(xyz, stride, n, m, out_sorted, out_order);
-  else fps_kernel<32><<<1, FPS_THREADS, 0, st>>>(xyz, stride, n, m, out_sorted, out_order);
+#define OCC4D_FPS(P) fps_kernel<P><<<1, FPS_THREADS, 0, st>>>(xyz, stride, n, m, out_sorted, out_order)
+  if (ppt <= 2) OCC4D_FPS(2);
+  else if (ppt <= 6) OCC4D_FPS(6);
+  else if (ppt <= 10) OCC4D_FPS(10);
+  else if (ppt <= 14) OCC4D_FPS(14);
+  else if (ppt <= 28) OCC4D_FPS(28);
+  else OCC4D_FPS(32);
+#undef OCC4D_FPS
   return occ4d::check_launch("occ4d_fps_f32");
 }

@@ -1,8 +1,11 @@
 // Streaming brute-force top-k kNN (K1/K6/K8 of SURVEY.md §2.1).
-// One thread per query; data points staged through LDS in tiles; the k best
-// (distance, index) pairs live sorted in registers.  Distance arithmetic is
-// pinned to the reference's CPU results (see occ4d.h); the translation unit is
-// built with -ffp-contract=off so that only explicit fmaf() fuses.
+// Data points are staged through LDS in tiles; each query's k best (distance, index)
+// pairs live sorted in registers.  TPQ threads cooperate on one query (each scans a
+// strided share of every tile, the TPQ sorted lists are merged through LDS at the end):
+// the encoder's self-kNN has only 14 336 queries, which would fill 56 of 256 CUs with
+// one thread per query.  Distance arithmetic is pinned to the reference's CPU results
+// (see occ4d.h); the translation unit is built with -ffp-contract=off so that only the
+// explicit fmaf() fuses.  Ties: (distance, index) lexicographic, lowest index first.
 #include "common.hpp"
 
 namespace {
@@ -20,22 +23,30 @@ __device__ __forceinline__ float point_dist(float qx, float qy, float qz, float 
   }
 }
 
-template <int K, int METRIC, typename IdxT>
+// KT = compile-time list length (8 or 16) >= runtime k: the first k of a sorted top-KT list
+// are exactly the top-k.
+template <int KT, int METRIC, typename IdxT, int TPQ>
 __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const float* __restrict__ query, int64_t qs, int nq,
-                                                        const float* __restrict__ data, int64_t ds, int nd,
+                                                        const float* __restrict__ data, int64_t ds, int nd, int k,
                                                         IdxT* __restrict__ out_idx, float* __restrict__ out_dist) {
+  constexpr int QPB = KNN_BLOCK / TPQ;   // queries per block
   __shared__ float sx[KNN_TILE], sy[KNN_TILE], sz[KNN_TILE];
-  const int qi = blockIdx.x * KNN_BLOCK + threadIdx.x;
+  // merge scratch (TPQ > 1): per thread KT (dist, idx) pairs; +1 pad against bank conflicts
+  __shared__ float m_d[TPQ > 1 ? KNN_BLOCK * (KT + 1) : 1];
+  __shared__ int m_i[TPQ > 1 ? KNN_BLOCK * (KT + 1) : 1];
+
+  const int ql = threadIdx.x / TPQ, sub = threadIdx.x % TPQ;
+  const int qi = blockIdx.x * QPB + ql;
   const bool live = qi < nq;
   float qx = 0.f, qy = 0.f, qz = 0.f;
   if (live) {
     const float* q = query + (int64_t)qi * qs;
     qx = q[0]; qy = q[1]; qz = q[2];
   }
-  float bd[K];
-  int bi[K];
+  float bd[KT];
+  int bi[KT];
 #pragma unroll
-  for (int s = 0; s < K; ++s) { bd[s] = __builtin_inff(); bi[s] = 0x7fffffff; }
+  for (int s = 0; s < KT; ++s) { bd[s] = __builtin_inff(); bi[s] = 0x7fffffff; }
 
   for (int base = 0; base < nd; base += KNN_TILE) {
     const int cnt = min(KNN_TILE, nd - base);
@@ -46,13 +57,13 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const float* __restrict_
     }
     __syncthreads();
     if (live) {
-      for (int t = 0; t < cnt; ++t) {
+      for (int t = sub; t < cnt; t += TPQ) {
         const float d = point_dist<METRIC>(qx, qy, qz, sx[t], sy[t], sz[t]);
-        if (d < bd[K - 1]) {  // strict: an equal distance keeps the earlier (lower) index
-          bd[K - 1] = d;
-          bi[K - 1] = base + t;
+        if (d < bd[KT - 1]) {  // strict: an equal distance keeps the earlier (lower) index
+          bd[KT - 1] = d;
+          bi[KT - 1] = base + t;
 #pragma unroll
-          for (int s = K - 1; s > 0; --s) {
+          for (int s = KT - 1; s > 0; --s) {
             if (bd[s] < bd[s - 1]) {
               float td = bd[s]; bd[s] = bd[s - 1]; bd[s - 1] = td;
               int ti = bi[s]; bi[s] = bi[s - 1]; bi[s - 1] = ti;
@@ -62,25 +73,74 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const float* __restrict_
       }
     }
   }
-  if (live) {
+
+  if (TPQ == 1) {
+    if (live) {
 #pragma unroll
-    for (int s = 0; s < K; ++s) {
-      out_idx[(int64_t)qi * K + s] = (IdxT)bi[s];
-      if (out_dist) out_dist[(int64_t)qi * K + s] = bd[s];
+      for (int s = 0; s < KT; ++s) {
+        if (s < k) {
+          out_idx[(int64_t)qi * k + s] = (IdxT)bi[s];
+          if (out_dist) out_dist[(int64_t)qi * k + s] = bd[s];
+        }
+      }
+    }
+    return;
+  }
+  // ---- merge the TPQ sorted lists of each query (lexicographic on (distance, index))
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < KT; ++s) {
+    m_d[threadIdx.x * (KT + 1) + s] = bd[s];
+    m_i[threadIdx.x * (KT + 1) + s] = bi[s];
+  }
+  __syncthreads();
+  if (live && sub == 0) {
+    int head[TPQ];
+#pragma unroll
+    for (int u = 0; u < TPQ; ++u) head[u] = 0;
+    const int t0 = ql * TPQ;
+    for (int s = 0; s < k; ++s) {
+      float best_d = __builtin_inff();
+      int best_i = 0x7fffffff, best_u = 0;
+#pragma unroll
+      for (int u = 0; u < TPQ; ++u) {
+        const int h = head[u];
+        const float d = h < KT ? m_d[(t0 + u) * (KT + 1) + h] : __builtin_inff();
+        const int i = h < KT ? m_i[(t0 + u) * (KT + 1) + h] : 0x7fffffff;
+        if (d < best_d || (d == best_d && i < best_i)) { best_d = d; best_i = i; best_u = u; }
+      }
+#pragma unroll
+      for (int u = 0; u < TPQ; ++u) head[u] += (u == best_u) ? 1 : 0;
+      out_idx[(int64_t)qi * k + s] = (IdxT)best_i;
+      if (out_dist) out_dist[(int64_t)qi * k + s] = best_d;
     }
   }
 }
 
-template <int K>
-int launch_k(const float* q, int64_t qs, int nq, const float* d, int64_t ds, int nd, int metric, void* oi,
+template <int KT, int METRIC, typename IdxT>
+void launch_t(int tpq, const float* q, int64_t qs, int nq, const float* d, int64_t ds, int nd, int k, IdxT* oi,
+              float* od, hipStream_t st) {
+  dim3 block(KNN_BLOCK);
+  if (tpq == 1) knn_kernel<KT, METRIC, IdxT, 1><<<occ4d::cdiv(nq, KNN_BLOCK), block, 0, st>>>(q, qs, nq, d, ds, nd, k, oi, od);
+  else if (tpq == 4) knn_kernel<KT, METRIC, IdxT, 4><<<occ4d::cdiv(nq, KNN_BLOCK / 4), block, 0, st>>>(q, qs, nq, d, ds, nd, k, oi, od);
+  else knn_kernel<KT, METRIC, IdxT, 16><<<occ4d::cdiv(nq, KNN_BLOCK / 16), block, 0, st>>>(q, qs, nq, d, ds, nd, k, oi, od);
+}
+
+template <int KT>
+int launch_k(const float* q, int64_t qs, int nq, const float* d, int64_t ds, int nd, int k, int metric, void* oi,
              int i64, float* od, hipStream_t st) {
-  dim3 grid(occ4d::cdiv(nq, KNN_BLOCK)), block(KNN_BLOCK);
+  // enough blocks to fill 256 CUs a few times over, but never split tiny data sets
+  int tpq = 1;
+  if (nd >= 256) {
+    if (nq < 256 * 256 / 4) tpq = 4;      // < 16384 queries: 64 per block
+    if (nq < 256 * 256 / 32) tpq = 16;    // < 2048 queries: 16 per block
+  }
   if (metric == 0) {
-    if (i64) knn_kernel<K, 0, int64_t><<<grid, block, 0, st>>>(q, qs, nq, d, ds, nd, (int64_t*)oi, od);
-    else knn_kernel<K, 0, int32_t><<<grid, block, 0, st>>>(q, qs, nq, d, ds, nd, (int32_t*)oi, od);
+    if (i64) launch_t<KT, 0, int64_t>(tpq, q, qs, nq, d, ds, nd, k, (int64_t*)oi, od, st);
+    else launch_t<KT, 0, int32_t>(tpq, q, qs, nq, d, ds, nd, k, (int32_t*)oi, od, st);
   } else {
-    if (i64) knn_kernel<K, 1, int64_t><<<grid, block, 0, st>>>(q, qs, nq, d, ds, nd, (int64_t*)oi, od);
-    else knn_kernel<K, 1, int32_t><<<grid, block, 0, st>>>(q, qs, nq, d, ds, nd, (int32_t*)oi, od);
+    if (i64) launch_t<KT, 1, int64_t>(tpq, q, qs, nq, d, ds, nd, k, (int64_t*)oi, od, st);
+    else launch_t<KT, 1, int32_t>(tpq, q, qs, nq, d, ds, nd, k, (int32_t*)oi, od, st);
   }
   return occ4d::check_launch("occ4d_knn_f32");
 }
@@ -97,14 +157,6 @@ extern "C" int occ4d_knn_f32(const float* query, int64_t q_stride, int n_query, 
   OCC4D_REQUIRE(query && data && out_idx, "occ4d_knn_f32: null pointer");
   if (n_query == 0) return OCC4D_OK;
   hipStream_t st = (hipStream_t)stream;
-#define OCC4D_KNN_CASE(KK) \
-  case KK: return launch_k<KK>(query, q_stride, n_query, data, d_stride, n_data, metric, out_idx, idx_is_i64, out_dist, st);
-  switch (k) {
-    OCC4D_KNN_CASE(1) OCC4D_KNN_CASE(2) OCC4D_KNN_CASE(3) OCC4D_KNN_CASE(4)
-    OCC4D_KNN_CASE(5) OCC4D_KNN_CASE(6) OCC4D_KNN_CASE(7) OCC4D_KNN_CASE(8)
-    OCC4D_KNN_CASE(9) OCC4D_KNN_CASE(10) OCC4D_KNN_CASE(11) OCC4D_KNN_CASE(12)
-    OCC4D_KNN_CASE(13) OCC4D_KNN_CASE(14) OCC4D_KNN_CASE(15) OCC4D_KNN_CASE(16)
-  }
-#undef OCC4D_KNN_CASE
-  return OCC4D_EINVAL;
+  if (k <= 8) return launch_k<8>(query, q_stride, n_query, data, d_stride, n_data, k, metric, out_idx, idx_is_i64, out_dist, st);
+  return launch_k<16>(query, q_stride, n_query, data, d_stride, n_data, k, metric, out_idx, idx_is_i64, out_dist, st);
 }

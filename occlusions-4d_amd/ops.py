@@ -10,28 +10,47 @@ import torch
 from . import _lib
 
 
-class LinearProfiler:
-    """Times selected occ4d_linear_f32 launches with HIP events on the launch stream
-    (bench.py's roofline leg).  `match(M, K, N)` picks the launches; durations are read
-    after a synchronise via `summary()`."""
+class KernelTimer:
+    """Times selected launches with HIP events recorded on the launch stream (= torch's current
+    stream, which is the stream every libocc4d kernel is launched on) -- bench.py's roofline leg.
+    `want(name, **shape)` picks launches; `summary()` synchronises and reports per name."""
 
-    def __init__(self, match):
-        self.match = match
+    def __init__(self, want):
+        self.want = want
         self.events = []
+
+    def launch(self, name, flops, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn()
+        e1.record()
+        self.events.append((name, e0, e1, float(flops)))
+        return rc
 
     def summary(self):
         torch.cuda.synchronize()
-        ms = [a.elapsed_time(b) for a, b, _ in self.events]
-        flops = [f for _, _, f in self.events]
-        return dict(launches=len(ms), total_ms=sum(ms), total_flops=float(sum(flops)))
+        out = {}
+        for name, a, b, f in self.events:
+            d = out.setdefault(name, dict(launches=0, total_ms=0.0, total_flops=0.0))
+            d['launches'] += 1
+            d['total_ms'] += a.elapsed_time(b)
+            d['total_flops'] += f
+        return out
 
 
-_linear_profiler = None
+_timer = None
 
 
-def set_linear_profiler(p):
-    global _linear_profiler
-    _linear_profiler = p
+def set_kernel_timer(t):
+    global _timer
+    _timer = t
+
+
+def _launch(name, shape, flops, fn):
+    t = _timer
+    if t is not None and t.want(name, **shape):
+        return t.launch(name, flops, fn)
+    return fn()
 
 
 def _stream():
@@ -129,15 +148,8 @@ def linear(x, w, b=None, relu_in=False, relu_out=False, residual=None, out=None,
         si = _dev(sub_idx, torch.int32, 'sub_idx')
         assert sr.shape[1] == N and si.is_contiguous() and si.numel() == M
         a.sub_rows, a.ld_sub, a.sub_idx = sr.data_ptr(), lds, si.data_ptr()
-    prof = _linear_profiler
-    if prof is not None and prof.match(M, K, N):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _lib.check(_lib.lib().occ4d_linear_f32(C.byref(a), _stream()))
-        e1.record()
-        prof.events.append((e0, e1, 2.0 * M * K * N))
-        return out
-    _lib.check(_lib.lib().occ4d_linear_f32(C.byref(a), _stream()))
+    _lib.check(_launch('linear', dict(M=M, K=K, N=N), 2.0 * M * K * N,
+                       lambda: _lib.lib().occ4d_linear_f32(C.byref(a), _stream())))
     return out
 
 
@@ -211,10 +223,12 @@ def pt_cross_attn(aq, qpos, apos, idx, kt, vt, P1, c1, wp, w2, b2, p2, c2, out=N
     o, ldo = _rows(out, 'out')
     assert o is out and o.shape == (n, d)
     divisor = float(torch.tensor(math.sqrt(d), dtype=torch.float32))
-    _lib.check(_lib.lib().occ4d_pt_cross_attn_f32(
+    # FLOPs this launch executes (useful, unpadded): per pair Wp (32 x 2d) + W2 (2d x d) + P2 (32 x d)
+    flops = 2.0 * n * k * (32 * 2 * d + 2 * d * d + 32 * d)
+    _lib.check(_launch('cross_attn', dict(n=n, k=k, d=d), flops, lambda: _lib.lib().occ4d_pt_cross_attn_f32(
         _ptr(aq), ld_aq, _ptr(qp), qs, _ptr(ap), as_, _ptr(idx), _ptr(kt), ld_kt, _ptr(vt), ld_vt,
         _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(ws[3]), _ptr(ws[4]), _ptr(ws[5]), _ptr(ws[6]),
-        _ptr(o), ldo, n, kt.shape[0], k, d, divisor, _stream()))
+        _ptr(o), ldo, n, kt.shape[0], k, d, divisor, _stream())))
     return out
 
 
