@@ -4,10 +4,15 @@
 // (N*K, D) positional encodings of the reference (1.5 GB + 0.76 GB + 0.76 GB per 32768
 // queries at D = 416) are never written to HBM.
 //
-// Work decomposition (wave64, one wave per SIMD, 4 waves per workgroup):
-//   wave  = 32 "pair rows" = 2 queries x 16 neighbour slots (slots >= K are masked),
-//           ALL D = 32*NT output channels -> 16*NT fp32 accumulators per lane.
-//   block = 8 queries; the weight stream (W2: D x 2D, Wp: 2D x 32) is shared by the 4
+// Work decomposition (wave64, TWO waves per SIMD, 8 waves per workgroup):
+//   wave  = 32 "pair rows" = 2 queries x 16 neighbour slots (slots >= K are masked) x one
+//           HALF of the D = 32*NT output channels (7 + 6 tiles of 32 at D = 416) -> <= 112
+//           fp32 accumulators per lane, so two waves fit a SIMD's 512-entry register file and
+//           one wave's LDS / barrier / global-load waits are covered by the other's MFMAs
+//           (measured with one 13-tile wave per SIMD: MFMA pipe 73 % busy, 17 % of wave
+//           cycles parked in s_waitcnt / s_barrier).  The price: both channel halves run
+//           GEMM1 for the same rows (+7 % MFMA work).
+//   block = 8 queries; the weight stream (W2: D x 2D, Wp: 2D x 32) is shared by the 8
 //           waves through LDS, one 32-wide hidden block at a time, double buffered,
 //           one barrier per block.
 // Chained MFMAs, no data movement between the two GEMMs of attn_mlp:
@@ -50,17 +55,19 @@ struct CrossAttnArgs {
 
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
 
-template <int NT>
-__global__ __launch_bounds__(256, 1) void cross_attn_kernel(const CrossAttnArgs a) {
+// Body for one channel group: tiles [CBEG, CBEG + NTW) of the NT channel tiles (compile-time, so
+// the MFMA / ds_read stream of a hidden block is one straight-line basic block).
+template <int NT, int CBEG, int NTW>
+__device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* smem, int* s_idx) {
   constexpr int D = 32 * NT;
   constexpr int H2 = 2 * D;
   constexpr int NHB = H2 / HB;
-  constexpr int W2_LOADS = (D * 8) / 256;          // float4 per thread per hidden block (NT)
+  constexpr int W2_F4 = D * 8;                     // float4 per hidden block of W2
+  constexpr int W2_LOADS = (W2_F4 + 511) / 512;    // per thread
   constexpr int BUF = (D + HB) * LDW;              // floats per LDS buffer: W2 block + Wp block
-  __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
-  __shared__ int s_idx[QPB * 16];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = (tid >> 6) & 3;                 // row tile (2 queries)
+  constexpr int cbeg = CBEG;
   const int half = lane >> 5, prow = lane & 31;
   const int q0 = blockIdx.x * QPB;
 
@@ -95,24 +102,26 @@ __global__ __launch_bounds__(256, 1) void cross_attn_kernel(const CrossAttnArgs 
   auto gload = [&](int hb) {
 #pragma unroll
     for (int i = 0; i < W2_LOADS; ++i) {
-      const int f = tid + 256 * i;
-      pw[i] = *reinterpret_cast<const f32x4*>(a.w2 + (int64_t)(f >> 3) * H2 + hb * HB + 4 * (f & 7));
+      const int f = tid + 512 * i;
+      if (f < W2_F4)
+        pw[i] = *reinterpret_cast<const f32x4*>(a.w2 + (int64_t)(f >> 3) * H2 + hb * HB + 4 * (f & 7));
     }
-    pp = *reinterpret_cast<const f32x4*>(a.wp + (int64_t)(hb * HB + (tid >> 3)) * 32 + 4 * (tid & 7));
+    if (tid < 256)
+      pp = *reinterpret_cast<const f32x4*>(a.wp + (int64_t)(hb * HB + (tid >> 3)) * 32 + 4 * (tid & 7));
   };
   auto sstore = [&](int buf) {
     float* W = smem + buf * BUF;
 #pragma unroll
     for (int i = 0; i < W2_LOADS; ++i) {
-      const int f = tid + 256 * i;
-      *reinterpret_cast<f32x4*>(W + (f >> 3) * LDW + 4 * (f & 7)) = pw[i];
+      const int f = tid + 512 * i;
+      if (f < W2_F4) *reinterpret_cast<f32x4*>(W + (f >> 3) * LDW + 4 * (f & 7)) = pw[i];
     }
-    *reinterpret_cast<f32x4*>(W + D * LDW + (tid >> 3) * LDW + 4 * (tid & 7)) = pp;
+    if (tid < 256) *reinterpret_cast<f32x4*>(W + D * LDW + (tid >> 3) * LDW + 4 * (tid & 7)) = pp;
   };
 
-  f32x16 acc[NT];
+  f32x16 acc[NTW];
 #pragma unroll
-  for (int c = 0; c < NT; ++c)
+  for (int c = 0; c < NTW; ++c)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
 
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(256, 1) void cross_attn_kernel(const CrossAttnArgs 
   //   top of block hb : issue weight loads (W2/Wp block hb+1) and the Aq/Kt slices of hb+1
   //   body            : GEMM1 -> relu -> GEMM2 on LDS buffer hb&1
   //   bottom          : registers -> LDS buffer (hb+1)&1, one barrier
-  f32x4 av[4], kv[4], nav[4], nkv[4];
+  f32x4 av[4], kv[4];
   auto iload = [&](int hb, f32x4* A, f32x4* Kk) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -137,10 +146,9 @@ __global__ __launch_bounds__(256, 1) void cross_attn_kernel(const CrossAttnArgs 
 
   for (int hb = 0; hb < NHB; ++hb) {
     const int buf = hb & 1;
-    if (hb + 1 < NHB) {
-      gload(hb + 1);
-      iload(hb + 1, nav, nkv);
-    }
+#ifndef OCC4D_ABLATE_NOLOAD
+    if (hb + 1 < NHB) gload(hb + 1);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     const float* W = smem + buf * BUF;
     // GEMM1 accumulator init: Aq[q][hid] - Kt[j][hid], hid = 32 hb + 8 g + 4 half + i  (reg = 4 g + i)
@@ -150,6 +158,11 @@ __global__ __launch_bounds__(256, 1) void cross_attn_kernel(const CrossAttnArgs 
       hacc[4 * g + 0] = av[g].x - kv[g].x; hacc[4 * g + 1] = av[g].y - kv[g].y;
       hacc[4 * g + 2] = av[g].z - kv[g].z; hacc[4 * g + 3] = av[g].w - kv[g].w;
     }
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef OCC4D_ABLATE_NOINIT
+    if (hb + 1 < NHB) iload(hb + 1, av, kv);    // same registers: consumed just above
+#endif
+    __builtin_amdgcn_sched_barrier(0);
     const float* Wp = W + D * LDW + frag_off;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -161,12 +174,12 @@ __global__ __launch_bounds__(256, 1) void cross_attn_kernel(const CrossAttnArgs 
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) hacc[i] = fmaxf(hacc[i], 0.f);
-    // GEMM2
-    const float* W2 = W + frag_off;
+    // GEMM2 over this wave's channel tiles
+    const float* W2 = W + cbeg * 32 * LDW + frag_off;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
 #pragma unroll
-      for (int c = 0; c < NT; ++c) {
+      for (int c = 0; c < NTW; ++c) {
         const f32x4 bv = *reinterpret_cast<const f32x4*>(W2 + c * 32 * LDW + 8 * g);
         acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(hacc[4 * g + 0], bv.x, acc[c], 0, 0, 0);
         acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(hacc[4 * g + 1], bv.y, acc[c], 0, 0, 0);
@@ -175,13 +188,24 @@ __global__ __launch_bounds__(256, 1) void cross_attn_kernel(const CrossAttnArgs 
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (hb + 1 < NHB) {
-      sstore(buf ^ 1);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) { av[g] = nav[g]; kv[g] = nkv[g]; }
-    }
+#ifndef OCC4D_ABLATE_NOLOAD
+    if (hb + 1 < NHB) sstore(buf ^ 1);
+#endif
+#ifndef OCC4D_ABLATE_NOBAR
     __syncthreads();
+#endif
   }
+#ifdef OCC4D_ABLATE_NOEPI
+  {
+    float t = 0.f;
+#pragma unroll
+    for (int c = 0; c < NTW; ++c)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t += acc[c][i];
+    if (t == 123.456f) a.agg[0] = t;   // keep the accumulators live
+    return;
+  }
+#endif
 
   // ---- epilogue: positional-encoding GEMM, per-channel softmax over the slots, weighted sum
   // C/D rows of this lane: row(reg) = (reg&3) + 8*(reg>>2) + 4*half ; regs 0-7 -> query A, 8-15 -> query B
@@ -194,12 +218,13 @@ __global__ __launch_bounds__(256, 1) void cross_attn_kernel(const CrossAttnArgs 
     vrow[i] = (row & 15) < a.K;
   }
   const int qa = q0 + wave * 2, qb = qa + 1;
+  const float inv_div = 1.0f / a.divisor;
   // P2 fragments and gathered V rows are fetched one channel tile ahead (single wave per
   // SIMD: nothing else hides their latency)
   f32x4 pv[4], npv[4];
   float vv[16], nvv[16];
   auto eload = [&](int c, f32x4* P, float* V) {
-    const int ch = 32 * c + prow;
+    const int ch = 32 * (cbeg + c) + prow;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
       P[g] = *reinterpret_cast<const f32x4*>(a.p2 + (int64_t)ch * 32 + 8 * g + 4 * half);
@@ -208,9 +233,9 @@ __global__ __launch_bounds__(256, 1) void cross_attn_kernel(const CrossAttnArgs 
   };
   eload(0, pv, vv);
 #pragma unroll
-  for (int c = 0; c < NT; ++c) {
-    const int ch = 32 * c + prow;
-    if (c + 1 < NT) eload(c + 1, npv, nvv);
+  for (int c = 0; c < NTW; ++c) {
+    const int ch = 32 * (cbeg + c) + prow;
+    if (c + 1 < NTW) eload(c + 1, npv, nvv);
     __builtin_amdgcn_sched_barrier(0);
     f32x16 pe;
 #pragma unroll
@@ -231,7 +256,7 @@ __global__ __launch_bounds__(256, 1) void cross_attn_kernel(const CrossAttnArgs 
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int reg = 8 * qq + i;
-        lg[i] = vrow[reg] ? (acc[c][reg] + b2c) / a.divisor : -__builtin_inff();
+        lg[i] = vrow[reg] ? (acc[c][reg] + b2c) * inv_div : -__builtin_inff();
         mx = fmaxf(mx, lg[i]);
       }
       mx = fmaxf(mx, xhalf(mx));
@@ -239,7 +264,8 @@ __global__ __launch_bounds__(256, 1) void cross_attn_kernel(const CrossAttnArgs 
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int reg = 8 * qq + i;
-        const float e = vrow[reg] ? expf(lg[i] - mx) : 0.f;
+        // exp(x) = 2^(x log2 e) on the hardware v_exp_f32 (1 ulp); arguments are <= 0
+        const float e = vrow[reg] ? __builtin_amdgcn_exp2f((lg[i] - mx) * 1.44269504088896f) : 0.f;
         const float val = (pe[reg] + c2c) + vv[reg];
         den += e;
         num += e * val;
@@ -252,13 +278,23 @@ __global__ __launch_bounds__(256, 1) void cross_attn_kernel(const CrossAttnArgs 
     const int qs = half ? qb : qa;
     if (qs < a.N) a.agg[(int64_t)qs * a.ld_agg + ch] = half ? out2[1] : out2[0];
     __builtin_amdgcn_sched_barrier(0);
-    if (c + 1 < NT) {
+    if (c + 1 < NTW) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) pv[g] = npv[g];
 #pragma unroll
       for (int i = 0; i < 16; ++i) vv[i] = nvv[i];
     }
   }
+}
+
+template <int NT>
+__global__ __launch_bounds__(512, 2) void cross_attn_kernel(const CrossAttnArgs a) {
+  constexpr int BUF = (32 * NT + HB) * LDW;
+  __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+  __shared__ int s_idx[QPB * 16];
+  constexpr int NTW0 = (NT + 1) / 2;               // channel group 0: tiles [0, NTW0), group 1: the rest
+  if (threadIdx.x < 256) cross_attn_body<NT, 0, NTW0>(a, smem, s_idx);
+  else cross_attn_body<NT, NTW0, NT - NTW0>(a, smem, s_idx);
 }
 
 }  // namespace
@@ -282,7 +318,7 @@ extern "C" int occ4d_pt_cross_attn_f32(const float* aq, int64_t ld_aq, const flo
   if (n == 0) return OCC4D_OK;
   CrossAttnArgs a{aq, ld_aq, qpos, qs, apos, as, idx, kt, ld_kt, vt, ld_vt, P1, c1, wp, w2, b2, p2, c2,
                   agg, ld_agg, n, m, k, divisor};
-  dim3 grid(occ4d::cdiv(n, QPB)), block(256);
+  dim3 grid(occ4d::cdiv(n, QPB)), block(512);
   if (d == 416) cross_attn_kernel<13><<<grid, block, 0, (hipStream_t)stream>>>(a);
   else cross_attn_kernel<9><<<grid, block, 0, (hipStream_t)stream>>>(a);
   return occ4d::check_launch("occ4d_pt_cross_attn_f32");

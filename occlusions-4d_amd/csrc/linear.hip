@@ -94,16 +94,24 @@ __global__ __launch_bounds__(256, 1) void linear_kernel(const occ4d_linear_args 
     __builtin_amdgcn_sched_barrier(0);   // keep the prefetch at the top (hipcc sinks it next to sstore)
     const float* Ab = As0 + buf * BM * LDT + wave * 32 * LDT + frag_off;
     const float* Wb = Ws0 + buf * BN * LDT + frag_off;
+    // consecutive MFMAs target different accumulators (never back to back on the same one)
+    constexpr int GH = NT > 7 ? (NT + 1) / 2 : NT;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const f32x4 av = *reinterpret_cast<const f32x4*>(Ab + 8 * j);
 #pragma unroll
-      for (int c = 0; c < NT; ++c) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(Wb + c * 32 * LDT + 8 * j);
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[c], 0, 0, 0);
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[c], 0, 0, 0);
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[c], 0, 0, 0);
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[c], 0, 0, 0);
+      for (int c0 = 0; c0 < NT; c0 += GH) {
+        f32x4 bv[GH];
+#pragma unroll
+        for (int cc = 0; cc < GH; ++cc)
+          if (c0 + cc < NT) bv[cc] = *reinterpret_cast<const f32x4*>(Wb + (c0 + cc) * 32 * LDT + 8 * j);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int cc = 0; cc < GH; ++cc)
+            if (c0 + cc < NT)
+              acc[c0 + cc] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[cc][i], acc[c0 + cc], 0, 0, 0);
+        }
       }
     }
     __builtin_amdgcn_sched_barrier(0);

@@ -51,10 +51,12 @@ def abstract_shape(pcl_net, n_points):
 
 
 def sharded_inference(pcl_input, points_query, pcl_net, implicit_net, batch_size, color_mode,
-                      predict_segmentation=False, track_mode='none', semantic_classes=13, gather=False):
+                      predict_segmentation=False, track_mode='none', semantic_classes=13, gather=False,
+                      squash=None):
     """pcl_input (1,N,8) and points_query (Nq,4) are CUDA tensors present on every rank (the query
     grid is deterministic, every rank builds it).  Returns (local_output (n_local,G), (lo, hi)) or the
-    gathered (Nq,G) tensor when gather=True."""
+    gathered (Nq,G) tensor when gather=True.  `squash(out, codes)` applies the per-channel post-ops in
+    place (default: the HIP kernel; the gloo/CPU test of the sharding logic injects a CPU one)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     device = points_query.device
@@ -66,8 +68,8 @@ def sharded_inference(pcl_input, points_query, pcl_net, implicit_net, batch_size
         e = min(hi, b + batch_size)
         (o, _) = implicit_net(points_query[b:e], pcl_abstract, features_global, None)
         out[b - lo:e - lo] = o
-    ops.squash(out, inference.squash_codes(implicit_net.d_out, color_mode, predict_segmentation, track_mode,
-                                           semantic_classes))
+    (squash or ops.squash)(out, inference.squash_codes(implicit_net.d_out, color_mode, predict_segmentation,
+                                                       track_mode, semantic_classes))
     if not gather:
         return out, (lo, hi)
     per = (points_query.shape[0] + world - 1) // world

@@ -1,0 +1,128 @@
+"""CPU, world_size 2, gloo: the query-sharding / broadcast / gather logic of
+occlusions-4d_amd/distributed.py.  The HIP modules cannot run without a GPU, so the two
+networks are stand-ins that expose the same interface and compute with the CPU oracle; what
+is under test is the host-side distribution logic (who encodes, what is broadcast, which
+slice each rank decodes, how outputs are gathered), checked against the single-process
+oracle result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import golden_cases as gc
+import occlusions4d_amd as pk
+from oracle import path as op
+
+
+class OracleEncoder(torch.nn.Module):
+    def __init__(self, sd, pa, calls):
+        super().__init__()
+        self.sd, self.pa, self.calls = sd, pa, calls
+        self.down_blocks, self.transition_factor = pa['down_blocks'], pa['transition_factor']
+        self.abstract_levels, self.d_feat, self.global_dim = pa['abstract_levels'], pa['d_feat'], pa['global_dim']
+
+    def forward(self, pcl, return_intermediate):
+        self.calls.append('encode')
+        out, xg = op.encoder_forward(self.sd, self.pa, pcl)
+        return out, xg, None
+
+
+class OracleDecoder(torch.nn.Module):
+    def __init__(self, sd, ia):
+        super().__init__()
+        self.sd, self.ia, self.d_out = sd, ia, ia['d_out']
+
+    def forward(self, q, abstract, fglob, _):
+        return op.decoder_forward(self.sd, self.ia, q, abstract, fglob)
+
+
+def cpu_squash(out, codes):
+    for c, code in enumerate(codes):
+        if code == 1:
+            out[:, c] = torch.sigmoid(out[:, c])
+        elif code == 2:
+            out[:, c] = torch.clamp(out[:, c], 0.0, 1.0)
+    return out
+
+
+def _worker(rank, world, port, kind, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        case = dict(kind=kind, n=384, video_len=4, seed=77)
+        pa, ia, inf = pk.configs.model_args(kind, case['n'])
+        pcl = pk.configs.synthetic_pcl(kind, case['n'], 4, 77)
+        esd, dsd = pk.configs.synthetic_weights(pa, ia, 77)
+        calls = []
+        enc, dec = OracleEncoder(esd, pa, calls), OracleDecoder(dsd, ia)
+        q = torch.from_numpy(op.sample_query_points(700, inf['min_z'], inf['cube_bounds'], 1, kind, 4, 'grid'))
+        with torch.no_grad():
+            full = pk.distributed.sharded_inference(pcl, q, enc, dec, 128, inf['color_mode'],
+                                                    inf['predict_segmentation'], 'none', 13, gather=True,
+                                                    squash=cpu_squash)
+            local, (lo, hi) = pk.distributed.sharded_inference(pcl, q, enc, dec, 128, inf['color_mode'],
+                                                               inf['predict_segmentation'], 'none', 13,
+                                                               squash=cpu_squash)
+        assert torch.equal(full[lo:hi], local)
+        assert calls == (['encode', 'encode'] if rank == 0 else []), calls   # only rank 0 encodes
+        if rank == 0:
+            ret['full'] = full.numpy()
+            ret['n'] = q.shape[0]
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize('kind', ['greater', 'carla'])
+def test_sharded_inference_two_ranks_matches_single_process(kind):
+    ctx = mp.get_context('spawn')
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, kind, ret)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(600)
+            assert p.exitcode == 0
+        full = ret['full']
+    pa, ia, inf = pk.configs.model_args(kind, 384)
+    pcl = pk.configs.synthetic_pcl(kind, 384, 4, 77)
+    esd, dsd = pk.configs.synthetic_weights(pa, ia, 77)
+    ref = op.perform_inference(pcl, esd, pa, dsd, ia, inf['min_z'], inf['cube_bounds'], inf['color_mode'], 1,
+                               num_sample=700, point_sample_mode='grid', batch_size=128,
+                               predict_segmentation=inf['predict_segmentation'], track_mode='none',
+                               semantic_classes=13, data_kind=kind, cube_mode=4)
+    assert full.shape == ref['implicit_output'].shape
+    # identical arithmetic on both sides up to batch-boundary placement (row-independent ops)
+    np.testing.assert_allclose(full, ref['implicit_output'], rtol=0, atol=2e-6)
+
+
+def test_shard_bounds_cover_exactly_once():
+    for n in (0, 1, 7, 534528, 2125568):
+        for world in (1, 2, 3, 4, 8):
+            spans = [pk.distributed.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert all(lo <= hi for lo, hi in spans)
+
+
+def test_abstract_shape_matches_survey_sizes():
+    class E:
+        down_blocks, transition_factor, d_feat = 3, 3, 36
+    E.abstract_levels = 1
+    assert pk.distributed.abstract_shape(E, 14336) == (531, 291)
+    assert pk.distributed.abstract_shape(E, 2048) == (76, 291)
+    E.abstract_levels = 2
+    assert pk.distributed.abstract_shape(E, 14336) == (2124, 291)
+    assert pk.distributed.abstract_shape(E, 28672) == (4248, 291)

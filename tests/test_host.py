@@ -1,0 +1,106 @@
+"""CPU: host-side logic of the product package that needs no GPU (grid generation, post-op
+codes, configuration tables, state-dict naming, derived/merged weights)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+import occlusions4d_amd as pk
+from conftest import load_golden
+from oracle import path as op
+
+
+def test_grid_matches_reference_golden():
+    g = load_golden('g9_grid')
+    for case in gc.GRID_CASES:
+        pts = pk.geometry.sample_implicit_points_blind_numpy(case['num_sample'], case['min_z'], case['cube_bounds'],
+                                                             case['time_idx'], case['kind'], 4, 'grid')
+        n = case['name']
+        assert pts.dtype == np.float32 and pts.shape == (int(g[n + '_n'][0]), 4)
+        assert np.array_equal(pts[:130], g[n + '_head']) and np.array_equal(pts[-130:], g[n + '_tail'])
+        assert np.array_equal(pts.astype(np.float64).sum(axis=0), g[n + '_sum'])
+
+
+def test_grid_random_mode_and_errors():
+    np.random.seed(3)
+    a = pk.geometry.sample_implicit_points_blind_numpy(100, -1.0, 5.0, 2, 'greater', 4, 'random')
+    np.random.seed(3)
+    b = op.sample_query_points(100, -1.0, 5.0, 2, 'greater', 4, 'random')
+    assert np.array_equal(a, b) and a.shape == (100, 4) and (a[:, 3] == 2).all()
+    with pytest.raises(ValueError):
+        pk.geometry.sample_implicit_points_blind_numpy(10, -1.0, 5.0, 0, 'kitti', 4, 'grid')
+    with pytest.raises(ValueError):
+        pk.geometry.sample_implicit_points_blind_numpy(10, -1.0, 5.0, 0, 'greater', 4, 'sobol')
+
+
+@pytest.mark.parametrize('color_mode,g,seg,track', [('rgb_nosigmoid', 5, False, 'none'), ('rgb', 18, True, 'none'),
+                                                    ('rgb', 5, False, 'one'), ('hsv', 16, False, 'none'),
+                                                    ('bins', 11, False, 'one')])
+def test_squash_codes_equal_reference_sequence(color_mode, g, seg, track):
+    codes = pk.inference.squash_codes(g, color_mode, seg, track, 13)
+    x = torch.randn(64, g) * 3
+    ref = op.squash_outputs(x.clone(), color_mode, seg, track, 13)
+    got = x.clone()
+    for c, code in enumerate(codes):
+        if code == 1:
+            got[:, c] = torch.sigmoid(got[:, c])
+        elif code == 2:
+            got[:, c] = got[:, c].clamp(0, 1)
+    assert torch.equal(got, ref)
+
+
+def test_state_dict_names_follow_reference_layout():
+    for kind in ('greater', 'carla'):
+        pa, ia, _ = pk.configs.model_args(kind, 2048)
+        enc = pk.model.PointCompletionNetV3(**pa)
+        dec = pk.implicit.LocalPclResnetFC(**ia)
+        assert {k: tuple(v.shape) for k, v in enc.state_dict().items()} == pk.configs.encoder_param_shapes(pa)
+        assert {k: tuple(v.shape) for k, v in dec.state_dict().items()} == pk.configs.decoder_param_shapes(ia)
+    assert sum(p.numel() for p in enc.parameters()) > 1_100_000
+    assert sum(v.numel() for v in pk.model.PointCompletionNetV3(**pk.configs.model_args('greater')[0]).parameters()) == 1122568
+    assert sum(v.numel() for v in pk.implicit.LocalPclResnetFC(**pk.configs.model_args('greater')[1]).parameters()) == 6087173
+
+
+def test_cross_attention_placement_and_errors():
+    _, ia, _ = pk.configs.model_args('greater')
+    dec = pk.implicit.LocalPclResnetFC(**ia)
+    assert dec.use_pt_inds == {2: 0, 4: 1}
+    with pytest.raises(NotImplementedError):
+        pk.implicit.LocalPclResnetFC(**dict(ia, cr_attn_type='cs'))
+    with pytest.raises(ValueError):
+        pk.implicit.LocalPclResnetFC(**dict(ia, cr_attn_type='cx'))
+    with pytest.raises(ValueError):
+        pk.implicit.ResnetBlockFC(activation='gelu')
+    with pytest.raises(ValueError):
+        pk.modules.DownTransition(8, 16, norm_type='group')
+
+
+def test_merged_weights_are_exact_in_fp64():
+    """Refactoring (i): W1 (q - k + pe) + b1 == (W1 Wq L1) x + (W1 Wq l1b + W1 c2 + b1) - (W1 Wk) f + (W1 P2) r."""
+    torch.manual_seed(0)
+    blk = pk.modules.PointTransformerBlock(32, 32, 32, num_neighbors=4, d_hidden_abstract=16).double()
+    lyr = blk.layer2
+    x, f, r = torch.randn(5, 32).double(), torch.randn(5, 16).double(), torch.relu(torch.randn(5, 32)).double()
+    q = lyr.to_q(blk.layer1(x))
+    k = lyr.to_k(f)
+    pe = lyr.pos_mlp[2](r)
+    want = lyr.attn_mlp[0](q - k + pe)
+    m = lyr.merged_weights(pre=blk.layer1)
+    got = x.float() @ m['wq'].T + m['bq'] - f.float() @ m['wk'].T + r.float() @ m['wp'].T
+    assert torch.allclose(got.double(), want, atol=2e-5)
+
+
+def test_training_forward_is_rejected_loudly():
+    blk = pk.implicit.ResnetBlockFC(8, 8, 8)
+    with pytest.raises(NotImplementedError, match='inference forward only'):
+        blk(torch.zeros(2, 8, requires_grad=True))
+
+
+def test_synthetic_inputs_are_deterministic_and_tie_free():
+    a = pk.configs.synthetic_pcl('carla', 2048, 12, 5)
+    b = pk.configs.synthetic_pcl('carla', 2048, 12, 5)
+    assert torch.equal(a, b) and a.shape == (1, 2048, 8)
+    assert np.unique(a[0, :, :3].numpy(), axis=0).shape[0] == 2048
+    w1 = pk.configs.fill_state_dict({'l.weight': (4, 8), 'l.bias': (4,)}, 3)
+    w2 = pk.configs.fill_state_dict({'l.weight': (4, 8), 'l.bias': (4,)}, 3)
+    assert all(torch.equal(w1[k], w2[k]) for k in w1) and w1['l.weight'].abs().max() <= 1 / np.sqrt(8)
