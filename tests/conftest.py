@@ -14,6 +14,9 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the CPU oracle's small ops thrash on many-core hosts (256 threads on the GPU box: ~100x slower)
+    import torch
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 16)))
 
 
 def load_golden(name):
