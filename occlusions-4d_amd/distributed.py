@@ -64,10 +64,13 @@ def sharded_inference(pcl_input, points_query, pcl_net, implicit_net, batch_size
     pcl_abstract, features_global = encode_and_share(pcl_input, pcl_net, shape, pcl_net.global_dim, device)
     lo, hi = shard_bounds(points_query.shape[0], rank, world)
     out = torch.empty((hi - lo, implicit_net.d_out), dtype=torch.float32, device=device)
-    for b in range(lo, hi, batch_size):
-        e = min(hi, b + batch_size)
-        (o, _) = implicit_net(points_query[b:e], pcl_abstract, features_global, None)
-        out[b - lo:e - lo] = o
+    if points_query.is_cuda:
+        inference.decode_batches(implicit_net, points_query, lo, hi, batch_size, pcl_abstract, features_global, out)
+    else:   # CPU stand-ins (gloo test of the sharding logic): plain loop, no streams
+        for b in range(lo, hi, batch_size):
+            e = min(hi, b + batch_size)
+            (o, _) = implicit_net(points_query[b:e], pcl_abstract, features_global, None)
+            out[b - lo:e - lo] = o
     (squash or ops.squash)(out, inference.squash_codes(implicit_net.d_out, color_mode, predict_segmentation,
                                                        track_mode, semantic_classes))
     if not gather:

@@ -131,9 +131,39 @@ def infer_device(pcl_input, points_query, pcl_net, implicit_net, batch_size, col
     features_global = features_global.squeeze(0)
     n = points_query.shape[0]
     out = torch.empty((n, implicit_net.d_out), dtype=torch.float32, device=points_query.device)
-    for lo in range(0, n, batch_size):
-        (o, _) = implicit_net(points_query[lo:lo + batch_size], pcl_abstract, features_global, None)
-        out[lo:lo + batch_size] = o
+    decode_batches(implicit_net, points_query, 0, n, batch_size, pcl_abstract, features_global, out)
     ops.squash(out, squash_codes(implicit_net.d_out, color_mode, predict_segmentation, track_mode,
                                  semantic_classes))
     return dict(implicit_output=out, pcl_abstract=pcl_abstract, features_global=features_global)
+
+
+DECODE_STREAMS = int(os.environ.get('OCC4D_DECODE_STREAMS', '2'))   # 1 = the reference's strictly serial loop
+
+
+def decode_batches(implicit_net, points_query, lo, hi, batch_size, pcl_abstract, features_global, out, out_offset=0):
+    """Runs implicit_net on points_query[lo:hi] in mini-batches of `batch_size` (the reference's
+    loop, eval/inference.py:204-246) and writes rows into out[out_offset:].  Mini-batches are
+    independent, so consecutive ones alternate between DECODE_STREAMS HIP streams: a 32768-query
+    batch is exactly one wave of 256 workgroups for the row-tiled kernels, and the next batch's
+    kernels fill the tail of the previous one's instead of waiting behind it.  The first batch runs
+    on the caller's stream so the per-scene tables are built (and cached) before the side streams
+    start."""
+    main = torch.cuda.current_stream()
+    starts = list(range(lo, hi, batch_size))
+    side = [torch.cuda.Stream() for _ in range(DECODE_STREAMS)] if DECODE_STREAMS > 1 and len(starts) > 2 else []
+    for bi, b in enumerate(starts):
+        e = min(hi, b + batch_size)
+        if bi == 0 or not side:
+            (o, _) = implicit_net(points_query[b:e], pcl_abstract, features_global, None)
+            out[out_offset + b - lo:out_offset + e - lo] = o
+            if bi == 0:
+                for st in side:
+                    st.wait_stream(main)
+            continue
+        st = side[bi % len(side)]
+        with torch.cuda.stream(st):
+            (o, _) = implicit_net(points_query[b:e], pcl_abstract, features_global, None)
+            out[out_offset + b - lo:out_offset + e - lo] = o
+    for st in side:
+        main.wait_stream(st)
+    return out
