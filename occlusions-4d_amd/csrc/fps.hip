@@ -1,17 +1,25 @@
-// Farthest point sampling (K5): one 1024-thread workgroup, points and their running
-// min-distance resident in VGPRs (interleaved: point i lives in thread i % 1024,
-// slot i / 1024), one barrier per selected point.  The dependent chain
-// (m - 1 argmax steps) is the reason this is a single-CU kernel: a grid barrier
-// costs more than a whole step does here (MI355X_MICROARCH.md barrier-xcd row).
+// Farthest point sampling (K5): ONE workgroup, points and their running min-distance resident
+// in VGPRs (interleaved: point i lives in thread i % T, slot i / T), one barrier per selected
+// point.  The m - 1 dependent argmax steps are why this is a single-CU kernel: a grid barrier
+// costs more than a whole step does (MI355X_MICROARCH.md, barrier-xcd row).
+//
+// Per step: packed-fp32 distance update of the thread's points, per-thread best, two DPP wave
+// reductions (max distance bits, then min index among the maxima), the wave winner publishes
+// (key, xyz) to LDS, one barrier, every thread picks the block winner with a max tree over the
+// per-wave 64-bit keys (distance bits << 32 | ~index : larger distance first, then lower index).
 //
 // Arithmetic pinned to oracle/cluster.py: d = ((dx*dx + dy*dy) + dz*dz) (no FMA:
 // -ffp-contract=off), running min, first (lowest-index) argmax.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
 
-constexpr int FPS_THREADS = 1024;
-constexpr int FPS_WAVES = FPS_THREADS / 64;
+typedef unsigned long long u64;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int FLAG_WORDS = 1024;  // selection bitmask, n <= 32768
 
 // wave64 all-lanes -> lane 63 reduction on the DPP network (no LDS traffic).
 template <bool IS_MAX>
@@ -31,21 +39,17 @@ __device__ __forceinline__ unsigned wave_reduce_u32(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// PPT (even) points per thread, held as PPT/2 float2 pairs so that the distance update maps to
-// packed fp32 VALU ops (v_pk_add_f32 / v_pk_mul_f32: two points per instruction).
-template <int PPT>
-__global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restrict__ xyz, int64_t stride, int n,
-                                                          int m, int32_t* __restrict__ out_sorted,
-                                                          int32_t* __restrict__ out_order) {
+// PPT (even) points per thread as PPT/2 float2 pairs -> v_pk_add_f32 / v_pk_mul_f32.
+template <int PPT, int T>
+__global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, int64_t stride, int n, int m,
+                                                int32_t* __restrict__ out_sorted, int32_t* __restrict__ out_order) {
   static_assert(PPT % 2 == 0, "PPT must be even");
   constexpr int PP = PPT / 2;
-  __shared__ unsigned s_d[2][FPS_WAVES];
-  __shared__ unsigned s_i[2][FPS_WAVES];
-  __shared__ float s_p[2][FPS_WAVES][4];
-  __shared__ unsigned s_flags[FPS_THREADS];  // bitmask of selected points (n <= 32768)
-  __shared__ int s_scan[FPS_THREADS];
+  constexpr int NW = T / 64;
+  __shared__ u64 s_key[2][NW];
+  __shared__ float s_p[2][NW][4];
+  __shared__ unsigned s_flags[FLAG_WORDS];
+  __shared__ int s_cnt[T];
 
   const int t = threadIdx.x;
   const int wave = t >> 6;
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
   for (int u = 0; u < PP; ++u) {
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
-      const int i = t + FPS_THREADS * (2 * u + v);
+      const int i = t + T * (2 * u + v);
       float x = 0.f, y = 0.f, z = 0.f, d0 = -1.f;   // d0 = -1: never wins (live running mins are >= 0)
       if (i < n) {
         const float* p = xyz + (int64_t)i * stride;
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
       px[u][v] = x; py[u][v] = y; pz[u][v] = z; md[u][v] = d0;
     }
   }
-  s_flags[t] = 0u;
+  for (int w = t; w < FLAG_WORDS; w += T) s_flags[w] = 0u;
   __syncthreads();
   float cx = xyz[0], cy = xyz[1], cz = xyz[2];
   if (t == 0) {
@@ -86,10 +90,14 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
         const float old = md[u][v];
         const float nv = d[v] < old ? d[v] : old;              // dead slots: old = -1 stays
         md[u][v] = nv;
-        if (nv > bd) {  // strict: slots ascend in index, so the lowest index wins ties
-          bd = nv; bi = (unsigned)(t + FPS_THREADS * (2 * u + v));
-          bx = px[u][v]; by = py[u][v]; bz = pz[u][v];
-        }
+        // the candidate's xyz travel with it (a wave-uniform "switch on the winner's slot" after
+        // the reduction was measured slower: hipcc lowers it to a longer v_cndmask chain)
+        const bool better = nv > bd;                            // strict: slots ascend in index
+        bd = better ? nv : bd;
+        bi = better ? (unsigned)(t + T * (2 * u + v)) : bi;
+        bx = better ? px[u][v] : bx;
+        by = better ? py[u][v] : by;
+        bz = better ? pz[u][v] : bz;
       }
     }
     // bd >= 0 for live candidates, so its bit pattern orders like the float; dead lanes map to 0.
@@ -98,17 +106,19 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
     const unsigned cand = (dbits == wmax) ? bi : 0xffffffffu;
     const unsigned wmin = wave_reduce_u32<false>(cand);
     if (dbits == wmax && bi == wmin) {  // exactly one lane per wave (or a dead wave: bi = ~0)
-      s_d[par][wave] = wmax; s_i[par][wave] = wmin;
+      s_key[par][wave] = ((u64)wmax << 32) | (u64)(0xffffffffu - wmin);
       s_p[par][wave][0] = bx; s_p[par][wave][1] = by; s_p[par][wave][2] = bz;
     }
     __syncthreads();
-    unsigned gd = s_d[par][0], gi = s_i[par][0];
-    int gw = 0;
+    u64 k[NW];
 #pragma unroll
-    for (int w = 1; w < FPS_WAVES; ++w) {
-      const unsigned d2 = s_d[par][w], i2 = s_i[par][w];
-      if (d2 > gd || (d2 == gd && i2 < gi)) { gd = d2; gi = i2; gw = w; }
-    }
+    for (int w = 0; w < NW; ++w) k[w] = s_key[par][w];
+#pragma unroll
+    for (int span = NW / 2; span > 0; span >>= 1)
+#pragma unroll
+      for (int w = 0; w < span; ++w) k[w] = k[w] > k[w + span] ? k[w] : k[w + span];
+    const unsigned gi = 0xffffffffu - (unsigned)(k[0] & 0xffffffffu);
+    const int gw = (int)((gi % T) >> 6);
     cx = s_p[par][gw][0]; cy = s_p[par][gw][1]; cz = s_p[par][gw][2];
     if (t == 0) {
       s_flags[gi >> 5] |= 1u << (gi & 31);
@@ -118,25 +128,51 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
   }
   __syncthreads();
 
-  // stream-compact the selection mask into ascending indices (block-wide scan of popcounts)
-  const unsigned word = s_flags[t];
-  const int cnt = __popc(word);
-  s_scan[t] = cnt;
+  // stream-compact the selection mask into ascending indices: each thread owns a contiguous
+  // chunk of mask words; chunk totals are scanned serially (executed once, T <= 1024 adds)
+  constexpr int CH = FLAG_WORDS / T;
+  int cnt = 0;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) cnt += __popc(s_flags[t * CH + c]);
+  s_cnt[t] = cnt;
   __syncthreads();
-  for (int off = 1; off < FPS_THREADS; off <<= 1) {
-    const int add = (t >= off) ? s_scan[t - off] : 0;
-    __syncthreads();
-    s_scan[t] += add;
-    __syncthreads();
+  if (t == 0) {
+    int run = 0;
+    for (int i = 0; i < T; ++i) {
+      const int c = s_cnt[i];
+      s_cnt[i] = run;
+      run += c;
+    }
   }
-  int pos = s_scan[t] - cnt;
-  unsigned wbits = word;
-  while (wbits) {
-    const int b = __ffs(wbits) - 1;
-    wbits &= wbits - 1;
-    if (pos < m) out_sorted[pos] = t * 32 + b;
-    ++pos;
+  __syncthreads();
+  int pos = s_cnt[t];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    unsigned wbits = s_flags[t * CH + c];
+    while (wbits) {
+      const int b = __ffs(wbits) - 1;
+      wbits &= wbits - 1;
+      if (pos < m) out_sorted[pos] = (t * CH + c) * 32 + b;
+      ++pos;
+    }
   }
+}
+
+template <int T>
+int launch_threads(const float* xyz, int64_t stride, int n, int m, int32_t* os, int32_t* oo, hipStream_t st) {
+  const int ppt = occ4d::cdiv(n, T);
+#define OCC4D_FPS(P) fps_kernel<P, T><<<1, T, 0, st>>>(xyz, stride, n, m, os, oo)
+  if (ppt <= 2) OCC4D_FPS(2);
+  else if (ppt <= 6) OCC4D_FPS(6);
+  else if (ppt <= 10) OCC4D_FPS(10);
+  else if (ppt <= 14) OCC4D_FPS(14);
+  else if (ppt <= 20) OCC4D_FPS(20);
+  else if (ppt <= 28) OCC4D_FPS(28);
+  else if (ppt <= 32) OCC4D_FPS(32);
+  else if (ppt <= 56 && T <= 512) OCC4D_FPS(56);
+  else return -1;
+#undef OCC4D_FPS
+  return 0;
 }
 
 }  // namespace
@@ -148,14 +184,14 @@ extern "C" int occ4d_fps_f32(const float* xyz, int64_t stride, int n, int m, int
   OCC4D_REQUIRE(m >= 1 && m <= n, "occ4d_fps_f32: m=%d outside [1,n=%d]", m, n);
   OCC4D_REQUIRE(stride >= 3, "occ4d_fps_f32: stride=%lld < 3", (long long)stride);
   hipStream_t st = (hipStream_t)stream;
-  const int ppt = occ4d::cdiv(n, FPS_THREADS);
-#define OCC4D_FPS(P) fps_kernel<P><<<1, FPS_THREADS, 0, st>>>(xyz, stride, n, m, out_sorted, out_order)
-  if (ppt <= 2) OCC4D_FPS(2);
-  else if (ppt <= 6) OCC4D_FPS(6);
-  else if (ppt <= 10) OCC4D_FPS(10);
-  else if (ppt <= 14) OCC4D_FPS(14);
-  else if (ppt <= 28) OCC4D_FPS(28);
-  else OCC4D_FPS(32);
-#undef OCC4D_FPS
+  // Threads per workgroup: fewer waves = cheaper per-step reduce/broadcast, more points per thread.
+  // (OCC4D_FPS_THREADS overrides for experiments.)
+  int threads = n <= 2048 ? 256 : 512;   // measured: 14336 pts 1024/512/256 threads = 10.7/9.4/15.3 ms
+  if (const char* e = getenv("OCC4D_FPS_THREADS")) threads = atoi(e);
+  int rc;
+  if (threads == 256) rc = launch_threads<256>(xyz, stride, n, m, out_sorted, out_order, st);
+  else if (threads == 512) rc = launch_threads<512>(xyz, stride, n, m, out_sorted, out_order, st);
+  else rc = launch_threads<1024>(xyz, stride, n, m, out_sorted, out_order, st);
+  OCC4D_REQUIRE(rc == 0, "occ4d_fps_f32: n=%d does not fit %d threads", n, threads);
   return occ4d::check_launch("occ4d_fps_f32");
 }

@@ -50,6 +50,33 @@ class PointCompletionNetV3(torch.nn.Module):
                  for lv in range(abstract_levels - 1)])
         self.blocks = torch.nn.ModuleList(blocks)
 
+    def _geometry_chain(self, pos):
+        """FPS -> sub-cloud -> pooling-kNN of every DownTransition, for all levels, enqueued on a side
+        stream: they depend on coordinates only, and the FPS steps are a ~10 ms single-CU dependent
+        chain that would otherwise serialise the whole encode.  Returns {block index: (per-batch
+        geometry, event)}; the main stream waits on the event right before the block needs it."""
+        main = torch.cuda.current_stream()
+        if self._geom_stream is None:
+            self._geom_stream = torch.cuda.Stream()
+        side = self._geom_stream
+        side.wait_stream(main)
+        out = {}
+        with torch.cuda.stream(side):
+            cur = [pos[b].contiguous() for b in range(pos.shape[0])]
+            for i, block in enumerate(self.blocks):
+                if isinstance(block, modules.DownTransition):
+                    g = [block.geometry(c) for c in cur]
+                    for tup in g:               # produced on `side`, consumed on `main`
+                        for t in tup:
+                            t.record_stream(main)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    out[i] = (g, ev)
+                    cur = [t[1] for t in g]
+        return out
+
+    _geom_stream = None
+
     def forward(self, pcl, return_intermediate):
         """pcl (B,N,d_in) rows (x,y,z,...) -> (pcl_out (B,M,3+D) | None, x_global (B,F) | None,
         layer_coords list | None)."""
@@ -62,8 +89,14 @@ class PointCompletionNetV3(torch.nn.Module):
                          for b in range(B)])
         skips = []
         x_global = None
+        geom = self._geometry_chain(pos)
         for i, block in enumerate(self.blocks):
-            (x, pos) = block(x, pos)
+            if isinstance(block, modules.DownTransition):
+                g, ev = geom[i]
+                torch.cuda.current_stream().wait_event(ev)
+                (x, pos) = block(x, pos, geometry=g)
+            else:
+                (x, pos) = block(x, pos)
             if self.output_global_emb and i == self.center_block_idx:
                 g0, g2 = self.global_mlp[0], self.global_mlp[2]
                 x_global = torch.stack([

@@ -60,22 +60,32 @@ class DownTransition(torch.nn.Module):
         else:
             raise ValueError()
 
-    def forward(self, x, p):
-        """x (B,N,d_in), p (B,N,3) -> (z (B,ceil(N/factor),d_out), p_sub (B,ceil(N/factor),3))."""
-        assert x.shape[:2] == p.shape[:2]
-        _no_autograd(x, p)
+    def geometry(self, p):
+        """Feature-independent half of forward() for ONE cloud p (N,3): farthest-point subset
+        (ascending indices), its coordinates and the knn_k nearest full-cloud points of every
+        sampled point.  Depends on coordinates only, so the encoder runs the three levels of this
+        chain (the FPS steps are one long dependent chain on a single CU) on a side stream,
+        concurrently with the attention / Linear kernels (model.py)."""
         if self.fps_random_start:
             raise NotImplementedError('fps_random_start=True (training-time randomness) is not part of the '
                                       'inference path; the reference forces False at test time '
                                       '(eval/inference.py:59)')
+        n_new = int(np.ceil(p.shape[0] / self.factor))
+        inds = ops.fps(p, n_new)                                       # ascending int32
+        p_sub = ops.gather_rows(p, inds)                               # (n_new,3)
+        nn_idx = ops.knn(p_sub, p, self.knn_k, metric=0)               # (n_new,k)
+        return (inds, p_sub, nn_idx)
+
+    def forward(self, x, p, geometry=None):
+        """x (B,N,d_in), p (B,N,3) -> (z (B,ceil(N/factor),d_out), p_sub (B,ceil(N/factor),3)).
+        `geometry` (extension, optional): per-batch-element results of self.geometry(p[b])."""
+        assert x.shape[:2] == p.shape[:2]
+        _no_autograd(x, p)
         (B, N, d_in) = x.shape
-        n_new = int(np.ceil(N / self.factor))
         lin = self.mlp[0]
         zs, ps = [], []
         for b in range(B):
-            inds = ops.fps(p[b], n_new)                                   # ascending int32
-            p_sub = ops.gather_rows(p[b], inds)                            # (n_new,3)
-            nn_idx = ops.knn(p_sub, p[b], self.knn_k, metric=0)            # (n_new,k)
+            (inds, p_sub, nn_idx) = geometry[b] if geometry is not None else self.geometry(p[b])
             if self.norm_type == 'layer':
                 y = ops.linear(x[b], lin.weight, lin.bias)
                 ln = self.mlp[1]
