@@ -121,7 +121,8 @@ int occ4d_pt_softmax_agg_f32(const float* logits, const float* v, int64_t ldv, c
  *   h_p      = relu(aq[i,:] - kt[j,:] + wp @ r_p)                (2d)   [aq, kt: see DESIGN.md
  *   logit_p  = w2 @ h_p + b2                                     (d)     refactoring (i)]
  *   agg[i,c] = sum_s softmax_s(logit_p[c] / divisor) * (vt[j,c] + (p2 @ r_p + c2)[c])
- * aq (n,2d), kt (m,2d), vt (m,d), wp (2d,32), w2 (d,2d), p2 (d,32), P1 (32,3); k <= 16.
+ * aq (n,2d), kt (m,2d), vt (m,d), wp (2d,32), w2 (d,2d), p2 (d,32), P1 (32,3); k <= 14
+ * (9 queries x 14 neighbours are packed into the 128 MFMA rows of a workgroup).
  * aq, kt, w2, wp, p2 16-byte aligned, ld_aq % 4 == 0, ld_kt % 4 == 0. */
 int occ4d_pt_cross_attn_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t qs,
                             const float* apos, int64_t as, const int32_t* idx,

@@ -1,20 +1,24 @@
-// Fused vector attention over K <= 16 neighbours (E3 of SURVEY.md §8(a); K2-K4 of §2.1):
+// Fused vector attention over K <= 14 neighbours (E3 of SURVEY.md §8(a); K2-K4 of §2.1):
 // for a tile of queries, everything between the per-point projections and the aggregated
 // output stays on chip -- the (N*K, 2D) hidden activations, the (N*K, D) logits and the
 // (N*K, D) positional encodings of the reference (1.5 GB + 0.76 GB + 0.76 GB per 32768
 // queries at D = 416) are never written to HBM.
 //
-// Work decomposition (wave64, TWO waves per SIMD, 8 waves per workgroup):
-//   wave  = 32 "pair rows" = 2 queries x 16 neighbour slots (slots >= K are masked) x one
-//           HALF of the D = 32*NT output channels (7 + 6 tiles of 32 at D = 416) -> <= 112
-//           fp32 accumulators per lane, so two waves fit a SIMD's 512-entry register file and
-//           one wave's LDS / barrier / global-load waits are covered by the other's MFMAs
+// Work decomposition (wave64, TWO waves per SIMD, 8 waves per workgroup, 9 queries per workgroup):
+//   row tile = 32 "pair rows" of the 32x32 MFMA = 14 neighbours of query A + 14 of query B +
+//           4 of the workgroup's 9th query, whose 14 (<= 16) neighbours are spread over the 4 row
+//           tiles: 128 MFMA rows carry 126 live pairs (padding every query to 16 rows wasted
+//           12.5 % of the MFMA work).  Row labels are free, so they are assigned such that BOTH
+//           half-waves see the same register pattern in the C/D layout: registers 0-6 = query
+//           A, 7-13 = query B, 14-15 = the 9th query (each half-wave holds 7 + 7 + 2 rows).
+//   wave  = one row tile x one HALF of the D = 32*NT output channels (7 + 6 tiles of 32 at
+//           D = 416) -> <= 112 fp32 accumulators per lane, so two waves share a SIMD and one
+//           wave's LDS / barrier / global-load waits are covered by the other's MFMAs
 //           (measured with one 13-tile wave per SIMD: MFMA pipe 73 % busy, 17 % of wave
-//           cycles parked in s_waitcnt / s_barrier).  The price: both channel halves run
-//           GEMM1 for the same rows (+7 % MFMA work).
-//   block = 8 queries; the weight stream (W2: D x 2D, Wp: 2D x 32) is shared by the 8
-//           waves through LDS, one 32-wide hidden block at a time, double buffered,
-//           one barrier per block.
+//           cycles parked in s_waitcnt / s_barrier).  Price: both channel halves run GEMM1
+//           for the same rows (+7 % MFMA work).
+//   block = the weight stream (W2: D x 2D, Wp: 2D x 32) is shared by the 8 waves through LDS,
+//           one 32-wide hidden block at a time, double buffered, one barrier per block.
 // Chained MFMAs, no data movement between the two GEMMs of attn_mlp:
 //   GEMM1 (transposed form)  Hpre^T[hid][pair] = Wp[hid][:] . r[pair][:]   (K = 32)
 //          accumulator initialised with Aq[query][hid] - Kt[neighbour][hid];
@@ -24,8 +28,9 @@
 //          consumes hid = (s&3) + 8*(s>>2) + 4*(lane>>5), and the W2 fragment is read
 //          from LDS with the same map.
 //   GEMM3  pe[pair][ch] = r[pair][:] . P2[ch][:]  reuses the r registers as A operand.
-// Per-channel softmax over the 16 slots: 8 live in a lane's registers, the other 8 in
-// lane ^ 32 -> one cross-half exchange per reduction.
+// Per-channel softmax over a query's neighbours: 7 live in a lane's registers, the other 7 in
+// lane ^ 32 -> one cross-half exchange per reduction.  The 9th query's four per-row-tile partial
+// softmaxes (max, sum, weighted sum) are merged through LDS after the main loop.
 #include "common.hpp"
 
 namespace {
@@ -35,7 +40,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int HB = 32;        // hidden block (k-tile of GEMM2)
 constexpr int LDW = 36;       // padded LDS row (floats): stride 9 x 16 B -> conflict-free ds_read_b128
-constexpr int QPB = 8;        // queries per block (4 waves x 2)
+constexpr int QPB = 9;        // queries per block
+constexpr int KMAX = 14;      // neighbours per query supported by the row packing
 
 struct CrossAttnArgs {
   const float* aq; int64_t ld_aq;
@@ -55,6 +61,13 @@ struct CrossAttnArgs {
 
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
 
+// (local query, neighbour slot) carried by C/D register `reg` of half-wave `half` in row tile `w`
+__device__ __forceinline__ void pair_of(int w, int half, int reg, int& ql, int& slot) {
+  if (reg < 7) { ql = 2 * w; slot = 7 * half + reg; }
+  else if (reg < 14) { ql = 2 * w + 1; slot = 7 * half + reg - 7; }
+  else { ql = 8; slot = 4 * w + 2 * half + reg - 14; }
+}
+
 // Body for one channel group: tiles [CBEG, CBEG + NTW) of the NT channel tiles (compile-time, so
 // the MFMA / ds_read stream of a hidden block is one straight-line basic block).
 template <int NT, int CBEG, int NTW>
@@ -71,18 +84,19 @@ __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* s
   const int half = lane >> 5, prow = lane & 31;
   const int q0 = blockIdx.x * QPB;
 
-  // ---- neighbour indices of the block's 8 queries -> LDS (invalid slots/queries repeat a valid one)
+  // ---- neighbour indices of the block's 9 queries -> LDS (invalid slots/queries repeat a valid one)
   if (tid < QPB * 16) {
     const int q = min(q0 + (tid >> 4), a.N - 1);
     const int s = min(tid & 15, a.K - 1);
     s_idx[tid] = a.idx[(int64_t)q * a.K + s];
   }
-  // ---- this lane's pair: query, neighbour, r = relu(P1 d + c1) for its 16 k-slots
-  const int my_q = min(q0 + wave * 2 + (prow >> 4), a.N - 1);
-  const int my_slot = prow & 15;
+  // ---- this lane's pair (A-operand row prow <-> C/D (half, reg) of that row)
+  int my_ql, my_slot;
+  pair_of(wave, (prow >> 2) & 1, (prow & 3) + 4 * (prow >> 3), my_ql, my_slot);
+  const int my_q = min(q0 + my_ql, a.N - 1);
   const bool my_valid = my_slot < a.K;
   const int my_j = a.idx[(int64_t)my_q * a.K + min(my_slot, a.K - 1)];
-  float r[16];
+  float r[16];   // r = relu(P1 d + c1) for this lane's 16 k-slots
   {
     const float* qp = a.qpos + (int64_t)my_q * a.qs;
     const float* ap = a.apos + (int64_t)my_j * a.as;
@@ -207,24 +221,28 @@ __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* s
   }
 #endif
 
-  // ---- epilogue: positional-encoding GEMM, per-channel softmax over the slots, weighted sum
-  // C/D rows of this lane: row(reg) = (reg&3) + 8*(reg>>2) + 4*half ; regs 0-7 -> query A, 8-15 -> query B
+  // ---- epilogue: positional-encoding GEMM, per-channel softmax over the neighbours, weighted sum.
+  // C/D registers of this lane: 0-6 query A, 7-13 query B (slot 7*half + i), 14-15 the 9th query.
+  // The weight buffers are free now (last loop barrier passed): the first 3*4*D floats of smem hold
+  // the 9th query's per-row-tile partial softmax (max, sum, weighted sum).
+  float* s_part = smem;
   int jrow[16];
   bool vrow[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
-    jrow[i] = s_idx[wave * 32 + row];
-    vrow[i] = (row & 15) < a.K;
+    int ql, slot;
+    pair_of(wave, half, i, ql, slot);
+    jrow[i] = s_idx[ql * 16 + min(slot, 15)];
+    vrow[i] = slot < a.K;
   }
-  const int qa = q0 + wave * 2, qb = qa + 1;
+  const int qa = q0 + 2 * wave, qb = qa + 1;
   const float inv_div = 1.0f / a.divisor;
-  // P2 fragments and gathered V rows are fetched one channel tile ahead (single wave per
-  // SIMD: nothing else hides their latency)
+  constexpr float LOG2E = 1.44269504088896f;
+  // P2 fragments and gathered V rows are fetched one channel tile ahead
   f32x4 pv[4], npv[4];
   float vv[16], nvv[16];
   auto eload = [&](int c, f32x4* P, float* V) {
-    const int ch = 32 * (cbeg + c) + prow;
+    const int ch = 32 * (CBEG + c) + prow;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
       P[g] = *reinterpret_cast<const f32x4*>(a.p2 + (int64_t)ch * 32 + 8 * g + 4 * half);
@@ -234,7 +252,7 @@ __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* s
   eload(0, pv, vv);
 #pragma unroll
   for (int c = 0; c < NTW; ++c) {
-    const int ch = 32 * (cbeg + c) + prow;
+    const int ch = 32 * (CBEG + c) + prow;
     if (c + 1 < NTW) eload(c + 1, npv, nvv);
     __builtin_amdgcn_sched_barrier(0);
     f32x16 pe;
@@ -248,27 +266,27 @@ __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* s
       pe = __builtin_amdgcn_mfma_f32_32x32x2f32(r[4 * g + 3], pv[g].w, pe, 0, 0, 0);
     }
     const float b2c = a.b2[ch], c2c = a.c2[ch];
+    float lg[16], val[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      lg[i] = vrow[i] ? (acc[c][i] + b2c) * inv_div : -__builtin_inff();
+      val[i] = (pe[i] + c2c) + vv[i];
+    }
+    // queries A (regs 0-6) and B (regs 7-13): complete softmax with one cross-half exchange each
     float out2[2];
 #pragma unroll
     for (int qq = 0; qq < 2; ++qq) {
-      float lg[8];
       float mx = -__builtin_inff();
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int reg = 8 * qq + i;
-        lg[i] = vrow[reg] ? (acc[c][reg] + b2c) * inv_div : -__builtin_inff();
-        mx = fmaxf(mx, lg[i]);
-      }
+      for (int i = 0; i < 7; ++i) mx = fmaxf(mx, lg[7 * qq + i]);
       mx = fmaxf(mx, xhalf(mx));
       float den = 0.f, num = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int reg = 8 * qq + i;
-        // exp(x) = 2^(x log2 e) on the hardware v_exp_f32 (1 ulp); arguments are <= 0
-        const float e = vrow[reg] ? __builtin_amdgcn_exp2f((lg[i] - mx) * 1.44269504088896f) : 0.f;
-        const float val = (pe[reg] + c2c) + vv[reg];
+      for (int i = 0; i < 7; ++i) {
+        // exp(x) = 2^(x log2 e) on the hardware v_exp_f32; arguments are <= 0, exp2(-inf) = 0
+        const float e = __builtin_amdgcn_exp2f((lg[7 * qq + i] - mx) * LOG2E);
         den += e;
-        num += e * val;
+        num += e * val[7 * qq + i];
       }
       den += xhalf(den);
       num += xhalf(num);
@@ -277,6 +295,27 @@ __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* s
     // half 0 stores query A, half 1 stores query B (128 B coalesced each)
     const int qs = half ? qb : qa;
     if (qs < a.N) a.agg[(int64_t)qs * a.ld_agg + ch] = half ? out2[1] : out2[0];
+    // 9th query: this row tile's partial over its 4 slots (regs 14, 15 of both halves)
+    {
+      float mx = fmaxf(lg[14], lg[15]);
+      mx = fmaxf(mx, xhalf(mx));
+      float den = 0.f, num = 0.f;
+      if (mx > -__builtin_inff()) {
+#pragma unroll
+        for (int i = 14; i < 16; ++i) {
+          const float e = __builtin_amdgcn_exp2f((lg[i] - mx) * LOG2E);
+          den += e;
+          num += e * val[i];
+        }
+      }
+      den += xhalf(den);
+      num += xhalf(num);
+      if (half == 0) {
+        s_part[(0 * 4 + wave) * D + ch] = mx;
+        s_part[(1 * 4 + wave) * D + ch] = den;
+        s_part[(2 * 4 + wave) * D + ch] = num;
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (c + 1 < NTW) {
 #pragma unroll
@@ -285,11 +324,30 @@ __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* s
       for (int i = 0; i < 16; ++i) vv[i] = nvv[i];
     }
   }
+  __syncthreads();
+  // merge the four partials of the 9th query: row tile 0's wave of each channel group, one channel per lane
+  const int q8 = q0 + 8;
+  if (wave == 0 && q8 < a.N) {
+    for (int ch = 32 * CBEG + lane; ch < 32 * (CBEG + NTW); ch += 64) {
+      float m = -__builtin_inff();
+#pragma unroll
+      for (int w = 0; w < 4; ++w) m = fmaxf(m, s_part[(0 * 4 + w) * D + ch]);
+      float den = 0.f, num = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float sc = __builtin_amdgcn_exp2f((s_part[(0 * 4 + w) * D + ch] - m) * LOG2E);
+        den += sc * s_part[(1 * 4 + w) * D + ch];
+        num += sc * s_part[(2 * 4 + w) * D + ch];
+      }
+      a.agg[(int64_t)q8 * a.ld_agg + ch] = num / den;
+    }
+  }
 }
 
 template <int NT>
 __global__ __launch_bounds__(512, 2) void cross_attn_kernel(const CrossAttnArgs a) {
   constexpr int BUF = (32 * NT + HB) * LDW;
+  static_assert(2 * BUF >= 12 * 32 * NT, "partial-softmax scratch must fit the weight buffers");
   __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
   __shared__ int s_idx[QPB * 16];
   constexpr int NTW0 = (NT + 1) / 2;               // channel group 0: tiles [0, NTW0), group 1: the rest
@@ -308,7 +366,8 @@ extern "C" int occ4d_pt_cross_attn_f32(const float* aq, int64_t ld_aq, const flo
   OCC4D_REQUIRE(aq && qpos && apos && idx && kt && vt && P1 && c1 && wp && w2 && b2 && p2 && c2 && agg,
                 "occ4d_pt_cross_attn_f32: null pointer");
   OCC4D_REQUIRE(d == 416 || d == 288, "occ4d_pt_cross_attn_f32: fused kernel is built for d in {288, 416}, got %d", d);
-  OCC4D_REQUIRE(k >= 1 && k <= 16 && m >= 1 && n >= 0, "occ4d_pt_cross_attn_f32: bad n/m/k");
+  OCC4D_REQUIRE(k >= 1 && k <= KMAX, "occ4d_pt_cross_attn_f32: k=%d outside [1,%d]", k, KMAX);
+  OCC4D_REQUIRE(m >= 1 && n >= 0, "occ4d_pt_cross_attn_f32: bad n/m");
   OCC4D_REQUIRE(ld_aq >= 2 * d && ld_kt >= 2 * d && ld_vt >= d && ld_agg >= d && qs >= 3 && as >= 3,
                 "occ4d_pt_cross_attn_f32: leading dimension too small");
   OCC4D_REQUIRE(ld_aq % 4 == 0 && ld_kt % 4 == 0 && ((uintptr_t)aq % 16) == 0 && ((uintptr_t)kt % 16) == 0 &&

@@ -203,6 +203,7 @@ def pt_softmax_agg(logits, v, pe, idx, out=None):
 
 
 FUSED_ATTN_DIMS = (288, 416)
+FUSED_ATTN_MAX_K = 14
 
 
 def pt_cross_attn(aq, qpos, apos, idx, kt, vt, P1, c1, wp, w2, b2, p2, c2, out=None):

@@ -148,7 +148,8 @@ class PointTransformerLayer(nn.Module):
             hi = min(n, lo + _PAIR_CHUNK)
             idx = ops.knn(pos[lo:hi], pos2, K, metric=0)                        # (c,K) int32
             aq = aq_all[lo:hi] if aq_all is not None else ops.linear(x[lo:hi], m['wq'], m['bq'])
-            if self.dim in ops.FUSED_ATTN_DIMS and self.pos_mlp[0].out_features == 32 and USE_FUSED_ATTENTION:
+            if (self.dim in ops.FUSED_ATTN_DIMS and K <= ops.FUSED_ATTN_MAX_K
+                    and self.pos_mlp[0].out_features == 32 and USE_FUSED_ATTENTION):
                 ops.pt_cross_attn(aq, pos[lo:hi], pos2, idx, kt, vt, P1, c1, m['wp'], W2, b2, P2, c2,
                                   out=agg[lo:hi])
                 continue

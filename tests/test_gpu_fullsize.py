@@ -76,12 +76,14 @@ def test_full_grid_decode_properties(scene):
         res2 = pk.inference.infer_device(scene['pcl'].cuda(), q, scene['enc'], dec, BATCH, inf['color_mode'],
                                          inf['predict_segmentation'], 'none', 13)
         assert torch.equal(out, res2['implicit_output'])
-        # batch-split invariance: a different mini-batching gives bit-identical rows
+        # batch-split invariance: a different mini-batching gives the same rows up to fp32 rounding
+        # (a query's place inside its 9-query workgroup decides whether its softmax is reduced in
+        # one piece or merged from four partials, so the last bits may differ)
         lo = 200000
         part, _ = dec(q[lo:lo + 5000], scene['ab'], scene['fg'], None)
         pk.ops.squash(part, pk.inference.squash_codes(dec.d_out, inf['color_mode'], inf['predict_segmentation'],
                                                       'none', 13))
-        assert torch.equal(part, out[lo:lo + 5000])
+        assert (part - out[lo:lo + 5000]).abs().max() <= 1e-5
     # post-op ranges (eval/inference.py:218-243)
     assert (out[:, 0] >= 0).all() and (out[:, 0] <= 1).all()
     assert (out[:, 1:4] >= 0).all() and (out[:, 1:4] <= 1).all()

@@ -195,7 +195,7 @@ def test_decoder(pk, case):
 
 
 def test_decoder_batch_split_invariance(pk):
-    """A query's result must not depend on which mini-batch it travels in."""
+    """A query's result must not depend on which mini-batch it travels in (beyond fp32 rounding)."""
     case = gc.DEC_CASES[1]
     q, abstract, fglob, ia, sd = gc.dec_inputs(case)
     net = pk.implicit.LocalPclResnetFC(**ia).cuda().eval()
@@ -204,7 +204,7 @@ def test_decoder_batch_split_invariance(pk):
     with torch.no_grad():
         full, _ = net(dev(q), a, g, None)
         parts = torch.cat([net(dev(q[lo:lo + 100]), a, g, None)[0] for lo in range(0, q.shape[0], 100)])
-    assert torch.equal(full, parts)
+    assert (full - parts).abs().max() <= 1e-5     # equal up to the rounding of the in-workgroup reduction order
 
 
 # ------------------------------------------------------------------ perform_inference (D8)
@@ -252,18 +252,23 @@ def test_perform_inference(pk, case):
 
 
 # ------------------------------------------------------------------ fused vs unfused attention
-def test_fused_attention_matches_unfused_chain(pk):
-    case = gc.PTL_CASES[2]          # cross, d = 416, e = 288, k = 14
-    x, pos, x2, pos2, sd = gc.ptl_inputs(case)
-    rng = np.random.default_rng(9)
-    n = 1003                        # not a multiple of the 8-query block
-    x = rng.normal(size=(n, case['dim'])).astype(np.float32)
+@pytest.mark.parametrize('k,n,dim,dim2', [(14, 1003, 416, 288), (13, 100, 416, 288), (12, 9, 416, 288),
+                                          (8, 37, 416, 288), (7, 500, 416, 288), (3, 64, 416, 288),
+                                          (1, 10, 416, 288), (14, 531, 288, 288), (5, 1, 416, 288)])
+def test_fused_attention_matches_unfused_chain(pk, k, n, dim, dim2):
+    """The fused kernel (9 queries x 14 rows packed per workgroup, masked slots for k < 14, ragged
+    tail for n % 9 != 0) against the unfused kernel chain on the same inputs."""
+    rng = np.random.default_rng(1000 * k + n)
+    m = 76
+    x = rng.normal(size=(n, dim)).astype(np.float32)
     pos = rng.uniform(-5, 5, size=(n, 3)).astype(np.float32)
-    layer = pk.point_transformer_layer.PointTransformerLayer(case['dim'], num_neighbors=case['k'],
-                                                             dim2=case['dim2']).cuda()
+    x2 = rng.normal(size=(m, dim2)).astype(np.float32)
+    pos2 = rng.uniform(-5, 5, size=(m, 3)).astype(np.float32)
+    ptl = pk.point_transformer_layer
+    layer = ptl.PointTransformerLayer(dim, num_neighbors=k, dim2=dim2).cuda()
+    sd = pk.configs.fill_state_dict(layer, 4242 + k)
     layer.load_state_dict(sd)
     args = (dev(x)[None], dev(pos)[None], dev(x2)[None], dev(pos2)[None])
-    ptl = pk.point_transformer_layer
     with torch.no_grad():
         fused = layer(*args)[0]
         ptl.USE_FUSED_ATTENTION = False
@@ -271,4 +276,5 @@ def test_fused_attention_matches_unfused_chain(pk):
             chain = layer(*args)[0]
         finally:
             ptl.USE_FUSED_ATTENTION = True
+    assert torch.isfinite(fused).all()
     close(fused, chain, 2e-5)
