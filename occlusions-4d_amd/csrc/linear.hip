@@ -4,9 +4,9 @@
 // BN = 32*NT columns (NT = 13 covers the decoder's 416-wide layers with no padding
 // waste: 416 = 13 * 32).  Wave w owns row tile w and ALL NT column tiles, so one A
 // fragment feeds NT MFMAs and the 16*NT accumulators stay in the unified VGPR/AGPR
-// file.  x and w tiles (BK = 16) are staged global -> registers -> LDS, double
-// buffered, one barrier per k-tile; rows are padded to 20 floats so the
-// ds_read_b128 fragment reads are bank-conflict free (stride 5 x 16 B is odd).
+// file.  x and w tiles (BK = 32) are staged global -> registers -> LDS, double
+// buffered, one barrier per k-tile; rows are padded to 36 floats so the
+// ds_read_b128 fragment reads are bank-conflict free (stride 9 x 16 B is odd).
 //
 // Fragment / k mapping: lane l supplies row (l & 31); within an 8-wide k group the
 // lower half-wave reads k = 0..3 and the upper k = 4..7 as one float4 each, and MFMA
@@ -21,13 +21,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128;
-constexpr int BK = 16;
-constexpr int LDT = 20;  // padded LDS row (floats)
+#ifndef OCC4D_LINEAR_BK
+#define OCC4D_LINEAR_BK 32
+#endif
+constexpr int BK = OCC4D_LINEAR_BK;   // k-tile depth
+constexpr int LDT = BK + 4;           // padded LDS row (floats): stride 5 or 9 x 16 B is odd -> conflict-free ds_read_b128
 
-template <int NT, bool VEC>
+// EPI: 0 = scalar epilogue (unaligned / N % 4 != 0), 1 = float4 epilogue with bias / relu only,
+//      2 = float4 epilogue with residual and/or gathered row terms (their loads are batched).
+template <int NT, int EPI>
 __global__ __launch_bounds__(256, 1) void linear_kernel(const occ4d_linear_args a) {
   constexpr int BN = 32 * NT;
-  constexpr int WLOADS = (NT * 128 + 255) / 256;  // float4 per thread for the w tile
+  constexpr int F4K = BK / 4;                              // float4 per tile row
+  constexpr int ALOADS = (BM * F4K) / 256;
+  constexpr int WLOADS = (NT * 32 * F4K + 255) / 256;      // float4 per thread for the w tile
   __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDT];
   float* const As0 = smem;
   float* const Ws0 = smem + 2 * BM * LDT;
@@ -38,13 +45,13 @@ __global__ __launch_bounds__(256, 1) void linear_kernel(const occ4d_linear_args 
   const int col0 = blockIdx.y * BN;
   const int M = a.M, K = a.K, N = a.N;
 
-  f32x4 ra[2], rw[WLOADS];
+  f32x4 ra[ALOADS], rw[WLOADS];
 
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < ALOADS; ++i) {
       const int f = tid + 256 * i;
-      const int r = row0 + (f >> 2), k = k0 + 4 * (f & 3);
+      const int r = row0 + f / F4K, k = k0 + 4 * (f % F4K);
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (r < M && k < K) v = *reinterpret_cast<const f32x4*>(a.x + (int64_t)r * a.ldx + k);
       ra[i] = v;
@@ -52,9 +59,9 @@ __global__ __launch_bounds__(256, 1) void linear_kernel(const occ4d_linear_args 
 #pragma unroll
     for (int i = 0; i < WLOADS; ++i) {
       const int f = tid + 256 * i;
-      const int c = col0 + (f >> 2), k = k0 + 4 * (f & 3);
+      const int c = col0 + f / F4K, k = k0 + 4 * (f % F4K);
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if ((f >> 2) < BN && c < N && k < K) v = *reinterpret_cast<const f32x4*>(a.w + (int64_t)c * a.ldw + k);
+      if (f / F4K < BN && c < N && k < K) v = *reinterpret_cast<const f32x4*>(a.w + (int64_t)c * a.ldw + k);
       rw[i] = v;
     }
   };
@@ -62,18 +69,18 @@ __global__ __launch_bounds__(256, 1) void linear_kernel(const occ4d_linear_args 
     float* As = As0 + buf * BM * LDT;
     float* Ws = Ws0 + buf * BN * LDT;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < ALOADS; ++i) {
       const int f = tid + 256 * i;
       f32x4 v = ra[i];
       if (a.relu_in) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       }
-      *reinterpret_cast<f32x4*>(As + (f >> 2) * LDT + 4 * (f & 3)) = v;
+      *reinterpret_cast<f32x4*>(As + (f / F4K) * LDT + 4 * (f % F4K)) = v;
     }
 #pragma unroll
     for (int i = 0; i < WLOADS; ++i) {
       const int f = tid + 256 * i;
-      if ((f >> 2) < BN) *reinterpret_cast<f32x4*>(Ws + (f >> 2) * LDT + 4 * (f & 3)) = rw[i];
+      if (f / F4K < BN) *reinterpret_cast<f32x4*>(Ws + (f / F4K) * LDT + 4 * (f % F4K)) = rw[i];
     }
   };
 
@@ -90,14 +97,16 @@ __global__ __launch_bounds__(256, 1) void linear_kernel(const occ4d_linear_args 
   const int frag_off = (lane & 31) * LDT + 4 * (lane >> 5);
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
+#ifndef OCC4D_ABLATE_NOLOAD
     if (kt + 1 < nk) gload((kt + 1) * BK);
+#endif
     __builtin_amdgcn_sched_barrier(0);   // keep the prefetch at the top (hipcc sinks it next to sstore)
     const float* Ab = As0 + buf * BM * LDT + wave * 32 * LDT + frag_off;
     const float* Wb = Ws0 + buf * BN * LDT + frag_off;
     // consecutive MFMAs target different accumulators (never back to back on the same one)
     constexpr int GH = NT > 7 ? (NT + 1) / 2 : NT;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < BK / 8; ++j) {
       const f32x4 av = *reinterpret_cast<const f32x4*>(Ab + 8 * j);
 #pragma unroll
       for (int c0 = 0; c0 < NT; c0 += GH) {
@@ -115,13 +124,26 @@ __global__ __launch_bounds__(256, 1) void linear_kernel(const occ4d_linear_args 
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+#ifndef OCC4D_ABLATE_NOLOAD
     if (kt + 1 < nk) sstore(buf ^ 1);
+#endif
     __syncthreads();
   }
+#ifdef OCC4D_ABLATE_NOEPI
+  {
+    float t = 0.f;
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += acc[c][r];
+    if (t == 123.456f) a.y[0] = t;
+    return;
+  }
+#endif
 
   // epilogue: C/D map of 32x32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const int half = lane >> 5;
-  if (VEC) {
+  if (EPI != 0) {
     // Through LDS (free after the k-loop's last barrier) so that every global access is a
     // 16-byte, row-contiguous one: per-lane 4-byte stores at a row stride were latency/issue
     // bound (the K = 32 pair GEMM ran at 0.6 TB/s).  Each wave transposes its own 32 x (32*CT)
@@ -146,33 +168,58 @@ __global__ __launch_bounds__(256, 1) void linear_kernel(const occ4d_linear_args 
       }
       // (same wave wrote and reads: program order + lgkmcnt is enough, no barrier)
       const int ncol4 = 8 * ((NT - c0) < CT ? (NT - c0) : CT);     // live float4 per row in this chunk
-      if (F4_PER_ROW <= 64) {
-        const int c4 = lane % F4_PER_ROW, rsub = lane / F4_PER_ROW;
+      const int c4 = lane % F4_PER_ROW, rsub = lane / F4_PER_ROW;
+      const int col = col0 + 32 * c0 + 4 * c4;
+      const bool col_ok = c4 < ncol4 && col < N && rsub < ROWS_PER_PASS;   // 64 % F4_PER_ROW lanes idle
+      f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias && col_ok) bias4 = *reinterpret_cast<const f32x4*>(a.bias + col);
+      if (EPI == 1) {
         for (int rp = 0; rp < 32; rp += ROWS_PER_PASS) {
           const int rl = rp + rsub;
           const int row = row0 + wave * 32 + rl;
-          const int col = col0 + 32 * c0 + 4 * c4;
-          if (rl < 32 && c4 < ncol4 && row < M && col < N) {
+          if (col_ok && row < M) {
             f32x4 v = *reinterpret_cast<const f32x4*>(E + rl * LDE + 4 * c4);
-            if (a.bias) {
-              const f32x4 t = *reinterpret_cast<const f32x4*>(a.bias + col);
-              v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-            }
-            if (a.add_rows) {
-              const f32x4 t = *reinterpret_cast<const f32x4*>(a.add_rows + (int64_t)(row / a.add_div) * a.ld_add + col);
-              v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-            }
-            if (a.sub_rows) {
-              const f32x4 t = *reinterpret_cast<const f32x4*>(a.sub_rows + (int64_t)a.sub_idx[row] * a.ld_sub + col);
-              v.x -= t.x; v.y -= t.y; v.z -= t.z; v.w -= t.w;
-            }
+            v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
             if (a.relu_out) {
               v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
-            if (a.residual) {
-              const f32x4 t = *reinterpret_cast<const f32x4*>(a.residual + (int64_t)row * a.ldr + col);
-              v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            *reinterpret_cast<f32x4*>(a.y + (int64_t)row * a.ldy + col) = v;
+          }
+        }
+        continue;
+      }
+      // All global loads of the chunk (residual, gathered rows) are issued before the first store:
+      // y may alias residual (in-place residual blocks), so the compiler keeps source order, and a
+      // load-add-store per pass serialised 16 HBM round trips per chunk (measured: 29 us of a 147 us
+      // launch).
+      constexpr int PASSES = 32 / ROWS_PER_PASS;
+      constexpr int PB = PASSES > 8 ? 8 : PASSES;          // passes per load batch (register budget)
+#pragma unroll
+      for (int p0 = 0; p0 < PASSES; p0 += PB) {
+        f32x4 res[PB], addv[PB], subv[PB];
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+          const int row = row0 + wave * 32 + (p0 + p) * ROWS_PER_PASS + rsub;
+          const bool ok = col_ok && row < M;
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          res[p] = (a.residual && ok) ? *reinterpret_cast<const f32x4*>(a.residual + (int64_t)row * a.ldr + col) : z;
+          addv[p] = (a.add_rows && ok)
+                        ? *reinterpret_cast<const f32x4*>(a.add_rows + (int64_t)(row / a.add_div) * a.ld_add + col) : z;
+          subv[p] = (a.sub_rows && ok)
+                        ? *reinterpret_cast<const f32x4*>(a.sub_rows + (int64_t)a.sub_idx[row] * a.ld_sub + col) : z;
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+          const int rl = (p0 + p) * ROWS_PER_PASS + rsub;
+          const int row = row0 + wave * 32 + rl;
+          if (col_ok && row < M) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(E + rl * LDE + 4 * c4);
+            v.x += bias4.x + addv[p].x - subv[p].x; v.y += bias4.y + addv[p].y - subv[p].y;
+            v.z += bias4.z + addv[p].z - subv[p].z; v.w += bias4.w + addv[p].w - subv[p].w;
+            if (a.relu_out) {
+              v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
+            v.x += res[p].x; v.y += res[p].y; v.z += res[p].z; v.w += res[p].w;
             *reinterpret_cast<f32x4*>(a.y + (int64_t)row * a.ldy + col) = v;
           }
         }
@@ -211,8 +258,10 @@ int launch(const occ4d_linear_args& a, hipStream_t st) {
                    (!a.residual || (al16(a.residual) && a.ldr % 4 == 0)) &&
                    (!a.add_rows || (al16(a.add_rows) && a.ld_add % 4 == 0)) &&
                    (!a.sub_rows || (al16(a.sub_rows) && a.ld_sub % 4 == 0));
-  if (vec) linear_kernel<NT, true><<<grid, block, 0, st>>>(a);
-  else linear_kernel<NT, false><<<grid, block, 0, st>>>(a);
+  const bool extras = a.residual || a.add_rows || a.sub_rows;
+  if (!vec) linear_kernel<NT, 0><<<grid, block, 0, st>>>(a);
+  else if (!extras) linear_kernel<NT, 1><<<grid, block, 0, st>>>(a);
+  else linear_kernel<NT, 2><<<grid, block, 0, st>>>(a);
   return occ4d::check_launch("occ4d_linear_f32");
 }
 
