@@ -34,7 +34,7 @@ def encode_and_share(pcl_input, pcl_net, abstract_shape, global_dim, device, src
     else:
         pcl_abstract = torch.empty(abstract_shape, dtype=torch.float32, device=device)
         features_global = torch.empty((global_dim,), dtype=torch.float32, device=device)
-    if world > 1:
+    if dist.is_initialized():
         dist.broadcast(pcl_abstract, src=src)
         dist.broadcast(features_global, src=src)
     return pcl_abstract, features_global
