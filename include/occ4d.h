@@ -173,6 +173,51 @@ int occ4d_interp_add_f32(float* x, int64_t ldx, const float* cvec, const float* 
  * 0 = identity, 1 = sigmoid, 2 = clamp to [0,1].  In place. */
 int occ4d_squash_f32(float* out, int64_t ld, int n, int g, const int32_t* ops_host, void* stream);
 
+/* ========================================================================
+ * Backward pass (the reference trains through torch autograd over the
+ * ATen ops above, train.py:101-118).  Scatter reductions use fp32 atomics.
+ * ======================================================================== */
+
+/* dW (N,K) (+)= g^T x for y = x W^T: g (M,N) = dL/dy, x (M,K).  Split over M; `workspace` holds
+ * splits*N*K floats (sizes from occ4d_linear_wgrad_workspace, which does not touch the GPU).
+ * N, K, ldg, ldx multiples of 4; g, x 16-byte aligned. */
+int occ4d_linear_wgrad_workspace(int M, int N, int K, int* splits_out, int64_t* floats_out);
+int occ4d_linear_wgrad_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int M, int N, int K,
+                           float* dw, int accumulate, float* workspace, int splits, void* stream);
+/* out (d) (+)= column sums of x (n,d)  (bias gradients); workspace: chunks*d floats */
+int occ4d_colsum_f32(const float* x, int64_t ldx, int n, int d, float* out, int accumulate,
+                     float* workspace, int chunks, void* stream);
+/* out = ref > 0 ? g : 0   (ReLU backward) */
+int occ4d_relu_mask_f32(const float* g, int64_t ldg, const float* ref, int64_t ldr, int n, int d,
+                        float* out, int64_t ldo, void* stream);
+/* out[idx[i],:] += scale * src[i,:]   (gather backward) */
+int occ4d_scatter_add_rows_f32(const float* src, int64_t lds, const int32_t* idx, int n, int d, float scale,
+                               float* out, int64_t ldo, void* stream);
+/* out[i,:] = sum_{j<k} src[i*k+j,:]   (broadcast-over-neighbours backward) */
+int occ4d_segment_sum_f32(const float* src, int n, int k, int d, float* out, int64_t ldo, void* stream);
+/* dy[idx[i,j*],c] += dz[i,c], j* = first argmax_j y[idx[i,j],c]   (occ4d_maxpool_gather_f32 backward) */
+int occ4d_maxpool_gather_bwd_f32(const float* y, int64_t ldy, const int32_t* idx, int n_out, int k, int d,
+                                 const float* dz, int64_t ldz, float* dy, int64_t ldd, void* stream);
+/* LayerNorm backward: g = dL/d(output before ReLU); dgamma/dbeta accumulate (both or neither) */
+int occ4d_layernorm_bwd_f32(const float* x, int64_t ldx, const float* gamma, const float* g, int64_t ldg,
+                            float eps, int n, int d, float* dx, int64_t lddx, float* dgamma, float* dbeta,
+                            void* stream);
+/* occ4d_pt_softmax_agg_f32 backward: dlogits (n*k,d), dpe (n*k,d) or NULL, dv (m,d) accumulates */
+int occ4d_pt_softmax_agg_bwd_f32(const float* logits, const float* v, int64_t ldv, const float* pe,
+                                 const int32_t* idx, int n, int k, int d, float divisor, const float* dagg,
+                                 int64_t ldda, float* dlogits, float* dpe, float* dv, int64_t lddv, void* stream);
+/* occ4d_pt_pos_hidden_f32 backward wrt P1 (h,3) and c1 (h) (accumulate); r = forward output, gr = dL/dr */
+int occ4d_pt_pos_hidden_bwd_f32(const float* pos, int64_t ps, const float* pos2, int64_t p2s, const int32_t* idx,
+                                int n, int k, int h, const float* r, const float* gr, float* dP1, float* dc1,
+                                void* stream);
+/* interpolation backward wrt the table: dtable[idx[i,j],:] += w[i,j] * dy[i,:] */
+int occ4d_interp_bwd_f32(const float* dy, int64_t ldy, const int32_t* idx, const float* w, int n, int k, int d,
+                         float* dtable, int64_t ldt, void* stream);
+/* out = alpha*a + beta*b (b may be NULL);  out[i,:] = scale*vec  (mean backward) */
+int occ4d_axpby_f32(const float* a, int64_t lda, float alpha, const float* b, int64_t ldb, float beta, int n, int d,
+                    float* out, int64_t ldo, void* stream);
+int occ4d_broadcast_rows_f32(const float* vec, float scale, int n, int d, float* out, int64_t ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,8 @@ fallback.  ``configs`` is pure host code (named configurations, synthetic inputs
 from . import configs  # noqa: F401
 from . import _lib  # noqa: F401
 from . import ops  # noqa: F401
-from . import point_transformer_layer, modules, model, geometry, implicit, inference, distributed  # noqa: F401
+from . import autograd  # noqa: F401
+from . import point_transformer_layer, modules, model, geometry, implicit, inference, distributed, training  # noqa: F401
 
 __all__ = ['configs', 'ops', 'point_transformer_layer', 'modules', 'model', 'geometry', 'implicit',
-           'inference', 'distributed']
+           'inference', 'distributed', 'autograd', 'training']

@@ -54,6 +54,26 @@ SIGNATURES = {
     'occ4d_interp_weights_f32': (C.c_int, [_f, C.c_int, C.c_int, _f, _s]),
     'occ4d_interp_add_f32': (C.c_int, [_f, C.c_int64, _f, _f, C.c_int64, _i, _f, C.c_int, C.c_int, C.c_int, _s]),
     'occ4d_squash_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int32), _s]),
+    # backward pass
+    'occ4d_linear_wgrad_workspace': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    'occ4d_linear_wgrad_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, C.c_int, C.c_int, C.c_int, _f, C.c_int, _f,
+                                         C.c_int, _s]),
+    'occ4d_colsum_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, _f, C.c_int, _f, C.c_int, _s]),
+    'occ4d_relu_mask_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, C.c_int, C.c_int, _f, C.c_int64, _s]),
+    'occ4d_scatter_add_rows_f32': (C.c_int, [_f, C.c_int64, _i, C.c_int, C.c_int, C.c_float, _f, C.c_int64, _s]),
+    'occ4d_segment_sum_f32': (C.c_int, [_f, C.c_int, C.c_int, C.c_int, _f, C.c_int64, _s]),
+    'occ4d_maxpool_gather_bwd_f32': (C.c_int, [_f, C.c_int64, _i, C.c_int, C.c_int, C.c_int, _f, C.c_int64, _f,
+                                               C.c_int64, _s]),
+    'occ4d_layernorm_bwd_f32': (C.c_int, [_f, C.c_int64, _f, _f, C.c_int64, C.c_float, C.c_int, C.c_int, _f,
+                                          C.c_int64, _f, _f, _s]),
+    'occ4d_pt_softmax_agg_bwd_f32': (C.c_int, [_f, _f, C.c_int64, _f, _i, C.c_int, C.c_int, C.c_int, C.c_float, _f,
+                                               C.c_int64, _f, _f, _f, C.c_int64, _s]),
+    'occ4d_pt_pos_hidden_bwd_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _i, C.c_int, C.c_int, C.c_int, _f, _f,
+                                              _f, _f, _s]),
+    'occ4d_interp_bwd_f32': (C.c_int, [_f, C.c_int64, _i, _f, C.c_int, C.c_int, C.c_int, _f, C.c_int64, _s]),
+    'occ4d_axpby_f32': (C.c_int, [_f, C.c_int64, C.c_float, _f, C.c_int64, C.c_float, C.c_int, C.c_int, _f,
+                                  C.c_int64, _s]),
+    'occ4d_broadcast_rows_f32': (C.c_int, [_f, C.c_float, C.c_int, C.c_int, _f, C.c_int64, _s]),
 }
 
 _lib = None

@@ -1,0 +1,477 @@
+// Backward-pass kernels (training step of BASELINE config 5).
+// The reference trains through torch autograd over ATen ops (train.py:101-118); these are the
+// native gradients of the ops in occ4d.h.  GEMM-shaped work (weight gradients) runs on the fp32
+// MFMA; everything else is HBM / L2-bound element-wise, gather or scatter work.  Scatter
+// reductions use fp32 atomicAdd (order-dependent rounding, ~1e-7 relative).
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int TPB = 256;
+inline dim3 grid1d(int64_t total) { return dim3((unsigned)((total + TPB - 1) / TPB)); }
+
+// ------------------------------------------------------------------------------------------
+// dW[n][k] = sum_m g[m][n] * x[m][k]      (weight gradient of y = x W^T), split over m.
+// Workgroup = 128 n-rows x 32*NT k-columns of dW for one m-chunk; g and x tiles ([16 m] x cols,
+// exactly as they lie in memory) go through LDS; the MFMA A operand is read TRANSPOSED from the
+// g tile (A[i=n][kk=m] = gs[m][n]).  Partials [split][N][K] are summed by wgrad_reduce_kernel.
+// ------------------------------------------------------------------------------------------
+constexpr int WG_BM = 16;   // contraction (m) depth per tile
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__ g, int64_t ldg,
+                                                       const float* __restrict__ x, int64_t ldx, int M, int N,
+                                                       int K, int m_per_split, float* __restrict__ part) {
+  constexpr int BNn = 128, BKk = 32 * NT;
+  constexpr int LDG = BNn + 4, LDX = BKk + 4;
+  __shared__ __attribute__((aligned(16))) float gs[2][WG_BM * LDG];
+  __shared__ __attribute__((aligned(16))) float xs[2][WG_BM * LDX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * BNn, k0 = blockIdx.y * BKk;
+  const int m_begin = blockIdx.z * m_per_split, m_end = min(M, m_begin + m_per_split);
+
+  constexpr int GL = (WG_BM * BNn / 4) / 256;                 // float4 per thread, g tile (= 2)
+  constexpr int XL = (WG_BM * BKk / 4 + 255) / 256;           // float4 per thread, x tile
+  f32x4 rg[GL], rx[XL];
+  auto gload = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < GL; ++i) {
+      const int f = tid + 256 * i;
+      const int mm = m0 + f / (BNn / 4), n = n0 + 4 * (f % (BNn / 4));
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (mm < m_end && n < N) v = *reinterpret_cast<const f32x4*>(g + (int64_t)mm * ldg + n);
+      rg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      const int f = tid + 256 * i;
+      const int mm = m0 + f / (BKk / 4), k = k0 + 4 * (f % (BKk / 4));
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (f < WG_BM * BKk / 4 && mm < m_end && k < K) v = *reinterpret_cast<const f32x4*>(x + (int64_t)mm * ldx + k);
+      rx[i] = v;
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < GL; ++i) {
+      const int f = tid + 256 * i;
+      *reinterpret_cast<f32x4*>(&gs[buf][(f / (BNn / 4)) * LDG + 4 * (f % (BNn / 4))]) = rg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      const int f = tid + 256 * i;
+      if (f < WG_BM * BKk / 4) *reinterpret_cast<f32x4*>(&xs[buf][(f / (BKk / 4)) * LDX + 4 * (f % (BKk / 4))]) = rx[i];
+    }
+  };
+  f32x16 acc[NT];
+#pragma unroll
+  for (int c = 0; c < NT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+  const int nt = (m_end - m_begin + WG_BM - 1) / WG_BM;
+  if (nt > 0) {
+    gload(m_begin);
+    sstore(0);
+  }
+  __syncthreads();
+  const int col = lane & 31, kh = lane >> 5;
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nt) gload(m_begin + (t + 1) * WG_BM);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < WG_BM / 2; ++s) {
+      const float av = gs[buf][(2 * s + kh) * LDG + wave * 32 + col];      // A[i = n][kk = m]
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {
+        const float bv = xs[buf][(2 * s + kh) * LDX + 32 * c + col];       // B[kk = m][j = k]
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[c], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < nt) sstore(buf ^ 1);
+    __syncthreads();
+  }
+  float* P = part + (int64_t)blockIdx.z * N * K;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = n0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+    if (n >= N) continue;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+      const int k = k0 + 32 * c + col;
+      if (k < K) P[(int64_t)n * K + k] = acc[c][r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int64_t nk,
+                                                           float* __restrict__ dw, int accumulate) {
+  const int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (e >= nk) return;
+  float s = accumulate ? dw[e] : 0.f;
+  for (int z = 0; z < splits; ++z) s += part[(int64_t)z * nk + e];
+  dw[e] = s;
+}
+
+// column sums: out[c] (+)= sum_i x[i][c]; stage 1 per row chunk, stage 2 reduce (deterministic)
+__global__ __launch_bounds__(TPB) void colsum_partial_kernel(const float* __restrict__ x, int64_t ldx, int n, int d,
+                                                             int rows_per_chunk, float* __restrict__ part) {
+  const int c = blockIdx.x * TPB + threadIdx.x;
+  if (c >= d) return;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
+  float s = 0.f;
+  for (int i = r0; i < r1; ++i) s += x[(int64_t)i * ldx + c];
+  part[(int64_t)blockIdx.y * d + c] = s;
+}
+
+// out = ref > 0 ? g : 0
+__global__ __launch_bounds__(TPB) void relu_mask_kernel(const float* __restrict__ g, int64_t ldg,
+                                                        const float* __restrict__ ref, int64_t ldr, int64_t total,
+                                                        int d, float* __restrict__ out, int64_t ldo) {
+  const int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)(e % d);
+  const int64_t i = e / d;
+  out[i * ldo + c] = ref[i * ldr + c] > 0.f ? g[i * ldg + c] : 0.f;
+}
+
+// out[idx[i]][c] += scale * src[i][c]
+__global__ __launch_bounds__(TPB) void scatter_add_rows_kernel(const float* __restrict__ src, int64_t lds,
+                                                               const int32_t* __restrict__ idx, int64_t total, int d,
+                                                               float scale, float* __restrict__ out, int64_t ldo) {
+  const int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)(e % d);
+  const int64_t i = e / d;
+  atomicAdd(out + (int64_t)idx[i] * ldo + c, scale * src[i * lds + c]);
+}
+
+// out[i][c] = sum_{j<k} src[i*k + j][c]
+__global__ __launch_bounds__(TPB) void segment_sum_kernel(const float* __restrict__ src, int64_t total, int k, int d,
+                                                          float* __restrict__ out, int64_t ldo) {
+  const int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)(e % d);
+  const int64_t i = e / d;
+  float s = 0.f;
+  for (int j = 0; j < k; ++j) s += src[(i * k + j) * d + c];
+  out[i * ldo + c] = s;
+}
+
+// max pool backward: dy[idx[i][j*]][c] += dz[i][c], j* = first argmax_j y[idx[i][j]][c]
+__global__ __launch_bounds__(TPB) void maxpool_bwd_kernel(const float* __restrict__ y, int64_t ldy,
+                                                          const int32_t* __restrict__ idx, int64_t total, int k, int d,
+                                                          const float* __restrict__ dz, int64_t ldz,
+                                                          float* __restrict__ dy, int64_t ldd) {
+  const int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)(e % d);
+  const int64_t i = e / d;
+  int best = idx[i * k];
+  float m = y[(int64_t)best * ldy + c];
+  for (int j = 1; j < k; ++j) {
+    const int r = idx[i * k + j];
+    const float v = y[(int64_t)r * ldy + c];
+    if (v > m) { m = v; best = r; }
+  }
+  atomicAdd(dy + (int64_t)best * ldd + c, dz[i * ldz + c]);
+}
+
+// LayerNorm backward, one wave per row: y = (x - mean) * rstd * gamma + beta;  g = dL/dy (already relu-masked)
+// dx = rstd * (gh - mean(gh) - xhat * mean(gh * xhat)), gh = g * gamma;  dgamma += g * xhat;  dbeta += g (atomics)
+__global__ __launch_bounds__(TPB) void layernorm_bwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ g, int64_t ldg, float eps, int n,
+                                                            int d, float* __restrict__ dx, int64_t lddx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int row = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const float* xr = x + (int64_t)row * ldx;
+  const float* gr = g + (int64_t)row * ldg;
+  float s = 0.f;
+  for (int c = lane; c < d; c += 64) s += xr[c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)d;
+  float q = 0.f;
+  for (int c = lane; c < d; c += 64) { const float t = xr[c] - mean; q += t * t; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = 1.0f / sqrtf(q / (float)d + eps);
+  float a = 0.f, b = 0.f;
+  for (int c = lane; c < d; c += 64) {
+    const float gh = gr[c] * (gamma ? gamma[c] : 1.f);
+    const float xh = (xr[c] - mean) * rstd;
+    a += gh; b += gh * xh;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+  a /= (float)d; b /= (float)d;
+  float* dr = dx + (int64_t)row * lddx;
+  for (int c = lane; c < d; c += 64) {
+    const float xh = (xr[c] - mean) * rstd;
+    const float gh = gr[c] * (gamma ? gamma[c] : 1.f);
+    dr[c] = rstd * (gh - a - xh * b);
+    if (dgamma) { atomicAdd(dgamma + c, gr[c] * xh); atomicAdd(dbeta + c, gr[c]); }
+  }
+}
+
+// softmax-aggregate backward (per (i, c)): a_j = softmax_j(l_j / div), val_j = v[idx_j] + pe_j, agg = sum a_j val_j
+// dval_j = a_j dagg ; da_j = val_j dagg ; dl_j = a_j (da_j - sum_t a_t da_t) / div
+template <int KMAX>
+__global__ __launch_bounds__(TPB) void softmax_agg_bwd_kernel(const float* __restrict__ logits,
+                                                              const float* __restrict__ v, int64_t ldv,
+                                                              const float* __restrict__ pe,
+                                                              const int32_t* __restrict__ idx, int64_t total, int k,
+                                                              int d, float divisor, const float* __restrict__ dagg,
+                                                              int64_t ldda, float* __restrict__ dlogits,
+                                                              float* __restrict__ dpe, float* __restrict__ dv,
+                                                              int64_t lddv) {
+  const int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)(e % d);
+  const int64_t i = e / d;
+  float a[KMAX], val[KMAX];
+  float mx = -__builtin_inff();
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j)
+    if (j < k) { a[j] = logits[(i * k + j) * d + c] / divisor; mx = fmaxf(mx, a[j]); }
+  float den = 0.f;
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j)
+    if (j < k) { a[j] = expf(a[j] - mx); den += a[j]; }
+  const float go = dagg[i * ldda + c];
+  float dot = 0.f;
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j)
+    if (j < k) {
+      const int64_t p = i * k + j;
+      a[j] = a[j] / den;
+      val[j] = v[(int64_t)idx[p] * ldv + c] + (pe ? pe[p * d + c] : 0.f);
+      dot += a[j] * val[j] * go;
+    }
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j)
+    if (j < k) {
+      const int64_t p = i * k + j;
+      const float dval = a[j] * go;
+      dlogits[p * d + c] = a[j] * (val[j] * go - dot) / divisor;
+      if (dpe) dpe[p * d + c] = dval;
+      atomicAdd(dv + (int64_t)idx[p] * lddv + c, dval);
+    }
+}
+
+// pos-MLP first layer backward: r = relu(P1 delta + c1); gr = dL/dr (n*k, h)
+// dP1[m][:] += sum_p [r>0] gr[p][m] delta_p ; dc1[m] += sum_p [r>0] gr[p][m]      (block partials + atomics)
+__global__ __launch_bounds__(TPB) void pos_hidden_bwd_kernel(const float* __restrict__ pos, int64_t ps,
+                                                             const float* __restrict__ pos2, int64_t p2s,
+                                                             const int32_t* __restrict__ idx, int64_t npairs, int k,
+                                                             int h, const float* __restrict__ r,
+                                                             const float* __restrict__ gr, float* __restrict__ dP1,
+                                                             float* __restrict__ dc1) {
+  // thread = hidden unit m (h <= 64 threads active per pair-slice); blockDim = 256 = 4 pair lanes x 64
+  const int m = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  float ax = 0.f, ay = 0.f, az = 0.f, ac = 0.f;
+  if (m < h) {
+    for (int64_t p = (int64_t)blockIdx.x * 4 + sl; p < npairs; p += (int64_t)gridDim.x * 4) {
+      const float gv = r[p * h + m] > 0.f ? gr[p * h + m] : 0.f;
+      const float* a = pos + (p / k) * ps;
+      const float* b = pos2 + (int64_t)idx[p] * p2s;
+      ax += gv * (a[0] - b[0]); ay += gv * (a[1] - b[1]); az += gv * (a[2] - b[2]); ac += gv;
+    }
+    atomicAdd(dP1 + 3 * m + 0, ax); atomicAdd(dP1 + 3 * m + 1, ay); atomicAdd(dP1 + 3 * m + 2, az);
+    atomicAdd(dc1 + m, ac);
+  }
+}
+
+// interpolation backward: y[i] = sum_j w[i][j] table[idx[i][j]]  ->  dtable[idx[i][j]] += w[i][j] dy[i]
+__global__ __launch_bounds__(TPB) void interp_bwd_kernel(const float* __restrict__ dy, int64_t ldy,
+                                                         const int32_t* __restrict__ idx, const float* __restrict__ w,
+                                                         int64_t total, int k, int d, float* __restrict__ dtable,
+                                                         int64_t ldt) {
+  const int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)(e % d);
+  const int64_t i = e / d;
+  const float gv = dy[i * ldy + c];
+  for (int j = 0; j < k; ++j) atomicAdd(dtable + (int64_t)idx[i * k + j] * ldt + c, w[i * k + j] * gv);
+}
+
+// out[i][c] = alpha * a[i][c] + beta * b[i][c]   (b may be NULL)
+__global__ __launch_bounds__(TPB) void axpby_kernel(const float* __restrict__ a, int64_t lda, float alpha,
+                                                    const float* __restrict__ b, int64_t ldb, float beta, int64_t total,
+                                                    int d, float* __restrict__ out, int64_t ldo) {
+  const int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)(e % d);
+  const int64_t i = e / d;
+  float v = alpha * a[i * lda + c];
+  if (b) v += beta * b[i * ldb + c];
+  out[i * ldo + c] = v;
+}
+
+// out[i][c] = scale * vec[c]  (broadcast a row vector to n rows: mean backward)
+__global__ __launch_bounds__(TPB) void broadcast_rows_kernel(const float* __restrict__ vec, float scale, int64_t total,
+                                                             int d, float* __restrict__ out, int64_t ldo) {
+  const int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (e >= total) return;
+  out[(e / d) * ldo + (e % d)] = scale * vec[e % d];
+}
+
+template <int NT>
+void launch_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx, int M, int N, int K, int splits,
+                  int mps, float* part, hipStream_t st) {
+  dim3 grid(occ4d::cdiv(N, 128), occ4d::cdiv(K, 32 * NT), splits);
+  wgrad_kernel<NT><<<grid, 256, 0, st>>>(g, ldg, x, ldx, M, N, K, mps, part);
+}
+
+}  // namespace
+
+extern "C" {
+
+int occ4d_linear_wgrad_workspace(int M, int N, int K, int* splits_out, int64_t* floats_out) {
+  OCC4D_REQUIRE(M >= 0 && N >= 1 && K >= 1 && splits_out && floats_out, "occ4d_linear_wgrad_workspace: bad arguments");
+  // enough m-chunks to give every CU a workgroup, each at least 256 rows deep
+  const int tiles = occ4d::cdiv(N, 128) * occ4d::cdiv(K, 416);
+  int splits = occ4d::cdiv(512, tiles);
+  const int cap = M / 256 > 1 ? M / 256 : 1;
+  if (splits > cap) splits = cap;
+  *splits_out = splits > 1 ? splits : 1;
+  *floats_out = (int64_t)(*splits_out) * N * K;
+  return OCC4D_OK;
+}
+
+int occ4d_linear_wgrad_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int M, int N, int K, float* dw,
+                           int accumulate, float* workspace, int splits, void* stream) {
+  OCC4D_REQUIRE(g && x && dw && workspace, "occ4d_linear_wgrad_f32: null pointer");
+  OCC4D_REQUIRE(M >= 1 && N >= 1 && K >= 1 && splits >= 1, "occ4d_linear_wgrad_f32: bad sizes");
+  OCC4D_REQUIRE(N % 4 == 0 && K % 4 == 0 && ldg % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)g % 16) == 0 &&
+                    ((uintptr_t)x % 16) == 0,
+                "occ4d_linear_wgrad_f32: N, K, ldg, ldx must be multiples of 4 and g, x 16-byte aligned");
+  OCC4D_REQUIRE(ldg >= N && ldx >= K, "occ4d_linear_wgrad_f32: leading dimension too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int mps = occ4d::cdiv(occ4d::cdiv(M, splits), WG_BM) * WG_BM;
+  if (K <= 32) launch_wgrad<1>(g, ldg, x, ldx, M, N, K, splits, mps, workspace, st);
+  else if (K <= 64) launch_wgrad<2>(g, ldg, x, ldx, M, N, K, splits, mps, workspace, st);
+  else if (K <= 96) launch_wgrad<3>(g, ldg, x, ldx, M, N, K, splits, mps, workspace, st);
+  else if (K <= 160) launch_wgrad<5>(g, ldg, x, ldx, M, N, K, splits, mps, workspace, st);
+  else if (K <= 288) launch_wgrad<9>(g, ldg, x, ldx, M, N, K, splits, mps, workspace, st);
+  else launch_wgrad<13>(g, ldg, x, ldx, M, N, K, splits, mps, workspace, st);
+  int rc = occ4d::check_launch("occ4d_linear_wgrad_f32");
+  if (rc) return rc;
+  const int64_t nk = (int64_t)N * K;
+  wgrad_reduce_kernel<<<grid1d(nk), TPB, 0, st>>>(workspace, splits, nk, dw, accumulate);
+  return occ4d::check_launch("occ4d_linear_wgrad_f32(reduce)");
+}
+
+int occ4d_colsum_f32(const float* x, int64_t ldx, int n, int d, float* out, int accumulate, float* workspace,
+                     int chunks, void* stream) {
+  OCC4D_REQUIRE(x && out && workspace && n >= 1 && d >= 1 && chunks >= 1 && ldx >= d, "occ4d_colsum_f32: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int rpc = occ4d::cdiv(n, chunks);
+  colsum_partial_kernel<<<dim3(occ4d::cdiv(d, TPB), chunks), TPB, 0, st>>>(x, ldx, n, d, rpc, workspace);
+  wgrad_reduce_kernel<<<grid1d(d), TPB, 0, st>>>(workspace, chunks, d, out, accumulate);
+  return occ4d::check_launch("occ4d_colsum_f32");
+}
+
+int occ4d_relu_mask_f32(const float* g, int64_t ldg, const float* ref, int64_t ldr, int n, int d, float* out,
+                        int64_t ldo, void* stream) {
+  OCC4D_REQUIRE(g && ref && out && n >= 0 && d >= 1, "occ4d_relu_mask_f32: bad arguments");
+  const int64_t total = (int64_t)n * d;
+  if (!total) return OCC4D_OK;
+  relu_mask_kernel<<<grid1d(total), TPB, 0, (hipStream_t)stream>>>(g, ldg, ref, ldr, total, d, out, ldo);
+  return occ4d::check_launch("occ4d_relu_mask_f32");
+}
+
+int occ4d_scatter_add_rows_f32(const float* src, int64_t lds, const int32_t* idx, int n, int d, float scale,
+                               float* out, int64_t ldo, void* stream) {
+  OCC4D_REQUIRE(src && idx && out && n >= 0 && d >= 1, "occ4d_scatter_add_rows_f32: bad arguments");
+  const int64_t total = (int64_t)n * d;
+  if (!total) return OCC4D_OK;
+  scatter_add_rows_kernel<<<grid1d(total), TPB, 0, (hipStream_t)stream>>>(src, lds, idx, total, d, scale, out, ldo);
+  return occ4d::check_launch("occ4d_scatter_add_rows_f32");
+}
+
+int occ4d_segment_sum_f32(const float* src, int n, int k, int d, float* out, int64_t ldo, void* stream) {
+  OCC4D_REQUIRE(src && out && n >= 0 && k >= 1 && d >= 1 && ldo >= d, "occ4d_segment_sum_f32: bad arguments");
+  const int64_t total = (int64_t)n * d;
+  if (!total) return OCC4D_OK;
+  segment_sum_kernel<<<grid1d(total), TPB, 0, (hipStream_t)stream>>>(src, total, k, d, out, ldo);
+  return occ4d::check_launch("occ4d_segment_sum_f32");
+}
+
+int occ4d_maxpool_gather_bwd_f32(const float* y, int64_t ldy, const int32_t* idx, int n_out, int k, int d,
+                                 const float* dz, int64_t ldz, float* dy, int64_t ldd, void* stream) {
+  OCC4D_REQUIRE(y && idx && dz && dy && n_out >= 0 && k >= 1 && d >= 1, "occ4d_maxpool_gather_bwd_f32: bad arguments");
+  const int64_t total = (int64_t)n_out * d;
+  if (!total) return OCC4D_OK;
+  maxpool_bwd_kernel<<<grid1d(total), TPB, 0, (hipStream_t)stream>>>(y, ldy, idx, total, k, d, dz, ldz, dy, ldd);
+  return occ4d::check_launch("occ4d_maxpool_gather_bwd_f32");
+}
+
+int occ4d_layernorm_bwd_f32(const float* x, int64_t ldx, const float* gamma, const float* g, int64_t ldg, float eps,
+                            int n, int d, float* dx, int64_t lddx, float* dgamma, float* dbeta, void* stream) {
+  OCC4D_REQUIRE(x && g && dx && n >= 0 && d >= 1, "occ4d_layernorm_bwd_f32: bad arguments");
+  OCC4D_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "occ4d_layernorm_bwd_f32: dgamma/dbeta both or neither");
+  if (!n) return OCC4D_OK;
+  layernorm_bwd_kernel<<<occ4d::cdiv(n, TPB / 64), TPB, 0, (hipStream_t)stream>>>(x, ldx, gamma, g, ldg, eps, n, d, dx,
+                                                                                    lddx, dgamma, dbeta);
+  return occ4d::check_launch("occ4d_layernorm_bwd_f32");
+}
+
+int occ4d_pt_softmax_agg_bwd_f32(const float* logits, const float* v, int64_t ldv, const float* pe,
+                                 const int32_t* idx, int n, int k, int d, float divisor, const float* dagg,
+                                 int64_t ldda, float* dlogits, float* dpe, float* dv, int64_t lddv, void* stream) {
+  OCC4D_REQUIRE(logits && v && idx && dagg && dlogits && dv, "occ4d_pt_softmax_agg_bwd_f32: null pointer");
+  OCC4D_REQUIRE(n >= 0 && k >= 1 && k <= 16 && d >= 1 && divisor > 0.f, "occ4d_pt_softmax_agg_bwd_f32: bad sizes");
+  const int64_t total = (int64_t)n * d;
+  if (!total) return OCC4D_OK;
+  softmax_agg_bwd_kernel<16><<<grid1d(total), TPB, 0, (hipStream_t)stream>>>(logits, v, ldv, pe, idx, total, k, d,
+                                                                             divisor, dagg, ldda, dlogits, dpe, dv, lddv);
+  return occ4d::check_launch("occ4d_pt_softmax_agg_bwd_f32");
+}
+
+int occ4d_pt_pos_hidden_bwd_f32(const float* pos, int64_t ps, const float* pos2, int64_t p2s, const int32_t* idx,
+                                int n, int k, int h, const float* r, const float* gr, float* dP1, float* dc1,
+                                void* stream) {
+  OCC4D_REQUIRE(pos && pos2 && idx && r && gr && dP1 && dc1, "occ4d_pt_pos_hidden_bwd_f32: null pointer");
+  OCC4D_REQUIRE(n >= 0 && k >= 1 && h >= 1 && h <= 64, "occ4d_pt_pos_hidden_bwd_f32: need h <= 64");
+  const int64_t npairs = (int64_t)n * k;
+  if (!npairs) return OCC4D_OK;
+  const int64_t want = (npairs + 3) / 4;
+  const int blocks = (int)(want < 1024 ? want : 1024);
+  pos_hidden_bwd_kernel<<<blocks, TPB, 0, (hipStream_t)stream>>>(pos, ps, pos2, p2s, idx, npairs, k, h, r, gr, dP1, dc1);
+  return occ4d::check_launch("occ4d_pt_pos_hidden_bwd_f32");
+}
+
+int occ4d_interp_bwd_f32(const float* dy, int64_t ldy, const int32_t* idx, const float* w, int n, int k, int d,
+                         float* dtable, int64_t ldt, void* stream) {
+  OCC4D_REQUIRE(dy && idx && w && dtable && n >= 0 && k >= 1 && d >= 1, "occ4d_interp_bwd_f32: bad arguments");
+  const int64_t total = (int64_t)n * d;
+  if (!total) return OCC4D_OK;
+  interp_bwd_kernel<<<grid1d(total), TPB, 0, (hipStream_t)stream>>>(dy, ldy, idx, w, total, k, d, dtable, ldt);
+  return occ4d::check_launch("occ4d_interp_bwd_f32");
+}
+
+int occ4d_axpby_f32(const float* a, int64_t lda, float alpha, const float* b, int64_t ldb, float beta, int n, int d,
+                    float* out, int64_t ldo, void* stream) {
+  OCC4D_REQUIRE(a && out && n >= 0 && d >= 1, "occ4d_axpby_f32: bad arguments");
+  const int64_t total = (int64_t)n * d;
+  if (!total) return OCC4D_OK;
+  axpby_kernel<<<grid1d(total), TPB, 0, (hipStream_t)stream>>>(a, lda, alpha, b, ldb, beta, total, d, out, ldo);
+  return occ4d::check_launch("occ4d_axpby_f32");
+}
+
+int occ4d_broadcast_rows_f32(const float* vec, float scale, int n, int d, float* out, int64_t ldo, void* stream) {
+  OCC4D_REQUIRE(vec && out && n >= 0 && d >= 1 && ldo >= d, "occ4d_broadcast_rows_f32: bad arguments");
+  const int64_t total = (int64_t)n * d;
+  if (!total) return OCC4D_OK;
+  broadcast_rows_kernel<<<grid1d(total), TPB, 0, (hipStream_t)stream>>>(vec, scale, total, d, out, ldo);
+  return occ4d::check_launch("occ4d_broadcast_rows_f32");
+}
+
+}  // extern "C"

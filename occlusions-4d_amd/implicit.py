@@ -17,7 +17,8 @@ import torch
 from . import geometry  # noqa: F401  (same module graph as the reference)
 from . import modules
 from . import ops
-from .point_transformer_layer import _no_autograd
+from . import autograd
+from .point_transformer_layer import needs_grad
 
 _QUERY_CHUNK = 32768
 
@@ -51,9 +52,15 @@ class ResnetBlockFC(torch.nn.Module):
         self.shortcut = None if d_in == d_out else torch.nn.Linear(d_in, d_out, bias=False)
 
     def forward(self, x):
-        _no_autograd(x)
         flat = x.reshape(-1, x.shape[-1])
+        if needs_grad(self, x):
+            return self._run_train(flat).reshape(*x.shape[:-1], self.d_out)
         return self._run(flat).reshape(*x.shape[:-1], self.d_out)
+
+    def _run_train(self, x):
+        h = autograd.linear(x, self.fc_0, relu_in=True)
+        xs = x if self.shortcut is None else autograd.linear(x, self.shortcut)
+        return autograd.linear(h, self.fc_1, relu_in=True, residual=xs)
 
     def _run(self, x, inplace=False):
         h = ops.linear(x, self.fc_0.weight, self.fc_0.bias, relu_in=True)
@@ -98,7 +105,9 @@ class ResnetFC(torch.nn.Module):
 
     def do_forward(self, points, features):
         """points (B,N,d_in) or (N,d_in); features (B,D) or (B,N,D) -> (output (B,N,G), penult (B,N,H))."""
-        _no_autograd(points, features)
+        if needs_grad(self, points, features):
+            raise NotImplementedError('training is implemented for the published configuration '
+                                      "(local_mode='attention'); ResnetFC.do_forward is inference-only")
         no_batch = points.dim() == 2
         if no_batch:
             points, features = points[None], features[None]
@@ -203,7 +212,8 @@ class LocalPclResnetFC(ResnetFC):
         """points_query (B,N,4) or (N,4); points_abstract (B,M,3) (or (B,M,3+E) with
         features_abstract None); features_global (B,D); features_abstract (B,M,E).
         B must be 1.  Returns (output (B,N,G), penult (B,N,H)) (no batch dim if none came in)."""
-        _no_autograd(points_query, points_abstract, features_global, features_abstract)
+        if needs_grad(self, points_abstract, features_global, features_abstract):
+            return self._forward_train(points_query, points_abstract, features_global, features_abstract)
         if self.num_local_features <= 0:
             return super().do_forward(points_query, features_global)
         if self.local_mode == 'function':
@@ -264,3 +274,43 @@ class LocalPclResnetFC(ResnetFC):
             pen[lo:lo + _QUERY_CHUNK] = x
             ops.linear(x, self.lin_out.weight, self.lin_out.bias, relu_in=True, out=out[lo:lo + _QUERY_CHUNK])
         return out, pen
+
+    # -- training path (as-written op order, differentiable kernels) ------------------------
+    def _forward_train(self, points_query, points_abstract, features_global, features_abstract):
+        """Same contract as forward(); every op is a occlusions4d_amd.autograd Function, so gradients
+        reach this module's parameters and, through features_abstract / features_global, the encoder."""
+        assert self.local_mode == 'attention' and self.num_local_features > 0, \
+            "training is implemented for the published configuration (local_mode='attention')"
+        no_batch = points_query.dim() == 2
+        q = points_query if no_batch else points_query[0]
+        pa, fa, fg = points_abstract, features_abstract, features_global
+        if fa is None:
+            fa, pa = pa[..., 3:], pa[..., :3]
+        if pa.dim() == 3:
+            assert pa.shape[0] == 1, 'LocalPclResnetFC supports B == 1 only (model/implicit.py:317)'
+            pa, fa = pa[0], fa[0]
+        if fg.dim() == 2:
+            fg = fg[0]
+        pa = pa.detach().contiguous()
+        fa = fa.contiguous()
+        n = q.shape[0]
+        dg = self.d_latent - self.d_latent_local
+        idx8, dist = ops.knn(q, pa, self.num_local_features, metric=1, return_dist=True)
+        w8 = ops.interp_weights(dist)
+        f_local = autograd.InterpFn.apply(fa, idx8, w8)                                   # (n, E)
+        f_query = torch.cat([fg[None, :].expand(n, dg), f_local], dim=-1)                 # (n, D)
+        x = autograd.linear(ops.posenc(q, self.pos_encoding_freqs, 0.1), self.lin_in)
+        qxyz = q[:, :3]
+        for i in range(self.n_blocks):
+            x = autograd.linear(f_query, self.lin_z[i], residual=x)
+            x = self.blocks[i]._run_train(x)
+            if i in self.use_pt_inds:
+                blk = self.pt_blocks[self.use_pt_inds[i]]
+                y = autograd.linear(x, blk.layer1)
+                agg = blk.layer2.forward_train(y, qxyz, fa, pa)
+                x = autograd.linear(agg, blk.layer3, residual=x)
+        output = autograd.linear(x, self.lin_out, relu_in=True)
+        penult = x
+        if not no_batch:
+            output, penult = output[None], penult[None]
+        return (output, penult)

@@ -11,7 +11,8 @@ import torch
 
 from . import modules
 from . import ops
-from .point_transformer_layer import _no_autograd
+from . import autograd
+from .point_transformer_layer import needs_grad
 
 
 class PointCompletionNetV3(torch.nn.Module):
@@ -80,13 +81,16 @@ class PointCompletionNetV3(torch.nn.Module):
     def forward(self, pcl, return_intermediate):
         """pcl (B,N,d_in) rows (x,y,z,...) -> (pcl_out (B,M,3+D) | None, x_global (B,F) | None,
         layer_coords list | None)."""
-        _no_autograd(pcl)
+        train = needs_grad(self, pcl)
         B = pcl.shape[0]
-        pos = pcl[..., :3]
+        pos = pcl[..., :3].detach()
         layer_coords = [pos, pos] if return_intermediate else None
         l0, l2 = self.pre_mlp[0], self.pre_mlp[2]
-        x = torch.stack([ops.linear(ops.linear(pcl[b], l0.weight, l0.bias, relu_out=True), l2.weight, l2.bias)
-                         for b in range(B)])
+        if train:
+            x = torch.stack([autograd.linear(autograd.linear(pcl[b], l0, relu_out=True), l2) for b in range(B)])
+        else:
+            x = torch.stack([ops.linear(ops.linear(pcl[b], l0.weight, l0.bias, relu_out=True), l2.weight, l2.bias)
+                             for b in range(B)])
         skips = []
         x_global = None
         geom = self._geometry_chain(pos)
@@ -99,21 +103,34 @@ class PointCompletionNetV3(torch.nn.Module):
                 (x, pos) = block(x, pos)
             if self.output_global_emb and i == self.center_block_idx:
                 g0, g2 = self.global_mlp[0], self.global_mlp[2]
-                x_global = torch.stack([
-                    ops.linear(ops.linear(ops.mean_rows(x[b])[None], g0.weight, g0.bias, relu_out=True),
-                               g2.weight, g2.bias)[0] for b in range(B)])
+                if train:
+                    x_global = torch.stack([
+                        autograd.linear(autograd.linear(autograd.MeanRowsFn.apply(x[b])[None], g0, relu_out=True),
+                                        g2)[0] for b in range(B)])
+                else:
+                    x_global = torch.stack([
+                        ops.linear(ops.linear(ops.mean_rows(x[b])[None], g0.weight, g0.bias, relu_out=True),
+                                   g2.weight, g2.bias)[0] for b in range(B)])
             if return_intermediate:
                 layer_coords.append(pos)
             if self.abstract_levels > 1 and isinstance(block, modules.DownTransition):
                 for j, skip in enumerate(self.abstract_skip_mlps):
                     if skip.in_features == x.shape[-1]:
-                        y = torch.stack([ops.linear(x[b], skip.weight, skip.bias) for b in range(B)])
-                        y[..., -1] = j + 1.0
+                        if train:
+                            y = torch.stack([autograd.linear(x[b], skip) for b in range(B)])
+                            y = torch.cat([y[..., :-1], torch.full_like(y[..., :1], j + 1.0)], dim=-1)
+                        else:
+                            y = torch.stack([ops.linear(x[b], skip.weight, skip.bias) for b in range(B)])
+                            y[..., -1] = j + 1.0
                         skips.append(torch.cat([pos, y], dim=-1))
         if self.output_featurized:
             pcl_out = torch.cat([pos, x], dim=-1)
             if self.abstract_levels > 1:
-                pcl_out[..., -1] = self.abstract_levels
+                if train:    # (no in-place write on a taped tensor)
+                    pcl_out = torch.cat([pcl_out[..., :-1],
+                                         torch.full_like(pcl_out[..., :1], float(self.abstract_levels))], dim=-1)
+                else:
+                    pcl_out[..., -1] = self.abstract_levels
                 assert len(skips) == self.abstract_levels - 1
                 pcl_out = torch.cat([torch.cat(skips, dim=1), pcl_out], dim=1)
         else:

@@ -11,7 +11,8 @@ import torch
 
 from . import ops
 from . import point_transformer_layer
-from .point_transformer_layer import _no_autograd
+from . import autograd
+from .point_transformer_layer import needs_grad
 
 
 class PointTransformerBlock(torch.nn.Module):
@@ -34,11 +35,13 @@ class PointTransformerBlock(torch.nn.Module):
         assert x.shape[:2] == p.shape[:2]
         if x2 is not None:
             assert x2.shape[:2] == p2.shape[:2]
-        _no_autograd(x, p, x2, p2)
         # layer1 is folded into the query-side merged matrix (cross) or applied once (self)
         agg = self.layer2._forward(x, p, x2, p2, pre=self.layer1, scene_owner=scene_owner)
-        z = torch.stack([ops.linear(agg[b], self.layer3.weight, self.layer3.bias, residual=x[b])
-                         for b in range(x.shape[0])])
+        if needs_grad(self, x, x2):
+            z = torch.stack([autograd.linear(agg[b], self.layer3, residual=x[b]) for b in range(x.shape[0])])
+        else:
+            z = torch.stack([ops.linear(agg[b], self.layer3.weight, self.layer3.bias, residual=x[b])
+                             for b in range(x.shape[0])])
         return (z, p)
 
 
@@ -80,12 +83,21 @@ class DownTransition(torch.nn.Module):
         """x (B,N,d_in), p (B,N,3) -> (z (B,ceil(N/factor),d_out), p_sub (B,ceil(N/factor),3)).
         `geometry` (extension, optional): per-batch-element results of self.geometry(p[b])."""
         assert x.shape[:2] == p.shape[:2]
-        _no_autograd(x, p)
         (B, N, d_in) = x.shape
         lin = self.mlp[0]
+        train = needs_grad(self, x)
         zs, ps = [], []
         for b in range(B):
-            (inds, p_sub, nn_idx) = geometry[b] if geometry is not None else self.geometry(p[b])
+            (inds, p_sub, nn_idx) = geometry[b] if geometry is not None else self.geometry(p[b].detach())
+            if train:
+                if self.norm_type == 'layer':
+                    ln = self.mlp[1]
+                    y = autograd.LayerNormReluFn.apply(autograd.linear(x[b], lin), ln.weight, ln.bias, ln.eps)
+                else:
+                    y = autograd.linear(x[b], lin, relu_out=True)
+                zs.append(autograd.MaxPoolGatherFn.apply(y, nn_idx))
+                ps.append(p_sub)
+                continue
             if self.norm_type == 'layer':
                 y = ops.linear(x[b], lin.weight, lin.bias)
                 ln = self.mlp[1]

@@ -319,3 +319,155 @@ def squash(out, ops):
     arr = (C.c_int32 * g)(*[int(v) for v in ops])
     _lib.check(_lib.lib().occ4d_squash_f32(_ptr(out), ld, n, g, arr, _stream()))
     return out
+
+
+# --------------------------------------------------------------------------------------
+# backward-pass kernels (include/occ4d.h, "Backward pass")
+# --------------------------------------------------------------------------------------
+def _cont(t, name='tensor'):
+    t = _dev(t, name=name)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def linear_wgrad(g, x, out=None, accumulate=False):
+    """dW (N,K) (+)= g^T x with g (M,N), x (M,K)."""
+    g = _cont(g, 'g')
+    x = _cont(x, 'x')
+    M, N = g.shape
+    K = x.shape[1]
+    assert x.shape[0] == M
+    n4, k4 = (N + 3) // 4 * 4, (K + 3) // 4 * 4
+    if n4 != N:
+        g = torch.nn.functional.pad(g, (0, n4 - N))
+    if k4 != K:
+        x = torch.nn.functional.pad(x, (0, k4 - K))
+    splits, floats = C.c_int(0), C.c_int64(0)
+    _lib.check(_lib.lib().occ4d_linear_wgrad_workspace(M, n4, k4, C.byref(splits), C.byref(floats)))
+    ws = torch.empty((floats.value,), dtype=torch.float32, device=g.device)
+    direct = out is not None and n4 == N and k4 == K and out.is_contiguous()
+    dw = out if direct else torch.empty((n4, k4), dtype=torch.float32, device=g.device)
+    _lib.check(_lib.lib().occ4d_linear_wgrad_f32(_ptr(g), n4, _ptr(x), k4, M, n4, k4, _ptr(dw),
+                                                 int(accumulate and direct), _ptr(ws), splits.value, _stream()))
+    if direct:
+        return out
+    dw = dw[:N, :K]
+    if out is not None:
+        if accumulate:
+            out += dw
+        else:
+            out.copy_(dw)
+        return out
+    return dw.contiguous()
+
+
+def colsum(x):
+    x, ldx = _rows(_dev(x, name='x'), 'x')
+    n, d = x.shape
+    chunks = max(1, min(256, n // 512))
+    ws = torch.empty((chunks * d,), dtype=torch.float32, device=x.device)
+    out = torch.empty((d,), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().occ4d_colsum_f32(_ptr(x), ldx, n, d, _ptr(out), 0, _ptr(ws), chunks, _stream()))
+    return out
+
+
+def relu_mask(g, ref):
+    g, ldg = _rows(_dev(g, name='g'), 'g')
+    ref, ldr = _rows(_dev(ref, name='ref'), 'ref')
+    n, d = g.shape
+    assert ref.shape == (n, d)
+    out = torch.empty((n, d), dtype=torch.float32, device=g.device)
+    _lib.check(_lib.lib().occ4d_relu_mask_f32(_ptr(g), ldg, _ptr(ref), ldr, n, d, _ptr(out), d, _stream()))
+    return out
+
+
+def scatter_add_rows(src, idx, n_out, scale=1.0):
+    src, lds = _rows(_dev(src, name='src'), 'src')
+    idx = _dev(idx, torch.int32, 'idx').contiguous().view(-1)
+    n, d = src.shape
+    assert idx.numel() == n
+    out = torch.zeros((n_out, d), dtype=torch.float32, device=src.device)
+    _lib.check(_lib.lib().occ4d_scatter_add_rows_f32(_ptr(src), lds, _ptr(idx), n, d, float(scale), _ptr(out), d,
+                                                     _stream()))
+    return out
+
+
+def segment_sum(src, k):
+    src = _cont(src, 'src')
+    nk, d = src.shape
+    assert nk % k == 0
+    out = torch.empty((nk // k, d), dtype=torch.float32, device=src.device)
+    _lib.check(_lib.lib().occ4d_segment_sum_f32(_ptr(src), nk // k, k, d, _ptr(out), d, _stream()))
+    return out
+
+
+def maxpool_gather_bwd(y, idx, dz):
+    y, ldy = _rows(_dev(y, name='y'), 'y')
+    dz, ldz = _rows(_dev(dz, name='dz'), 'dz')
+    idx = _dev(idx, torch.int32, 'idx')
+    n_out, k = idx.shape
+    d = y.shape[1]
+    dy = torch.zeros_like(y, memory_format=torch.contiguous_format)
+    _lib.check(_lib.lib().occ4d_maxpool_gather_bwd_f32(_ptr(y), ldy, _ptr(idx), n_out, k, d, _ptr(dz), ldz, _ptr(dy), d,
+                                                       _stream()))
+    return dy
+
+
+def layernorm_bwd(x, gamma, g, eps):
+    x, ldx = _rows(_dev(x, name='x'), 'x')
+    g, ldg = _rows(_dev(g, name='g'), 'g')
+    n, d = x.shape
+    dx = torch.empty((n, d), dtype=torch.float32, device=x.device)
+    dgamma = torch.zeros((d,), dtype=torch.float32, device=x.device)
+    dbeta = torch.zeros((d,), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().occ4d_layernorm_bwd_f32(_ptr(x), ldx, _ptr(_cont(gamma)), _ptr(g), ldg, float(eps), n, d,
+                                                  _ptr(dx), d, _ptr(dgamma), _ptr(dbeta), _stream()))
+    return dx, dgamma, dbeta
+
+
+def pt_softmax_agg_bwd(logits, v, pe, idx, dagg):
+    logits = _cont(logits, 'logits')
+    v, ldv = _rows(_dev(v, name='v'), 'v')
+    dagg, ldda = _rows(_dev(dagg, name='dagg'), 'dagg')
+    n, k = idx.shape
+    d = logits.shape[1]
+    pe = _cont(pe, 'pe') if pe is not None else None
+    dlogits = torch.empty_like(logits)
+    dpe = torch.empty_like(logits) if pe is not None else None
+    dv = torch.zeros((v.shape[0], d), dtype=torch.float32, device=logits.device)
+    divisor = float(torch.tensor(math.sqrt(d), dtype=torch.float32))
+    _lib.check(_lib.lib().occ4d_pt_softmax_agg_bwd_f32(_ptr(logits), _ptr(v), ldv, _ptr(pe),
+                                                       _ptr(_dev(idx, torch.int32)), n, k, d, divisor, _ptr(dagg), ldda,
+                                                       _ptr(dlogits), _ptr(dpe), _ptr(dv), d, _stream()))
+    return dlogits, dpe, dv
+
+
+def pt_pos_hidden_bwd(pos, pos2, idx, r, gr):
+    p, ps = _rows(_dev(pos, name='pos'), 'pos')
+    p2, p2s = _rows(_dev(pos2, name='pos2'), 'pos2')
+    n, k = idx.shape
+    r = _cont(r, 'r')
+    gr = _cont(gr, 'gr')
+    h = r.shape[1]
+    dP1 = torch.zeros((h, 3), dtype=torch.float32, device=r.device)
+    dc1 = torch.zeros((h,), dtype=torch.float32, device=r.device)
+    _lib.check(_lib.lib().occ4d_pt_pos_hidden_bwd_f32(_ptr(p), ps, _ptr(p2), p2s, _ptr(_dev(idx, torch.int32)), n, k, h,
+                                                      _ptr(r), _ptr(gr), _ptr(dP1), _ptr(dc1), _stream()))
+    return dP1, dc1
+
+
+def interp_bwd(dy, idx, w, n_table):
+    dy, ldy = _rows(_dev(dy, name='dy'), 'dy')
+    n, k = idx.shape
+    d = dy.shape[1]
+    dtable = torch.zeros((n_table, d), dtype=torch.float32, device=dy.device)
+    _lib.check(_lib.lib().occ4d_interp_bwd_f32(_ptr(dy), ldy, _ptr(_dev(idx, torch.int32)), _ptr(_cont(w)), n, k, d,
+                                               _ptr(dtable), d, _stream()))
+    return dtable
+
+
+def broadcast_rows(vec, n, scale=1.0):
+    vec = _cont(vec, 'vec')
+    d = vec.numel()
+    out = torch.empty((n, d), dtype=torch.float32, device=vec.device)
+    _lib.check(_lib.lib().occ4d_broadcast_rows_f32(_ptr(vec), float(scale), n, d, _ptr(out), d, _stream()))
+    return out

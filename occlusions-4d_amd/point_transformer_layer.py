@@ -18,17 +18,22 @@ What runs instead of the reference's ATen ops
 import torch
 from torch import nn
 
+from . import autograd
 from . import ops
 
 _PAIR_CHUNK = 32768      # query rows per pass (bounds the (rows*K, 2D) workspace)
 USE_FUSED_ATTENTION = True   # tests flip this to cover the unfused kernel chain as well
 
 
-def _no_autograd(*tensors):
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
-        raise NotImplementedError(
-            'occlusions4d_amd implements the inference forward only; the backward pass of the fused '
-            'kernels is a later scope row (run under torch.no_grad()).')
+def needs_grad(module, *tensors):
+    """True when the call must be recorded for autograd: the training path (occlusions4d_amd.autograd,
+    unfused differentiable kernels in the reference's as-written op order) is taken instead of the
+    fused inference kernels."""
+    if not torch.is_grad_enabled():
+        return False
+    if any(t is not None and t.requires_grad for t in tensors):
+        return True
+    return module is not None and any(p.requires_grad for p in module.parameters())
 
 
 def square_distance(src, dst):
@@ -118,13 +123,35 @@ class PointTransformerLayer(nn.Module):
         return self._forward(x, pos, x2, pos2, pre=None, scene_owner=None)
 
     def _forward(self, x, pos, x2, pos2, pre, scene_owner):
-        _no_autograd(x, pos, x2, pos2)
+        if needs_grad(self, x, x2) or (pre is not None and needs_grad(pre)):
+            out = []
+            for b in range(x.shape[0]):
+                y = x[b] if pre is None else autograd.linear(x[b], pre)
+                out.append(self.forward_train(y, pos[b], None if x2 is None else x2[b],
+                                              None if pos2 is None else pos2[b]))
+            return torch.stack(out)
         out = []
         for b in range(x.shape[0]):
             xb2 = None if x2 is None else x2[b]
             pb2 = None if pos2 is None else pos2[b]
             out.append(self._forward_one(x[b], pos[b], xb2, pb2, pre, scene_owner))
         return torch.stack(out)
+
+    def forward_train(self, x, pos, x2=None, pos2=None):
+        """Differentiable forward for one cloud, as written in the reference (:167-179): x (N,D)."""
+        K = self.num_neighbors
+        if x2 is None:
+            x2, pos2 = x, pos
+        idx = ops.knn(pos.detach(), pos2.detach(), K, metric=0)
+        q = autograd.linear(x, self.to_q)
+        kf = autograd.linear(x2, self.to_k)
+        vf = autograd.linear(x2, self.to_v)
+        r = autograd.PosHiddenFn.apply(pos.detach(), pos2.detach(), idx, self.pos_mlp[0].weight, self.pos_mlp[0].bias)
+        pe = autograd.linear(r, self.pos_mlp[2])
+        a = autograd.AttnInFn.apply(q, kf, pe, idx)
+        h = autograd.linear(a, self.attn_mlp[0], relu_out=True)
+        logits = autograd.linear(h, self.attn_mlp[2])
+        return autograd.SoftmaxAggFn.apply(logits, vf, pe, idx)
 
     def _forward_one(self, x, pos, x2, pos2, pre, scene_owner):
         K = self.num_neighbors

@@ -90,9 +90,9 @@ def test_merged_weights_are_exact_in_fp64():
     assert torch.allclose(got.double(), want, atol=2e-5)
 
 
-def test_training_forward_is_rejected_loudly():
+def test_training_forward_has_no_cpu_fallback_either():
     blk = pk.implicit.ResnetBlockFC(8, 8, 8)
-    with pytest.raises(NotImplementedError, match='inference forward only'):
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
         blk(torch.zeros(2, 8, requires_grad=True))
 
 
