@@ -196,3 +196,30 @@ def test_end_to_end_training_step_gradients():
     loss.backward()
     check_grads(dec, red, kinks=True)
     check_grads(enc, res, kinks=True)
+
+
+def test_train_step_reduces_loss():
+    """TrainStep (forward, losses, backward, clip, AdamW) on a small CARLA-layout problem: the loss on a fixed
+    batch goes down and every parameter moves."""
+    kind, n = 'carla', 512
+    pa, ia, inf = pk.configs.model_args(kind, n)
+    pa = dict(pa)
+    pcl = pk.configs.synthetic_pcl(kind, n, 4, 41).cuda()
+    esd, dsd = pk.configs.synthetic_weights(pa, ia, 42)
+    enc = pk.model.PointCompletionNetV3(**pa).cuda().train()
+    dec = pk.implicit.LocalPclResnetFC(**ia).cuda().train()
+    enc.load_state_dict(esd)
+    dec.load_state_dict(dsd)
+    rng = np.random.default_rng(43)
+    q = torch.stack([T(op.sample_query_points(128, inf['min_z'], inf['cube_bounds'], t, kind, 4, 'random'))
+                     for t in range(2)]).cuda()
+    target = torch.from_numpy(np.concatenate(
+        [rng.integers(0, 2, size=(2, 128, 1)), rng.uniform(size=(2, 128, 3)), np.zeros((2, 128, 1)),
+         rng.integers(-1, 13, size=(2, 128, 1))], -1).astype(np.float32)).cuda()
+    before = {k: v.detach().clone() for k, v in list(enc.named_parameters()) + list(dec.named_parameters())}
+    step = pk.training.TrainStep(enc, dec, lr=2e-3, grad_clip=0.2,
+                                 loss_kwargs=dict(density_lw=1.0, segmentation_lw=0.6))
+    losses = [float(step(pcl, q, target)) for _ in range(6)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    moved = [k for k, v in list(enc.named_parameters()) + list(dec.named_parameters()) if not torch.equal(v, before[k])]
+    assert len(moved) == len(before)
