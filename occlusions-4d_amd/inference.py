@@ -6,7 +6,7 @@ Differences that do not change results: the query grid is uploaded once and ever
 mini-batch, the post-ops (sigmoid / clamp, :218-243) and the concatenation stay on the
 device; one device-to-host copy happens at the end instead of one per batch (:206,245).
 The optional ground-truth 1-NN labelling branch (:270-276, sklearn KDTree on targets)
-needs dataset targets and is out of the timed path; it is not provided here.
+is provided on the streaming k = 1 kernel; track_mode 'all' reruns the path once per instance id.
 """
 import os
 
@@ -93,31 +93,92 @@ def perform_inference(pcl_input, pcl_input_sem, pcl_target_frame, networks, devi
     implicit_output, points_query) of float32 numpy arrays."""
     assert task == 'if'
     assert sample_implicit
-    if track_mode == 'all':
-        raise NotImplementedError("track_mode 'all' (one rerun per instance id, eval/inference.py:144-161) "
-                                  "is not part of the benchmarked path")
-    if pcl_target_frame is not None:
-        raise NotImplementedError('ground-truth 1-NN labelling (eval/inference.py:270-276) is out of scope')
+    output_track_idx = get_track_idx(color_mode)
+    input_inst_idx = 0 if data_kind == 'greater' else 1
     pcl_net, implicit_net = networks
     if isinstance(pcl_input, np.ndarray):
         pcl_input = torch.from_numpy(pcl_input).unsqueeze(0)
     pcl_input = pcl_input.to(device)
+
+    # One rerun per tracked instance (track_mode 'all', :144-161), otherwise a single run.
+    if track_mode in ('none', 'one'):
+        track_instance_ids = [-1]
+    else:
+        assert data_kind == 'greater'
+        assert pcl_input_sem.shape[-1] == 1
+        if isinstance(pcl_input_sem, np.ndarray):
+            sem_numpy = pcl_input_sem
+            pcl_input_sem = torch.from_numpy(pcl_input_sem).unsqueeze(0).to(device)
+        else:
+            sem_numpy = pcl_input_sem[0].detach().cpu().numpy()
+            pcl_input_sem = pcl_input_sem.to(device)
+        ids, counts = np.unique(sem_numpy, return_counts=True)
+        track_instance_ids = [int(i) for i, c in zip(ids, counts) if i >= 0 and c >= 16]
+
     points_query = geometry.sample_implicit_points_blind_numpy(
         num_sample, min_z, cube_bounds, time_idx, data_kind, cube_mode, point_sample_mode)
+    queries_dev = torch.from_numpy(points_query).to(device)
+    all_abstract, all_global, all_output = [], [], []
     with torch.no_grad():
-        res = infer_device(pcl_input, torch.from_numpy(points_query).to(device), pcl_net, implicit_net,
-                           batch_size, color_mode, predict_segmentation, track_mode, semantic_classes)
-        implicit_output = res['implicit_output'].cpu().numpy()
-        pcl_abstract = res['pcl_abstract'].cpu().numpy() if res['pcl_abstract'] is not None else None
-        features_global = res['features_global'].cpu().numpy()
+        for inst_id in track_instance_ids:
+            if inst_id >= 0:                  # mark the instance to follow in the input cloud (:190-193)
+                pcl_input[..., -1] = (pcl_input_sem[..., input_inst_idx] == inst_id)
+            res = infer_device(pcl_input, queries_dev, pcl_net, implicit_net, batch_size, color_mode,
+                               predict_segmentation, track_mode, semantic_classes)
+            all_output.append(res['implicit_output'].cpu().numpy())
+            all_abstract.append(res['pcl_abstract'].cpu().numpy() if res['pcl_abstract'] is not None else None)
+            all_global.append(res['features_global'].cpu().numpy())
+        (pcl_abstract, features_global, implicit_output) = multi_track_merge(
+            track_instance_ids, all_abstract, all_global, all_output, output_track_idx)
+
+        gt_available = pcl_target_frame is not None
+        if gt_available:                      # nearest ground-truth point of every query (:270-276)
+            target_labels, nn_indices = get_1nn_label(queries_dev[:, :3], pcl_target_frame, point_occupancy_radius,
+                                                      device)
+            points_nngt = np.concatenate([target_labels[:, None], pcl_target_frame[nn_indices]], axis=-1)
+
     points_io = np.concatenate([points_query, implicit_output], axis=-1)
-    solid = points_io[points_io[..., 4] >= density_threshold]
-    air = points_io[points_io[..., 4] < density_threshold]
+    solid_mask = points_io[..., 4] >= density_threshold
+    solid, air = points_io[solid_mask], points_io[~solid_mask]
     if compress_air:
         air_segm = air[..., -semantic_classes:].argmax(axis=-1)
         air = np.concatenate([air[..., :3], air[..., 4:5], air_segm[..., None]], axis=-1)
-    return dict(output_solid=solid, output_air=air, pcl_abstract=pcl_abstract,
-                features_global=features_global, implicit_output=implicit_output, points_query=points_query)
+    result = dict(output_solid=solid, output_air=air, pcl_abstract=pcl_abstract,
+                  features_global=features_global, implicit_output=implicit_output, points_query=points_query)
+    if gt_available:
+        gt_solid, gt_air = points_nngt[solid_mask], points_nngt[~solid_mask]
+        if compress_air:
+            gt_air = np.concatenate([gt_air[..., :1], gt_air[..., 4:5]], axis=-1)
+        result['gt_solid'], result['gt_air'] = gt_solid, gt_air
+    return result
+
+
+def get_1nn_label(points_query_xyz, pcl_target_frame, thresh, device):
+    """Pseudo label of every query from its nearest target point (utils/geometry.py:444-455, an sklearn
+    KDTree there): label = (distance < thresh), plus the neighbour's index.  Streaming k = 1 kernel."""
+    target_xyz = torch.from_numpy(np.ascontiguousarray(pcl_target_frame[..., :3], dtype=np.float32)).to(device)
+    idx, dist = ops.knn(points_query_xyz, target_xyz, 1, metric=1, return_dist=True)
+    labels = (dist[:, 0] < thresh).cpu().numpy() * 1
+    return labels, idx[:, 0].cpu().numpy().astype(np.int64)
+
+
+def multi_track_merge(track_instance_ids, pcl_abstract, features_global, implicit_output, output_track_idx):
+    """Merge the per-instance reruns (utils/utils.py:343-397): features and outputs are averaged, the
+    mark_track channel becomes the id of the most confident run (>= 0.5), else -1."""
+    assert len(pcl_abstract) == len(features_global) == len(implicit_output)
+    if len(pcl_abstract) == 1 and track_instance_ids[0] == -1:
+        return (pcl_abstract[0], features_global[0], implicit_output[0])
+    merged_abstract = np.mean(pcl_abstract, axis=0) if pcl_abstract[0] is not None else None
+    merged_global = np.mean(features_global, axis=0)
+    merged_output = np.mean(implicit_output, axis=0)
+    winner = -np.ones_like(merged_output[..., 0])
+    best = np.zeros_like(merged_output[..., 0])
+    for inst_id, out in zip(track_instance_ids, implicit_output):
+        score = out[..., output_track_idx]
+        winner[np.logical_and(score >= 0.5, score >= best)] = inst_id
+        best = np.maximum(score, best)
+    merged_output[..., output_track_idx] = winner
+    return (merged_abstract, merged_global, merged_output)
 
 
 def infer_device(pcl_input, points_query, pcl_net, implicit_net, batch_size, color_mode,

@@ -137,6 +137,27 @@ def main():
              n_solid=np.array([res['output_solid'].shape[0]]), n_air=np.array([res['output_air'].shape[0]]),
              air_head=res['output_air'][:64], solid_head=res['output_solid'][:64])
 
+    # G11: perform_inference with track_mode 'all' (one rerun per instance, multi_track_merge) and the
+    # ground-truth 1-NN labelling branch (sklearn KDTree in the reference)
+    for case in gc.TRACK_CASES:
+        pcl, sem, target, pa, ia, ia_inf, esd, dsd = gc.track_inputs(case)
+        enc = mdl.PointCompletionNetV3(**pa)
+        enc.load_state_dict(esd)
+        dec = imp.LocalPclResnetFC(**ia)
+        dec.load_state_dict(dsd)
+        enc.eval()
+        dec.eval()
+        res = inf.perform_inference(
+            pcl.clone(), sem.copy(), target.copy(), [enc, dec], torch.device('cpu'), 'if', ia_inf['min_z'],
+            ia_inf['cube_bounds'], ia_inf['color_mode'], case['time_idx'], None,
+            sample_implicit=True, num_sample=case['num_sample'], point_sample_mode='grid',
+            batch_size=case['batch_size'], predict_segmentation=False, track_mode='all', semantic_classes=13,
+            density_threshold=0.5, data_kind='greater', cube_mode=4, compress_air=True,
+            point_occupancy_radius=0.8)
+        save('g11_tracks_' + case['name'], implicit_output=res['implicit_output'], pcl_abstract=res['pcl_abstract'],
+             features_global=res['features_global'], gt_solid=res['gt_solid'], gt_air=res['gt_air'],
+             n_solid=np.array([res['output_solid'].shape[0]]))
+
 
 if __name__ == '__main__':
     main()

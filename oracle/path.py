@@ -348,30 +348,79 @@ def squash_outputs(o, color_mode, predict_segmentation, track_mode, semantic_cla
     return o
 
 
+def merge_tracks(track_instance_ids, pcl_abstract, features_global, implicit_output, output_track_idx):
+    """utils/utils.py:343-397 (multi_track_merge)."""
+    if len(pcl_abstract) == 1 and track_instance_ids[0] == -1:                # :369-370
+        return pcl_abstract[0], features_global[0], implicit_output[0]
+    m_abs = np.mean(pcl_abstract, axis=0)                                     # :373-378
+    m_glob = np.mean(features_global, axis=0)
+    m_out = np.mean(implicit_output, axis=0)
+    mark = -np.ones_like(m_out[..., 0])                                       # :383-390
+    conf = np.zeros_like(m_out[..., 0])
+    for t, inst in enumerate(track_instance_ids):
+        score = implicit_output[t][..., output_track_idx]
+        mark[np.logical_and(score >= 0.5, score >= conf)] = inst
+        conf = np.maximum(score, conf)
+    m_out[..., output_track_idx] = mark
+    return m_abs, m_glob, m_out
+
+
+def nn1_label(points_query, pcl_target_xyz, thresh):
+    """utils/geometry.py:444-455 (get_1nn_label): sklearn KDTree, Euclidean."""
+    import sklearn.neighbors
+    kdt = sklearn.neighbors.KDTree(pcl_target_xyz, leaf_size=30, metric='euclidean')
+    dist, ind = kdt.query(points_query, k=1, return_distance=True)
+    return (dist[:, 0] < thresh) * 1, ind
+
+
 def perform_inference(pcl_input, enc_sd, enc_cfg, dec_sd, dec_cfg, min_z, cube_bounds, color_mode,
                       time_idx, num_sample=16384, point_sample_mode='random', batch_size=1024,
                       predict_segmentation=False, track_mode='none', semantic_classes=13,
-                      density_threshold=0.5, data_kind='', cube_mode=4, compress_air=False):
-    assert track_mode in ('none', 'one')                         # :140-142 (one rerun)
+                      density_threshold=0.5, data_kind='', cube_mode=4, compress_air=False,
+                      pcl_input_sem=None, pcl_target_frame=None, point_occupancy_radius=0.2):
     if isinstance(pcl_input, np.ndarray):
         pcl_input = torch.from_numpy(pcl_input).unsqueeze(0)
+    ti = track_channel(color_mode)
+    inst_col = 0 if data_kind == 'greater' else 1
+    if track_mode in ('none', 'one'):                                         # :140-142
+        track_ids = [-1]
+    else:                                                                     # :144-161
+        assert data_kind == 'greater' and pcl_input_sem.shape[-1] == 1
+        sem_np = pcl_input_sem if isinstance(pcl_input_sem, np.ndarray) else pcl_input_sem[0].numpy()
+        sem = torch.from_numpy(sem_np).unsqueeze(0) if isinstance(pcl_input_sem, np.ndarray) else pcl_input_sem
+        ids, counts = np.unique(sem_np, return_counts=True)
+        track_ids = [int(i) for i, c in zip(ids, counts) if i >= 0 and c >= 16]
     points_query = sample_query_points(num_sample, min_z, cube_bounds, time_idx, data_kind,
                                        cube_mode, point_sample_mode)          # :175
-    pcl_abstract, f_global = encoder_forward(enc_sd, enc_cfg, pcl_input)      # :195
-    pcl_abstract, f_global = pcl_abstract[0], f_global[0]
-    outs = []
-    for lo in range(0, points_query.shape[0], batch_size):                    # :204
-        q = torch.from_numpy(points_query[lo:lo + batch_size])
-        o, _ = decoder_forward(dec_sd, dec_cfg, q, pcl_abstract, f_global)    # :211
-        outs.append(squash_outputs(o, color_mode, predict_segmentation, track_mode,
-                                   semantic_classes).numpy())
-    implicit_output = np.concatenate(outs, axis=0)
+    runs_abs, runs_glob, runs_out = [], [], []
+    for inst in track_ids:                                                    # :187
+        if inst >= 0:
+            pcl_input[..., -1] = (sem[..., inst_col] == inst)                 # :190-193
+        pcl_abstract, f_global = encoder_forward(enc_sd, enc_cfg, pcl_input)  # :195
+        pcl_abstract, f_global = pcl_abstract[0], f_global[0]
+        outs = []
+        for lo in range(0, points_query.shape[0], batch_size):                # :204
+            q = torch.from_numpy(points_query[lo:lo + batch_size])
+            o, _ = decoder_forward(dec_sd, dec_cfg, q, pcl_abstract, f_global)    # :211
+            outs.append(squash_outputs(o, color_mode, predict_segmentation, track_mode,
+                                       semantic_classes).numpy())
+        runs_out.append(np.concatenate(outs, axis=0))
+        runs_abs.append(pcl_abstract.numpy())
+        runs_glob.append(f_global.numpy())
+    pcl_abstract, f_global, implicit_output = merge_tracks(track_ids, runs_abs, runs_glob, runs_out, ti)   # :265
     io = np.concatenate([points_query, implicit_output], axis=-1)             # :279
-    solid = io[io[..., 4] >= density_threshold]                               # :283-284
-    air = io[io[..., 4] < density_threshold]
-    if compress_air:                                                          # :299-305
+    keep = io[..., 4] >= density_threshold                                    # :283-284
+    solid, air = io[keep], io[~keep]
+    result = dict(pcl_abstract=pcl_abstract, features_global=f_global, implicit_output=implicit_output,
+                  points_query=points_query)
+    if pcl_target_frame is not None:                                          # :270-276, :285-287
+        labels, nn_idx = nn1_label(points_query[:, :3], pcl_target_frame[..., :3], point_occupancy_radius)
+        nngt = np.concatenate([labels[:, None], pcl_target_frame[nn_idx][:, 0, :]], axis=-1)
+        result['gt_solid'], result['gt_air'] = nngt[keep], nngt[~keep]
+    if compress_air:                                                          # :299-311
         seg = air[..., -semantic_classes:].argmax(axis=-1)
         air = np.concatenate([air[..., :3], air[..., 4:5], seg[..., None]], axis=-1)
-    return dict(output_solid=solid, output_air=air, pcl_abstract=pcl_abstract.numpy(),
-                features_global=f_global.numpy(), implicit_output=implicit_output,
-                points_query=points_query)
+        if pcl_target_frame is not None:
+            result['gt_air'] = np.concatenate([result['gt_air'][..., :1], result['gt_air'][..., 4:5]], axis=-1)
+    result['output_solid'], result['output_air'] = solid, air
+    return result

@@ -193,5 +193,29 @@ def infer_inputs(case):
     return pcl, pa, ia, inf, esd, dsd
 
 
+TRACK_CASES = [
+    dict(name='greater_tracks_gt', kind='greater', n=768, video_len=4, num_sample=1500, batch_size=512,
+         time_idx=1, seed=1840, n_instances=3, n_target=400),
+]
+
+
+def track_inputs(case):
+    """GREATER-layout clip with per-point instance ids (some ids below the 16-point minimum, some -1) and
+    a target frame (x, y, z, instance_id, view_idx, R, G, B, mark_track) for the 1-NN labelling branch."""
+    pa, ia, inf = cfg.model_args(case['kind'], case['n'])
+    pcl = cfg.synthetic_pcl(case['kind'], case['n'], case['video_len'], case['seed'])
+    esd, dsd = cfg.synthetic_weights(pa, ia, case['seed'])
+    rng = _rng(case['seed'] + 7)
+    sem = rng.integers(-1, case['n_instances'], size=(case['n'], 1)).astype(np.float32)
+    sem[:5] = 7.0                      # an instance with fewer than 16 points: must be ignored
+    (x0, x1), (y0, y1), (z0, z1) = cfg.input_cuboid(case['kind'])
+    txyz = rng.uniform([x0, y0, z0], [x1, y1, z1], size=(case['n_target'], 3))
+    rest = np.concatenate([rng.integers(-1, case['n_instances'], size=(case['n_target'], 1)),
+                           rng.integers(0, 3, size=(case['n_target'], 1)), rng.uniform(size=(case['n_target'], 3)),
+                           rng.integers(0, 2, size=(case['n_target'], 1))], axis=1)
+    target = np.concatenate([txyz, rest], axis=1).astype(np.float32)
+    return pcl, sem, target, pa, ia, inf, esd, dsd
+
+
 def as_tensor(a):
     return torch.from_numpy(np.ascontiguousarray(a))

@@ -146,3 +146,22 @@ def test_stable_tie_rule_agrees_with_reference_where_defined(case):
         out, _ = op.decoder_forward(dsd, ia, T(q), T(g['pcl_abstract']), T(g['features_global']))
     out = op.squash_outputs(out, inf['color_mode'], inf['predict_segmentation'], 'none', 13).numpy()
     close(out[~amb], g['implicit_output'][~amb], 1e-4)
+
+
+@pytest.mark.parametrize('case', gc.TRACK_CASES, ids=lambda c: c['name'])
+def test_g11_tracks_and_gt_labels(case):
+    """track_mode 'all' (one rerun per instance id with >= 16 points, multi_track_merge) and the 1-NN
+    ground-truth labelling branch of perform_inference."""
+    pcl, sem, target, pa, ia, inf, esd, dsd = gc.track_inputs(case)
+    res = op.perform_inference(
+        pcl.clone(), esd, pa, dsd, ia, inf['min_z'], inf['cube_bounds'], inf['color_mode'], case['time_idx'],
+        num_sample=case['num_sample'], point_sample_mode='grid', batch_size=case['batch_size'],
+        predict_segmentation=False, track_mode='all', semantic_classes=13, density_threshold=0.5,
+        data_kind='greater', cube_mode=4, compress_air=True, pcl_input_sem=sem.copy(),
+        pcl_target_frame=target.copy(), point_occupancy_radius=0.8)
+    g = load_golden('g11_tracks_' + case['name'])
+    close(res['implicit_output'], g['implicit_output'])
+    close(res['pcl_abstract'], g['pcl_abstract'])
+    assert set(np.unique(res['implicit_output'][:, 4])) <= {-1.0, 0.0, 1.0, 2.0}      # merged mark_track = ids
+    assert res['output_solid'].shape[0] == int(g['n_solid'][0])
+    assert np.array_equal(res['gt_solid'], g['gt_solid']) and np.array_equal(res['gt_air'], g['gt_air'])
