@@ -206,8 +206,26 @@ FUSED_ATTN_DIMS = (288, 416)
 FUSED_ATTN_MAX_K = 14
 
 
-def pt_cross_attn(aq, qpos, apos, idx, kt, vt, P1, c1, wp, w2, b2, p2, c2, out=None):
-    """Fused vector attention (occ4d_pt_cross_attn_f32): agg (n,d)."""
+def pack_w2_bf16x3(w2):
+    """(d, 2d) fp32 attn_mlp[2] weight -> same-shaped fp32 container holding, per 32-wide hidden block
+    and channel, [32 hi | 32 lo] bf16 (hi = bf16(w), lo = bf16(w - hi)) in MFMA fragment order: position
+    16*(2t + half) + j holds hidden 16t + 8(j>>2) + 4half + (j&3)."""
+    d, h2 = w2.shape
+    assert h2 % 32 == 0
+    w2 = w2.detach().float()
+    hi = w2.bfloat16()
+    lo = (w2 - hi.float()).bfloat16()
+    perm = torch.tensor([16 * t + 8 * (j >> 2) + 4 * half + (j & 3)
+                         for t in range(2) for half in range(2) for j in range(8)], device=w2.device)
+    hi = hi.view(d, h2 // 32, 32)[:, :, perm]
+    lo = lo.view(d, h2 // 32, 32)[:, :, perm]
+    packed = torch.cat([hi, lo], dim=2).contiguous()            # (d, blocks, 64) bf16 = 128 B per block
+    return packed.view(torch.float32).reshape(d, h2).contiguous()
+
+
+def pt_cross_attn(aq, qpos, apos, idx, kt, vt, P1, c1, wp, w2, b2, p2, c2, out=None, w2_packed=None):
+    """Fused vector attention (occ4d_pt_cross_attn_f32): agg (n,d).  With w2_packed (pack_w2_bf16x3) the
+    attention-logit GEMM runs on the split-bf16 MFMA path (occ4d_pt_cross_attn_bf16x3_f32)."""
     aq, ld_aq = _aligned_rows(_dev(aq, name='aq'), 'aq')
     kt, ld_kt = _aligned_rows(_dev(kt, name='kt'), 'kt')
     vt, ld_vt = _rows(_dev(vt, name='vt'), 'vt')
@@ -226,9 +244,14 @@ def pt_cross_attn(aq, qpos, apos, idx, kt, vt, P1, c1, wp, w2, b2, p2, c2, out=N
     divisor = float(torch.tensor(math.sqrt(d), dtype=torch.float32))
     # FLOPs this launch executes (useful, unpadded): per pair Wp (32 x 2d) + W2 (2d x d) + P2 (32 x d)
     flops = 2.0 * n * k * (32 * 2 * d + 2 * d * d + 32 * d)
-    _lib.check(_launch('cross_attn', dict(n=n, k=k, d=d), flops, lambda: _lib.lib().occ4d_pt_cross_attn_f32(
+    fn = _lib.lib().occ4d_pt_cross_attn_f32
+    w2_arg = ws[3]
+    if w2_packed is not None:
+        assert w2_packed.shape == ws[3].shape and w2_packed.dtype == torch.float32 and w2_packed.is_contiguous()
+        fn, w2_arg = _lib.lib().occ4d_pt_cross_attn_bf16x3_f32, w2_packed
+    _lib.check(_launch('cross_attn', dict(n=n, k=k, d=d), flops, lambda: fn(
         _ptr(aq), ld_aq, _ptr(qp), qs, _ptr(ap), as_, _ptr(idx), _ptr(kt), ld_kt, _ptr(vt), ld_vt,
-        _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(ws[3]), _ptr(ws[4]), _ptr(ws[5]), _ptr(ws[6]),
+        _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(w2_arg), _ptr(ws[4]), _ptr(ws[5]), _ptr(ws[6]),
         _ptr(o), ldo, n, kt.shape[0], k, d, divisor, _stream())))
     return out
 

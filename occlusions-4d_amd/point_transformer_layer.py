@@ -15,6 +15,8 @@ What runs instead of the reference's ATen ops
   pair GEMM's epilogue.  Merged weights are formed in fp64 and rounded once.
 * softmax over the K neighbours per channel + weighted sum: one fused kernel.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -23,6 +25,9 @@ from . import ops
 
 _PAIR_CHUNK = 32768      # query rows per pass (bounds the (rows*K, 2D) workspace)
 USE_FUSED_ATTENTION = True   # tests flip this to cover the unfused kernel chain as well
+# 'f32' (default): every GEMM exact fp32 on v_mfma_f32_32x32x2_f32.  'bf16x3': the attention-logit GEMM of the
+# fused kernel on split-bf16 MFMAs (occ4d_pt_cross_attn_bf16x3_f32); everything else unchanged.  Opt-in.
+LOGIT_PRECISION = os.environ.get('OCC4D_LOGIT_PRECISION', 'f32')
 
 
 def needs_grad(module, *tensors):
@@ -101,6 +106,8 @@ class PointTransformerLayer(nn.Module):
             wq=wq.float().contiguous(), bq=bq.float().contiguous(),
             wk=(W1 @ self.to_k.weight.detach().to(f64)).float().contiguous(),
             wp=(W1 @ P2).float().contiguous())
+        if self.attn_mlp[2].weight.shape[1] % 32 == 0:
+            m['w2_bf16x3'] = ops.pack_w2_bf16x3(self.attn_mlp[2].weight)
         self._merged[pre is not None] = (key, m)
         return m
 
@@ -177,8 +184,10 @@ class PointTransformerLayer(nn.Module):
             aq = aq_all[lo:hi] if aq_all is not None else ops.linear(x[lo:hi], m['wq'], m['bq'])
             if (self.dim in ops.FUSED_ATTN_DIMS and K <= ops.FUSED_ATTN_MAX_K
                     and self.pos_mlp[0].out_features == 32 and USE_FUSED_ATTENTION):
+                assert LOGIT_PRECISION in ('f32', 'bf16x3'), LOGIT_PRECISION
                 ops.pt_cross_attn(aq, pos[lo:hi], pos2, idx, kt, vt, P1, c1, m['wp'], W2, b2, P2, c2,
-                                  out=agg[lo:hi])
+                                  out=agg[lo:hi],
+                                  w2_packed=m['w2_bf16x3'] if LOGIT_PRECISION == 'bf16x3' else None)
                 continue
             r = ops.pt_pos_hidden(pos[lo:hi], pos2, idx, P1, c1)                # (c*K,32)
             h = ops.linear(r, m['wp'], relu_out=True, add_rows=aq, add_div=K,
