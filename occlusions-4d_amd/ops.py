@@ -339,6 +339,8 @@ def squash(out, ops):
     o, ld = _rows(_dev(out, name='out'), 'out')
     assert o is out
     n, g = out.shape
+    if n == 0:
+        return out
     arr = (C.c_int32 * g)(*[int(v) for v in ops])
     _lib.check(_lib.lib().occ4d_squash_f32(_ptr(out), ld, n, g, arr, _stream()))
     return out

@@ -363,3 +363,49 @@ def test_perform_inference_with_split_bf16_logits(pk, bf16x3_logits):
         point_sample_mode='grid', batch_size=case['batch_size'], predict_segmentation=False, track_mode='none',
         semantic_classes=13, density_threshold=0.5, data_kind='greater', cube_mode=4, compress_air=True)
     close(res['implicit_output'], load_golden('g10_infer_' + case['name'])['implicit_output'], 2e-5)
+
+
+# ------------------------------------------------------------------ edge cases
+def test_empty_and_single_query_batches(pk):
+    case = gc.DEC_CASES[0]
+    q, abstract, fglob, ia, sd = gc.dec_inputs(case)
+    net = pk.implicit.LocalPclResnetFC(**ia).cuda().eval()
+    net.load_state_dict(sd)
+    a, g = dev(abstract), dev(fglob)
+    with torch.no_grad():
+        out0, pen0 = net(dev(q[:0]), a, g, None)
+        assert out0.shape == (0, ia['d_out']) and pen0.shape == (0, ia['d_hidden'])
+        full, _ = net(dev(q[:10]), a, g, None)
+        one, _ = net(dev(q[3:4]), a, g, None)
+    assert (one[0] - full[3]).abs().max() <= 1e-5
+    # the device-resident driver with fewer queries than one mini-batch, and with none at all
+    enc_pa, _, inf = pk.configs.model_args('greater', 512)
+    enc = pk.model.PointCompletionNetV3(**enc_pa).cuda().eval()
+    enc.load_state_dict(pk.configs.fill_state_dict(pk.configs.encoder_param_shapes(enc_pa), 3))
+    pcl = pk.configs.synthetic_pcl('greater', 512, 4, 3).cuda()
+    with torch.no_grad():
+        res = pk.inference.infer_device(pcl, dev(q[:7]), enc, net, 4, 'rgb_nosigmoid')
+        assert res['implicit_output'].shape == (7, 5) and torch.isfinite(res['implicit_output']).all()
+        res0 = pk.inference.infer_device(pcl, dev(q[:0]), enc, net, 4, 'rgb_nosigmoid')
+        assert res0['implicit_output'].shape == (0, 5)
+
+
+def test_minimum_cloud_sizes(pk):
+    """Smallest clouds the architecture admits: every level needs >= its neighbour count."""
+    pa, _, _ = pk.configs.model_args('greater', 432)       # 432 -> 144 -> 48 -> 16 points (K = 16 at the last level)
+    enc = pk.model.PointCompletionNetV3(**pa).cuda().eval()
+    sd = pk.configs.fill_state_dict(pk.configs.encoder_param_shapes(pa), 9)
+    enc.load_state_dict(sd)
+    pcl = pk.configs.synthetic_pcl('greater', 432, 4, 9)
+    from oracle import path as op
+    with torch.no_grad():
+        out, xg, _ = enc(pcl.cuda(), False)
+    ref_out, ref_xg = op.encoder_forward(sd, pa, pcl)
+    assert out.shape == (1, 16, 291)
+    close(out[0], ref_out[0])
+    close(xg[0], ref_xg[0])
+    with pytest.raises(AssertionError):                    # one point fewer at the last level: kNN cannot be served
+        pa2, _, _ = pk.configs.model_args('greater', 405)  # 405 -> 135 -> 45 -> 15
+        enc2 = pk.model.PointCompletionNetV3(**pa2).cuda().eval()
+        with torch.no_grad():
+            enc2(pk.configs.synthetic_pcl('greater', 405, 4, 9).cuda(), False)
