@@ -116,15 +116,20 @@ __global__ __launch_bounds__(TPB) void wgrad_reduce_kernel(const float* __restri
   dw[e] = s;
 }
 
-// column sums: out[c] (+)= sum_i x[i][c]; stage 1 per row chunk, stage 2 reduce (deterministic)
+// column sums: out[c] (+)= sum_i x[i][c]; stage 1 per (row chunk, 64-column strip), stage 2 reduce
+// (deterministic).  Block = 64 columns x 4 row lanes: 256-byte coalesced row segments, 4 rows in flight.
 __global__ __launch_bounds__(TPB) void colsum_partial_kernel(const float* __restrict__ x, int64_t ldx, int n, int d,
                                                              int rows_per_chunk, float* __restrict__ part) {
-  const int c = blockIdx.x * TPB + threadIdx.x;
-  if (c >= d) return;
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   const int r0 = blockIdx.y * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
   float s = 0.f;
-  for (int i = r0; i < r1; ++i) s += x[(int64_t)i * ldx + c];
-  part[(int64_t)blockIdx.y * d + c] = s;
+  if (c < d)
+    for (int i = r0 + rl; i < r1; i += 4) s += x[(int64_t)i * ldx + c];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < d) part[(int64_t)blockIdx.y * d + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
 // out = ref > 0 ? g : 0
@@ -373,7 +378,7 @@ int occ4d_colsum_f32(const float* x, int64_t ldx, int n, int d, float* out, int 
   OCC4D_REQUIRE(x && out && workspace && n >= 1 && d >= 1 && chunks >= 1 && ldx >= d, "occ4d_colsum_f32: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   const int rpc = occ4d::cdiv(n, chunks);
-  colsum_partial_kernel<<<dim3(occ4d::cdiv(d, TPB), chunks), TPB, 0, st>>>(x, ldx, n, d, rpc, workspace);
+  colsum_partial_kernel<<<dim3(occ4d::cdiv(d, 64), chunks), TPB, 0, st>>>(x, ldx, n, d, rpc, workspace);
   wgrad_reduce_kernel<<<grid1d(d), TPB, 0, st>>>(workspace, chunks, d, out, accumulate);
   return occ4d::check_launch("occ4d_colsum_f32");
 }

@@ -388,7 +388,7 @@ def linear_wgrad(g, x, out=None, accumulate=False):
 def colsum(x):
     x, ldx = _rows(_dev(x, name='x'), 'x')
     n, d = x.shape
-    chunks = max(1, min(256, n // 512))
+    chunks = max(1, min(512, n // 256))
     ws = torch.empty((chunks * d,), dtype=torch.float32, device=x.device)
     out = torch.empty((d,), dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().occ4d_colsum_f32(_ptr(x), ldx, n, d, _ptr(out), 0, _ptr(ws), chunks, _stream()))
