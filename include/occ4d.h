@@ -134,14 +134,15 @@ int occ4d_pt_cross_attn_f32(const float* aq, int64_t ld_aq, const float* qpos, i
 
 /* Same kernel with the attention-logit GEMM (w2) on the bf16 MFMA with split operands
  * (h = h_hi + h_lo, w = w_hi + w_lo; three bf16 products, fp32 accumulate), 5.3x the fp32 MFMA rate
- * for that GEMM.  Everything else (Wp, P2, V, softmax, accumulation) stays fp32.  w2_packed: per
- * 32-wide hidden block and channel [32 hi | 32 lo] bf16 in fragment order, same bytes/shape as w2
+ * for that GEMM; the small K = 32 GEMM (wp @ r) that feeds the same logit branch is split the same
+ * way.  Everything on the value path (P2, V, softmax, accumulation) stays fp32.  w2_packed / wp_packed:
+ * per 32-wide block and row [32 hi | 32 lo] bf16 in fragment order, same bytes/shape as w2 / wp
  * (built by the host: occlusions-4d_amd/ops.py:pack_w2_bf16x3).  Opt-in; measured output change
  * <= 1e-6 (the logits are divided by sqrt(d) and soft-maxed). */
 int occ4d_pt_cross_attn_bf16x3_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t qs,
                                    const float* apos, int64_t as, const int32_t* idx,
                                    const float* kt, int64_t ld_kt, const float* vt, int64_t ld_vt,
-                                   const float* P1, const float* c1, const float* wp,
+                                   const float* P1, const float* c1, const float* wp_packed,
                                    const float* w2_packed, const float* b2, const float* p2, const float* c2,
                                    float* agg, int64_t ld_agg, int n, int m, int k, int d,
                                    float divisor, void* stream);

@@ -120,6 +120,20 @@ __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* s
       r[s] = my_valid ? fmaxf(v, 0.f) : 0.f;
     }
   }
+  // split-bf16 pieces of r for GEMM1 (k-step t uses r[8t .. 8t+7]: the same k permutation as GEMM2)
+  u32x4 rs_hi[2], rs_lo[2];
+  if (SPLIT) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        unsigned h0, l0, h1, l1;
+        bf16_split(r[8 * t + 2 * jj], h0, l0);
+        bf16_split(r[8 * t + 2 * jj + 1], h1, l1);
+        rs_hi[t][jj] = h0 | (h1 << 16);
+        rs_lo[t][jj] = l0 | (l1 << 16);
+      }
+  }
   const float* aq_row = a.aq + (int64_t)my_q * a.ld_aq + 4 * half;
   const float* kt_row = a.kt + (int64_t)my_j * a.ld_kt + 4 * half;
 
@@ -188,14 +202,30 @@ __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* s
     if (hb + 1 < NHB) iload(hb + 1, av, kv);    // same registers: consumed just above
 #endif
     __builtin_amdgcn_sched_barrier(0);
-    const float* Wp = W + D * LDW + frag_off;
+    if (SPLIT) {
+      // GEMM1 on split-bf16 MFMAs as well (it feeds only the logit branch): Wp rows are packed
+      // [32 hi | 32 lo] bf16 in fragment order like W2; r was split once (rs_hi / rs_lo).
+      const float* Wps = W + D * LDW + prow * LDW;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 wv = *reinterpret_cast<const f32x4*>(Wp + 8 * g);
-      hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, r[4 * g + 0], hacc, 0, 0, 0);
-      hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, r[4 * g + 1], hacc, 0, 0, 0);
-      hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, r[4 * g + 2], hacc, 0, 0, 0);
-      hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, r[4 * g + 3], hacc, 0, 0, 0);
+      for (int t = 0; t < 2; ++t) {
+        const u32x4 wh = *reinterpret_cast<const u32x4*>(Wps + 4 * (2 * t + half));
+        const u32x4 wl = *reinterpret_cast<const u32x4*>(Wps + 16 + 4 * (2 * t + half));
+        const bf16x8 w_hi = __builtin_bit_cast(bf16x8, wh), w_lo = __builtin_bit_cast(bf16x8, wl);
+        const bf16x8 r_hi = __builtin_bit_cast(bf16x8, rs_hi[t]), r_lo = __builtin_bit_cast(bf16x8, rs_lo[t]);
+        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_lo, r_hi, hacc, 0, 0, 0);
+        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi, r_lo, hacc, 0, 0, 0);
+        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi, r_hi, hacc, 0, 0, 0);
+      }
+    } else {
+      const float* Wp = W + D * LDW + frag_off;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(Wp + 8 * g);
+        hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, r[4 * g + 0], hacc, 0, 0, 0);
+        hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, r[4 * g + 1], hacc, 0, 0, 0);
+        hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, r[4 * g + 2], hacc, 0, 0, 0);
+        hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, r[4 * g + 3], hacc, 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) hacc[i] = fmaxf(hacc[i], 0.f);

@@ -223,7 +223,8 @@ def pack_w2_bf16x3(w2):
     return packed.view(torch.float32).reshape(d, h2).contiguous()
 
 
-def pt_cross_attn(aq, qpos, apos, idx, kt, vt, P1, c1, wp, w2, b2, p2, c2, out=None, w2_packed=None):
+def pt_cross_attn(aq, qpos, apos, idx, kt, vt, P1, c1, wp, w2, b2, p2, c2, out=None, w2_packed=None,
+                  wp_packed=None):
     """Fused vector attention (occ4d_pt_cross_attn_f32): agg (n,d).  With w2_packed (pack_w2_bf16x3) the
     attention-logit GEMM runs on the split-bf16 MFMA path (occ4d_pt_cross_attn_bf16x3_f32)."""
     aq, ld_aq = _aligned_rows(_dev(aq, name='aq'), 'aq')
@@ -245,13 +246,14 @@ def pt_cross_attn(aq, qpos, apos, idx, kt, vt, P1, c1, wp, w2, b2, p2, c2, out=N
     # FLOPs this launch executes (useful, unpadded): per pair Wp (32 x 2d) + W2 (2d x d) + P2 (32 x d)
     flops = 2.0 * n * k * (32 * 2 * d + 2 * d * d + 32 * d)
     fn = _lib.lib().occ4d_pt_cross_attn_f32
-    w2_arg = ws[3]
+    w2_arg, wp_arg = ws[3], ws[2]
     if w2_packed is not None:
         assert w2_packed.shape == ws[3].shape and w2_packed.dtype == torch.float32 and w2_packed.is_contiguous()
-        fn, w2_arg = _lib.lib().occ4d_pt_cross_attn_bf16x3_f32, w2_packed
+        assert wp_packed is not None and wp_packed.shape == ws[2].shape and wp_packed.is_contiguous()
+        fn, w2_arg, wp_arg = _lib.lib().occ4d_pt_cross_attn_bf16x3_f32, w2_packed, wp_packed
     _lib.check(_launch('cross_attn', dict(n=n, k=k, d=d), flops, lambda: fn(
         _ptr(aq), ld_aq, _ptr(qp), qs, _ptr(ap), as_, _ptr(idx), _ptr(kt), ld_kt, _ptr(vt), ld_vt,
-        _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(w2_arg), _ptr(ws[4]), _ptr(ws[5]), _ptr(ws[6]),
+        _ptr(ws[0]), _ptr(ws[1]), _ptr(wp_arg), _ptr(w2_arg), _ptr(ws[4]), _ptr(ws[5]), _ptr(ws[6]),
         _ptr(o), ldo, n, kt.shape[0], k, d, divisor, _stream())))
     return out
 

@@ -108,6 +108,7 @@ class PointTransformerLayer(nn.Module):
             wp=(W1 @ P2).float().contiguous())
         if self.attn_mlp[2].weight.shape[1] % 32 == 0:
             m['w2_bf16x3'] = ops.pack_w2_bf16x3(self.attn_mlp[2].weight)
+            m['wp_bf16x3'] = ops.pack_w2_bf16x3(m['wp']) if m['wp'].shape[1] == 32 else None
         self._merged[pre is not None] = (key, m)
         return m
 
@@ -187,7 +188,8 @@ class PointTransformerLayer(nn.Module):
                 assert LOGIT_PRECISION in ('f32', 'bf16x3'), LOGIT_PRECISION
                 ops.pt_cross_attn(aq, pos[lo:hi], pos2, idx, kt, vt, P1, c1, m['wp'], W2, b2, P2, c2,
                                   out=agg[lo:hi],
-                                  w2_packed=m['w2_bf16x3'] if LOGIT_PRECISION == 'bf16x3' else None)
+                                  w2_packed=m['w2_bf16x3'] if LOGIT_PRECISION == 'bf16x3' else None,
+                                  wp_packed=m['wp_bf16x3'] if LOGIT_PRECISION == 'bf16x3' else None)
                 continue
             r = ops.pt_pos_hidden(pos[lo:hi], pos2, idx, P1, c1)                # (c*K,32)
             h = ops.linear(r, m['wp'], relu_out=True, add_rows=aq, add_div=K,
