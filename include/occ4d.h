@@ -188,6 +188,22 @@ int occ4d_interp_add_f32(float* x, int64_t ldx, const float* cvec, const float* 
  * 0 = identity, 1 = sigmoid, 2 = clamp to [0,1].  In place. */
 int occ4d_squash_f32(float* out, int64_t ld, int n, int g, const int32_t* ops_host, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Device-side pre/post steps of perform_inference.
+ * grid_points: cell-centred query grid (utils/geometry.py:1257-1283), x slowest / z fastest, rows
+ *   (x,y,z,t); fp32 arithmetic in numpy's order, bit-identical to the reference's host grid.
+ * split_count + split_write: density-threshold split (eval/inference.py:279-287) as an
+ *   order-preserving stream compaction; solid rows (x,y,z,t, out[0..g)); air rows the same, or
+ *   (x,y,z, density, argmax over the last n_classes channels) when compress_air (:299-305).
+ *   block_counts: ceil(n/256) ints (becomes the exclusive prefix); total_solid: 1 int (device). */
+int occ4d_grid_points_f32(int nx, int ny, int nz, float x0, float sx, float y0, float sy, float z0, float sz,
+                          float t, float* out, void* stream);
+int occ4d_split_count_f32(const float* implicit_output, int64_t ld, int n, float threshold, int* block_counts,
+                          int* total_solid, void* stream);
+int occ4d_split_write_f32(const float* points_query, const float* implicit_output, int64_t ld, int n, int g,
+                          float threshold, const int* block_offsets, int compress_air, int n_classes,
+                          float* solid, float* air, void* stream);
+
 /* ========================================================================
  * Backward pass (the reference trains through torch autograd over the
  * ATen ops above, train.py:101-118).  Scatter reductions use fp32 atomics.

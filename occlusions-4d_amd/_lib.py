@@ -57,6 +57,11 @@ SIGNATURES = {
     'occ4d_interp_weights_f32': (C.c_int, [_f, C.c_int, C.c_int, _f, _s]),
     'occ4d_interp_add_f32': (C.c_int, [_f, C.c_int64, _f, _f, C.c_int64, _i, _f, C.c_int, C.c_int, C.c_int, _s]),
     'occ4d_squash_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int32), _s]),
+    'occ4d_grid_points_f32': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                        C.c_float, C.c_float, _f, _s]),
+    'occ4d_split_count_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_float, _i, _i, _s]),
+    'occ4d_split_write_f32': (C.c_int, [_f, _f, C.c_int64, C.c_int, C.c_int, C.c_float, _i, C.c_int, C.c_int, _f, _f,
+                                        _s]),
     # backward pass
     'occ4d_linear_wgrad_workspace': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     'occ4d_linear_wgrad_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, C.c_int, C.c_int, C.c_int, _f, C.c_int, _f,

@@ -115,9 +115,9 @@ def perform_inference(pcl_input, pcl_input_sem, pcl_target_frame, networks, devi
         ids, counts = np.unique(sem_numpy, return_counts=True)
         track_instance_ids = [int(i) for i, c in zip(ids, counts) if i >= 0 and c >= 16]
 
-    points_query = geometry.sample_implicit_points_blind_numpy(
-        num_sample, min_z, cube_bounds, time_idx, data_kind, cube_mode, point_sample_mode)
-    queries_dev = torch.from_numpy(points_query).to(device)
+    queries_dev = geometry.sample_implicit_points_blind_device(
+        num_sample, min_z, cube_bounds, time_idx, data_kind, cube_mode, point_sample_mode, device)
+    points_query = queries_dev.cpu().numpy()
     all_abstract, all_global, all_output = [], [], []
     with torch.no_grad():
         for inst_id in track_instance_ids:
@@ -125,7 +125,8 @@ def perform_inference(pcl_input, pcl_input_sem, pcl_target_frame, networks, devi
                 pcl_input[..., -1] = (pcl_input_sem[..., input_inst_idx] == inst_id)
             res = infer_device(pcl_input, queries_dev, pcl_net, implicit_net, batch_size, color_mode,
                                predict_segmentation, track_mode, semantic_classes)
-            all_output.append(res['implicit_output'].cpu().numpy())
+            output_dev = res['implicit_output']
+            all_output.append(output_dev.cpu().numpy())
             all_abstract.append(res['pcl_abstract'].cpu().numpy() if res['pcl_abstract'] is not None else None)
             all_global.append(res['features_global'].cpu().numpy())
         (pcl_abstract, features_global, implicit_output) = multi_track_merge(
@@ -137,15 +138,17 @@ def perform_inference(pcl_input, pcl_input_sem, pcl_target_frame, networks, devi
                                                       device)
             points_nngt = np.concatenate([target_labels[:, None], pcl_target_frame[nn_indices]], axis=-1)
 
-    points_io = np.concatenate([points_query, implicit_output], axis=-1)
-    solid_mask = points_io[..., 4] >= density_threshold
-    solid, air = points_io[solid_mask], points_io[~solid_mask]
-    if compress_air:
-        air_segm = air[..., -semantic_classes:].argmax(axis=-1)
-        air = np.concatenate([air[..., :3], air[..., 4:5], air_segm[..., None]], axis=-1)
+        # density-threshold split + compress_air on the device (:279-305): order-preserving compaction
+        if not (len(track_instance_ids) == 1 and track_instance_ids[0] == -1):   # merged on the host; one upload
+            output_dev = torch.from_numpy(implicit_output).to(device)
+        solid, air = ops.split_solid_air(queries_dev, output_dev, density_threshold, compress_air, semantic_classes)
+        solid, air = solid.cpu().numpy(), air.cpu().numpy()
+        if compress_air:
+            air = air.astype(np.float64)      # the reference's concatenate with the int64 argmax promotes
     result = dict(output_solid=solid, output_air=air, pcl_abstract=pcl_abstract,
                   features_global=features_global, implicit_output=implicit_output, points_query=points_query)
     if gt_available:
+        solid_mask = implicit_output[..., 0] >= density_threshold
         gt_solid, gt_air = points_nngt[solid_mask], points_nngt[~solid_mask]
         if compress_air:
             gt_air = np.concatenate([gt_air[..., :1], gt_air[..., 4:5]], axis=-1)

@@ -348,6 +348,37 @@ def squash(out, ops):
     return out
 
 
+def grid_points(counts, mins, spacings, time_idx, device):
+    """(nx*ny*nz, 4) float32 cell-centred query grid generated on the device (x slowest, z fastest)."""
+    nx, ny, nz = (int(c) for c in counts)
+    out = torch.empty((nx * ny * nz, 4), dtype=torch.float32, device=device)
+    _dev(out, name='out')
+    _lib.check(_lib.lib().occ4d_grid_points_f32(nx, ny, nz, float(mins[0]), float(spacings[0]), float(mins[1]),
+                                                float(spacings[1]), float(mins[2]), float(spacings[2]),
+                                                float(time_idx), _ptr(out), _stream()))
+    return out
+
+
+def split_solid_air(points_query, implicit_output, threshold, compress_air=False, n_classes=13):
+    """Order-preserving split of the decoded queries by density (channel 0) >= threshold.
+    Returns (solid (Ns, 4+G), air (Na, 4+G) or (Na, 5) when compress_air) on the device; one 4-byte
+    device->host read (the solid count) sizes the outputs."""
+    pts = _cont(points_query, 'points_query')
+    o, ld = _rows(_dev(implicit_output, name='implicit_output'), 'implicit_output')
+    n, g = o.shape
+    assert pts.shape == (n, 4)
+    nb = (n + 255) // 256
+    scratch = torch.empty(nb + 1, dtype=torch.int32, device=o.device)
+    st = _stream()
+    _lib.check(_lib.lib().occ4d_split_count_f32(_ptr(o), ld, n, float(threshold), _ptr(scratch), _ptr(scratch[nb:]), st))
+    n_solid = int(scratch[nb].item())
+    solid = torch.empty((n_solid, 4 + g), dtype=torch.float32, device=o.device)
+    air = torch.empty((n - n_solid, 5 if compress_air else 4 + g), dtype=torch.float32, device=o.device)
+    _lib.check(_lib.lib().occ4d_split_write_f32(_ptr(pts), _ptr(o), ld, n, g, float(threshold), _ptr(scratch),
+                                                int(bool(compress_air)), int(n_classes), _ptr(solid), _ptr(air), st))
+    return solid, air
+
+
 # --------------------------------------------------------------------------------------
 # backward-pass kernels (include/occ4d.h, "Backward pass")
 # --------------------------------------------------------------------------------------

@@ -1,0 +1,107 @@
+"""GPU parity for the device-side pre/post steps of perform_inference: query-grid
+generation against the reference's golden grid (G9) and the host generator bit for bit, and the density-threshold
+split / compress_air against the numpy statements the reference executes (eval/inference.py:279-305)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def pk():
+    import occlusions4d_amd
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    occlusions4d_amd._lib.lib()
+    return occlusions4d_amd
+
+
+@pytest.mark.parametrize('case', gc.GRID_CASES, ids=lambda c: c['name'])
+def test_device_grid_is_bit_identical_to_reference_grid(pk, case):
+    g = load_golden('g9_grid')
+    dev = pk.geometry.sample_implicit_points_blind_device(case['num_sample'], case['min_z'], case['cube_bounds'],
+                                                          case['time_idx'], case['kind'], 4, 'grid', 'cuda')
+    assert dev.is_cuda and dev.dtype == torch.float32
+    pts = dev.cpu().numpy()
+    name = case['name']
+    assert pts.shape[0] == int(g[name + '_n'][0])
+    assert np.array_equal(pts[:130], g[name + '_head'])
+    assert np.array_equal(pts[-130:], g[name + '_tail'])
+    assert np.array_equal(pts.astype(np.float64).sum(axis=0), g[name + '_sum'])
+    host = pk.geometry.sample_implicit_points_blind_numpy(case['num_sample'], case['min_z'], case['cube_bounds'],
+                                                          case['time_idx'], case['kind'], 4, 'grid')
+    assert np.array_equal(pts, host)
+
+
+def _numpy_split(points_query, implicit_output, thr, compress, n_cls):
+    points_io = np.concatenate([points_query, implicit_output], axis=-1)
+    mask = points_io[..., 4] >= thr
+    solid, air = points_io[mask], points_io[~mask]
+    if compress:
+        segm = air[..., -n_cls:].argmax(axis=-1)
+        air = np.concatenate([air[..., :3], air[..., 4:5], segm[..., None]], axis=-1)
+    return solid, air
+
+
+@pytest.mark.parametrize('n,g,n_cls,compress,p_solid', [
+    (0, 9, 3, True, 0.5), (1, 9, 3, True, 1.0), (1, 9, 3, False, 0.0), (255, 5, 5, True, 0.3),
+    (256, 18, 13, True, 0.5), (257, 18, 13, False, 0.5), (5000, 9, 9, True, 0.0), (5000, 9, 4, True, 1.0),
+    (70001, 22, 13, True, 0.1), (534528, 9, 3, True, 0.05), (534528, 5, 1, False, 0.7)])
+def test_split_solid_air_matches_numpy(pk, n, g, n_cls, compress, p_solid):
+    rng = np.random.default_rng(n * 31 + g)
+    pts = rng.uniform(-5, 5, size=(n, 4)).astype(np.float32)
+    out = rng.uniform(0, 1, size=(n, g)).astype(np.float32)
+    out[:, 0] = (rng.uniform(size=n) < p_solid) * 0.5 + rng.uniform(0, 0.5, size=n).astype(np.float32) * 0.999
+    if n > 20:
+        out[3, 0] = 0.5                              # exactly on the threshold: solid (>=)
+        out[7, g - n_cls:] = 0.25                    # all classes tie: argmax is the first
+        out[9, 0] = np.float32(0.5) - np.float32(3e-8)
+    out = out.astype(np.float32)
+    solid, air = pk.ops.split_solid_air(torch.from_numpy(pts).cuda(), torch.from_numpy(out).cuda(), 0.5, compress,
+                                        n_cls)
+    ref_solid, ref_air = _numpy_split(pts, out, 0.5, compress, n_cls)
+    assert np.array_equal(solid.cpu().numpy(), ref_solid.astype(np.float32))
+    assert np.array_equal(air.cpu().numpy().astype(np.float64), ref_air.astype(np.float64))
+
+
+def test_split_on_strided_output_view(pk):
+    """implicit_output may be a column slice of a wider buffer (row stride > G)."""
+    rng = np.random.default_rng(5)
+    n = 3000
+    pts = torch.from_numpy(rng.uniform(-5, 5, size=(n, 4)).astype(np.float32)).cuda()
+    wide = torch.from_numpy(rng.uniform(0, 1, size=(n, 16)).astype(np.float32)).cuda()
+    view = wide[:, :9]
+    solid, air = pk.ops.split_solid_air(pts, view, 0.4, True, 3)
+    ref_solid, ref_air = _numpy_split(pts.cpu().numpy(), view.cpu().numpy(), 0.4, True, 3)
+    assert np.array_equal(solid.cpu().numpy(), ref_solid)
+    assert np.array_equal(air.cpu().numpy().astype(np.float64), ref_air)
+
+
+def test_perform_inference_split_matches_reference_rows(pk):
+    """End to end (G10 config 1): the device split returns the reference's solid / air rows -- same counts and
+    same leading rows wherever the density is not within tolerance of the threshold."""
+    case = gc.INFER_CASES[0]
+    g = load_golden('g10_infer_' + case['name'])
+    pcl, pa, ia, inf, esd, dsd = gc.infer_inputs(case)
+    enc = pk.model.PointCompletionNetV3(**pa).cuda()
+    enc.load_state_dict(esd)
+    dec = pk.implicit.LocalPclResnetFC(**ia).cuda()
+    dec.load_state_dict(dsd)
+    res = pk.inference.perform_inference(
+        pcl.clone(), None, None, [enc.eval(), dec.eval()], torch.device('cuda'), 'if', inf['min_z'], inf['cube_bounds'],
+        inf['color_mode'], case['time_idx'], None, sample_implicit=True, num_sample=case['num_sample'],
+        point_sample_mode='grid', batch_size=case['batch_size'], predict_segmentation=inf['predict_segmentation'],
+        track_mode='none', semantic_classes=13, density_threshold=0.5, data_kind=inf['data_kind'], cube_mode=4,
+        compress_air=True)
+    ref_solid, ref_air = _numpy_split(res['points_query'], res['implicit_output'], 0.5, True, 13)
+    assert np.array_equal(res['output_solid'], ref_solid)
+    assert np.array_equal(res['output_air'], ref_air) and res['output_air'].dtype == ref_air.dtype
+    near = int((np.abs(g['implicit_output'][:, 0] - 0.5) < 1e-4).sum())
+    assert abs(res['output_solid'].shape[0] - int(g['n_solid'][0])) <= near
+    if near == 0:
+        assert np.abs(res['output_solid'][:64] - g['solid_head']).max() <= 1e-4
+        assert np.array_equal(res['output_air'][:64, 4], g['air_head'][:, 4])
+        assert np.abs(res['output_air'][:64, :4] - g['air_head'][:, :4]).max() <= 1e-4
