@@ -194,7 +194,8 @@ int occ4d_squash_f32(float* out, int64_t ld, int n, int g, const int32_t* ops_ho
  *   (x,y,z,t); fp32 arithmetic in numpy's order, bit-identical to the reference's host grid.
  * split_count + split_write: density-threshold split (eval/inference.py:279-287) as an
  *   order-preserving stream compaction; solid rows (x,y,z,t, out[0..g)); air rows the same, or
- *   (x,y,z, density, argmax over the last n_classes channels) when compress_air (:299-305).
+ *   (x,y,z, density, argmax over the last n_classes columns of the (x,y,z,t,out) row -- numpy negative-slice
+ *   semantics: a window wider than G reaches into the coordinates) when compress_air (:299-305).
  *   block_counts: ceil(n/256) ints (becomes the exclusive prefix); total_solid: 1 int (device). */
 int occ4d_grid_points_f32(int nx, int ny, int nz, float x0, float sx, float y0, float sy, float z0, float sz,
                           float t, float* out, void* stream);

@@ -90,11 +90,15 @@ __global__ __launch_bounds__(TPB) void split_write_kernel(const float* __restric
     const int64_t rank_air = (int64_t)i - rank_solid;          // rows before i that are not solid
     if (compress) {
       float* d = air + rank_air * 5;
+      // numpy argmax (first maximum) over the last n_cls columns of the concatenated row (x,y,z,t, out...); like
+      // the reference's negative slice, a window wider than the outputs reaches into the coordinates
+      const int width = 4 + g;
+      const int start = width > n_cls ? width - n_cls : 0;
       int best = 0;
-      float bv = o[g - n_cls];
-      for (int c = 1; c < n_cls; ++c) {                        // first maximum (numpy argmax)
-        const float v = o[g - n_cls + c];
-        if (v > bv) { bv = v; best = c; }
+      float bv = start < 4 ? p[start] : o[start - 4];
+      for (int c = start + 1; c < width; ++c) {
+        const float v = c < 4 ? p[c] : o[c - 4];
+        if (v > bv) { bv = v; best = c - start; }
       }
       d[0] = p[0]; d[1] = p[1]; d[2] = p[2]; d[3] = o[0]; d[4] = (float)best;
     } else {
@@ -133,7 +137,7 @@ int occ4d_split_write_f32(const float* points_query, const float* implicit_outpu
                           float* air, void* stream) {
   OCC4D_REQUIRE(points_query && implicit_output && block_offsets && n >= 0 && g >= 1 && ld >= g,
                 "occ4d_split_write_f32: bad arguments");
-  OCC4D_REQUIRE(!compress_air || (n_classes >= 1 && n_classes <= g), "occ4d_split_write_f32: bad n_classes");
+  OCC4D_REQUIRE(!compress_air || n_classes >= 1, "occ4d_split_write_f32: bad n_classes");
   if (n == 0) return OCC4D_OK;
   split_write_kernel<<<occ4d::cdiv(n, TPB), TPB, 0, (hipStream_t)stream>>>(points_query, implicit_output, ld, n, g, threshold,
                                                                           block_offsets, compress_air, n_classes, solid, air);

@@ -367,6 +367,9 @@ def split_solid_air(points_query, implicit_output, threshold, compress_air=False
     o, ld = _rows(_dev(implicit_output, name='implicit_output'), 'implicit_output')
     n, g = o.shape
     assert pts.shape == (n, 4)
+    if n == 0:
+        return (torch.empty((0, 4 + g), dtype=torch.float32, device=o.device),
+                torch.empty((0, 5 if compress_air else 4 + g), dtype=torch.float32, device=o.device))
     nb = (n + 255) // 256
     scratch = torch.empty(nb + 1, dtype=torch.int32, device=o.device)
     st = _stream()

@@ -49,7 +49,7 @@ def _numpy_split(points_query, implicit_output, thr, compress, n_cls):
 @pytest.mark.parametrize('n,g,n_cls,compress,p_solid', [
     (0, 9, 3, True, 0.5), (1, 9, 3, True, 1.0), (1, 9, 3, False, 0.0), (255, 5, 5, True, 0.3),
     (256, 18, 13, True, 0.5), (257, 18, 13, False, 0.5), (5000, 9, 9, True, 0.0), (5000, 9, 4, True, 1.0),
-    (70001, 22, 13, True, 0.1), (534528, 9, 3, True, 0.05), (534528, 5, 1, False, 0.7)])
+    (70001, 22, 13, True, 0.1), (3000, 5, 13, True, 0.4), (3000, 5, 7, True, 0.4), (534528, 9, 3, True, 0.05), (534528, 5, 1, False, 0.7)])
 def test_split_solid_air_matches_numpy(pk, n, g, n_cls, compress, p_solid):
     rng = np.random.default_rng(n * 31 + g)
     pts = rng.uniform(-5, 5, size=(n, 4)).astype(np.float32)
