@@ -153,9 +153,8 @@ def main():
     dec = pk.implicit.LocalPclResnetFC(**ia).to(device).eval()
     enc.load_state_dict(esd)
     dec.load_state_dict(dsd)
-    queries_np = pk.geometry.sample_implicit_points_blind_numpy(
-        NUM_SAMPLE * world, inf['min_z'], inf['cube_bounds'], 3, inf['data_kind'], inf['cube_mode'], 'grid')
-    queries = torch.from_numpy(queries_np).to(device)
+    queries = pk.geometry.sample_implicit_points_blind_device(
+        NUM_SAMPLE * world, inf['min_z'], inf['cube_bounds'], 3, inf['data_kind'], inf['cube_mode'], 'grid', device)
     pcl = pcl_cpu.to(device)
     n_total = queries.shape[0]
     lo, hi = pk.distributed.shard_bounds(n_total, rank, world)
@@ -208,6 +207,24 @@ def main():
             alt = dict(mode='attention-logit GEMM on bf16x3 split MFMA (fp32 accumulate), all else fp32',
                        ms_per_step=1e3 * alt_elapsed / args.steps, value=n_total * args.steps / alt_elapsed,
                        max_abs_diff_vs_f32=float((out_alt - out).abs().max()))
+        # Host-boundary figure (informational, never `value`): the full perform_inference call as the reference's
+        # eval loop makes it -- host point cloud in (H2D), grid generated on the device, encode + decode, split /
+        # compress_air on the device, every result array copied back to host numpy (D2H over PCIe).
+        host_boundary = None
+        if world == 1:
+            reps = 3
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            for _ in range(reps):
+                res = pk.inference.perform_inference(
+                    pcl_cpu.clone(), None, None, [enc, dec], device, 'if', inf['min_z'], inf['cube_bounds'],
+                    inf['color_mode'], 3, None, sample_implicit=True, num_sample=NUM_SAMPLE, point_sample_mode='grid',
+                    batch_size=BATCH, predict_segmentation=inf['predict_segmentation'], track_mode='none',
+                    semantic_classes=13, density_threshold=0.5, data_kind=inf['data_kind'], cube_mode=inf['cube_mode'],
+                    compress_air=True)
+            t_host = (time.perf_counter() - th) / reps
+            host_boundary = dict(ms_per_call=1e3 * t_host, value=res['points_query'].shape[0] / t_host,
+                                 what='perform_inference with host numpy inputs and outputs (PCIe inclusive)')
         # encode share, measured separately (informational)
         torch.cuda.synchronize()
         te = time.perf_counter()
@@ -224,7 +241,7 @@ def main():
 
     if rank == 0:
         m_abs = pk.distributed.abstract_shape(enc, N_POINTS)[0]
-        calls = -(-(hi - lo) // BATCH)
+        calls = -(-(hi - lo) // pk.inference.decode_chunk(BATCH))
         fl = as_written_flops(hi - lo, calls, m_abs, ia['d_out'])
         executed = psum['total_flops'] / (psum['total_ms'] * 1e-3) if psum['total_ms'] > 0 else 0.0
         H, K = 416, 14
@@ -242,13 +259,15 @@ def main():
                                       ', %d per GPU' % (hi - lo) if world > 1 else '', BATCH),
                        'abstract_points': m_abs, 'outputs_per_query': ia['d_out'],
                        'parallelism': 'query-sharded x%d, abstract cloud broadcast' % world,
-                       'decode_streams': pk.inference.DECODE_STREAMS},
+                       'decode_streams': pk.inference.DECODE_STREAMS,
+                       'decode_chunk': pk.inference.decode_chunk(BATCH)},
             'roofline': {
                 'bound': 'mfma', 'achieved': achieved / 1e12, 'peak': FP32_MFMA_PEAK / 1e12, 'unit': 'TFLOP/s',
                 'frac': achieved / FP32_MFMA_PEAK,
-                # HBM bytes per full 32768-query launch from the PMC pass committed as profiles/r01_pmc_final.txt:
-                # (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE correction); not re-measured live
-                'traffic': 232.4e6 if args.kind == 'greater' else None,
+                # HBM bytes per launch from the PMC pass committed as profiles/r01_pmc_final.txt (232.4 MB per 32768
+                # queries: (2 x FETCH_SIZE + WRITE_SIZE) x 1024, gfx950 FETCH_SIZE correction), scaled to the
+                # launch size; not re-measured live
+                'traffic': 232.4e6 * pk.inference.decode_chunk(BATCH) / 32768 if args.kind == 'greater' else None,
                 'traffic_source': 'profiles/r01_pmc_final.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)',
                 'kernel': 'cross_attn_kernel<13> (fused vector attention: pos-MLP + attn-MLP + softmax + '
                           'aggregate, 14 neighbours, D=416)',
@@ -263,6 +282,8 @@ def main():
         }
         if alt is not None:
             line['alt_precision'] = alt
+        if host_boundary is not None:
+            line['host_boundary'] = host_boundary
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.kind, world)
         print(json.dumps(line), flush=True)

@@ -202,6 +202,17 @@ def infer_device(pcl_input, points_query, pcl_net, implicit_net, batch_size, col
 
 
 DECODE_STREAMS = int(os.environ.get('OCC4D_DECODE_STREAMS', '2'))   # 1 = the reference's strictly serial loop
+# The fused attention kernel packs 9 queries per workgroup and one workgroup occupies a CU (129 KB LDS): a mini-batch
+# of 9 * 256 * r queries is exactly r full rounds of the 256 CUs.  The caller's batch_size (a memory knob in the
+# reference) is rounded DOWN to such a multiple (32768 -> 32256: 14 full rounds instead of 14.2 -> 15); every query
+# is still decoded, results do not depend on the split (tests).  0 disables.
+DECODE_ALIGN = int(os.environ.get('OCC4D_DECODE_ALIGN', str(9 * 256)))
+
+
+def decode_chunk(batch_size):
+    if DECODE_ALIGN > 0 and batch_size >= DECODE_ALIGN:
+        return batch_size - batch_size % DECODE_ALIGN
+    return batch_size
 
 
 def decode_batches(implicit_net, points_query, lo, hi, batch_size, pcl_abstract, features_global, out, out_offset=0):
@@ -213,6 +224,7 @@ def decode_batches(implicit_net, points_query, lo, hi, batch_size, pcl_abstract,
     on the caller's stream so the per-scene tables are built (and cached) before the side streams
     start."""
     main = torch.cuda.current_stream()
+    batch_size = decode_chunk(batch_size)
     starts = list(range(lo, hi, batch_size))
     side = [torch.cuda.Stream() for _ in range(DECODE_STREAMS)] if DECODE_STREAMS > 1 and len(starts) > 2 else []
     for bi, b in enumerate(starts):
