@@ -165,6 +165,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
+        pk.ops.check_pending()     # cooperative-FPS status words: a timed-out launch voids the run
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()

@@ -58,6 +58,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
+        pk.ops.check_pending()     # cooperative-FPS status words: a timed-out launch voids the run
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -66,6 +66,17 @@ int occ4d_knn_f32(const float* query, int64_t q_stride, int n_query,
 int occ4d_fps_f32(const float* xyz, int64_t stride, int n, int m,
                   int32_t* out_sorted, int32_t* out_order, void* stream);
 
+/* The same sampling over up to 16 cooperating workgroups (n <= 262144): the dataloader's reduction of
+ * a whole clip to n_points (utils/geometry.py:353-364, torch_cluster.fps on ~172 K points) and the
+ * 28 672-point training clouds.  `start` = index of the first sample (torch_cluster's random_start draws
+ * it; the caller passes the draw).  Indices are bit-identical to occ4d_fps_f32 for start = 0.
+ * workspace: occ4d_fps_coop_workspace_bytes() bytes of device memory, 8-byte aligned, reset by the call
+ * itself (stream-ordered); after completion its LAST 8-byte word is 0, or 1 if a bounded spin timed
+ * out (results undefined).  n_workgroups 0 = automatic. */
+int64_t occ4d_fps_coop_workspace_bytes(void);
+int occ4d_fps_coop_f32(const float* xyz, int64_t stride, int n, int m, int start, int n_workgroups,
+                       int32_t* out_sorted, int32_t* out_order, void* workspace, void* stream);
+
 /* ------------------------------------------------------------------------
  * K3 / K11  torch.nn.Linear on row tiles with fused prologue/epilogue, exact
  * fp32 on v_mfma_f32_32x32x2_f32:

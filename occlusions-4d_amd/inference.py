@@ -145,6 +145,7 @@ def perform_inference(pcl_input, pcl_input_sem, pcl_target_frame, networks, devi
         solid, air = solid.cpu().numpy(), air.cpu().numpy()
         if compress_air:
             air = air.astype(np.float64)      # the reference's concatenate with the int64 argmax promotes
+    ops.check_pending()                      # cooperative-FPS status words (everything above has completed)
     result = dict(output_solid=solid, output_air=air, pcl_abstract=pcl_abstract,
                   features_global=features_global, implicit_output=implicit_output, points_query=points_query)
     if gt_available:

@@ -69,12 +69,11 @@ class DownTransition(torch.nn.Module):
         sampled point.  Depends on coordinates only, so the encoder runs the three levels of this
         chain (the FPS steps are one long dependent chain on a single CU) on a side stream,
         concurrently with the attention / Linear kernels (model.py)."""
-        if self.fps_random_start:
-            raise NotImplementedError('fps_random_start=True (training-time randomness) is not part of the '
-                                      'inference path; the reference forces False at test time '
-                                      '(eval/inference.py:59)')
         n_new = int(np.ceil(p.shape[0] / self.factor))
-        inds = ops.fps(p, n_new)                                       # ascending int32
+        # torch_cluster draws the first sample at random when random_start (training default); the reference
+        # forces False at test time (eval/inference.py:59).  The draw uses torch's global CPU generator.
+        start = int(torch.randint(p.shape[0], (1,)).item()) if self.fps_random_start else 0
+        inds = ops.fps_auto(p, n_new, start=start)                     # ascending int32
         p_sub = ops.gather_rows(p, inds)                               # (n_new,3)
         nn_idx = ops.knn(p_sub, p, self.knn_k, metric=0)               # (n_new,k)
         return (inds, p_sub, nn_idx)

@@ -115,6 +115,68 @@ def fps(xyz, m, return_order=False):
     return (out, order) if return_order else out
 
 
+def fps_coop(xyz, m, start=0, n_workgroups=0, return_order=False, check=True):
+    """Farthest-point sample over up to 16 cooperating workgroups (n <= 262144), first sample = `start`.
+    Returns ascending int32 indices (m) [, selection order (m)].  check=True reads the kernel's status word
+    (one 8-byte device->host read) and raises if a bounded inter-workgroup spin timed out."""
+    p, ps = _rows(_dev(xyz, name='xyz'), 'xyz')
+    out = torch.empty((m,), dtype=torch.int32, device=p.device)
+    order = torch.empty((m,), dtype=torch.int32, device=p.device) if return_order else None
+    ws = torch.empty((_lib.lib().occ4d_fps_coop_workspace_bytes() // 8,), dtype=torch.int64, device=p.device)
+    _lib.check(_lib.lib().occ4d_fps_coop_f32(_ptr(p), ps, p.shape[0], m, int(start), int(n_workgroups), _ptr(out),
+                                             _ptr(order), _ptr(ws), _stream()))
+    if check:
+        if int(ws[-1].item()) != 0:
+            raise RuntimeError(_FPS_TIMEOUT)
+    else:
+        # deferred check without a stall: status word -> pinned host memory in stream order + an event
+        host = torch.empty(1, dtype=torch.int64, pin_memory=True)
+        host.copy_(ws[-1:], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        _pending_status.append((host, ev))
+        if len(_pending_status) > 256:
+            check_pending(wait=False)
+    return (out, order) if return_order else out
+
+
+_FPS_TIMEOUT = ('occ4d_fps_coop_f32: an inter-workgroup wait timed out (device oversubscribed?); the sampled '
+                'indices are undefined')
+_pending_status = []
+
+
+def check_pending(wait=True):
+    """Verifies the status word of the fps_coop(..., check=False) launches issued since the last call.  wait=True
+    blocks on their completion events; wait=False only looks at launches that have already finished (no stall).
+    perform_inference / TrainStep / bench.py call it; raises RuntimeError if any inter-workgroup wait timed out."""
+    keep = []
+    bad = False
+    for host, ev in _pending_status:
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            keep.append((host, ev))
+            continue
+        bad = bad or int(host[0]) != 0
+    _pending_status[:] = keep
+    if bad:
+        raise RuntimeError(_FPS_TIMEOUT)
+
+
+FPS_COOP_MIN_POINTS = 12288     # measured (profiles/time_fps.py): 4779 pts single 1.05 vs coop 1.5 us/step;
+                                # 14336: 1.95 vs 1.74; 28672: 4.40 vs 1.89
+
+
+def fps_auto(xyz, m, start=0):
+    """Ascending FPS indices with the faster kernel for the cloud size: one workgroup with the cloud in registers
+    (fps) below FPS_COOP_MIN_POINTS points and start 0, the cooperative multi-workgroup kernel otherwise."""
+    n = xyz.shape[0]
+    if start == 0 and n < FPS_COOP_MIN_POINTS:
+        return fps(xyz, m)
+    wgs = -(-n // 4096) if n <= 16384 else 16
+    return fps_coop(xyz, m, start=start, n_workgroups=wgs, check=False)
+
+
 def linear(x, w, b=None, relu_in=False, relu_out=False, residual=None, out=None,
            add_rows=None, add_div=1, sub_rows=None, sub_idx=None):
     """y = [relu]( [relu](x) @ w.T + b + add_rows[row // add_div] - sub_rows[sub_idx[row]] ) + residual."""

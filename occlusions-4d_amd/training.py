@@ -16,6 +16,8 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from . import ops
+
 
 def implicit_loss(implicit_output, implicit_target, density_lw=1.0, color_lw=0.0, segmentation_lw=0.0,
                   tracking_lw=0.0, color_mode='rgb', semantic_classes=13):
@@ -79,6 +81,7 @@ class TrainStep:
         return implicit_loss(torch.stack(outs), implicit_target, **self.loss_kwargs)
 
     def __call__(self, pcl_input, points_query, implicit_target):
+        ops.check_pending(wait=False)          # status of earlier steps' cooperative FPS launches (no stall)
         self.optimizer.zero_grad(set_to_none=True)
         loss = self.forward_loss(pcl_input, points_query, implicit_target)
         loss.backward()

@@ -6,8 +6,10 @@ calls these at model/modules.py:133-134 (fps) and :142-143 (knn); the library
 /root/reference and is not installed here, so what follows restates its
 documented behaviour:
 
-* fps(src, batch, ratio, random_start=False): per batch element, start at local
-  index 0, repeatedly take the argmax (first maximal index) of the running
+* fps(src, batch, ratio, random_start): per batch element, start at local
+  index 0 (random_start=False) or at ``torch.randint(n, (1,))`` from torch's global
+  CPU generator (random_start=True; the library's own draw is not reproducible
+  offline), repeatedly take the argmax (first maximal index) of the running
   minimum of squared Euclidean distances to the already-selected set;
   ``ceil(ratio * n)`` samples; indices are global (flattened) and in selection
   order (the reference sorts them afterwards, model/modules.py:135).
@@ -28,7 +30,6 @@ def _sqdist_to(p, i):
 
 
 def fps(src, batch=None, ratio=0.5, random_start=True):
-    assert not random_start, 'oracle restates the deterministic (test-time) branch only'
     src = src.detach()
     n_total = src.shape[0]
     if batch is None:
@@ -42,9 +43,10 @@ def fps(src, batch=None, ratio=0.5, random_start=True):
         # sample count as the library computes it: float32(n) * float32(ratio), ceil
         m = int(torch.ceil(torch.tensor(float(n), dtype=torch.float32)
                            * torch.tensor(ratio, dtype=torch.float32)).item())
+        first = int(torch.randint(n, (1,)).item()) if random_start else 0
         chosen = torch.empty(m, dtype=torch.long)
-        chosen[0] = 0
-        mind = _sqdist_to(p, 0)
+        chosen[0] = first
+        mind = _sqdist_to(p, first)
         for s in range(1, m):
             nxt = int(torch.argmax(mind))
             chosen[s] = nxt

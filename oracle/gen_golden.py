@@ -158,6 +158,18 @@ def main():
              features_global=res['features_global'], gt_solid=res['gt_solid'], gt_air=res['gt_air'],
              n_solid=np.array([res['output_solid'].shape[0]]))
 
+    # G12: dataloader subsample / pad (utils/geometry.py:294-376); the random draws are reproduced by seeding
+    # numpy's and torch's global generators with the case seed (fps start: oracle/cluster.py's torch.randint)
+    g12 = {}
+    for case in gc.SUBSAMPLE_CASES:
+        pcl = gc.subsample_inputs(case)
+        np.random.seed(case['seed'])
+        torch.manual_seed(case['seed'])
+        res = geo.subsample_pad_pcl_torch(t(pcl), case['n_desired'], sample_mode=case['mode'],
+                                          retain_vehped=bool(case.get('retain')), segm_idx=case.get('segm_idx'))
+        g12[case['name']] = res.numpy()
+    save('g12_subsample', **g12)
+
 
 if __name__ == '__main__':
     main()

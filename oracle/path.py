@@ -324,6 +324,49 @@ def sample_query_points(num_sample, min_z, cube_bounds, time_idx, data_kind, cub
 # ----------------------------------------------------------------------------
 # D8: perform_inference   (eval/inference.py:83-325), track_mode none/one
 # ----------------------------------------------------------------------------
+def subsample_pad_pcl(pcl, n_desired, sample_mode='random', subsample_only=False, retain_vehped=False,
+                      segm_idx=None):
+    """utils/geometry.py:294-376: zero-pad a too-small cloud; subsample a too-large one uniformly at random
+    (numpy global stream, sorted indices) or by torch_cluster.fps with ratio n_remain/N - 1e-7 and a random
+    start (oracle/cluster.py: torch global stream), indices sorted; retain_vehped keeps tags 4 and 10 and
+    samples the rest from everything except tag 10 (the reference's masks)."""
+    assert sample_mode in ['random', 'farthest_point']
+    no_batch = pcl.dim() == 2
+    if no_batch:
+        pcl = pcl[None]
+    (B, N, D) = pcl.shape
+    if N < n_desired:
+        if subsample_only:
+            raise RuntimeError('Too few input points: %d vs %d.' % (N, n_desired))
+        result = torch.cat([pcl, torch.zeros((B, n_desired - N, D), dtype=pcl.dtype)], dim=1)
+        return result[0] if no_batch else result
+    if N == n_desired:
+        return pcl[0] if no_batch else pcl
+    assert B == 1
+    n_remain = n_desired
+    if retain_vehped:
+        tags = pcl[0, :, segm_idx].numpy()
+        retain_inds = np.where(np.logical_or(tags == 4, tags == 10))[0]
+        remain_inds = np.where(tags != 10)[0]
+        n_remain -= retain_inds.shape[0]
+    else:
+        remain_inds = np.arange(N)
+    if sample_mode == 'random':
+        inds = np.random.choice(remain_inds, n_remain, replace=False)
+        inds.sort()
+        result = pcl[:, inds]
+    else:
+        assert not retain_vehped
+        inds = torch.sort(cluster.fps(pcl[0, :, :3], None, n_remain / N - 1e-7, True))[0]
+        result = pcl[0][inds].view(B, n_remain, D)
+    if no_batch:
+        result = result[0]
+    if retain_vehped:
+        result = torch.cat([pcl[0][retain_inds], result], dim=0)
+    assert result.shape[0] == n_desired
+    return result
+
+
 def track_channel(color_mode):                                   # utils/utils.py:204-224
     return {'rgb': 4, 'rgb_nosigmoid': 4, 'hsv': 15, 'bins': 10}[color_mode]
 

@@ -217,5 +217,26 @@ def track_inputs(case):
     return pcl, sem, target, pa, ia, inf, esd, dsd
 
 
+# ---------------------------------------------------------------- G12 (dataloader subsample / pad, 8(f) rank 4)
+SUBSAMPLE_CASES = [
+    dict(name='pad_n700_to1024', n=700, d=8, n_desired=1024, mode='random', seed=121),
+    dict(name='equal_n512', n=512, d=8, n_desired=512, mode='farthest_point', seed=122),
+    dict(name='random_n3000_to1024', n=3000, d=8, n_desired=1024, mode='random', seed=123),
+    dict(name='fps_n3000_to1024', n=3000, d=8, n_desired=1024, mode='farthest_point', seed=124),
+    dict(name='fps_n20000_to2048', n=20000, d=9, n_desired=2048, mode='farthest_point', seed=125),
+    dict(name='retain_n4000_to1500', n=4000, d=9, n_desired=1500, mode='random', seed=126, retain=True, segm_idx=8),
+]
+
+
+def subsample_inputs(case):
+    """(N, D) cloud: xyz in the GREATER cuboid, remaining columns uniform; an integer semantic-tag column when the
+    case retains vehicles / pedestrians."""
+    rng = _rng(case['seed'])
+    pcl = rng.uniform(-5.0, 5.0, size=(case['n'], case['d'])).astype(np.float32)
+    if case.get('retain'):
+        pcl[:, case['segm_idx']] = rng.integers(0, 13, size=case['n']).astype(np.float32)
+    return pcl
+
+
 def as_tensor(a):
     return torch.from_numpy(np.ascontiguousarray(a))

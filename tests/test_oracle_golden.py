@@ -165,3 +165,17 @@ def test_g11_tracks_and_gt_labels(case):
     assert set(np.unique(res['implicit_output'][:, 4])) <= {-1.0, 0.0, 1.0, 2.0}      # merged mark_track = ids
     assert res['output_solid'].shape[0] == int(g['n_solid'][0])
     assert np.array_equal(res['gt_solid'], g['gt_solid']) and np.array_equal(res['gt_air'], g['gt_air'])
+
+
+# ------------------------------------------------------------------ G12 dataloader subsample / pad (8(f) rank 4)
+@pytest.mark.parametrize('case', gc.SUBSAMPLE_CASES, ids=lambda c: c['name'])
+def test_subsample_pad_pcl_matches_reference(case):
+    g = load_golden('g12_subsample')
+    pcl = gc.subsample_inputs(case)
+    np.random.seed(case['seed'])
+    torch.manual_seed(case['seed'])
+    res = op.subsample_pad_pcl(T(pcl), case['n_desired'], sample_mode=case['mode'],
+                               retain_vehped=bool(case.get('retain')), segm_idx=case.get('segm_idx'))
+    assert np.array_equal(res.numpy(), g[case['name']])
+    with pytest.raises(RuntimeError):
+        op.subsample_pad_pcl(T(pcl[:10]), 11, subsample_only=True)
