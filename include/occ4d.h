@@ -227,6 +227,11 @@ int occ4d_split_write_f32(const float* points_query, const float* implicit_outpu
 int occ4d_linear_wgrad_workspace(int M, int N, int K, int* splits_out, int64_t* floats_out);
 int occ4d_linear_wgrad_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int M, int N, int K,
                            float* dw, int accumulate, float* workspace, int splits, void* stream);
+/* The same with the bias gradient db[n] (+)= sum_m g[m][n] fused (column sums of the staged g tiles; db may be
+ * NULL) and, when relu_x, relu applied to x on load (weight gradient of a relu_in Linear). */
+int occ4d_linear_wgrad_bias_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int M, int N, int K,
+                                int relu_x, float* dw, float* db, int accumulate, float* workspace, int splits,
+                                void* stream);
 /* out (d) (+)= column sums of x (n,d)  (bias gradients); workspace: chunks*d floats */
 int occ4d_colsum_f32(const float* x, int64_t ldx, int n, int d, float* out, int accumulate,
                      float* workspace, int chunks, void* stream);

@@ -68,6 +68,8 @@ SIGNATURES = {
     'occ4d_linear_wgrad_workspace': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     'occ4d_linear_wgrad_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, C.c_int, C.c_int, C.c_int, _f, C.c_int, _f,
                                          C.c_int, _s]),
+    'occ4d_linear_wgrad_bias_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _f, _f,
+                                              C.c_int, _f, C.c_int, _s]),
     'occ4d_colsum_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, _f, C.c_int, _f, C.c_int, _s]),
     'occ4d_relu_mask_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, C.c_int, C.c_int, _f, C.c_int64, _s]),
     'occ4d_scatter_add_rows_f32': (C.c_int, [_f, C.c_int64, _i, C.c_int, C.c_int, C.c_float, _f, C.c_int64, _s]),

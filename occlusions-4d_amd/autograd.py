@@ -34,9 +34,12 @@ class LinearFn(Function):
             dx = ops.linear(g, w.t().contiguous())
             if relu_in:
                 dx = ops.relu_mask(dx, x)
+        want_db = has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = ops.linear_wgrad(g, ops.relu_mask(x, x) if relu_in else x)
-        if has_b and ctx.needs_input_grad[2]:
+            # one kernel: dW = g^T [relu](x) on the MFMA, db = column sums of the g tiles it stages
+            res = ops.linear_wgrad(g, x, bias=want_db, relu_x=relu_in)
+            (dw, db) = res if want_db else (res, None)
+        elif want_db:
             db = ops.colsum(g)
         if has_res and ctx.needs_input_grad[5]:
             dres = dy

@@ -17,13 +17,16 @@ inline dim3 grid1d(int64_t total) { return dim3((unsigned)((total + TPB - 1) / T
 // Workgroup = 128 n-rows x 32*NT k-columns of dW for one m-chunk; g and x tiles ([16 m] x cols,
 // exactly as they lie in memory) go through LDS; the MFMA A operand is read TRANSPOSED from the
 // g tile (A[i=n][kk=m] = gs[m][n]).  Partials [split][N][K] are summed by wgrad_reduce_kernel.
+// Fused: the bias gradient db[n] = sum_m g[m][n] (column sums of the g tile already staged in LDS; k-block 0
+// only) and relu on the x operand (weight gradient of a relu_in Linear) -- both were separate HBM passes.
 // ------------------------------------------------------------------------------------------
 constexpr int WG_BM = 16;   // contraction (m) depth per tile
 
 template <int NT>
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__ g, int64_t ldg,
                                                        const float* __restrict__ x, int64_t ldx, int M, int N,
-                                                       int K, int m_per_split, float* __restrict__ part) {
+                                                       int K, int m_per_split, float* __restrict__ part,
+                                                       float* __restrict__ part_b, int relu_x) {
   constexpr int BNn = 128, BKk = 32 * NT;
   constexpr int LDG = BNn + 4, LDX = BKk + 4;
   __shared__ __attribute__((aligned(16))) float gs[2][WG_BM * LDG];
@@ -50,6 +53,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__
       const int mm = m0 + f / (BKk / 4), k = k0 + 4 * (f % (BKk / 4));
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (f < WG_BM * BKk / 4 && mm < m_end && k < K) v = *reinterpret_cast<const f32x4*>(x + (int64_t)mm * ldx + k);
+      if (relu_x) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       rx[i] = v;
     }
   };
@@ -77,10 +81,16 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__
   }
   __syncthreads();
   const int col = lane & 31, kh = lane >> 5;
+  const bool do_bias = part_b != nullptr && blockIdx.y == 0 && tid < BNn;
+  float bsum = 0.f;
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     if (t + 1 < nt) gload(m_begin + (t + 1) * WG_BM);
     __builtin_amdgcn_sched_barrier(0);
+    if (do_bias) {
+#pragma unroll
+      for (int mm = 0; mm < WG_BM; ++mm) bsum += gs[buf][mm * LDG + tid];   // rows past m_end are zero-filled
+    }
 #pragma unroll
     for (int s = 0; s < WG_BM / 2; ++s) {
       const float av = gs[buf][(2 * s + kh) * LDG + wave * 32 + col];      // A[i = n][kk = m]
@@ -94,6 +104,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__
     if (t + 1 < nt) sstore(buf ^ 1);
     __syncthreads();
   }
+  if (do_bias && n0 + tid < N) part_b[(int64_t)blockIdx.z * N + n0 + tid] = bsum;
   float* P = part + (int64_t)blockIdx.z * N * K;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -329,9 +340,9 @@ __global__ __launch_bounds__(TPB) void broadcast_rows_kernel(const float* __rest
 
 template <int NT>
 void launch_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx, int M, int N, int K, int splits,
-                  int mps, float* part, hipStream_t st) {
+                  int mps, float* part, float* part_b, int relu_x, hipStream_t st) {
   dim3 grid(occ4d::cdiv(N, 128), occ4d::cdiv(K, 32 * NT), splits);
-  wgrad_kernel<NT><<<grid, 256, 0, st>>>(g, ldg, x, ldx, M, N, K, mps, part);
+  wgrad_kernel<NT><<<grid, 256, 0, st>>>(g, ldg, x, ldx, M, N, K, mps, part, part_b, relu_x);
 }
 
 }  // namespace
@@ -346,12 +357,18 @@ int occ4d_linear_wgrad_workspace(int M, int N, int K, int* splits_out, int64_t* 
   const int cap = M / 256 > 1 ? M / 256 : 1;
   if (splits > cap) splits = cap;
   *splits_out = splits > 1 ? splits : 1;
-  *floats_out = (int64_t)(*splits_out) * N * K;
+  *floats_out = (int64_t)(*splits_out) * N * K + (int64_t)(*splits_out) * N;   // dW partials + db partials
   return OCC4D_OK;
 }
 
 int occ4d_linear_wgrad_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int M, int N, int K, float* dw,
                            int accumulate, float* workspace, int splits, void* stream) {
+  return occ4d_linear_wgrad_bias_f32(g, ldg, x, ldx, M, N, K, 0, dw, nullptr, accumulate, workspace, splits, stream);
+}
+
+int occ4d_linear_wgrad_bias_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int M, int N, int K,
+                                int relu_x, float* dw, float* db, int accumulate, float* workspace, int splits,
+                                void* stream) {
   OCC4D_REQUIRE(g && x && dw && workspace, "occ4d_linear_wgrad_f32: null pointer");
   OCC4D_REQUIRE(M >= 1 && N >= 1 && K >= 1 && splits >= 1, "occ4d_linear_wgrad_f32: bad sizes");
   OCC4D_REQUIRE(N % 4 == 0 && K % 4 == 0 && ldg % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)g % 16) == 0 &&
@@ -360,16 +377,20 @@ int occ4d_linear_wgrad_f32(const float* g, int64_t ldg, const float* x, int64_t 
   OCC4D_REQUIRE(ldg >= N && ldx >= K, "occ4d_linear_wgrad_f32: leading dimension too small");
   hipStream_t st = (hipStream_t)stream;
   const int mps = occ4d::cdiv(occ4d::cdiv(M, splits), WG_BM) * WG_BM;
-  if (K <= 32) launch_wgrad<1>(g, ldg, x, ldx, M, N, K, splits, mps, workspace, st);
-  else if (K <= 64) launch_wgrad<2>(g, ldg, x, ldx, M, N, K, splits, mps, workspace, st);
-  else if (K <= 96) launch_wgrad<3>(g, ldg, x, ldx, M, N, K, splits, mps, workspace, st);
-  else if (K <= 160) launch_wgrad<5>(g, ldg, x, ldx, M, N, K, splits, mps, workspace, st);
-  else if (K <= 288) launch_wgrad<9>(g, ldg, x, ldx, M, N, K, splits, mps, workspace, st);
-  else launch_wgrad<13>(g, ldg, x, ldx, M, N, K, splits, mps, workspace, st);
+  const int64_t nk = (int64_t)N * K;
+  float* part_b = db ? workspace + (int64_t)splits * nk : nullptr;
+#define OCC4D_WGRAD(NT) launch_wgrad<NT>(g, ldg, x, ldx, M, N, K, splits, mps, workspace, part_b, relu_x, st)
+  if (K <= 32) OCC4D_WGRAD(1);
+  else if (K <= 64) OCC4D_WGRAD(2);
+  else if (K <= 96) OCC4D_WGRAD(3);
+  else if (K <= 160) OCC4D_WGRAD(5);
+  else if (K <= 288) OCC4D_WGRAD(9);
+  else OCC4D_WGRAD(13);
+#undef OCC4D_WGRAD
   int rc = occ4d::check_launch("occ4d_linear_wgrad_f32");
   if (rc) return rc;
-  const int64_t nk = (int64_t)N * K;
   wgrad_reduce_kernel<<<grid1d(nk), TPB, 0, st>>>(workspace, splits, nk, dw, accumulate);
+  if (db) wgrad_reduce_kernel<<<grid1d(N), TPB, 0, st>>>(part_b, splits, N, db, accumulate);
   return occ4d::check_launch("occ4d_linear_wgrad_f32(reduce)");
 }
 

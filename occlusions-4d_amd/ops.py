@@ -163,8 +163,8 @@ def check_pending(wait=True):
         raise RuntimeError(_FPS_TIMEOUT)
 
 
-FPS_COOP_MIN_POINTS = 12288     # measured (profiles/time_fps.py): 4779 pts single 1.05 vs coop 1.5 us/step;
-                                # 14336: 1.95 vs 1.74; 28672: 4.40 vs 1.89
+FPS_COOP_MIN_POINTS = 16385     # measured (profiles/time_fps.py): 4779 pts single 1.05 vs coop 1.5 us/step;
+                                # 14336: 1.95 vs 1.74 alone but no gain inside the encoder; 28672: 4.40 vs 1.89
 
 
 def fps_auto(xyz, m, start=0):
@@ -452,8 +452,9 @@ def _cont(t, name='tensor'):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def linear_wgrad(g, x, out=None, accumulate=False):
-    """dW (N,K) (+)= g^T x with g (M,N), x (M,K)."""
+def linear_wgrad(g, x, out=None, accumulate=False, bias=False, relu_x=False):
+    """dW (N,K) (+)= g^T x with g (M,N), x (M,K) [x -> relu(x) when relu_x].  bias=True also returns
+    db (N) = column sums of g, accumulated from the g tiles the kernel stages anyway: (dW, db)."""
     g = _cont(g, 'g')
     x = _cont(x, 'x')
     M, N = g.shape
@@ -469,18 +470,24 @@ def linear_wgrad(g, x, out=None, accumulate=False):
     ws = torch.empty((floats.value,), dtype=torch.float32, device=g.device)
     direct = out is not None and n4 == N and k4 == K and out.is_contiguous()
     dw = out if direct else torch.empty((n4, k4), dtype=torch.float32, device=g.device)
-    _lib.check(_lib.lib().occ4d_linear_wgrad_f32(_ptr(g), n4, _ptr(x), k4, M, n4, k4, _ptr(dw),
-                                                 int(accumulate and direct), _ptr(ws), splits.value, _stream()))
+    db = torch.empty((n4,), dtype=torch.float32, device=g.device) if bias else None
+    assert not (bias and accumulate), 'linear_wgrad: bias gradient with accumulate is not supported'
+    _lib.check(_lib.lib().occ4d_linear_wgrad_bias_f32(_ptr(g), n4, _ptr(x), k4, M, n4, k4, int(relu_x), _ptr(dw),
+                                                      _ptr(db), int(accumulate and direct), _ptr(ws), splits.value,
+                                                      _stream()))
+    if bias:
+        db = db[:N]
     if direct:
-        return out
+        return (out, db) if bias else out
     dw = dw[:N, :K]
     if out is not None:
         if accumulate:
             out += dw
         else:
             out.copy_(dw)
-        return out
-    return dw.contiguous()
+        return (out, db) if bias else out
+    dw = dw.contiguous()
+    return (dw, db) if bias else dw
 
 
 def colsum(x):
