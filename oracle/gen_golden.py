@@ -170,6 +170,20 @@ def main():
         g12[case['name']] = res.numpy()
     save('g12_subsample', **g12)
 
+    # G13: GuidedImplicitPointSampler.forward (utils/geometry.py:578-1105) on CPU; the random draws are replayed
+    # by seeding numpy's and torch's global generators with the case seed
+    class _Log:
+        def warning(self, *a, **k):
+            pass
+    for case in gc.SAMPLER_CASES:
+        frames, sizes, valo, num_valo = gc.sampler_inputs(case)
+        sampler = geo.GuidedImplicitPointSampler(_Log(), **gc.sampler_config(case))
+        np.random.seed(case['seed'])
+        torch.manual_seed(case['seed'])
+        res = sampler([t(f) for f in frames], [t(z) for z in sizes], t(valo), t(num_valo), case['time_idx'])
+        save('g13_sampler_' + case['name'], **{k: v.numpy() for k, v in zip(
+            ['solid_input', 'air_input', 'solid_target', 'air_target', 'solid_sbs', 'air_sbs'], res)})
+
 
 if __name__ == '__main__':
     main()

@@ -238,5 +238,61 @@ def subsample_inputs(case):
     return pcl
 
 
+# ---------------------------------------------------------------- G13 (training-time point sampler, 8(f) rank 2)
+SAMPLER_CASES = [
+    dict(name='greater_none', kind='greater', bias='none', frames=3, m=2500, num_solid=512, num_air=768,
+         time_idx=1, segm=False, seed=131),
+    dict(name='greater_moving', kind='greater', bias='moving', frames=3, m=2500, num_solid=512, num_air=768,
+         time_idx=0, segm=False, seed=132),
+    dict(name='carla_all', kind='carla', bias='low_moving_vehped_ivalo_sembal', frames=3, m=5000, num_solid=640,
+         num_air=960, time_idx=2, segm=True, seed=133),
+    dict(name='carla_vehped_batch2', kind='carla', bias='vehped', frames=2, m=4000, num_solid=256, num_air=300,
+         time_idx=1, segm=True, seed=134, batch=2),
+]
+
+
+def sampler_config(case):
+    return dict(min_z=-1.0, cube_bounds=5.0 if case['kind'] == 'greater' else 16.0, point_occupancy_radius=0.2,
+                num_solid=case['num_solid'], num_air=case['num_air'], predict_segmentation=case['segm'],
+                semantic_classes=13, predict_tracking=False, data_kind=case['kind'], point_sample_bias=case['bias'],
+                cube_mode=4)
+
+
+def sampler_inputs(case):
+    """List-T of (B, M, E) target frames + sizes + vehicle/pedestrian ids.  A static background (shared by all
+    frames, jittered per frame) plus a blob that moves between frames, so that 'moving' finds dynamic regions.
+    GREATER rows: x,y,z,instance,view,R,G,B,mark (E=9); CARLA rows: x,y,z,cos,instance,semantic,view,R,G,B,mark."""
+    rng = _rng(case['seed'])
+    B, M, T = case.get('batch', 1), case['m'], case['frames']
+    carla = case['kind'] == 'carla'
+    lo, hi = (np.array([-5.0, -5.0, -1.0]), np.array([5.0, 5.0, 5.0])) if not carla else \
+        (np.array([-6.0, -16.0, -1.0]), np.array([42.0, 16.0, 6.4]))         # a little beyond the CARLA output cuboid
+    frames, sizes = [], []
+    n_blob = M // 5
+    base = rng.uniform(lo, hi, size=(B, M - n_blob, 3))
+    for t in range(T):
+        centre = lo + (hi - lo) * (0.3 + 0.2 * t)
+        blob = centre + rng.normal(scale=0.6, size=(B, n_blob, 3))
+        xyz = np.concatenate([base + rng.normal(scale=0.005, size=base.shape), blob], axis=1)
+        inst = rng.integers(-1, 6, size=(B, M, 1)).astype(np.float64)
+        view = rng.integers(0, 3, size=(B, M, 1)).astype(np.float64)
+        rgb = rng.uniform(size=(B, M, 3))
+        mark = rng.integers(0, 2, size=(B, M, 1)).astype(np.float64)
+        if carla:
+            cos = rng.uniform(-1, 1, size=(B, M, 1))
+            sem = rng.integers(0, 15, size=(B, M, 1)).astype(np.float64)          # 13, 14 map to "other"
+            rows = np.concatenate([xyz, cos, inst, sem, view, rgb, mark], axis=-1)
+        else:
+            rows = np.concatenate([xyz, inst, view, rgb, mark], axis=-1)
+        rows = rows.astype(np.float32)
+        for b in range(B):                                                     # shuffled clouds, as the loader makes them
+            rows[b] = rows[b][rng.permutation(M)]
+        frames.append(rows)
+        sizes.append(np.full((B,), M - 7 * t, dtype=np.int64))               # a few padded rows at the end
+    valo = np.tile(np.array([[0, 2, 5, 0, 0, 0]], dtype=np.int64), (B, 1))
+    num_valo = np.full((B,), 3, dtype=np.int64)
+    return frames, sizes, valo, num_valo
+
+
 def as_tensor(a):
     return torch.from_numpy(np.ascontiguousarray(a))
