@@ -212,6 +212,15 @@ int occ4d_grid_points_f32(int nx, int ny, int nz, float x0, float sx, float y0, 
                           float t, float* out, void* stream);
 int occ4d_split_count_f32(const float* implicit_output, int64_t ld, int n, float threshold, int* block_counts,
                           int* total_solid, void* stream);
+/* Generic order-preserving row compaction (training-time sampler, filter_air_solid_gap utils/geometry.py:1190-1194):
+ * keep row i when key[i] >= threshold (key[i] > threshold when strict).  compact_count fills block_counts
+ * (ceil(n/256) ints -> exclusive prefix) and *total_kept (device int); compact_rows writes the kept rows
+ * (row stride d) and, optionally, their keys. */
+int occ4d_compact_count_f32(const float* key, int64_t ld, int n, float threshold, int strict, int* block_counts,
+                            int* total_kept, void* stream);
+int occ4d_compact_rows_f32(const float* src, int64_t ld, int n, int d, const float* key, int64_t ld_key,
+                           float threshold, int strict, const int* block_offsets, float* out_rows, float* out_key,
+                           void* stream);
 int occ4d_split_write_f32(const float* points_query, const float* implicit_output, int64_t ld, int n, int g,
                           float threshold, const int* block_offsets, int compress_air, int n_classes,
                           float* solid, float* air, void* stream);

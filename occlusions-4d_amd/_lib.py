@@ -62,6 +62,9 @@ SIGNATURES = {
     'occ4d_grid_points_f32': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                         C.c_float, C.c_float, _f, _s]),
     'occ4d_split_count_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_float, _i, _i, _s]),
+    'occ4d_compact_count_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_float, C.c_int, _i, _i, _s]),
+    'occ4d_compact_rows_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, _f, C.c_int64, C.c_float, C.c_int, _i, _f, _f,
+                                         _s]),
     'occ4d_split_write_f32': (C.c_int, [_f, _f, C.c_int64, C.c_int, C.c_int, C.c_float, _i, C.c_int, C.c_int, _f, _f,
                                         _s]),
     # backward pass

@@ -25,12 +25,13 @@ __global__ __launch_bounds__(TPB) void grid_points_kernel(int nx, int ny, int nz
   reinterpret_cast<float4*>(out)[i] = v;
 }
 
-// pass 1: per block of 256 rows, number of solid rows (density >= threshold)
+// pass 1: per block of 256 rows, number of kept rows (key >= threshold, or key > threshold when strict)
 __global__ __launch_bounds__(TPB) void split_count_kernel(const float* __restrict__ dens, int64_t ld, int n,
-                                                          float threshold, int* __restrict__ block_counts) {
+                                                          float threshold, int strict, int* __restrict__ block_counts) {
   __shared__ int s_cnt[TPB / 64];
   const int i = blockIdx.x * TPB + threadIdx.x;
-  const bool solid = i < n && dens[(int64_t)i * ld] >= threshold;
+  const float kv = i < n ? dens[(int64_t)i * ld] : 0.f;
+  const bool solid = i < n && (strict ? kv > threshold : kv >= threshold);
   const unsigned long long m = __ballot(solid);
   if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(m);
   __syncthreads();
@@ -109,6 +110,30 @@ __global__ __launch_bounds__(TPB) void split_write_kernel(const float* __restric
   }
 }
 
+// keep the rows whose key passes the threshold, in order: out_rows[rank] = src[i][0..d), out_key[rank] = key[i]
+// (filter_air_solid_gap, utils/geometry.py:1190-1194)
+__global__ __launch_bounds__(TPB) void compact_rows_kernel(const float* __restrict__ src, int64_t ld, int n, int d,
+                                                           const float* __restrict__ key, int64_t ldk, float threshold,
+                                                           int strict, const int* __restrict__ block_offsets,
+                                                           float* __restrict__ out_rows, float* __restrict__ out_key) {
+  __shared__ int s_pre[TPB / 64];
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float kv = i < n ? key[(int64_t)i * ldk] : 0.f;
+  const bool keep = i < n && (strict ? kv > threshold : kv >= threshold);
+  const unsigned long long m = __ballot(keep);
+  if (lane == 0) s_pre[wave] = __popcll(m);
+  __syncthreads();
+  if (!keep) return;
+  int before = 0;
+  for (int w = 0; w < wave; ++w) before += s_pre[w];
+  const int64_t rank = block_offsets[blockIdx.x] + before + __popcll(m & ((1ull << lane) - 1ull));
+  const float* p = src + (int64_t)i * ld;
+  float* o = out_rows + rank * d;
+  for (int c = 0; c < d; ++c) o[c] = p[c];
+  if (out_key) out_key[rank] = kv;
+}
+
 }  // namespace
 
 extern "C" {
@@ -124,12 +149,28 @@ int occ4d_grid_points_f32(int nx, int ny, int nz, float x0, float sx, float y0, 
 
 int occ4d_split_count_f32(const float* implicit_output, int64_t ld, int n, float threshold, int* block_counts,
                           int* total_solid, void* stream) {
-  OCC4D_REQUIRE(implicit_output && block_counts && total_solid && n >= 0 && ld >= 1, "occ4d_split_count_f32: bad arguments");
+  return occ4d_compact_count_f32(implicit_output, ld, n, threshold, 0, block_counts, total_solid, stream);
+}
+
+int occ4d_compact_count_f32(const float* key, int64_t ld, int n, float threshold, int strict, int* block_counts,
+                            int* total_kept, void* stream) {
+  OCC4D_REQUIRE(key && block_counts && total_kept && n >= 0 && ld >= 1, "occ4d_compact_count_f32: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   const int nb = occ4d::cdiv(n, TPB);
-  if (nb > 0) split_count_kernel<<<nb, TPB, 0, st>>>(implicit_output, ld, n, threshold, block_counts);
-  split_scan_kernel<<<1, 1024, 0, st>>>(block_counts, nb, total_solid);
-  return occ4d::check_launch("occ4d_split_count_f32");
+  if (nb > 0) split_count_kernel<<<nb, TPB, 0, st>>>(key, ld, n, threshold, strict, block_counts);
+  split_scan_kernel<<<1, 1024, 0, st>>>(block_counts, nb, total_kept);
+  return occ4d::check_launch("occ4d_compact_count_f32");
+}
+
+int occ4d_compact_rows_f32(const float* src, int64_t ld, int n, int d, const float* key, int64_t ld_key,
+                           float threshold, int strict, const int* block_offsets, float* out_rows, float* out_key,
+                           void* stream) {
+  OCC4D_REQUIRE(src && key && block_offsets && n >= 0 && d >= 1 && ld >= d && ld_key >= 1,
+                "occ4d_compact_rows_f32: bad arguments");
+  if (n == 0) return OCC4D_OK;
+  compact_rows_kernel<<<occ4d::cdiv(n, TPB), TPB, 0, (hipStream_t)stream>>>(src, ld, n, d, key, ld_key, threshold, strict,
+                                                                           block_offsets, out_rows, out_key);
+  return occ4d::check_launch("occ4d_compact_rows_f32");
 }
 
 int occ4d_split_write_f32(const float* points_query, const float* implicit_output, int64_t ld, int n, int g,

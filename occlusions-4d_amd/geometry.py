@@ -143,3 +143,281 @@ def sample_implicit_points_blind_numpy(num_sample, min_z, cube_bounds, time_idx,
         raise ValueError(point_sample_mode)
     t = np.full((n, 1), time_idx, dtype=np.float32)
     return np.concatenate([xyz, t], axis=-1)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Training-time point sampler: utils/geometry.py:562-1196 of the reference.
+# The heavy part -- 1-NN distances of up to ~20 K candidates against ~57 K target points and the selection that
+# follows -- runs on the kNN and compaction kernels; index draws, bias bookkeeping and tensor glue stay on the
+# host / in torch.  Every random number comes from torch's or numpy's GLOBAL CPU generator in the reference's
+# call order (the reference draws the uniform air points from the device generator when it runs on a GPU; on
+# CPU it uses the same CPU generator as here), so equal seeds reproduce the reference's CPU results bit for bit.
+# --------------------------------------------------------------------------------------------------------------
+def sample_random_uniform_3ball(num_points, max_radius, min_radius=0.0):
+    """(N,3) CPU tensor of points uniform in the ball shell min_radius <= |v| <= max_radius."""
+    uvw = torch.nn.functional.normalize(torch.randn(num_points, 3, dtype=torch.float32), p=2, dim=-1)
+    radius = torch.tensor(np.cbrt(np.random.rand(num_points).astype(np.float32)))
+    radius = radius * (max_radius - min_radius) + min_radius
+    return uvw * radius[:, None]
+
+
+def filter_pcl_bounds_torch(pcl, x_min=-10.0, x_max=10.0, y_min=-10.0, y_max=10.0, z_min=-10.0, z_max=10.0):
+    mask_x = torch.logical_and(x_min <= pcl[..., 0], pcl[..., 0] <= x_max)
+    mask_y = torch.logical_and(y_min <= pcl[..., 1], pcl[..., 1] <= y_max)
+    mask_z = torch.logical_and(z_min <= pcl[..., 2], pcl[..., 2] <= z_max)
+    return pcl[torch.logical_and(torch.logical_and(mask_x, mask_y), mask_z)]
+
+
+_CARLA_OUTPUT_SCALE = {1: (2.0, 1.0, 0.5), 2: (2.4, 0.8, 0.4), 3: (2.2, 1.0, 0.4), 4: (2.5, 1.0, 0.4)}
+
+
+def filter_pcl_bounds_carla_output_torch(pcl, min_z=-0.5, other_bounds=16.0, padding=0.0, cube_mode=4):
+    sx, sy, sz = _CARLA_OUTPUT_SCALE[cube_mode]
+    return filter_pcl_bounds_torch(pcl, x_min=0.0 - padding, x_max=other_bounds * sx + padding,
+                                   y_min=-other_bounds * sy - padding, y_max=other_bounds * sy + padding,
+                                   z_min=min_z, z_max=other_bounds * sz)
+
+
+def get_vehped_points(pcl, segm_idx):
+    return torch.cat([pcl[pcl[..., segm_idx] == 4], pcl[pcl[..., segm_idx] == 10]], dim=0)
+
+
+def sample_implicit_points_blind_torch(data_kind, num_sample, cube_mode, cube_bounds, min_z, device):
+    """(N,3) uniform xyz inside the output cuboid, drawn on the host generator and uploaded."""
+    if data_kind == 'greater':
+        xy = torch.rand((num_sample, 2)) * cube_bounds * 2.0 - cube_bounds
+        z = torch.rand((num_sample, 1)) * (cube_bounds - min_z) + min_z
+        pts = torch.cat([xy, z], dim=-1)
+    elif data_kind == 'carla':
+        if cube_mode not in _CARLA_OUTPUT_SCALE:
+            raise ValueError()
+        sx, sy, sz = _CARLA_OUTPUT_SCALE[cube_mode]
+        x = torch.rand((num_sample, 1)) * cube_bounds * sx
+        y = torch.rand((num_sample, 1)) * cube_bounds * (2.0 * sy) - cube_bounds * sy
+        z = torch.rand((num_sample, 1)) * (cube_bounds * sz - min_z) + min_z
+        pts = torch.cat([x, y, z], dim=-1)
+    else:
+        raise ValueError()
+    return pts.to(device)
+
+
+def filter_air_solid_gap(to_filter, target_coords, target_slice_size, point_occupancy_radius):
+    """Rows of to_filter (N,D) whose nearest target point is farther than the radius -> (rows kept, their 1-NN
+    distances, kept fraction).  The reference bounds memory by taking the minimum over target slices; the
+    streaming kNN kernel never materialises N x M, so target_slice_size is accepted and unused (the minimum over
+    slices IS the global 1-NN distance)."""
+    _, dist = ops.knn(to_filter, target_coords, 1, metric=1, return_dist=True)
+    dist = dist[:, 0]
+    kept, kept_dist = ops.compact_rows(to_filter, dist, point_occupancy_radius, strict=True)
+    ratio = torch.tensor(kept.shape[0] / max(1, to_filter.shape[0]), device=to_filter.device)
+    return (kept, kept_dist, ratio)
+
+
+def _take(rows, cpu_inds):
+    """rows[cpu_inds] for a CPU LongTensor of indices, on the gather kernel."""
+    return ops.gather_rows(rows, cpu_inds.to(torch.int32).to(rows.device))
+
+
+class GuidedImplicitPointSampler(torch.nn.Module):
+    """Training-time sampler of solid / air supervision points (no learnable parameters).  Same constructor and
+    forward() as the reference class; target point clouds are CUDA tensors."""
+
+    def __init__(self, logger, min_z=-1.0, cube_bounds=10.0, point_occupancy_radius=0.25, num_solid=1024,
+                 num_air=1024, predict_segmentation=False, semantic_classes=13, predict_tracking=False,
+                 data_kind='', point_sample_bias='none', cube_mode=4):
+        super().__init__()
+        self.logger = logger
+        self.min_z, self.cube_bounds = min_z, cube_bounds
+        self.point_occupancy_radius = point_occupancy_radius
+        self.num_solid, self.num_air = num_solid, num_air
+        self.predict_segmentation, self.semantic_classes = predict_segmentation, semantic_classes
+        self.predict_tracking = predict_tracking
+        self.data_kind, self.point_sample_bias, self.cube_mode = data_kind, point_sample_bias, cube_mode
+        self.low_prefer_min_z, self.low_prefer_max_z = 0.0, 2.0
+
+    def forward(self, pcl_target, pcl_target_size, valo_ids, num_valo_ids, time_idx):
+        """pcl_target: list-T of (B,M,E); returns (solid_input (B,S,4), air_input (B,A,4), solid_target (B,S,6),
+        air_target (B,A,6), solid_sbs (B,6), air_sbs (B,4))."""
+        frame, sizes = pcl_target[time_idx], pcl_target_size[time_idx]
+        (B, M, E) = frame.shape
+        assert torch.all(sizes <= M)
+        if self.data_kind == 'greater':
+            assert E == 9
+        elif self.data_kind == 'carla':
+            assert E == 11
+        other = other_sizes = None
+        if len(pcl_target) > 1:
+            other_time = np.random.randint(len(pcl_target) - 1)
+            if other_time == time_idx:
+                other_time += 1
+            other, other_sizes = pcl_target[other_time], pcl_target_size[other_time]
+        carla = self.data_kind == 'carla'
+        outs = [[] for _ in range(6)]
+        for i in range(B):
+            tgt = frame[i, :int(sizes[i].item())]
+            ids = sorted(list(valo_ids[i, :int(num_valo_ids[i].item())].detach().cpu().numpy()))
+            if carla:
+                tgt = filter_pcl_bounds_carla_output_torch(tgt, min_z=self.min_z, other_bounds=self.cube_bounds,
+                                                           cube_mode=self.cube_mode)
+            if tgt.shape[0] < 256:
+                raise RuntimeError(f'Invalid due to cur_tgt_pcl_count: {tgt.shape[0]}')
+            max_slice = int((2 ** 27) // self.num_air)
+            used = tgt.shape[0] // int(np.ceil(tgt.shape[0] / max_slice)) + 1
+            tgt_unique = other_unique = None
+            if 'moving' in self.point_sample_bias:
+                oth_count = int(other_sizes[i].item())
+                oth = other[i, :oth_count]
+                if carla:
+                    oth = filter_pcl_bounds_carla_output_torch(oth, min_z=self.min_z, other_bounds=self.cube_bounds,
+                                                               cube_mode=self.cube_mode)
+                    oth_count = tgt.shape[0]            # sic (utils/geometry.py:704)
+                if oth_count < 256:
+                    raise RuntimeError(f'Invalid due to cur_other_pcl_count: {oth_count}')
+                tgt_sub, oth_sub = tgt[:used], oth[:used]
+                r2 = self.point_occupancy_radius * 2.0
+                tgt_unique = filter_air_solid_gap(tgt_sub, oth_sub[..., :3], used, r2)[0]
+                other_unique = filter_air_solid_gap(oth_sub, tgt_sub[..., :3], used, r2)[0]
+            (sq, st, ss) = self.construct_solid_input_target(tgt, tgt_unique, ids, time_idx)
+            (aq, at, as_) = self.construct_air_input_target(tgt, other_unique, sq, ids, time_idx)
+            for lst, v in zip(outs, (sq, aq, st, at, ss, as_)):
+                lst.append(v)
+        return tuple(torch.stack(v) for v in outs)
+
+    def construct_solid_input_target(self, cur_tgt_pcl, cur_tgt_unique, cur_valo_ids, time_idx):
+        tgt = cur_tgt_pcl
+        carla = self.data_kind == 'carla'
+        inst_idx, segm_idx, view_idx = (4, 5, 6) if carla else (3, 3, 4)
+        bias = self.point_sample_bias
+        shares = torch.tensor([1.0, 0.0, 0.0, 0.0, 0.0, 0.0])     # regular, low, moving, vehped, ivalo, sembal
+        if 'low' in bias:
+            low = tgt[torch.logical_and(self.low_prefer_min_z <= tgt[..., 2], tgt[..., 2] <= self.low_prefer_max_z)]
+            if low.shape[0] >= 256:
+                shares[1] += 1.0
+        if 'moving' in bias:
+            if cur_tgt_unique.shape[0] >= 256:
+                shares[2] += 0.4
+            elif cur_tgt_unique.shape[0] >= 16:
+                shares[2] += cur_tgt_unique.shape[0] * 0.4 / 256.0
+        if 'vehped' in bias:
+            assert carla
+            vehped = get_vehped_points(tgt, segm_idx)
+            if vehped.shape[0] >= 256:
+                shares[3] += 0.2
+            elif vehped.shape[0] >= 16:
+                shares[3] += vehped.shape[0] * 0.2 / 256.0
+        if 'ivalo' in bias:
+            assert carla
+            if len(cur_valo_ids) > 0:
+                visible = get_vehped_points(tgt[tgt[..., view_idx] == 0], segm_idx)
+                vis_ids = sorted(list(visible[..., inst_idx].type(torch.int32).unique().detach().cpu().numpy()))
+                hidden = get_vehped_points(tgt[tgt[..., view_idx] != 0], segm_idx)
+                parts = []
+                for vid in cur_valo_ids:
+                    rows = hidden[hidden[..., inst_idx] == vid]
+                    parts.append(rows)
+                    if vid not in vis_ids:                # total occlusion: oversample by adding twice
+                        parts.append(rows)
+                ivalo = torch.cat(parts, dim=0)
+                if ivalo.shape[0] >= 256:
+                    shares[4] += 0.2
+                elif ivalo.shape[0] >= 16:
+                    shares[4] += min(ivalo.shape[0] * 0.2 / 256.0, 0.2)
+        if 'sembal' in bias:
+            assert carla
+            shares[5] += 0.4
+        shares /= shares.sum()
+
+        pool = []
+        n_low, n_moving, n_vehped, n_ivalo, n_sembal = [int(shares[j] * self.num_solid) for j in range(1, 6)]
+        if n_low > 0:
+            pool.append(_take(low, torch.randint(0, low.shape[0], (n_low, ))))
+        if n_moving > 0:
+            pool.append(_take(cur_tgt_unique, torch.randint(0, cur_tgt_unique.shape[0], (n_moving, ))))
+        if n_vehped > 0:
+            pool.append(_take(vehped, torch.randint(0, vehped.shape[0], (n_vehped, ))))
+        if n_ivalo > 0:
+            pool.append(_take(ivalo, torch.randint(0, ivalo.shape[0], (n_ivalo, ))))
+        if n_sembal > 0:
+            seg_ids = list(tgt[..., segm_idx].type(torch.int32).unique().detach().cpu().numpy())
+            used = 0
+            for sid in seg_ids:
+                rows = tgt[tgt[..., segm_idx] == sid]
+                if rows.shape[0] >= 16:
+                    per = n_sembal // len(seg_ids)
+                    pool.append(_take(rows, torch.randint(0, rows.shape[0], (per, ))))
+                    used += per
+            n_sembal = used
+        n_regular = self.num_solid - n_low - n_moving - n_vehped - n_ivalo - n_sembal
+        if n_regular > 0:
+            pool.append(_take(tgt, torch.randint(0, tgt.shape[0], (n_regular, ))))
+        chosen = torch.cat(pool, dim=0)
+        assert chosen.shape[0] == self.num_solid
+        offset = sample_random_uniform_3ball(self.num_solid, self.point_occupancy_radius / 2.0).to(chosen.device)
+        xyz = ops.add_rows(chosen[..., :3], offset)
+        query = torch.cat([xyz, torch.ones_like(xyz[..., 0:1]) * time_idx], dim=-1)
+        target = torch.cat([torch.ones_like(xyz[..., 0:1]), chosen[..., -4:]], dim=-1)
+        if self.predict_segmentation:
+            segm = chosen[..., segm_idx:segm_idx + 1].clone()
+            segm[segm >= self.semantic_classes] = 3            # = Other
+            target = torch.cat([target, segm], dim=-1)
+        else:
+            target = torch.cat([target, -torch.ones_like(target[..., 0:1])], dim=-1)
+        return (query, target, shares)
+
+    def construct_air_input_target(self, cur_tgt_pcl, cur_other_unique, cur_solid_input, cur_valo_ids, time_idx):
+        tgt = cur_tgt_pcl
+        r = self.point_occupancy_radius
+        tgt_xyz = tgt[..., :3]
+        slice_size = tgt.shape[0] // int(np.ceil(tgt.shape[0] / int((2 ** 27) // self.num_air))) + 1
+        shares = torch.tensor([0.5, 0.0, 0.3, 0.2])           # regular, moving, hard_solid_query, hard_target
+        if 'moving' in self.point_sample_bias:
+            if cur_other_unique.shape[0] >= 256:
+                shares[1] += 0.4
+            elif cur_other_unique.shape[0] >= 16:
+                shares[1] += cur_other_unique.shape[0] * 0.4 / 256.0
+        shares /= shares.sum()
+        points, dists = [], []
+
+        def keep(cand, count, warn=True):
+            (kept, d, _) = filter_air_solid_gap(cand, tgt_xyz, slice_size, r)
+            points.append(self.select_safely(kept, count, warn_insufficient=warn))
+            dists.append(self.select_safely(d, count, warn_insufficient=warn))
+
+        n_moving = int(shares[1] * self.num_air)
+        if n_moving > 0:
+            draw = int(n_moving * 1.6)
+            cand = _take(cur_other_unique, torch.randint(0, cur_other_unique.shape[0], (draw, )))[..., :3]
+            keep(ops.add_rows(cand, sample_random_uniform_3ball(draw, r * 2.0).to(tgt.device)), n_moving, warn=False)
+        n_hsq = int(shares[2] * self.num_air)
+        if n_hsq > 0:
+            draw = int(n_hsq * 2.0)
+            cand = _take(cur_solid_input, torch.randint(0, cur_solid_input.shape[0], (draw, )))[..., :3]
+            keep(ops.add_rows(cand, sample_random_uniform_3ball(draw, max_radius=r * 3.0, min_radius=r).to(tgt.device)),
+                 n_hsq)
+        n_ht = int(shares[3] * self.num_air)
+        if n_ht > 0:
+            draw = int(n_ht * 2.0)
+            cand = _take(tgt, torch.randint(0, tgt.shape[0], (draw, )))[..., :3]
+            keep(ops.add_rows(cand, sample_random_uniform_3ball(draw, max_radius=r * 3.0, min_radius=r).to(tgt.device)),
+                 n_ht)
+        n_regular = self.num_air - n_moving - n_hsq - n_ht
+        if n_regular > 0:
+            draw = int(n_regular * (1.3 if self.data_kind == 'greater' else 1.1))
+            keep(sample_implicit_points_blind_torch(self.data_kind, draw, self.cube_mode, self.cube_bounds, self.min_z,
+                                                    tgt.device), n_regular)
+        xyz = torch.cat(points, dim=0)
+        assert xyz.shape[0] == self.num_air
+        query = torch.cat([xyz, torch.ones_like(xyz[..., 0:1]) * time_idx], dim=-1)
+        target = -torch.ones((self.num_air, 6), device=tgt.device, dtype=tgt.dtype)
+        target[..., 0] = 0.0
+        return (query, target, shares)
+
+    def select_safely(self, pcl, num_select, warn_insufficient=True):
+        """First num_select rows; a too-short tensor is doubled until it suffices."""
+        if pcl.shape[0] == 0:
+            raise RuntimeError('select_safely: no candidate survived the air / solid gap filter')
+        while pcl.shape[0] < num_select:
+            if warn_insufficient and self.logger is not None:
+                self.logger.warning(f'Size {pcl.shape[0]} is insufficient for {num_select}!')
+            pcl = torch.cat([pcl, pcl], dim=0)
+        return pcl[:num_select].clone()

@@ -444,6 +444,41 @@ def split_solid_air(points_query, implicit_output, threshold, compress_air=False
     return solid, air
 
 
+def compact_rows(rows, key, threshold, strict=True):
+    """Order-preserving selection rows[key > threshold] (>= when not strict) -> (rows kept (n', d), keys kept (n'));
+    one 4-byte device->host read (the kept count) sizes the outputs."""
+    r, ld = _rows(_dev(rows, name='rows'), 'rows')
+    k = _dev(key, name='key')
+    assert k.dim() == 1 and k.shape[0] == r.shape[0]
+    n, d = r.shape
+    if n == 0:
+        return r.new_empty((0, d)), k.new_empty((0,))
+    lk = k.stride(0) if n > 1 else 1
+    nb = (n + 255) // 256
+    scratch = torch.empty(nb + 1, dtype=torch.int32, device=r.device)
+    st = _stream()
+    _lib.check(_lib.lib().occ4d_compact_count_f32(_ptr(k), lk, n, float(threshold), int(strict), _ptr(scratch),
+                                                  _ptr(scratch[nb:]), st))
+    kept = int(scratch[nb].item())
+    out_rows = torch.empty((kept, d), dtype=torch.float32, device=r.device)
+    out_key = torch.empty((kept,), dtype=torch.float32, device=r.device)
+    _lib.check(_lib.lib().occ4d_compact_rows_f32(_ptr(r), ld, n, d, _ptr(k), lk, float(threshold), int(strict),
+                                                 _ptr(scratch), _ptr(out_rows), _ptr(out_key), st))
+    return out_rows, out_key
+
+
+def add_rows(a, b):
+    """a + b for two (n, d) tensors (exact fp32 add; the sampler's query = target point + offset)."""
+    a, lda = _rows(_dev(a, name='a'), 'a')
+    b, ldb = _rows(_dev(b, name='b'), 'b')
+    assert a.shape == b.shape
+    n, d = a.shape
+    out = torch.empty((n, d), dtype=torch.float32, device=a.device)
+    if n:
+        _lib.check(_lib.lib().occ4d_axpby_f32(_ptr(a), lda, 1.0, _ptr(b), ldb, 1.0, n, d, _ptr(out), d, _stream()))
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # backward-pass kernels (include/occ4d.h, "Backward pass")
 # --------------------------------------------------------------------------------------

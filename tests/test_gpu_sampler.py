@@ -1,0 +1,94 @@
+"""GPU parity for the training-time point sampler: with the reference's seeds the HIP-backed
+sampler returns the reference sampler's supervision points bit for bit (golden G13, produced by the reference class
+on CPU); at the training configuration's size the sampler's defining invariants are checked on the device."""
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+KEYS = ['solid_input', 'air_input', 'solid_target', 'air_target', 'solid_sbs', 'air_sbs']
+
+
+@pytest.fixture(scope='module')
+def pk():
+    import occlusions4d_amd
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    occlusions4d_amd._lib.lib()
+    return occlusions4d_amd
+
+
+class _Log:
+    def __init__(self):
+        self.warnings = 0
+
+    def warning(self, *a, **k):
+        self.warnings += 1
+
+
+@pytest.mark.parametrize('case', gc.SAMPLER_CASES, ids=lambda c: c['name'])
+def test_sampler_replays_reference_draws(pk, case):
+    g = load_golden('g13_sampler_' + case['name'])
+    frames, sizes, valo, num_valo = gc.sampler_inputs(case)
+    sampler = pk.geometry.GuidedImplicitPointSampler(_Log(), **gc.sampler_config(case))
+    np.random.seed(case['seed'])
+    torch.manual_seed(case['seed'])
+    res = sampler([torch.from_numpy(f).cuda() for f in frames], [torch.from_numpy(z).cuda() for z in sizes],
+                  torch.from_numpy(valo).cuda(), torch.from_numpy(num_valo).cuda(), case['time_idx'])
+    for key, val in zip(KEYS, res):
+        assert tuple(val.shape) == g[key].shape, key
+        assert np.array_equal(val.cpu().numpy(), g[key]), key
+    assert all(v.is_cuda for v in res[:4])
+
+
+def test_filter_air_solid_gap_matches_oracle(pk):
+    from oracle import sampler as osamp
+    rng = np.random.default_rng(4)
+    rows = rng.uniform(-5, 5, size=(3000, 7)).astype(np.float32)
+    tgt = rng.uniform(-5, 5, size=(2000, 3)).astype(np.float32)
+    kept, dist, ratio = pk.geometry.filter_air_solid_gap(torch.from_numpy(rows).cuda(), torch.from_numpy(tgt).cuda(), 512,
+                                                         0.35)
+    r_kept, r_dist, r_ratio = osamp.air_solid_gap(torch.from_numpy(rows), torch.from_numpy(tgt), 0.35)
+    assert np.array_equal(kept.cpu().numpy(), r_kept.numpy())
+    assert np.array_equal(dist.cpu().numpy(), r_dist.numpy())
+    assert abs(float(ratio) - float(r_ratio)) < 1e-6
+    # nothing survives / everything survives
+    k0, d0, _ = pk.geometry.filter_air_solid_gap(torch.from_numpy(rows).cuda(), torch.from_numpy(tgt).cuda(), 512, 1e3)
+    assert k0.shape == (0, 7) and d0.shape == (0,)
+    k1, _, _ = pk.geometry.filter_air_solid_gap(torch.from_numpy(rows).cuda(), torch.from_numpy(tgt).cuda(), 512, -1.0)
+    assert np.array_equal(k1.cpu().numpy(), rows)
+
+
+def test_sampler_invariants_at_training_size(pk):
+    """BASELINE config 5 sizes (num_solid 7168, num_air 10035, ~57 K target points, CARLA cuboid): every solid
+    query lies within radius/2 of a target point and carries that point's colour / tag; every air query is farther
+    than the radius from ALL target points and inside the output cuboid; counts and constant columns are exact."""
+    case = dict(name='big', kind='carla', bias='low_moving_vehped_sembal', frames=3, m=57344, num_solid=7168,
+                num_air=10035, time_idx=1, segm=True, seed=77)
+    frames, sizes, valo, num_valo = gc.sampler_inputs(case)
+    cfg = gc.sampler_config(case)
+    log = _Log()
+    sampler = pk.geometry.GuidedImplicitPointSampler(log, **cfg)
+    np.random.seed(1)
+    torch.manual_seed(1)
+    dev = [torch.from_numpy(f).cuda() for f in frames]
+    (sq, aq, st, at, ss, as_) = sampler(dev, [torch.from_numpy(z).cuda() for z in sizes], torch.from_numpy(valo).cuda(),
+                                        torch.from_numpy(num_valo).cuda(), case['time_idx'])
+    assert sq.shape == (1, 7168, 4) and aq.shape == (1, 10035, 4) and st.shape == (1, 7168, 6) and at.shape == (1, 10035, 6)
+    r = cfg['point_occupancy_radius']
+    tgt = pk.geometry.filter_pcl_bounds_carla_output_torch(dev[1][0, :int(sizes[1][0])], min_z=-1.0, other_bounds=16.0)
+    _, d_solid = pk.ops.knn(sq[0], tgt, 1, metric=1, return_dist=True)
+    assert float(d_solid.max()) <= r / 2.0 + 1e-6
+    _, d_air = pk.ops.knn(aq[0], tgt, 1, metric=1, return_dist=True)
+    assert float(d_air.min()) > r
+    assert torch.all(sq[0, :, 3] == 1.0) and torch.all(aq[0, :, 3] == 1.0)             # t = time_idx
+    assert torch.all(st[0, :, 0] == 1.0) and torch.all(at[0, :, 0] == 0.0) and torch.all(at[0, :, 1:] == -1.0)
+    assert torch.all((st[0, :, 5] >= 0) & (st[0, :, 5] < 13))
+    # regular air points (the last block) are inside the output cuboid
+    n_reg = 10035 - sum(int(as_[0, j] * 10035) for j in (1, 2, 3))
+    reg = aq[0, -n_reg:]
+    assert torch.all((reg[:, 0] >= 0) & (reg[:, 0] <= 40.0) & (reg[:, 1].abs() <= 16.0) & (reg[:, 2] >= -1.0) &
+                     (reg[:, 2] <= 6.4))
+    assert abs(float(ss.sum()) - 1.0) < 1e-5 and abs(float(as_.sum()) - 1.0) < 1e-5
