@@ -29,6 +29,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--sampler', action='store_true',
+                    help='draw the supervision points inside the step with GuidedImplicitPointSampler '
+                         '(57344-point target frames, bias low_moving_vehped_sembal) instead of fixed synthetic queries')
     args = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -63,15 +66,47 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    sampler_ms = None
+    if args.sampler:
+        frames, sizes, valo, num_valo = pk.configs.synthetic_target_frames('carla', 57344, FRAMES, SEED + 200 + rank)
+        frames = [f.to(device) for f in frames]
+        sizes = [z.to(device) for z in sizes]
+        valo, num_valo = valo.to(device), num_valo.to(device)
+        sampler = pk.geometry.GuidedImplicitPointSampler(
+            None, min_z=-1.0, cube_bounds=16.0, point_occupancy_radius=0.2, num_solid=7168, num_air=QUERIES - 7168,
+            predict_segmentation=True, semantic_classes=13, data_kind='carla',
+            point_sample_bias='low_moving_vehped_sembal', cube_mode=4)
+        np.random.seed(SEED + rank)
+        torch.manual_seed(SEED + rank)
+        sampler_time = [0.0]
+
+        def run_step():
+            ts = time.perf_counter()
+            qs, ts_ = [], []
+            for t in range(FRAMES):
+                (si, ai, st, at, _, _) = sampler(frames, sizes, valo, num_valo, t)
+                qs.append(torch.cat([si, ai], dim=1)[0])
+                ts_.append(torch.cat([st, at], dim=1)[0])
+            torch.cuda.synchronize()
+            sampler_time[0] += time.perf_counter() - ts
+            return step(pcl, torch.stack(qs), torch.stack(ts_))
+    else:
+        def run_step():
+            return step(pcl, q, target)
+
     losses = []
     for _ in range(args.warmup):
-        losses.append(float(step(pcl, q, target)))
+        losses.append(float(run_step()))
     fence()
+    if args.sampler:
+        sampler_time[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses.append(float(step(pcl, q, target)))
+        losses.append(float(run_step()))
     fence()
     elapsed = time.perf_counter() - t0
+    if args.sampler:
+        sampler_ms = 1e3 * sampler_time[0] / args.steps
     if world > 1:
         tm = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -81,7 +116,7 @@ def main():
             'metric': 'training step (BASELINE config 5: CARLA-4D, batch 1/GPU, n_points=28672, 4 x 17203 queries)',
             'value': world * args.steps / elapsed, 'unit': 'examples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'dtype': 'f32', 'data': 'synthetic', 'losses': losses,
+            'scaling': 'weak', 'dtype': 'f32', 'data': 'synthetic', 'losses': losses, 'sampler_ms_per_step': sampler_ms,
             'peak_mem_gb': torch.cuda.max_memory_allocated() / 2 ** 30}), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -171,3 +171,36 @@ def synthetic_weights(pcl_args, implicit_args, seed=1830):
     """(encoder_state_dict, decoder_state_dict) filled deterministically."""
     return (fill_state_dict(encoder_param_shapes(pcl_args), seed),
             fill_state_dict(decoder_param_shapes(implicit_args), seed + 1))
+
+
+def synthetic_target_frames(kind, m, frames, seed, batch=1):
+    """Seeded stand-in for the dataloader's supervision point clouds (datasets are unavailable): list-T of
+    (B, M, E) float32 frames + sizes + vehicle / pedestrian ids, in the layout GuidedImplicitPointSampler expects
+    (GREATER E=9: x,y,z,instance,view,R,G,B,mark; CARLA E=11: x,y,z,cos,instance,semantic,view,R,G,B,mark).
+    A static background shared by all frames plus a blob that moves from frame to frame."""
+    rng = np.random.default_rng(seed)
+    carla = kind == 'carla'
+    lo, hi = (np.array([-5.0, -5.0, -1.0]), np.array([5.0, 5.0, 5.0])) if not carla else \
+        (np.array([0.0, -16.0, -1.0]), np.array([40.0, 16.0, 6.4]))
+    n_blob = m // 5
+    base = rng.uniform(lo, hi, size=(batch, m - n_blob, 3))
+    out, sizes = [], []
+    for t in range(frames):
+        centre = lo + (hi - lo) * (0.25 + 0.5 * t / max(1, frames - 1))
+        blob = centre + rng.normal(scale=0.6, size=(batch, n_blob, 3))
+        xyz = np.concatenate([base + rng.normal(scale=0.005, size=base.shape), blob], axis=1)
+        cols = [xyz]
+        if carla:
+            cols.append(rng.uniform(-1, 1, size=(batch, m, 1)))
+        cols.append(rng.integers(-1, 6, size=(batch, m, 1)).astype(np.float64))
+        if carla:
+            cols.append(rng.integers(0, 13, size=(batch, m, 1)).astype(np.float64))
+        cols += [rng.integers(0, 3, size=(batch, m, 1)).astype(np.float64), rng.uniform(size=(batch, m, 3)),
+                 rng.integers(0, 2, size=(batch, m, 1)).astype(np.float64)]
+        rows = np.concatenate(cols, axis=-1).astype(np.float32)
+        for b in range(batch):
+            rows[b] = rows[b][rng.permutation(m)]
+        out.append(torch.from_numpy(rows))
+        sizes.append(torch.full((batch,), m, dtype=torch.int64))
+    valo = torch.tensor([[0, 2, 5, 0]] * batch, dtype=torch.int64)
+    return out, sizes, valo, torch.full((batch,), 3, dtype=torch.int64)
