@@ -312,32 +312,58 @@ __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* s
   const int qa = q0 + 2 * wave, qb = qa + 1;
   const float inv_div = 1.0f / a.divisor;
   constexpr float LOG2E = 1.44269504088896f;
-  // P2 fragments and gathered V rows are fetched one channel tile ahead
-  f32x4 pv[4], npv[4];
+  // Software pipeline over the channel tiles: the positional-encoding MFMAs of tile c + 1 are issued in the same
+  // region as the softmax VALU work of tile c (independent streams of one wave: the matrix pipe runs in the
+  // shadow of the VALU), gathered V rows are fetched one tile ahead, the P2 fragment of tile c + 2 is loaded into
+  // the registers the MFMAs of tile c + 1 have just consumed.
+  f32x4 pv[4];
   float vv[16], nvv[16];
-  auto eload = [&](int c, f32x4* P, float* V) {
+  auto loadP = [&](int c) {
     const int ch = 32 * (CBEG + c) + prow;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-      P[g] = *reinterpret_cast<const f32x4*>(a.p2 + (int64_t)ch * 32 + 8 * g + 4 * half);
+      pv[g] = *reinterpret_cast<const f32x4*>(a.p2 + (int64_t)ch * 32 + 8 * g + 4 * half);
+  };
+  auto loadV = [&](int c, float* V) {
+    const int ch = 32 * (CBEG + c) + prow;
+#ifndef OCC4D_ABLATE_EPI_NOV
 #pragma unroll
     for (int i = 0; i < 16; ++i) V[i] = a.vt[(int64_t)jrow[i] * a.ld_vt + ch];
-  };
-  eload(0, pv, vv);
+#else
 #pragma unroll
-  for (int c = 0; c < NTW; ++c) {
-    const int ch = 32 * (CBEG + c) + prow;
-    if (c + 1 < NTW) eload(c + 1, npv, nvv);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < 16; ++i) V[i] = (float)jrow[i];
+#endif
+  };
+  auto pos_gemm = [&]() {
     f32x16 pe;
 #pragma unroll
     for (int i = 0; i < 16; ++i) pe[i] = 0.f;
+#ifndef OCC4D_ABLATE_EPI_NOPE
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       pe = __builtin_amdgcn_mfma_f32_32x32x2f32(r[4 * g + 0], pv[g].x, pe, 0, 0, 0);
       pe = __builtin_amdgcn_mfma_f32_32x32x2f32(r[4 * g + 1], pv[g].y, pe, 0, 0, 0);
       pe = __builtin_amdgcn_mfma_f32_32x32x2f32(r[4 * g + 2], pv[g].z, pe, 0, 0, 0);
       pe = __builtin_amdgcn_mfma_f32_32x32x2f32(r[4 * g + 3], pv[g].w, pe, 0, 0, 0);
+    }
+#else
+    pe[0] = pv[0].x + pv[1].y + pv[2].z + pv[3].w;
+#endif
+    return pe;
+  };
+  loadP(0);
+  loadV(0, vv);
+  f32x16 pe = pos_gemm();
+  if (NTW > 1) loadP(1);
+#pragma unroll
+  for (int c = 0; c < NTW; ++c) {
+    const int ch = 32 * (CBEG + c) + prow;
+    if (c + 1 < NTW) loadV(c + 1, nvv);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 pe_next = pe;
+    if (c + 1 < NTW) {
+      pe_next = pos_gemm();
+      if (c + 2 < NTW) loadP(c + 2);
     }
     const float b2c = a.b2[ch], c2c = a.c2[ch];
     float lg[16], val[16];
@@ -392,8 +418,7 @@ __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* s
     }
     __builtin_amdgcn_sched_barrier(0);
     if (c + 1 < NTW) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) pv[g] = npv[g];
+      pe = pe_next;
 #pragma unroll
       for (int i = 0; i < 16; ++i) vv[i] = nvv[i];
     }

@@ -14,7 +14,8 @@ import occlusions4d_amd as pk  # noqa: E402
 
 CSRC = os.path.join(ROOT, 'occlusions-4d_amd', 'csrc')
 VARIANTS = {'base': [], 'noload': ['-DOCC4D_ABLATE_NOLOAD'], 'nobar': ['-DOCC4D_ABLATE_NOBAR', '-DOCC4D_ABLATE_NOLOAD'],
-            'noinit': ['-DOCC4D_ABLATE_NOINIT'], 'noepi': ['-DOCC4D_ABLATE_NOEPI'],
+            'noinit': ['-DOCC4D_ABLATE_NOINIT'], 'noepi': ['-DOCC4D_ABLATE_NOEPI'], 'epi_nov': ['-DOCC4D_ABLATE_EPI_NOV'], 'epi_nope': ['-DOCC4D_ABLATE_EPI_NOPE'],
+            'epi_nov_nope': ['-DOCC4D_ABLATE_EPI_NOV', '-DOCC4D_ABLATE_EPI_NOPE'],
             'all': ['-DOCC4D_ABLATE_NOLOAD', '-DOCC4D_ABLATE_NOBAR', '-DOCC4D_ABLATE_NOINIT', '-DOCC4D_ABLATE_NOEPI']}
 
 
@@ -28,7 +29,7 @@ def build(name, flags):
 
 
 def main():
-    n, m, k, d = 32768, 531, 14, 416
+    n, m, k, d = 32256, 531, 14, 416
     g = torch.Generator(device='cuda').manual_seed(0)
     R = lambda *s: torch.randn(*s, device='cuda', generator=g)
     aq, kt, vt = R(n, 2 * d), R(m, 2 * d), R(m, d)
