@@ -38,7 +38,10 @@ def main():
     P1, c1, wp, w2, b2, p2, c2 = R(32, 3), R(32), R(2 * d, 32) * 0.1, R(d, 2 * d) * 0.03, R(d), R(d, 32) * 0.1, R(d)
     agg = torch.empty(n, d, device='cuda')
     P = lambda t: C.c_void_p(t.data_ptr())
+    only = sys.argv[1:]
     for name, flags in VARIANTS.items():
+        if only and name not in only:
+            continue
         lib = C.CDLL(build(name, flags))
         fn = lib.occ4d_pt_cross_attn_f32
         fn.restype = C.c_int
