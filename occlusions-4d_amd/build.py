@@ -19,6 +19,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 OBJDIR = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libocc4d.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-I' + INCLUDE, '-I' + CSRC]
+FLAGS += os.environ.get('OCC4D_HIPCC_EXTRA', '').split()      # experiments only (e.g. -DOCC4D_CA_NO_XCD_MAP)
 
 
 def _hipcc():

@@ -93,7 +93,17 @@ __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* s
   const int wave = (tid >> 6) & 3;                 // row tile (2 queries)
   constexpr int cbeg = CBEG;
   const int half = lane >> 5, prow = lane & 31;
-  const int q0 = blockIdx.x * QPB;
+  // XCD-aware group assignment: workgroup b is dispatched to XCD b % 8 (each XCD has its own 4 MB L2); give every
+  // XCD one CONTIGUOUS range of query groups, so that its L2 only has to hold the Kt / Vt rows of the abstract
+  // points near that slab of the query grid (CARLA: Kt + Vt = 10.6 MB do not fit one L2).  Bijective for any grid.
+#ifndef OCC4D_CA_NO_XCD_MAP
+  const int nwg = gridDim.x, xcd = blockIdx.x & 7;
+  const int per = nwg >> 3, rem = nwg & 7;
+  const int group = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + (blockIdx.x >> 3);
+#else
+  const int group = blockIdx.x;
+#endif
+  const int q0 = group * QPB;
 
   // ---- neighbour indices of the block's 9 queries -> LDS (invalid slots/queries repeat a valid one)
   if (tid < QPB * 16) {
