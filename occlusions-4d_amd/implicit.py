@@ -134,7 +134,7 @@ class ResnetFC(torch.nn.Module):
                 x = self.blocks[i]._run(x, inplace=True)
             pens.append(x)
             outs.append(ops.linear(x, self.lin_out.weight, self.lin_out.bias, relu_in=True))
-        output, penult = torch.stack(outs), torch.stack(pens)
+        output, penult = ops.stack_batch(outs), ops.stack_batch(pens)
         if no_batch:
             output, penult = output[0], penult[0]
         return (output, penult)
@@ -243,7 +243,8 @@ class LocalPclResnetFC(ResnetFC):
         n = q_all.shape[0]
         H = self.d_hidden
         out = torch.empty((n, self.d_out), dtype=torch.float32, device=q_all.device)
-        pen = torch.empty((n, H), dtype=torch.float32, device=q_all.device)
+        single = 0 < n <= _QUERY_CHUNK        # one chunk: the trunk activation IS penult (no 54 MB copy)
+        pen = None if single else torch.empty((n, H), dtype=torch.float32, device=q_all.device)
         xyz, feats = sc['xyz'], sc['feats']
         for lo in range(0, n, _QUERY_CHUNK):
             q = q_all[lo:lo + _QUERY_CHUNK]
@@ -255,7 +256,10 @@ class LocalPclResnetFC(ResnetFC):
                 if i in self.use_pt_inds:
                     blk = self.pt_blocks[self.use_pt_inds[i]]
                     x = blk(x[None], q[None, :, :3], x2=feats[None], p2=xyz[None], scene_owner=owner)[0][0]
-            pen[lo:lo + _QUERY_CHUNK] = x
+            if single:
+                pen = x
+            else:
+                pen[lo:lo + _QUERY_CHUNK] = x
             ops.linear(x, self.lin_out.weight, self.lin_out.bias, relu_in=True, out=out[lo:lo + _QUERY_CHUNK])
         return out, pen
 

@@ -87,9 +87,9 @@ class PointCompletionNetV3(torch.nn.Module):
         layer_coords = [pos, pos] if return_intermediate else None
         l0, l2 = self.pre_mlp[0], self.pre_mlp[2]
         if train:
-            x = torch.stack([autograd.linear(autograd.linear(pcl[b], l0, relu_out=True), l2) for b in range(B)])
+            x = ops.stack_batch([autograd.linear(autograd.linear(pcl[b], l0, relu_out=True), l2) for b in range(B)])
         else:
-            x = torch.stack([ops.linear(ops.linear(pcl[b], l0.weight, l0.bias, relu_out=True), l2.weight, l2.bias)
+            x = ops.stack_batch([ops.linear(ops.linear(pcl[b], l0.weight, l0.bias, relu_out=True), l2.weight, l2.bias)
                              for b in range(B)])
         skips = []
         x_global = None
@@ -104,11 +104,11 @@ class PointCompletionNetV3(torch.nn.Module):
             if self.output_global_emb and i == self.center_block_idx:
                 g0, g2 = self.global_mlp[0], self.global_mlp[2]
                 if train:
-                    x_global = torch.stack([
+                    x_global = ops.stack_batch([
                         autograd.linear(autograd.linear(autograd.MeanRowsFn.apply(x[b])[None], g0, relu_out=True),
                                         g2)[0] for b in range(B)])
                 else:
-                    x_global = torch.stack([
+                    x_global = ops.stack_batch([
                         ops.linear(ops.linear(ops.mean_rows(x[b])[None], g0.weight, g0.bias, relu_out=True),
                                    g2.weight, g2.bias)[0] for b in range(B)])
             if return_intermediate:
@@ -117,10 +117,10 @@ class PointCompletionNetV3(torch.nn.Module):
                 for j, skip in enumerate(self.abstract_skip_mlps):
                     if skip.in_features == x.shape[-1]:
                         if train:
-                            y = torch.stack([autograd.linear(x[b], skip) for b in range(B)])
+                            y = ops.stack_batch([autograd.linear(x[b], skip) for b in range(B)])
                             y = torch.cat([y[..., :-1], torch.full_like(y[..., :1], j + 1.0)], dim=-1)
                         else:
-                            y = torch.stack([ops.linear(x[b], skip.weight, skip.bias) for b in range(B)])
+                            y = ops.stack_batch([ops.linear(x[b], skip.weight, skip.bias) for b in range(B)])
                             y[..., -1] = j + 1.0
                         skips.append(torch.cat([pos, y], dim=-1))
         if self.output_featurized:

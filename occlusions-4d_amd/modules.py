@@ -38,9 +38,9 @@ class PointTransformerBlock(torch.nn.Module):
         # layer1 is folded into the query-side merged matrix (cross) or applied once (self)
         agg = self.layer2._forward(x, p, x2, p2, pre=self.layer1, scene_owner=scene_owner)
         if needs_grad(self, x, x2):
-            z = torch.stack([autograd.linear(agg[b], self.layer3, residual=x[b]) for b in range(x.shape[0])])
+            z = ops.stack_batch([autograd.linear(agg[b], self.layer3, residual=x[b]) for b in range(x.shape[0])])
         else:
-            z = torch.stack([ops.linear(agg[b], self.layer3.weight, self.layer3.bias, residual=x[b])
+            z = ops.stack_batch([ops.linear(agg[b], self.layer3.weight, self.layer3.bias, residual=x[b])
                              for b in range(x.shape[0])])
         return (z, p)
 
@@ -105,4 +105,4 @@ class DownTransition(torch.nn.Module):
                 y = ops.linear(x[b], lin.weight, lin.bias, relu_out=True)
             zs.append(ops.maxpool_gather(y, nn_idx))
             ps.append(p_sub)
-        return (torch.stack(zs), torch.stack(ps))
+        return (ops.stack_batch(zs), ops.stack_batch(ps))

@@ -53,6 +53,13 @@ def _launch(name, shape, flops, fn):
     return fn()
 
 
+def stack_batch(tensors):
+    """torch.stack over the batch dimension; the usual B == 1 case is a view (torch.stack would copy 54 MB per
+    (32256, 416) activation -- four such copies per decode mini-batch)."""
+    tensors = list(tensors)
+    return tensors[0][None] if len(tensors) == 1 else torch.stack(tensors)
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 

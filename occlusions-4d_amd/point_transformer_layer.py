@@ -53,7 +53,7 @@ def kNN_torch(query, dataset, k):
     assert query.dim() == 3 and dataset.dim() == 3, "Input tensors should be 3D."
     assert query.shape[0] == dataset.shape[0], "Input tensors should have same batch size."
     assert query.shape[2] == dataset.shape[2], "Input tensors should have same dimension."
-    return torch.stack([ops.knn(query[b], dataset[b], k, metric=0, int64=True)
+    return ops.stack_batch([ops.knn(query[b], dataset[b], k, metric=0, int64=True)
                         for b in range(query.shape[0])])
 
 
@@ -61,7 +61,7 @@ def index_points(points, idx):
     """(B,N,C),(B,S[,K]) -> (B,S[,K],C) row gather on the device kernel."""
     B = idx.shape[0]
     out = [ops.gather_rows(points[b], idx[b].reshape(-1).to(torch.int32)) for b in range(B)]
-    return torch.stack(out).reshape(*idx.shape, points.shape[-1])
+    return ops.stack_batch(out).reshape(*idx.shape, points.shape[-1])
 
 
 class PointTransformerLayer(nn.Module):
@@ -137,13 +137,13 @@ class PointTransformerLayer(nn.Module):
                 y = x[b] if pre is None else autograd.linear(x[b], pre)
                 out.append(self.forward_train(y, pos[b], None if x2 is None else x2[b],
                                               None if pos2 is None else pos2[b]))
-            return torch.stack(out)
+            return ops.stack_batch(out)
         out = []
         for b in range(x.shape[0]):
             xb2 = None if x2 is None else x2[b]
             pb2 = None if pos2 is None else pos2[b]
             out.append(self._forward_one(x[b], pos[b], xb2, pb2, pre, scene_owner))
-        return torch.stack(out)
+        return ops.stack_batch(out)
 
     def forward_train(self, x, pos, x2=None, pos2=None):
         """Differentiable forward for one cloud, as written in the reference (:167-179): x (N,D)."""
