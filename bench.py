@@ -267,10 +267,9 @@ def main():
             'roofline': {
                 'bound': 'mfma', 'achieved': achieved / 1e12, 'peak': FP32_MFMA_PEAK / 1e12, 'unit': 'TFLOP/s',
                 'frac': achieved / FP32_MFMA_PEAK,
-                # HBM bytes per launch from the PMC pass committed as profiles/r01_pmc_final.txt (232.4 MB per 32768
-                # queries: (2 x FETCH_SIZE + WRITE_SIZE) x 1024, gfx950 FETCH_SIZE correction), scaled to the
-                # launch size; not re-measured live
-                'traffic': 232.4e6 * pk.inference.decode_chunk(BATCH) / 32768 if args.kind == 'greater' else None,
+                # HBM bytes per full 32256-query launch from the PMC passes committed as profiles/r01_pmc_final.txt:
+                # (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE correction); not re-measured live
+                'traffic': 234.1e6 if args.kind == 'greater' else None,
                 'traffic_source': 'profiles/r01_pmc_final.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)',
                 'kernel': 'cross_attn_kernel<13> (fused vector attention: pos-MLP + attn-MLP + softmax + '
                           'aggregate, 14 neighbours, D=416)',
