@@ -1,0 +1,154 @@
+"""Seeded random sweeps over the kernel argument space (shapes that are not multiples of any tile, strided views,
+every epilogue flag, all k, both metrics, every threads-per-query path): each kernel of the C ABI against a plain
+numpy / PyTorch-CPU statement of the same op.  Bit-exact for index / selection kernels, 2e-5 relative to the
+magnitude of the result for fp32 GEMM-like kernels (different summation order only)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def pk():
+    import occlusions4d_amd
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    occlusions4d_amd._lib.lib()
+    return occlusions4d_amd
+
+
+def C(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_linear_random_shapes_and_flags(pk):
+    rng = np.random.default_rng(2024)
+    for trial in range(48):
+        M = int(rng.choice([1, 2, 31, 127, 128, 129, 257, 1000, 4097]))
+        K = int(rng.choice([3, 8, 32, 36, 68, 72, 100, 144, 288, 416, 832]))
+        N = int(rng.choice([1, 5, 18, 32, 36, 72, 128, 144, 288, 416, 832]))
+        x = rng.normal(size=(M, K)).astype(np.float32)
+        w = (rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32)
+        b = rng.normal(size=(N,)).astype(np.float32) if rng.random() < 0.7 else None
+        relu_in, relu_out = bool(rng.random() < 0.5), bool(rng.random() < 0.5)
+        res = rng.normal(size=(M, N)).astype(np.float32) if (rng.random() < 0.4 and not relu_out) else None
+        add_div = int(rng.choice([1, 3, 14]))
+        add = rng.normal(size=(-(-M // add_div), N)).astype(np.float32) if rng.random() < 0.3 else None
+        sub = sub_idx = None
+        if rng.random() < 0.3:
+            sub = rng.normal(size=(17, N)).astype(np.float32)
+            sub_idx = rng.integers(0, 17, size=M).astype(np.int32)
+        xin = np.maximum(x, 0) if relu_in else x
+        ref = xin.astype(np.float64) @ w.T.astype(np.float64)
+        if b is not None:
+            ref = ref + b
+        if add is not None:
+            ref = ref + add[np.arange(M) // add_div]
+        if sub is not None:
+            ref = ref - sub[sub_idx]
+        if relu_out:
+            ref = np.maximum(ref, 0)
+        if res is not None:
+            ref = ref + res
+        xd = C(x)
+        if trial % 3 == 0 and K % 4 == 0:          # strided input view (row stride > K)
+            wide = torch.zeros((M, K + 8), device='cuda')
+            wide[:, :K] = xd
+            xd = wide[:, :K]
+        got = pk.ops.linear(xd, C(w), C(b) if b is not None else None, relu_in=relu_in, relu_out=relu_out,
+                            residual=C(res) if res is not None else None,
+                            add_rows=C(add) if add is not None else None, add_div=add_div,
+                            sub_rows=C(sub) if sub is not None else None,
+                            sub_idx=C(sub_idx) if sub_idx is not None else None)
+        err = np.abs(got.cpu().numpy() - ref).max()
+        assert err <= 2e-5 * max(1.0, np.abs(ref).max()), (trial, M, K, N, err)
+
+
+def _brute_knn(q, d, k, metric):
+    dx = q[:, None, 0] - d[None, :, 0]
+    dy = q[:, None, 1] - d[None, :, 1]
+    dz = q[:, None, 2] - d[None, :, 2]
+    if metric == 0:
+        dist = (dx * dx + dy * dy) + dz * dz
+    else:
+        dist = None                                # fused-multiply-add chain: compared through indices of metric 0
+    order = np.argsort(dist, axis=1, kind='stable')[:, :k]
+    return order, np.take_along_axis(dist, order, axis=1)
+
+
+def test_knn_random_shapes_all_paths(pk):
+    """metric 0 against a stable numpy argsort of the same fp32 arithmetic (bit-exact indices and distances), for
+    every k, query counts on both sides of the threads-per-query thresholds, strided inputs, duplicate points."""
+    rng = np.random.default_rng(7)
+    for trial in range(30):
+        nq = int(rng.choice([1, 5, 64, 255, 1000, 3000, 25000]))
+        nd = int(rng.choice([16, 100, 255, 256, 531, 1025, 4000]))
+        k = int(rng.integers(1, min(16, nd) + 1))
+        q = rng.uniform(-5, 5, size=(nq, 4)).astype(np.float32)
+        d = rng.uniform(-5, 5, size=(nd, 5)).astype(np.float32)
+        if trial % 4 == 0 and nd > 40:
+            d[20:30, :3] = d[5:15, :3]            # exact duplicates: lowest index first
+        idx, dist = pk.ops.knn(C(q)[:, :3], C(d)[:, :3], k, metric=0, return_dist=True)
+        ref_i, ref_d = _brute_knn(q, d, k, 0)
+        assert np.array_equal(idx.cpu().numpy(), ref_i), (trial, nq, nd, k)
+        assert np.array_equal(dist.cpu().numpy(), ref_d)
+        # metric 1 orders like metric 0 except where the square roots collide: distances must be non-decreasing,
+        # equal to sqrt of the fma chain of the returned index, and the index set equal wherever no two sqrt tie
+        idx1, dist1 = pk.ops.knn(C(q)[:, :3], C(d)[:, :3], k, metric=1, return_dist=True)
+        d1 = dist1.cpu().numpy()
+        assert np.all(np.diff(d1, axis=1) >= 0)
+        sel = d[idx1.cpu().numpy().astype(np.int64), :3]
+        diff = (q[:, None, :3] - sel).astype(np.float64)
+        assert np.abs(np.sqrt((diff ** 2).sum(-1)) - d1).max() <= 1e-5
+        assert np.allclose(d1, np.sqrt(ref_d), rtol=1e-6, atol=0)
+
+
+def test_fps_single_vs_cooperative_random(pk):
+    rng = np.random.default_rng(11)
+    for trial in range(10):
+        n = int(rng.choice([3, 64, 777, 2049, 9000, 20000, 32768]))
+        m = int(rng.integers(1, n + 1)) if n < 3000 else int(rng.integers(n // 8, n // 3))
+        p = C(rng.uniform(-5, 5, size=(n, 3)).astype(np.float32))
+        a, ao = pk.ops.fps(p, m, return_order=True)
+        wgs = int(rng.choice([0, 1, 2, 5, 16]))
+        if -(-n // max(1, wgs or 1)) > 16 * 512:
+            wgs = 0
+        b, bo = pk.ops.fps_coop(p, m, start=0, n_workgroups=wgs, return_order=True)
+        assert torch.equal(a, b) and torch.equal(ao, bo), (trial, n, m, wgs)
+
+
+def test_compaction_and_gather_random(pk):
+    rng = np.random.default_rng(13)
+    for trial in range(20):
+        n = int(rng.choice([1, 2, 255, 256, 257, 1000, 70000, 300000]))
+        d = int(rng.choice([1, 3, 4, 7, 9, 11]))
+        rows = rng.normal(size=(n, d)).astype(np.float32)
+        key = rng.uniform(0, 1, size=n).astype(np.float32)
+        thr = float(rng.choice([-1.0, 0.0, 0.3, 0.5, 0.99, 2.0]))
+        if n > 10:
+            key[3] = thr
+        strict = bool(rng.random() < 0.5)
+        kept, kk = pk.ops.compact_rows(C(rows), C(key), thr, strict=strict)
+        mask = key > np.float32(thr) if strict else key >= np.float32(thr)
+        assert np.array_equal(kept.cpu().numpy(), rows[mask]) and np.array_equal(kk.cpu().numpy(), key[mask])
+        idx = rng.integers(0, n, size=int(rng.integers(1, 2000))).astype(np.int32)
+        assert np.array_equal(pk.ops.gather_rows(C(rows), C(idx)).cpu().numpy(), rows[idx])
+
+
+def test_pool_norm_interp_random(pk):
+    rng = np.random.default_rng(17)
+    for trial in range(12):
+        n = int(rng.choice([1, 33, 500, 4779]))
+        m = int(rng.choice([1, 40, 531]))
+        d = int(rng.choice([4, 36, 72, 144, 288, 416]))
+        k = int(rng.integers(1, 13))
+        y = rng.normal(size=(n, d)).astype(np.float32)
+        idx = rng.integers(0, n, size=(m, k)).astype(np.int32)
+        got = pk.ops.maxpool_gather(C(y), C(idx)).cpu().numpy()
+        assert np.array_equal(got, y[idx].max(axis=1))
+        g, b = rng.normal(size=d).astype(np.float32), rng.normal(size=d).astype(np.float32)
+        ln = pk.ops.layernorm(C(y), C(g), C(b), eps=1e-5, relu=bool(trial % 2)).cpu().numpy()
+        ref = torch.nn.functional.layer_norm(torch.from_numpy(y), (d,), torch.from_numpy(g), torch.from_numpy(b), 1e-5)
+        ref = torch.relu(ref) if trial % 2 else ref
+        assert np.abs(ln - ref.numpy()).max() <= 2e-5
+        assert np.abs(pk.ops.mean_rows(C(y)).cpu().numpy() - y.astype(np.float64).mean(axis=0)).max() <= 1e-5
