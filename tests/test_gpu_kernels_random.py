@@ -152,3 +152,104 @@ def test_pool_norm_interp_random(pk):
         ref = torch.relu(ref) if trial % 2 else ref
         assert np.abs(ln - ref.numpy()).max() <= 2e-5
         assert np.abs(pk.ops.mean_rows(C(y)).cpu().numpy() - y.astype(np.float64).mean(axis=0)).max() <= 1e-5
+
+
+# ------------------------------------------------------------------ backward kernels vs torch autograd (CPU, fp64)
+def _rel(got, ref):
+    got = got.detach().cpu().double().numpy() if isinstance(got, torch.Tensor) else got
+    ref = ref.detach().double().numpy() if isinstance(ref, torch.Tensor) else ref
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return np.abs(got - ref).max() / max(1e-6, np.abs(ref).max())
+
+
+def test_weight_gradient_random(pk):
+    rng = np.random.default_rng(31)
+    for trial in range(24):
+        M = int(rng.choice([1, 15, 16, 17, 255, 1000, 5003, 40000]))
+        N = int(rng.choice([4, 5, 36, 72, 128, 130, 416, 832]))
+        K = int(rng.choice([3, 4, 32, 36, 68, 100, 288, 416, 832]))
+        g = rng.normal(size=(M, N)).astype(np.float32)
+        x = rng.normal(size=(M, K)).astype(np.float32)
+        relu_x, bias = bool(rng.random() < 0.5), bool(rng.random() < 0.6)
+        res = pk.ops.linear_wgrad(C(g), C(x), bias=bias, relu_x=relu_x)
+        dw, db = res if bias else (res, None)
+        xr = np.maximum(x, 0) if relu_x else x
+        ref = g.astype(np.float64).T @ xr.astype(np.float64)
+        assert _rel(dw, ref) <= 3e-6, (trial, M, N, K)
+        if bias:
+            assert _rel(db, g.astype(np.float64).sum(axis=0)) <= 3e-6
+        assert _rel(pk.ops.colsum(C(g)), g.astype(np.float64).sum(axis=0)) <= 3e-6
+        ref_mask = np.where(x[:, :min(N, K)] > 0, g[:, :min(N, K)], 0)
+        assert np.array_equal(pk.ops.relu_mask(C(g[:, :min(N, K)]), C(x[:, :min(N, K)])).cpu().numpy(), ref_mask)
+
+
+def test_scatter_and_pool_gradients_random(pk):
+    rng = np.random.default_rng(37)
+    for trial in range(12):
+        n, m, d, k = int(rng.choice([1, 40, 900])), int(rng.choice([1, 17, 531])), int(rng.choice([4, 36, 288, 416])), \
+            int(rng.integers(1, 15))
+        src = rng.normal(size=(n * k, d)).astype(np.float32)
+        idx = rng.integers(0, m, size=(n, k)).astype(np.int32)
+        got = pk.ops.scatter_add_rows(C(src), C(idx), m, scale=-1.0)
+        ref = np.zeros((m, d))
+        np.add.at(ref, idx.reshape(-1), -src.astype(np.float64))
+        assert _rel(got, ref) <= 1e-5
+        assert _rel(pk.ops.segment_sum(C(src), k), src.astype(np.float64).reshape(n, k, d).sum(axis=1)) <= 3e-6
+        # max-pool backward: gradient goes to the FIRST maximal neighbour
+        y = rng.normal(size=(m, d)).astype(np.float32)
+        dz = rng.normal(size=(n, d)).astype(np.float32)
+        yt = torch.from_numpy(y).double().requires_grad_(True)
+        gathered = yt[torch.from_numpy(idx).long()]                       # (n,k,d)
+        first = gathered.detach().numpy().argmax(axis=1)                   # first maximum
+        ref = np.zeros((m, d))
+        np.add.at(ref, (idx[np.arange(n)[:, None], first], np.arange(d)[None, :]), dz.astype(np.float64))
+        assert _rel(pk.ops.maxpool_gather_bwd(C(y), C(idx), C(dz)), ref) <= 1e-5
+        # interpolation backward
+        w = rng.uniform(size=(n, k)).astype(np.float32)
+        dy = rng.normal(size=(n, d)).astype(np.float32)
+        ref = np.zeros((m, d))
+        np.add.at(ref, idx.reshape(-1), (w[:, :, None] * dy[:, None, :]).reshape(n * k, d).astype(np.float64))
+        assert _rel(pk.ops.interp_bwd(C(dy), C(idx), C(w), m), ref) <= 1e-5
+
+
+def test_attention_chain_gradients_random(pk):
+    """softmax-aggregate, position-hidden and LayerNorm backward against torch autograd of the same formulas."""
+    rng = np.random.default_rng(41)
+    for trial in range(8):
+        n, m, d, k = int(rng.choice([1, 33, 300])), int(rng.choice([14, 76, 531])), int(rng.choice([36, 72, 288, 416])), \
+            int(rng.integers(1, 15))
+        idx = rng.integers(0, m, size=(n, k)).astype(np.int32)
+        logits = rng.normal(size=(n * k, d)).astype(np.float32)
+        v = rng.normal(size=(m, d)).astype(np.float32)
+        pe = rng.normal(size=(n * k, d)).astype(np.float32)
+        dagg = rng.normal(size=(n, d)).astype(np.float32)
+        lt, vt, pt = (torch.from_numpy(a).double().requires_grad_(True) for a in (logits, v, pe))
+        att = torch.softmax(lt.view(n, k, d) / float(np.float32(np.sqrt(d))), dim=1)
+        agg = (att * (vt[torch.from_numpy(idx).long()] + pt.view(n, k, d))).sum(dim=1)
+        agg.backward(torch.from_numpy(dagg).double())
+        fwd = pk.ops.pt_softmax_agg(C(logits), C(v), C(pe), C(idx))
+        assert _rel(fwd, agg) <= 3e-6
+        dl, dpe, dv = pk.ops.pt_softmax_agg_bwd(C(logits), C(v), C(pe), C(idx), C(dagg))
+        assert _rel(dl, lt.grad) <= 1e-5 and _rel(dpe, pt.grad) <= 1e-5 and _rel(dv, vt.grad) <= 1e-5
+        # position hidden
+        h = 32
+        pos, pos2 = rng.uniform(-5, 5, size=(n, 3)).astype(np.float32), rng.uniform(-5, 5, size=(m, 3)).astype(np.float32)
+        P1, c1 = rng.normal(size=(h, 3)).astype(np.float32), rng.normal(size=(h,)).astype(np.float32)
+        gr = rng.normal(size=(n * k, h)).astype(np.float32)
+        Pt, ct = torch.from_numpy(P1).double().requires_grad_(True), torch.from_numpy(c1).double().requires_grad_(True)
+        rel = (torch.from_numpy(pos).double()[:, None, :] - torch.from_numpy(pos2).double()[torch.from_numpy(idx).long()])
+        r = torch.relu(rel.view(n * k, 3) @ Pt.t() + ct)
+        r.backward(torch.from_numpy(gr).double())
+        r_dev = pk.ops.pt_pos_hidden(C(pos), C(pos2), C(idx), C(P1), C(c1))
+        assert _rel(r_dev, r) <= 3e-6
+        dP1, dc1 = pk.ops.pt_pos_hidden_bwd(C(pos), C(pos2), C(idx), r_dev, C(gr))
+        assert _rel(dP1, Pt.grad) <= 2e-5 and _rel(dc1, ct.grad) <= 2e-5
+        # LayerNorm backward
+        x = rng.normal(size=(n * k, d)).astype(np.float32)
+        gam = rng.normal(size=d).astype(np.float32)
+        go = rng.normal(size=(n * k, d)).astype(np.float32)
+        xt, gt = torch.from_numpy(x).double().requires_grad_(True), torch.from_numpy(gam).double().requires_grad_(True)
+        bt = torch.zeros(d, dtype=torch.float64, requires_grad=True)
+        torch.nn.functional.layer_norm(xt, (d,), gt, bt, 1e-5).backward(torch.from_numpy(go).double())
+        dx, dg, dbeta = pk.ops.layernorm_bwd(C(x), C(gam), C(go), 1e-5)
+        assert _rel(dx, xt.grad) <= 2e-5 and _rel(dg, gt.grad) <= 2e-5 and _rel(dbeta, bt.grad) <= 2e-5
