@@ -47,24 +47,27 @@ __global__ __launch_bounds__(256, 1) void linear_kernel(const occ4d_linear_args 
 
   f32x4 ra[ALOADS], rw[WLOADS];
 
+  // Unconditional, clamped loads + select (no exec-mask branches): the whole k-tile body must be ONE scheduling
+  // region so that the prefetch can be interleaved with the MFMA stream (sched_group_barrier below).
   auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < ALOADS; ++i) {
       const int f = tid + 256 * i;
       const int r = row0 + f / F4K, k = k0 + 4 * (f % F4K);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (r < M && k < K) v = *reinterpret_cast<const f32x4*>(a.x + (int64_t)r * a.ldx + k);
-      ra[i] = v;
+      const bool ok = r < M && k < K;
+      f32x4 v = *reinterpret_cast<const f32x4*>(a.x + (int64_t)min(r, M - 1) * a.ldx + min(k, K - 4));
+      ra[i].x = ok ? v.x : 0.f; ra[i].y = ok ? v.y : 0.f; ra[i].z = ok ? v.z : 0.f; ra[i].w = ok ? v.w : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < WLOADS; ++i) {
       const int f = tid + 256 * i;
       const int c = col0 + f / F4K, k = k0 + 4 * (f % F4K);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (f / F4K < BN && c < N && k < K) v = *reinterpret_cast<const f32x4*>(a.w + (int64_t)c * a.ldw + k);
-      rw[i] = v;
+      const bool ok = f / F4K < BN && c < N && k < K;
+      f32x4 v = *reinterpret_cast<const f32x4*>(a.w + (int64_t)min(c, N - 1) * a.ldw + min(k, K - 4));
+      rw[i].x = ok ? v.x : 0.f; rw[i].y = ok ? v.y : 0.f; rw[i].z = ok ? v.z : 0.f; rw[i].w = ok ? v.w : 0.f;
     }
   };
+  const float relu_floor = a.relu_in ? 0.f : -__builtin_inff();     // branch-free relu-on-load
   auto sstore = [&](int buf) {
     float* As = As0 + buf * BM * LDT;
     float* Ws = Ws0 + buf * BN * LDT;
@@ -72,15 +75,13 @@ __global__ __launch_bounds__(256, 1) void linear_kernel(const occ4d_linear_args 
     for (int i = 0; i < ALOADS; ++i) {
       const int f = tid + 256 * i;
       f32x4 v = ra[i];
-      if (a.relu_in) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-      }
+      v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
       *reinterpret_cast<f32x4*>(As + (f / F4K) * LDT + 4 * (f % F4K)) = v;
     }
 #pragma unroll
     for (int i = 0; i < WLOADS; ++i) {
       const int f = tid + 256 * i;
-      if (f / F4K < BN) *reinterpret_cast<f32x4*>(Ws + (f / F4K) * LDT + 4 * (f % F4K)) = rw[i];
+      if ((NT * 32 * F4K) % 256 == 0 || f / F4K < BN) *reinterpret_cast<f32x4*>(Ws + (f / F4K) * LDT + 4 * (f % F4K)) = rw[i];
     }
   };
 
@@ -98,12 +99,10 @@ __global__ __launch_bounds__(256, 1) void linear_kernel(const occ4d_linear_args 
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
 #ifndef OCC4D_ABLATE_NOLOAD
-    if (kt + 1 < nk) gload((kt + 1) * BK);
+    gload(kt + 1 < nk ? (kt + 1) * BK : 0);          // always (the last one is a harmless re-load of tile 0)
 #endif
-    __builtin_amdgcn_sched_barrier(0);   // keep the prefetch at the top (hipcc sinks it next to sstore)
     const float* Ab = As0 + buf * BM * LDT + wave * 32 * LDT + frag_off;
     const float* Wb = Ws0 + buf * BN * LDT + frag_off;
-    // consecutive MFMAs target different accumulators (never back to back on the same one)
     constexpr int GH = NT > 7 ? (NT + 1) / 2 : NT;
 #pragma unroll
     for (int j = 0; j < BK / 8; ++j) {
@@ -123,9 +122,32 @@ __global__ __launch_bounds__(256, 1) void linear_kernel(const occ4d_linear_args 
         }
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
 #ifndef OCC4D_ABLATE_NOLOAD
-    if (kt + 1 < nk) sstore(buf ^ 1);
+    sstore(buf ^ 1);
+#endif
+#ifndef OCC4D_LINEAR_NO_PIPE
+    // Pipeline description for the scheduler (one region = the whole k-tile): the ALOADS + WLOADS global loads ride
+    // in the shadow of the first MFMAs, the matching ds_write_b128s in the shadow of the last ones (by then the
+    // data has had > 100 MFMAs = 6000+ cycles to arrive); ds_read_b128 fragment reads are left to the compiler.
+    {
+      constexpr int NLD = ALOADS + WLOADS;
+      constexpr int NMFMA = (BK / 2) * NT;
+      constexpr int PER = 3;                                    // MFMAs between two memory instructions
+      static_assert(2 * NLD * PER <= NMFMA || NT < 4, "pipeline needs enough MFMAs");
+      if (NT >= 4) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);   // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - 2 * NLD * PER, 0);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // DS write
+        }
+      }
+    }
 #endif
     __syncthreads();
   }

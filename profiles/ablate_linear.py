@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 import occlusions4d_amd as pk  # noqa: E402
 
 CSRC = os.path.join(ROOT, 'occlusions-4d_amd', 'csrc')
-VARIANTS = {'bk32': ['-DOCC4D_LINEAR_BK=32'], 'bk16': ['-DOCC4D_LINEAR_BK=16'],
+VARIANTS = {'bk32': ['-DOCC4D_LINEAR_BK=32'], 'bk32-nopipe': ['-DOCC4D_LINEAR_BK=32', '-DOCC4D_LINEAR_NO_PIPE'],
             'bk32-noload': ['-DOCC4D_LINEAR_BK=32', '-DOCC4D_ABLATE_NOLOAD'],
             'bk32-noepi': ['-DOCC4D_LINEAR_BK=32', '-DOCC4D_ABLATE_NOEPI'],
             'bk32-both': ['-DOCC4D_LINEAR_BK=32', '-DOCC4D_ABLATE_NOLOAD', '-DOCC4D_ABLATE_NOEPI']}
