@@ -87,7 +87,7 @@ __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* s
   constexpr int H2 = 2 * D;
   constexpr int NHB = H2 / HB;
   constexpr int W2_F4 = D * 8;                     // float4 per hidden block of W2
-  constexpr int W2_LOADS = (W2_F4 + 511) / 512;    // per thread
+  constexpr int W2_LOADS = (W2_F4 + HB * 8) / 512; // float4 per thread per hidden block (W2 rows + Wp rows)
   constexpr int BUF = (D + HB) * LDW;              // floats per LDS buffer: W2 block + Wp block
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = (tid >> 6) & 3;                 // row tile (2 queries)
@@ -147,25 +147,32 @@ __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* s
   const float* aq_row = a.aq + (int64_t)my_q * a.ld_aq + 4 * half;
   const float* kt_row = a.kt + (int64_t)my_j * a.ld_kt + 4 * half;
 
-  f32x4 pw[W2_LOADS], pp;
+  // Weight staging, branch-free (the hidden-block body below must be ONE scheduling region): the block's D rows
+  // of W2 and HB rows of Wp form (D + HB) * 8 float4 = W2_LOADS * 512 exactly; thread t moves float4 number
+  // t + 512 i, whose LDS row (f >> 3) runs through the W2 rows and on into the Wp rows.
+  static_assert((D + HB) * 8 == W2_LOADS * 512, "weight block must be a whole number of float4 per thread");
+  f32x4 pw[W2_LOADS];
+  int woff[W2_LOADS];     // source offset (floats) of this thread's i-th float4 inside W2 (or the Wp block)
+#pragma unroll
+  for (int i = 0; i < W2_LOADS; ++i) {
+    const int f = tid + 512 * i;
+    woff[i] = f < W2_F4 ? (f >> 3) * H2 + 4 * (f & 7) : ((f >> 3) - D) * 32 + 4 * (f & 7);
+  }
   auto gload = [&](int hb) {
 #pragma unroll
     for (int i = 0; i < W2_LOADS; ++i) {
       const int f = tid + 512 * i;
-      if (f < W2_F4)
-        pw[i] = *reinterpret_cast<const f32x4*>(a.w2 + (int64_t)(f >> 3) * H2 + hb * HB + 4 * (f & 7));
+      const float* src = f < W2_F4 ? a.w2 + hb * HB + woff[i] : a.wp + hb * HB * 32 + woff[i];
+      pw[i] = *reinterpret_cast<const f32x4*>(src);
     }
-    if (tid < 256)
-      pp = *reinterpret_cast<const f32x4*>(a.wp + (int64_t)(hb * HB + (tid >> 3)) * 32 + 4 * (tid & 7));
   };
   auto sstore = [&](int buf) {
     float* W = smem + buf * BUF;
 #pragma unroll
     for (int i = 0; i < W2_LOADS; ++i) {
       const int f = tid + 512 * i;
-      if (f < W2_F4) *reinterpret_cast<f32x4*>(W + (f >> 3) * LDW + 4 * (f & 7)) = pw[i];
+      *reinterpret_cast<f32x4*>(W + (f >> 3) * LDW + 4 * (f & 7)) = pw[i];
     }
-    if (tid < 256) *reinterpret_cast<f32x4*>(W + D * LDW + (tid >> 3) * LDW + 4 * (tid & 7)) = pp;
   };
 
   f32x16 acc[NTW];
@@ -195,10 +202,7 @@ __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* s
 
   for (int hb = 0; hb < NHB; ++hb) {
     const int buf = hb & 1;
-#ifndef OCC4D_ABLATE_NOLOAD
-    if (hb + 1 < NHB) gload(hb + 1);
-#endif
-    __builtin_amdgcn_sched_barrier(0);
+    const int nb = hb + 1 < NHB ? hb + 1 : 0;      // the last iteration re-loads block 0 (harmless, keeps the body branch-free)
     const float* W = smem + buf * BUF;
     // GEMM1 accumulator init: Aq[q][hid] - Kt[j][hid], hid = 32 hb + 8 g + 4 half + i  (reg = 4 g + i)
     f32x16 hacc;
@@ -207,11 +211,12 @@ __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* s
       hacc[4 * g + 0] = av[g].x - kv[g].x; hacc[4 * g + 1] = av[g].y - kv[g].y;
       hacc[4 * g + 2] = av[g].z - kv[g].z; hacc[4 * g + 3] = av[g].w - kv[g].w;
     }
-    __builtin_amdgcn_sched_barrier(0);
 #ifndef OCC4D_ABLATE_NOINIT
-    if (hb + 1 < NHB) iload(hb + 1, av, kv);    // same registers: consumed just above
+    iload(nb, av, kv);                             // same registers: consumed just above
 #endif
-    __builtin_amdgcn_sched_barrier(0);
+#ifndef OCC4D_ABLATE_NOLOAD
+    gload(nb);
+#endif
     if (SPLIT) {
       // GEMM1 on split-bf16 MFMAs as well (it feeds only the logit branch): Wp rows are packed
       // [32 hi | 32 lo] bf16 in fragment order like W2; r was split once (rs_hi / rs_lo).
@@ -285,9 +290,32 @@ __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* s
         }
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
 #ifndef OCC4D_ABLATE_NOLOAD
-    if (hb + 1 < NHB) sstore(buf ^ 1);
+    sstore(buf ^ 1);
+#endif
+#ifndef OCC4D_CA_NO_PIPE
+    // Pipeline description for the scheduler (the whole hidden block is one region): the 8 Aq / Kt loads and the
+    // W2_LOADS weight loads of the next block ride in the shadow of the first MFMAs, the ds_write_b128s that publish
+    // the weights in the shadow of the last ones; fragment ds_reads and the VALU work are left to the compiler.
+    // (Pinned at the top / bottom of the block instead, every wave of the workgroup did its memory phase at the
+    // same time right after the barrier and the MFMA pipes idled: 13 % of the kernel.)
+    {
+      constexpr int NMFMA = SPLIT ? 6 + 6 * NTW : 16 + 16 * NTW;
+      constexpr int NVM = 8 + W2_LOADS;
+      constexpr int P1 = SPLIT ? 1 : 2, P2 = SPLIT ? 2 : 3;
+      static_assert(NVM * P1 + W2_LOADS * P2 <= NMFMA, "pipeline needs enough MFMAs");
+#pragma unroll
+      for (int i = 0; i < NVM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, P1, 0);    // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - NVM * P1 - W2_LOADS * P2, 0);
+#pragma unroll
+      for (int i = 0; i < W2_LOADS; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, P2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // DS write
+      }
+    }
 #endif
 #ifndef OCC4D_ABLATE_NOBAR
     __syncthreads();
