@@ -30,7 +30,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__
   constexpr int BNn = 128, BKk = 32 * NT;
   constexpr int LDG = BNn + 4, LDX = BKk + 4;
   __shared__ __attribute__((aligned(16))) float gs[2][WG_BM * LDG];
-  __shared__ __attribute__((aligned(16))) float xs[2][WG_BM * LDX];
+  constexpr int XL_ = (WG_BM * BKk / 4 + 255) / 256;
+  constexpr int XROWS = (XL_ * 256 + BKk / 4 - 1) / (BKk / 4);   // >= WG_BM: every thread stores all its float4 (no branch)
+  __shared__ __attribute__((aligned(16))) float xs[2][XROWS * LDX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * BNn, k0 = blockIdx.y * BKk;
   const int m_begin = blockIdx.z * m_per_split, m_end = min(M, m_begin + m_per_split);
@@ -38,23 +40,24 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__
   constexpr int GL = (WG_BM * BNn / 4) / 256;                 // float4 per thread, g tile (= 2)
   constexpr int XL = (WG_BM * BKk / 4 + 255) / 256;           // float4 per thread, x tile
   f32x4 rg[GL], rx[XL];
+  // unconditional clamped loads + select: the m-tile body below is one scheduling region (see linear.hip)
   auto gload = [&](int m0) {
 #pragma unroll
     for (int i = 0; i < GL; ++i) {
       const int f = tid + 256 * i;
       const int mm = m0 + f / (BNn / 4), n = n0 + 4 * (f % (BNn / 4));
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (mm < m_end && n < N) v = *reinterpret_cast<const f32x4*>(g + (int64_t)mm * ldg + n);
-      rg[i] = v;
+      const bool ok = mm < m_end && n < N;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(g + (int64_t)min(mm, M - 1) * ldg + min(n, N - 4));
+      rg[i].x = ok ? v.x : 0.f; rg[i].y = ok ? v.y : 0.f; rg[i].z = ok ? v.z : 0.f; rg[i].w = ok ? v.w : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
       const int f = tid + 256 * i;
       const int mm = m0 + f / (BKk / 4), k = k0 + 4 * (f % (BKk / 4));
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (f < WG_BM * BKk / 4 && mm < m_end && k < K) v = *reinterpret_cast<const f32x4*>(x + (int64_t)mm * ldx + k);
+      const bool ok = f < WG_BM * BKk / 4 && mm < m_end && k < K;
+      f32x4 v = *reinterpret_cast<const f32x4*>(x + (int64_t)min(mm, M - 1) * ldx + min(k, K - 4));
       if (relu_x) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      rx[i] = v;
+      rx[i].x = ok ? v.x : 0.f; rx[i].y = ok ? v.y : 0.f; rx[i].z = ok ? v.z : 0.f; rx[i].w = ok ? v.w : 0.f;
     }
   };
   auto sstore = [&](int buf) {
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
       const int f = tid + 256 * i;
-      if (f < WG_BM * BKk / 4) *reinterpret_cast<f32x4*>(&xs[buf][(f / (BKk / 4)) * LDX + 4 * (f % (BKk / 4))]) = rx[i];
+      *reinterpret_cast<f32x4*>(&xs[buf][(f / (BKk / 4)) * LDX + 4 * (f % (BKk / 4))]) = rx[i];
     }
   };
   f32x16 acc[NT];
@@ -85,12 +88,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__
   float bsum = 0.f;
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
-    if (t + 1 < nt) gload(m_begin + (t + 1) * WG_BM);
-    __builtin_amdgcn_sched_barrier(0);
-    if (do_bias) {
+    gload(t + 1 < nt ? m_begin + (t + 1) * WG_BM : m_begin);               // always (last: harmless re-load)
 #pragma unroll
-      for (int mm = 0; mm < WG_BM; ++mm) bsum += gs[buf][mm * LDG + tid];   // rows past m_end are zero-filled
-    }
+    for (int mm = 0; mm < WG_BM; ++mm) bsum += gs[buf][mm * LDG + (tid & (BNn - 1))];   // rows past m_end are zero-filled
 #pragma unroll
     for (int s = 0; s < WG_BM / 2; ++s) {
       const float av = gs[buf][(2 * s + kh) * LDG + wave * 32 + col];      // A[i = n][kk = m]
@@ -100,8 +100,24 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__
         acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[c], 0, 0, 0);
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + 1 < nt) sstore(buf ^ 1);
+    sstore(buf ^ 1);
+    {   // prefetch loads in the shadow of the first MFMAs, LDS stores in the shadow of the last (see linear.hip)
+      constexpr int NLD = GL + XL, NMFMA = (WG_BM / 2) * NT;
+      constexpr int PER = NMFMA / (2 * NLD) >= 3 ? 3 : (NMFMA / (2 * NLD) >= 1 ? NMFMA / (2 * NLD) : 0);
+      if (PER > 0) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - 2 * NLD * PER, 0);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+      }
+    }
     __syncthreads();
   }
   if (do_bias && n0 + tid < N) part_b[(int64_t)blockIdx.z * N + n0 + tid] = bsum;

@@ -302,7 +302,13 @@ __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* s
     {
       constexpr int NMFMA = SPLIT ? 6 + 6 * NTW : 16 + 16 * NTW;
       constexpr int NVM = 8 + W2_LOADS;
-      constexpr int P1 = SPLIT ? 1 : 2, P2 = SPLIT ? 2 : 3;
+#ifndef OCC4D_CA_P1
+#define OCC4D_CA_P1 2
+#endif
+#ifndef OCC4D_CA_P2
+#define OCC4D_CA_P2 3
+#endif
+      constexpr int P1 = SPLIT ? 1 : OCC4D_CA_P1, P2 = SPLIT ? 2 : OCC4D_CA_P2;
       static_assert(NVM * P1 + W2_LOADS * P2 <= NMFMA, "pipeline needs enough MFMAs");
 #pragma unroll
       for (int i = 0; i < NVM; ++i) {
