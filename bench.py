@@ -269,7 +269,7 @@ def main():
                 'frac': achieved / FP32_MFMA_PEAK,
                 # HBM bytes per full 32256-query launch from the PMC passes committed as profiles/r01_pmc_final.txt:
                 # (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE correction); not re-measured live
-                'traffic': 234.1e6 if args.kind == 'greater' else None,
+                'traffic': 236.5e6 if args.kind == 'greater' else None,
                 'traffic_source': 'profiles/r01_pmc_final.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)',
                 'kernel': 'cross_attn_kernel<13> (fused vector attention: pos-MLP + attn-MLP + softmax + '
                           'aggregate, 14 neighbours, D=416)',
