@@ -52,7 +52,7 @@ def abstract_shape(pcl_net, n_points):
 
 def sharded_inference(pcl_input, points_query, pcl_net, implicit_net, batch_size, color_mode,
                       predict_segmentation=False, track_mode='none', semantic_classes=13, gather=False,
-                      squash=None):
+                      squash=None, encoded=None):
     """pcl_input (1,N,8) and points_query (Nq,4) are CUDA tensors present on every rank (the query
     grid is deterministic, every rank builds it).  Returns (local_output (n_local,G), (lo, hi)) or the
     gathered (Nq,G) tensor when gather=True.  `squash(out, codes)` applies the per-channel post-ops in
@@ -60,8 +60,11 @@ def sharded_inference(pcl_input, points_query, pcl_net, implicit_net, batch_size
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     device = points_query.device
-    shape = abstract_shape(pcl_net, pcl_input.shape[1])
-    pcl_abstract, features_global = encode_and_share(pcl_input, pcl_net, shape, pcl_net.global_dim, device)
+    if encoded is None:
+        shape = abstract_shape(pcl_net, pcl_input.shape[1])
+        pcl_abstract, features_global = encode_and_share(pcl_input, pcl_net, shape, pcl_net.global_dim, device)
+    else:
+        pcl_abstract, features_global = encoded
     lo, hi = shard_bounds(points_query.shape[0], rank, world)
     out = torch.empty((hi - lo, implicit_net.d_out), dtype=torch.float32, device=device)
     if points_query.is_cuda:
@@ -84,3 +87,43 @@ def sharded_inference(pcl_input, points_query, pcl_net, implicit_net, batch_size
     else:
         parts = [padded]
     return torch.cat(parts)[:points_query.shape[0]]
+
+
+class ClipPipeline:
+    """Throughput mode for a stream of clips (one process per GPU): the encode (+ broadcast) of clip i + 1 is issued
+    on a side stream while clip i decodes.  The encoder's critical path is the farthest-point-sampling chain -- one
+    workgroup, ~11 ms of dependent steps -- which occupies ONE compute unit; next to the MFMA-bound decode of the
+    previous clip it is almost free.  Every clip is still encoded and decoded in full; only the order of issue
+    changes.  Usage: submit(clip0); then per clip: enc = take(); submit(next clip); out = decode(enc, queries)."""
+
+    def __init__(self, pcl_net, implicit_net, batch_size, color_mode, predict_segmentation=False, track_mode='none',
+                 semantic_classes=13):
+        self.pcl_net, self.implicit_net = pcl_net, implicit_net
+        self.args = (batch_size, color_mode, predict_segmentation, track_mode, semantic_classes)
+        self.stream = torch.cuda.Stream()
+        self.pending = None
+
+    def submit(self, pcl_input):
+        main = torch.cuda.current_stream()
+        self.stream.wait_stream(main)                       # pcl_input was produced on the caller's stream
+        with torch.cuda.stream(self.stream):
+            shape = abstract_shape(self.pcl_net, pcl_input.shape[1])
+            enc = encode_and_share(pcl_input, self.pcl_net, shape, self.pcl_net.global_dim, pcl_input.device)
+            ev = torch.cuda.Event()
+            ev.record()
+        self.pending = (enc, ev, pcl_input)
+
+    def take(self):
+        (enc, ev, pcl_input) = self.pending
+        self.pending = None
+        main = torch.cuda.current_stream()
+        main.wait_event(ev)
+        for t in enc:
+            t.record_stream(main)
+        return enc, pcl_input
+
+    def decode(self, taken, points_query):
+        (enc, pcl_input) = taken
+        (batch_size, color_mode, seg, track, classes) = self.args
+        return sharded_inference(pcl_input, points_query, self.pcl_net, self.implicit_net, batch_size, color_mode, seg,
+                                 track, classes, encoded=enc)

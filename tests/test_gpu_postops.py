@@ -105,3 +105,30 @@ def test_perform_inference_split_matches_reference_rows(pk):
         assert np.abs(res['output_solid'][:64] - g['solid_head']).max() <= 1e-4
         assert np.array_equal(res['output_air'][:64, 4], g['air_head'][:, 4])
         assert np.abs(res['output_air'][:64, :4] - g['air_head'][:, :4]).max() <= 1e-4
+
+
+def test_clip_pipeline_matches_sequential_calls(pk):
+    """Throughput mode: the encode of clip i + 1 issued while clip i decodes gives bit-identical outputs to
+    sequential encode + decode calls, for a stream of DIFFERENT clips."""
+    pa, ia, inf = pk.configs.model_args('greater', 1024)
+    esd, dsd = pk.configs.synthetic_weights(pa, ia, 3)
+    enc = pk.model.PointCompletionNetV3(**pa).cuda().eval()
+    dec = pk.implicit.LocalPclResnetFC(**ia).cuda().eval()
+    enc.load_state_dict(esd)
+    dec.load_state_dict(dsd)
+    clips = [pk.configs.synthetic_pcl('greater', 1024, 4, seed).cuda() for seed in (11, 12, 13, 14)]
+    q = pk.geometry.sample_implicit_points_blind_device(6000, -1.0, 5.0, 2, 'greater', 4, 'grid', 'cuda')
+    with torch.no_grad():
+        seq = [pk.distributed.sharded_inference(c, q, enc, dec, 2304, inf['color_mode'])[0].clone() for c in clips]
+        pipe = pk.distributed.ClipPipeline(enc, dec, 2304, inf['color_mode'])
+        pipe.submit(clips[0])
+        outs = []
+        for i in range(len(clips)):
+            taken = pipe.take()
+            if i + 1 < len(clips):
+                pipe.submit(clips[i + 1])
+            outs.append(pipe.decode(taken, q)[0].clone())
+    torch.cuda.synchronize()
+    for a, b in zip(seq, outs):
+        assert torch.equal(a, b)
+    assert not torch.equal(outs[0], outs[1])
