@@ -199,7 +199,11 @@ __global__ __launch_bounds__(TPB) void interp_add_kernel(float* __restrict__ x, 
   x[i * ldx + c] += s;
 }
 
-// float4 variant: one lane owns 4 consecutive channels -> 16-byte gathers from the L2-resident table
+// float4 variant: one lane owns 4 consecutive channels -> 16-byte gathers from the L2-resident table.
+// KC > 0: compile-time neighbour count, fully unrolled -- the KC index / weight loads and then the KC table
+// gathers are all in flight before the first add (the runtime-k loop was a chain of dependent loads).
+// Same operation order in both: s = (...((w0 t0) + w1 t1) + ...), then + cvec, then + x.
+template <int KC>
 __global__ __launch_bounds__(TPB) void interp_add4_kernel(float* __restrict__ x, int64_t ldx,
                                                           const float* __restrict__ cvec,
                                                           const float* __restrict__ table, int64_t ldt,
@@ -211,10 +215,22 @@ __global__ __launch_bounds__(TPB) void interp_add4_kernel(float* __restrict__ x,
   const int c = 4 * (int)(e % d4);
   const int64_t i = e / d4;
   f4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int j = 0; j < k; ++j) {
-    const float wj = w[i * k + j];
-    const f4 t = *reinterpret_cast<const f4*>(table + (int64_t)idx[i * k + j] * ldt + c);
-    s.x += wj * t.x; s.y += wj * t.y; s.z += wj * t.z; s.w += wj * t.w;
+  if (KC > 0) {
+    int jj[KC > 0 ? KC : 1];
+    float wj[KC > 0 ? KC : 1];
+    f4 t[KC > 0 ? KC : 1];
+#pragma unroll
+    for (int j = 0; j < KC; ++j) { jj[j] = idx[i * KC + j]; wj[j] = w[i * KC + j]; }
+#pragma unroll
+    for (int j = 0; j < KC; ++j) t[j] = *reinterpret_cast<const f4*>(table + (int64_t)jj[j] * ldt + c);
+#pragma unroll
+    for (int j = 0; j < KC; ++j) { s.x += wj[j] * t[j].x; s.y += wj[j] * t[j].y; s.z += wj[j] * t[j].z; s.w += wj[j] * t[j].w; }
+  } else {
+    for (int j = 0; j < k; ++j) {
+      const float wj = w[i * k + j];
+      const f4 t = *reinterpret_cast<const f4*>(table + (int64_t)idx[i * k + j] * ldt + c);
+      s.x += wj * t.x; s.y += wj * t.y; s.z += wj * t.z; s.w += wj * t.w;
+    }
   }
   if (cvec) {
     const f4 cv = *reinterpret_cast<const f4*>(cvec + c);
@@ -349,7 +365,10 @@ int occ4d_interp_add_f32(float* x, int64_t ldx, const float* cvec, const float* 
                    ((uintptr_t)table % 16) == 0 && (!cvec || ((uintptr_t)cvec % 16) == 0);
   if (vec) {
     const int64_t total4 = (int64_t)n * (d / 4);
-    interp_add4_kernel<<<grid1d(total4), TPB, 0, (hipStream_t)stream>>>(x, ldx, cvec, table, ldt, idx, w, total4, k, d / 4);
+    if (k == 8)
+      interp_add4_kernel<8><<<grid1d(total4), TPB, 0, (hipStream_t)stream>>>(x, ldx, cvec, table, ldt, idx, w, total4, k, d / 4);
+    else
+      interp_add4_kernel<0><<<grid1d(total4), TPB, 0, (hipStream_t)stream>>>(x, ldx, cvec, table, ldt, idx, w, total4, k, d / 4);
   } else {
     interp_add_kernel<<<grid1d(total), TPB, 0, (hipStream_t)stream>>>(x, ldx, cvec, table, ldt, idx, w, total, k, d);
   }
