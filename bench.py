@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 import occlusions4d_amd as pk  # noqa: E402
 
 FP32_MFMA_PEAK = 157.3e12
-N_POINTS, VIDEO_LEN, NUM_SAMPLE, BATCH = 14336, 12, 524288, 32768
+N_POINTS, VIDEO_LEN, NUM_SAMPLE, BATCH = 14336, 12, 524288, int(os.environ.get('OCC4D_BENCH_BATCH', '32768'))   # BASELINE: 32768
 SEED = 1830
 
 
@@ -197,7 +197,7 @@ def main():
         # GEMM on split-bf16 MFMAs (three bf16 products, fp32 accumulate); outputs stay within 1e-6 of
         # the fp32 path (tests/test_gpu_parity.py::test_decoder_with_split_bf16_logits).
         alt = None
-        if not args.no_alt:
+        if not args.no_alt and world == 1:
             pk.point_transformer_layer.LOGIT_PRECISION = 'bf16x3'
             step()
             fence()
@@ -213,24 +213,26 @@ def main():
         # Throughput mode (informational, never `value`): clips pipelined across steps -- the encode of step i + 1 is
         # issued on a side stream while step i decodes (distributed.ClipPipeline).  Every step still encodes and
         # decodes in full; K steps contain K encode launches and K decodes.
-        pipe = pk.distributed.ClipPipeline(enc, dec, BATCH, inf['color_mode'], inf['predict_segmentation'], 'none', 13)
-        pipe.submit(pcl)
-        for _ in range(max(1, args.warmup)):
-            taken = pipe.take()
+        pipelined = None
+        if world == 1:          # extra legs only on the single-GPU run: nothing optional may endanger an N > 1 line
+            pipe = pk.distributed.ClipPipeline(enc, dec, BATCH, inf['color_mode'], inf['predict_segmentation'], 'none', 13)
             pipe.submit(pcl)
-            out_pipe, _ = pipe.decode(taken, queries)
-        fence()
-        tp = time.perf_counter()
-        for _ in range(args.steps):
-            taken = pipe.take()
-            pipe.submit(pcl)
-            out_pipe, _ = pipe.decode(taken, queries)
-        pipe.take()                                         # the last encode issued inside the timed region
-        fence()
-        pipe_elapsed = time.perf_counter() - tp
-        pipelined = dict(mode='encode of step i+1 issued on a side stream while step i decodes (K encodes + K decodes)',
-                         ms_per_step=1e3 * pipe_elapsed / args.steps, value=n_total * args.steps / pipe_elapsed,
-                         max_abs_diff_vs_sequential=float((out_pipe - out).abs().max()))
+            for _ in range(max(1, args.warmup)):
+                taken = pipe.take()
+                pipe.submit(pcl)
+                out_pipe, _ = pipe.decode(taken, queries)
+            fence()
+            tp = time.perf_counter()
+            for _ in range(args.steps):
+                taken = pipe.take()
+                pipe.submit(pcl)
+                out_pipe, _ = pipe.decode(taken, queries)
+            pipe.take()                                         # the last encode issued inside the timed region
+            fence()
+            pipe_elapsed = time.perf_counter() - tp
+            pipelined = dict(mode='encode of step i+1 issued on a side stream while step i decodes (K encodes + K decodes)',
+                             ms_per_step=1e3 * pipe_elapsed / args.steps, value=n_total * args.steps / pipe_elapsed,
+                             max_abs_diff_vs_sequential=float((out_pipe - out).abs().max()))
         # Host-boundary figure (informational, never `value`): the full perform_inference call as the reference's
         # eval loop makes it -- host point cloud in (H2D), grid generated on the device, encode + decode, split /
         # compress_air on the device, every result array copied back to host numpy (D2H over PCIe).
@@ -305,7 +307,8 @@ def main():
         }
         if alt is not None:
             line['alt_precision'] = alt
-        line['pipelined'] = pipelined
+        if pipelined is not None:
+            line['pipelined'] = pipelined
         if host_boundary is not None:
             line['host_boundary'] = host_boundary
         if world == 1 and not args.no_cpu_baseline:
