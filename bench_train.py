@@ -29,6 +29,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--graph', action='store_true', help='replay the step as one captured hipGraph (GraphedTrainStep)')
     ap.add_argument('--sampler', action='store_true',
                     help='draw the supervision points inside the step with GuidedImplicitPointSampler '
                          '(57344-point target frames, bias low_moving_vehped_sembal) instead of fixed synthetic queries')
@@ -57,7 +58,13 @@ def main():
                              np.zeros((FRAMES, QUERIES, 1)), rng.integers(-1, 13, size=(FRAMES, QUERIES, 1))], -1)
     q = torch.from_numpy(q.astype(np.float32)).to(device)
     target = torch.from_numpy(target.astype(np.float32)).to(device)
-    step = pk.training.TrainStep(enc, dec, lr=1e-3, grad_clip=0.2, loss_kwargs=dict(density_lw=1.0, segmentation_lw=0.6))
+    lkw = dict(density_lw=1.0, segmentation_lw=0.6)
+    if args.graph:
+        assert not args.sampler, 'the guided sampler draws on the host: it cannot be part of a captured step'
+        step = pk.training.GraphedTrainStep(enc, dec, lr=1e-3, grad_clip=0.2, loss_kwargs=lkw)
+        step.capture(pcl, q, target)
+    else:
+        step = pk.training.TrainStep(enc, dec, lr=1e-3, grad_clip=0.2, loss_kwargs=lkw)
 
     def fence():
         torch.cuda.synchronize()
@@ -116,7 +123,7 @@ def main():
             'metric': 'training step (BASELINE config 5: CARLA-4D, batch 1/GPU, n_points=28672, 4 x 17203 queries)',
             'value': world * args.steps / elapsed, 'unit': 'examples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'dtype': 'f32', 'data': 'synthetic', 'losses': losses, 'sampler_ms_per_step': sampler_ms,
+            'scaling': 'weak', 'dtype': 'f32', 'data': 'synthetic', 'losses': losses, 'sampler_ms_per_step': sampler_ms, 'graph': bool(args.graph),
             'peak_mem_gb': torch.cuda.max_memory_allocated() / 2 ** 30}), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -135,6 +135,8 @@ def fps_coop(xyz, m, start=0, n_workgroups=0, return_order=False, check=True):
     if check:
         if int(ws[-1].item()) != 0:
             raise RuntimeError(_FPS_TIMEOUT)
+    elif torch.cuda.is_current_stream_capturing():
+        pass                  # inside a hipGraph capture: no host-side bookkeeping (the spins stay bounded)
     else:
         # deferred check without a stall: status word -> pinned host memory in stream order + an event
         host = torch.empty(1, dtype=torch.int64, pin_memory=True)

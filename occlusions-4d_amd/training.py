@@ -19,14 +19,39 @@ import torch.nn.functional as F
 from . import ops
 
 
+def _masked_mean(values, mask):
+    """mean of values[mask] without data-dependent shapes (capturable in a hipGraph); same value up to fp32
+    summation order."""
+    m = mask.to(values.dtype)
+    while m.dim() < values.dim():
+        m = m[..., None]
+    return (values * m).sum() / (m.sum() * (values.numel() // mask.numel()))
+
+
 def implicit_loss(implicit_output, implicit_target, density_lw=1.0, color_lw=0.0, segmentation_lw=0.0,
-                  tracking_lw=0.0, color_mode='rgb', semantic_classes=13):
+                  tracking_lw=0.0, color_mode='rgb', semantic_classes=13, static_shapes=False):
     """implicit_output (T,N,G) logits (density, R, G, B, mark_track, segm?); implicit_target (T,N,6) with
-    (density, R, G, B, mark_track, segm).  Per-frame means averaged over frames, weighted sum."""
+    (density, R, G, B, mark_track, segm).  Per-frame means averaged over frames, weighted sum.
+    static_shapes=True computes the masked means by weighting instead of boolean indexing (no host sync, no
+    data-dependent shapes): the form GraphedTrainStep captures."""
     total = implicit_output.new_zeros(())
     nf = implicit_output.shape[0]
     for t in range(nf):
         o, y = implicit_output[t], implicit_target[t]
+        if static_shapes:
+            if density_lw > 0.0:
+                total = total + density_lw * F.binary_cross_entropy_with_logits(o[:, 0], y[:, 0]) / nf
+            if color_lw > 0.0:
+                pred = torch.sigmoid(o[:, 1:4]) if color_mode == 'rgb' else o[:, 1:4]
+                total = total + color_lw * _masked_mean((pred - y[:, 1:4]).abs(), y[:, 0] >= 0.1) / nf
+            if segmentation_lw > 0.0:
+                lab = y[:, -1].to(torch.int64)
+                ce = F.cross_entropy(o[:, -semantic_classes:], lab.clamp(min=0), reduction='none')
+                total = total + segmentation_lw * _masked_mean(ce, lab >= 0) / nf
+            if tracking_lw > 0.0:
+                bce = F.binary_cross_entropy_with_logits(o[:, 4], y[:, 4].clamp(min=0.0), reduction='none')
+                total = total + tracking_lw * _masked_mean(bce, (y[:, 0] >= 0.1) & (y[:, 4] >= 0.0)) / nf
+            continue
         if density_lw > 0.0:
             total = total + density_lw * F.binary_cross_entropy_with_logits(o[:, 0], y[:, 0]) / nf
         if color_lw > 0.0:
@@ -90,3 +115,51 @@ class TrainStep:
             torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
         self.optimizer.step()
         return loss.detach()
+
+
+class GraphedTrainStep(TrainStep):
+    """TrainStep replayed as ONE captured hipGraph: forward, losses, backward, gradient all-reduce, clip and the
+    AdamW update of a step are ~2200 kernel launches issued from Python; captured once (static shapes, static input
+    buffers, capturable optimiser, masked-mean losses), a step is a single graph launch.  Restrictions: fixed
+    shapes, fps_random_start=False (the start index would be frozen into the graph), no guided sampler inside."""
+
+    def __init__(self, pcl_net, implicit_net, lr=1e-3, weight_decay=1e-2, grad_clip=0.2, loss_kwargs=None):
+        super().__init__(pcl_net, implicit_net, lr, weight_decay, grad_clip, dict(loss_kwargs or {}, static_shapes=True))
+        self.optimizer = torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay, capturable=True)
+        self.graph = None
+
+    def _eager(self, pcl_input, points_query, implicit_target):
+        loss = self.forward_loss(pcl_input, points_query, implicit_target)
+        loss.backward()
+        allreduce_gradients(self.params)
+        if self.grad_clip:
+            torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
+        self.optimizer.step()
+        return loss.detach()
+
+    def capture(self, pcl_input, points_query, implicit_target, warmup=2):
+        """Warm-up steps on a side stream (they DO update the parameters), then the capture."""
+        self.static = (pcl_input.clone(), points_query.clone(), implicit_target.clone())
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        losses = []
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.optimizer.zero_grad(set_to_none=True)
+                losses.append(self._eager(*self.static))
+        cur.wait_stream(side)
+        ops.check_pending()
+        self.optimizer.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_loss = self._eager(*self.static)
+        return losses
+
+    def __call__(self, pcl_input, points_query, implicit_target):
+        assert self.graph is not None, 'call capture(...) first'
+        for dst, src in zip(self.static, (pcl_input, points_query, implicit_target)):
+            if dst is not src:
+                dst.copy_(src)
+        self.graph.replay()
+        return self.static_loss
