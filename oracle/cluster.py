@@ -17,7 +17,6 @@ documented behaviour:
   of ``x`` (same batch element) by squared Euclidean distance, returned as a
   (2, k*|y|) index tensor [y index; x index], grouped by y, nearest first.
 """
-import math
 
 import torch
 

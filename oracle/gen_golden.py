@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 import golden_cases as gc  # noqa: E402
-import occlusions4d_amd as pk  # noqa: E402
+import occlusions4d_amd as pk  # noqa: E402,F401  (registers the package golden_cases imports)
 from oracle import ref_import  # noqa: E402
 
 OUT = os.path.join(ROOT, 'tests', 'golden')

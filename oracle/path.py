@@ -6,7 +6,6 @@ reference's).  Every function cites the reference lines it
 follows (paths relative to /root/reference).  It is checked against golden
 vectors produced by the real reference (tests/golden, oracle/gen_golden.py).
 """
-import math
 
 import numpy as np
 import torch

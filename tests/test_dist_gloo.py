@@ -13,7 +13,6 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-import golden_cases as gc
 import occlusions4d_amd as pk
 from oracle import path as op
 
