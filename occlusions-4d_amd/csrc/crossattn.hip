@@ -309,18 +309,23 @@ __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* s
 #define OCC4D_CA_P2 3
 #endif
       constexpr int P1 = SPLIT ? 1 : OCC4D_CA_P1, P2 = SPLIT ? 2 : OCC4D_CA_P2;
-      static_assert(NVM * P1 + W2_LOADS * P2 <= NMFMA, "pipeline needs enough MFMAs");
+#ifndef OCC4D_CA_TAIL
+#define OCC4D_CA_TAIL 0
+#endif
+      constexpr int TAIL = SPLIT ? 0 : OCC4D_CA_TAIL;          // MFMAs after the last ds_write (covers its latency before the barrier)
+      static_assert(NVM * P1 + W2_LOADS * P2 + TAIL <= NMFMA, "pipeline needs enough MFMAs");
 #pragma unroll
       for (int i = 0; i < NVM; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, P1, 0);    // MFMA
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - NVM * P1 - W2_LOADS * P2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - NVM * P1 - W2_LOADS * P2 - TAIL, 0);
 #pragma unroll
       for (int i = 0; i < W2_LOADS; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, P2, 0);
         __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // DS write
       }
+      if (TAIL > 0) __builtin_amdgcn_sched_group_barrier(0x008, TAIL, 0);
     }
 #endif
 #ifndef OCC4D_ABLATE_NOBAR

@@ -14,7 +14,7 @@ import occlusions4d_amd as pk  # noqa: E402
 
 CSRC = os.path.join(ROOT, 'occlusions-4d_amd', 'csrc')
 VARIANTS = {'base': [], 'p1_1': ['-DOCC4D_CA_P1=1'], 'p1_3': ['-DOCC4D_CA_P1=3'], 'p1_4': ['-DOCC4D_CA_P1=4'], 'p2_2': ['-DOCC4D_CA_P2=2'],
-            'p2_5': ['-DOCC4D_CA_P2=5'], 'p1_4_p2_5': ['-DOCC4D_CA_P1=4', '-DOCC4D_CA_P2=5'], 'nopipe': ['-DOCC4D_CA_NO_PIPE'], 'noload': ['-DOCC4D_ABLATE_NOLOAD'], 'nobar': ['-DOCC4D_ABLATE_NOBAR', '-DOCC4D_ABLATE_NOLOAD'],
+            'p2_5': ['-DOCC4D_CA_P2=5'], 'p1_4_p2_5': ['-DOCC4D_CA_P1=4', '-DOCC4D_CA_P2=5'], 'nopipe': ['-DOCC4D_CA_NO_PIPE'], 'tail8': ['-DOCC4D_CA_TAIL=8'], 'tail16': ['-DOCC4D_CA_TAIL=16'], 'tail32': ['-DOCC4D_CA_TAIL=32'], 'noload': ['-DOCC4D_ABLATE_NOLOAD'], 'nobar': ['-DOCC4D_ABLATE_NOBAR', '-DOCC4D_ABLATE_NOLOAD'],
             'noinit': ['-DOCC4D_ABLATE_NOINIT'], 'noepi': ['-DOCC4D_ABLATE_NOEPI'], 'epi_nov': ['-DOCC4D_ABLATE_EPI_NOV'], 'epi_nope': ['-DOCC4D_ABLATE_EPI_NOPE'],
             'epi_nov_nope': ['-DOCC4D_ABLATE_EPI_NOV', '-DOCC4D_ABLATE_EPI_NOPE'],
             'all': ['-DOCC4D_ABLATE_NOLOAD', '-DOCC4D_ABLATE_NOBAR', '-DOCC4D_ABLATE_NOINIT', '-DOCC4D_ABLATE_NOEPI']}
