@@ -181,11 +181,11 @@ __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* s
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
 
-  // Software pipeline, pinned with sched_barrier so hipcc cannot sink the prefetches next to
-  // their use (it did: both global latencies were exposed once per hidden block):
-  //   top of block hb : issue weight loads (W2/Wp block hb+1) and the Aq/Kt slices of hb+1
-  //   body            : GEMM1 -> relu -> GEMM2 on LDS buffer hb&1
-  //   bottom          : registers -> LDS buffer (hb+1)&1, one barrier
+  // Software pipeline over the hidden blocks (one branch-free scheduling region per block, ordered by the
+  // sched_group_barrier sequence at the end of the loop body):
+  //   first MFMAs : the Aq/Kt slices and the weight block (W2/Wp) of hb+1 are loaded in their shadow
+  //   body        : GEMM1 -> relu -> GEMM2 on LDS buffer hb&1
+  //   last MFMAs  : registers -> LDS buffer (hb+1)&1 in their shadow, then one barrier
   f32x4 av[4], kv[4];
   auto iload = [&](int hb, f32x4* A, f32x4* Kk) {
 #pragma unroll

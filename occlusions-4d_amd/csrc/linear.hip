@@ -6,7 +6,10 @@
 // fragment feeds NT MFMAs and the 16*NT accumulators stay in the unified VGPR/AGPR
 // file.  x and w tiles (BK = 32) are staged global -> registers -> LDS, double
 // buffered, one barrier per k-tile; rows are padded to 36 floats so the
-// ds_read_b128 fragment reads are bank-conflict free (stride 9 x 16 B is odd).
+// ds_read_b128 fragment reads are bank-conflict free (stride 9 x 16 B is odd).  A k-tile is one
+// branch-free scheduling region: a sched_group_barrier sequence puts the next tile's global loads
+// between the first MFMAs and its ds_write_b128s between the last (one wave per SIMD has nobody
+// else to cover a memory phase).
 //
 // Fragment / k mapping: lane l supplies row (l & 31); within an 8-wide k group the
 // lower half-wave reads k = 0..3 and the upper k = 4..7 as one float4 each, and MFMA
