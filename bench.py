@@ -1,7 +1,12 @@
 #!/usr/bin/env python
 """Benchmark of the occlusions-4d hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU over RCCL.  Either launched by `python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...` (RANK / WORLD_SIZE in the environment), or from a bare shell: without WORLD_SIZE the script
+re-launches itself under torch.distributed.run on 127.0.0.1 (and exits with a clear message when fewer than N GPUs
+are visible).
 
 One "step" = one perform_inference unit of work: ONE encode of the
 (1, 14336, 8) point-cloud video + decode of every grid query point of one output frame,
@@ -10,18 +15,25 @@ inputs (point cloud, query grid, weights) already resident in HBM, outputs left 
 Workload (BASELINE.json configs[1], "GREATER inference 1xMI355X"): n_points 14336,
 video_len 12, num_sample 524288 -> 534 528 grid queries, implicit_batch_size 32768,
 fp32, synthetic data + seeded random-init weights of the published architecture.
-At N GPUs the grid is num_sample = 524288 * N (N = 4 is configs[3]'s 2 M-query grid),
-rank 0 encodes and broadcasts the abstract cloud, every rank decodes a contiguous 1/N
-slice -> per-GPU work is fixed: "scaling": "weak".  value = total queries of all ranks /
-max-over-ranks time.
+N > 1 GPUs run BASELINE.json configs[3] ("GREATER dense grid 2 M queries sharded across
+8 x MI355X"): num_sample 2097152 -> 2 125 568 grid queries, rank 0 encodes and broadcasts the
+abstract cloud, every rank decodes a contiguous 1/N slice (265 696 queries per GPU at N = 8):
+the total work is the same for N = 2, 4, 8 -> "scaling": "strong".  value = total queries /
+max-over-ranks time.  Each line also carries the other grid as a secondary leg, so that both
+strong-scaling curves have all their points: `config4_single_gpu` on the N = 1 line (the 2 M
+grid on one GPU) and `strong_config2` on the N > 1 lines (the 534 528-query grid split N ways,
+where the serial 13 ms encode is the Amdahl term).
 
 Extra objects on the JSON line:
   roofline      the dominant kernel = cross_attn_kernel<13> (fused vector attention, 14
-                neighbours, D = 416).  achieved = ALGORITHMIC FLOP of the reference ops it
-                replaces (per pair 3*32 + 32*H + 2H*H + 2H*H MAC, as written)
-                / HIP-event time of those launches inside the timed region; the FLOP the
-                kernel really executes after the exact-in-R refactoring are reported next to
-                it (achieved_executed).  peak = 157.3 TFLOP/s fp32 MFMA.
+                neighbours, D = 416), timed with HIP events on its launch stream.  achieved / frac
+                = the FLOP the kernel EXECUTES (after the exact-in-R refactoring of DESIGN.md 4,
+                counted once: 2 * 14 * (32*832 + 832*416 + 32*416) per query) / time, against the
+                157.3 TFLOP/s fp32 MFMA peak: <= 1 by construction.  achieved_as_written /
+                frac_as_written = the FLOP of the reference ops it replaces (per
+                pair 3*32 + 32*H + 2H*H + 2H*H MAC) / the same time: may exceed 1, because the
+                refactoring removes 45 % of that work.  traffic = HBM bytes per launch from the
+                rocprofv3 PMC passes committed under profiles/ (file named in traffic_source).
   cpu_baseline  the CPU oracle (oracle/path.py = the reference's PyTorch-CPU op sequence)
                 timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
 """
@@ -41,7 +53,9 @@ sys.path.insert(0, ROOT)
 import occlusions4d_amd as pk  # noqa: E402
 
 FP32_MFMA_PEAK = 157.3e12
-N_POINTS, VIDEO_LEN, NUM_SAMPLE, BATCH = 14336, 12, 524288, int(os.environ.get('OCC4D_BENCH_BATCH', '32768'))   # BASELINE: 32768
+N_POINTS, VIDEO_LEN, BATCH = 14336, 12, int(os.environ.get('OCC4D_BENCH_BATCH', '32768'))   # BASELINE: 32768
+NUM_SAMPLE = 524288            # configs[1] / configs[2]: -> 534 528 (GREATER) / 541 314 (CARLA) grid queries
+NUM_SAMPLE_DENSE = 2097152     # configs[3]: -> 2 125 568 grid queries, sharded over the GPUs of the node
 SEED = 1830
 
 
@@ -54,7 +68,18 @@ def as_written_flops(n_queries, n_calls, m_abstract, g_out):
     return per_query * n_queries + per_call * n_calls + 18.35e9
 
 
-def cpu_baseline_worker(kind, world):
+def executed_flops(n_queries, m_abstract, g_out):
+    """Matmul FLOPs the build executes for the same results: lin_z through the per-scene table
+    (8 x H interpolation instead of H x H), attn_mlp[0] merged into the query / key projections (per pair
+    32 x 2H instead of H x 2H), to_k / to_v / W1 k per scene instead of per call; each counted once."""
+    H, E, P, B, L, K, KL = 416, 288, 68, 6, 2, 14, 8
+    per_query = 2 * (P * H + B * (2 * H * H + KL * H) + L * (H * 2 * H + K * (3 * 32 + 32 * 2 * H + 2 * H * H + 32 * H + H)
+                                                             + H * H) + H * g_out)
+    per_scene = 2 * m_abstract * E * (L * (2 * H + H) + B * H)
+    return per_query * n_queries + per_scene + 18.35e9
+
+
+def cpu_baseline_worker(kind):
     """Child process: the oracle timed on the host.  Prints one JSON object.  Decode first (cheap,
     exactly linear in N_q), then the encode (dominated by the oracle's Python FPS stand-in and the
     reference's N x N argsort kNN)."""
@@ -65,7 +90,7 @@ def cpu_baseline_worker(kind, world):
     pa, ia, inf = pk.configs.model_args(kind, N_POINTS)
     esd, dsd = pk.configs.synthetic_weights(pa, ia, SEED)
     pcl = pk.configs.synthetic_pcl(kind, N_POINTS, VIDEO_LEN, SEED)
-    q = pk.geometry.sample_implicit_points_blind_numpy(NUM_SAMPLE * world, inf['min_z'], inf['cube_bounds'], 3,
+    q = pk.geometry.sample_implicit_points_blind_numpy(NUM_SAMPLE, inf['min_z'], inf['cube_bounds'], 3,
                                                        inf['data_kind'], inf['cube_mode'], 'grid')
     m = pk.distributed.abstract_shape(type('E', (), pa), N_POINTS)[0]
     rng = np.random.default_rng(0)
@@ -73,9 +98,12 @@ def cpu_baseline_worker(kind, world):
     fg = torch.from_numpy((0.3 * rng.normal(size=(128,))).astype(np.float32))
     with torch.no_grad():
         op.decoder_forward(dsd, ia, torch.from_numpy(q[:256]), ab, fg)            # warm-up
-        for sample in (2048, 16384):      # the small sample first, so that a slow host still reports a figure
+        # the small sample first, so that a slow host still reports a figure; then two FULL implicit_batch_size
+        # mini-batches, decoded one after the other as eval/inference.py:204-246 does
+        for sample in (2048, 2 * BATCH):
             t0 = time.time()
-            op.decoder_forward(dsd, ia, torch.from_numpy(q[:sample]), ab, fg)
+            for lo in range(0, sample, BATCH):
+                op.decoder_forward(dsd, ia, torch.from_numpy(q[lo:min(sample, lo + BATCH)]), ab, fg)
             t_dec = time.time() - t0
             print(json.dumps(dict(stage='decode', t_dec=t_dec, sample=sample, cores=torch.get_num_threads(),
                                   n_total=int(q.shape[0]))), flush=True)
@@ -87,12 +115,12 @@ def cpu_baseline_worker(kind, world):
     print(json.dumps(dict(stage='encode', t_enc=t_enc)), flush=True)
 
 
-def cpu_baseline(kind, world, budget_s=240.0):
+def cpu_baseline(kind, budget_s=240.0):
     """Runs cpu_baseline_worker in a child with a wall-clock budget (the child is killed by PID if the
     encode overruns; the decode-only figure is then reported and said so)."""
     import subprocess
-    child = subprocess.Popen([sys.executable, os.path.abspath(__file__), '--_cpu-worker', '--kind', kind,
-                              '--gpus', str(world)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    child = subprocess.Popen([sys.executable, os.path.abspath(__file__), '--_cpu-worker', '--kind', kind],
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
     try:
         out, _ = child.communicate(timeout=budget_s)
     except subprocess.TimeoutExpired:
@@ -111,13 +139,44 @@ def cpu_baseline(kind, world, budget_s=240.0):
     if 't_enc' in rec:
         total = rec['t_enc'] + t_dec_full
         note = ('oracle/path.py on host CPU: %d-query decode %.2f s (extrapolated linearly to %d queries = %.0f s) + '
-                '1 encode (n_points=%d) %.1f s' % (sample, rec['t_dec'], n, t_dec_full, N_POINTS, rec['t_enc']))
+                '1 encode (n_points=%d, FPS by the oracle\'s torch_cluster stand-in) %.1f s'
+                % (sample, rec['t_dec'], n, t_dec_full, N_POINTS, rec['t_enc']))
     else:
         total = t_dec_full
         note = ('oracle/path.py on host CPU: %d-query decode %.2f s extrapolated linearly to %d queries; the encode '
                 'did not finish within the %.0f s budget and is NOT included (decode-only upper bound)'
                 % (sample, rec['t_dec'], n, budget_s))
     return dict(value=n / total, unit='query-points/s', cores=rec['cores'], kind='port', sample=note)
+
+
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` from a bare shell: re-run this command line as N ranks under torch.distributed.run
+    (one process per GPU, rendezvous on 127.0.0.1).  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n_gpus:
+        print('bench.py: --gpus %d needs %d visible GPUs, this machine has %d' % (n_gpus, n_gpus, have), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % n_gpus,
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.call(cmd, env=env)
+
+
+def pmc_traffic(kind):
+    """HBM bytes per full launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json, written by profiles/summarize_pmc.py from separate --pmc runs of this command)."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        with open(path) as f:
+            rec = json.load(f)[kind]
+        return rec['hbm_bytes_per_launch'], 'profiles/pmc_traffic.json: ' + rec['source']
+    except (OSError, KeyError, ValueError):
+        return None, 'no PMC pass committed for this workload'
 
 
 def main():
@@ -128,25 +187,40 @@ def main():
     ap.add_argument('--kind', default='greater', choices=['greater', 'carla'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt', action='store_true', help='skip the opt-in split-bf16 logits measurement')
+    ap.add_argument('--no-extra', action='store_true', help='skip every informational leg (secondary grid, pipelined, '
+                    'host boundary)')
     ap.add_argument('--_cpu-worker', dest='cpu_worker', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
-        cpu_baseline_worker(args.kind, args.gpus)
-        return
+        cpu_baseline_worker(args.kind)
+        return 0
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        return self_launch(args.gpus)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    if world != args.gpus:
+        print('bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d)' % (args.gpus, world, args.gpus),
+              file=sys.stderr)
+        return 2
+    if torch.cuda.device_count() <= local_rank:
+        print('bench.py: rank %d needs GPU %d, only %d visible' % (rank, local_rank, torch.cuda.device_count()),
+              file=sys.stderr)
+        return 2
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     use_dist = world > 1 or os.environ.get('OCC4D_FORCE_DIST') == '1'   # (1-rank RCCL: smoke test of the N > 1 path)
+    rccl_ranks = 1
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', str(rank))
         os.environ.setdefault('WORLD_SIZE', str(world))
         dist.init_process_group('nccl', device_id=device)
+        ones = torch.ones((), device=device)
+        dist.all_reduce(ones)                   # the ranks RCCL really connected
+        rccl_ranks = int(ones.item())
 
     pa, ia, inf = pk.configs.model_args(args.kind, N_POINTS)
     esd, dsd = pk.configs.synthetic_weights(pa, ia, SEED)
@@ -155,14 +229,20 @@ def main():
     dec = pk.implicit.LocalPclResnetFC(**ia).to(device).eval()
     enc.load_state_dict(esd)
     dec.load_state_dict(dsd)
-    queries = pk.geometry.sample_implicit_points_blind_device(
-        NUM_SAMPLE * world, inf['min_z'], inf['cube_bounds'], 3, inf['data_kind'], inf['cube_mode'], 'grid', device)
     pcl = pcl_cpu.to(device)
+
+    def grid(num_sample):
+        return pk.geometry.sample_implicit_points_blind_device(
+            num_sample, inf['min_z'], inf['cube_bounds'], 3, inf['data_kind'], inf['cube_mode'], 'grid', device)
+
+    # N = 1: configs[1] (the configuration the metric is quoted on).  N > 1: configs[3], the dense grid, sharded.
+    num_sample = NUM_SAMPLE if world == 1 else NUM_SAMPLE_DENSE
+    queries = grid(num_sample)
     n_total = queries.shape[0]
     lo, hi = pk.distributed.shard_bounds(n_total, rank, world)
 
-    def step():
-        return pk.distributed.sharded_inference(pcl, queries, enc, dec, BATCH, inf['color_mode'],
+    def step(q=None):
+        return pk.distributed.sharded_inference(pcl, queries if q is None else q, enc, dec, BATCH, inf['color_mode'],
                                                 inf['predict_segmentation'], 'none', 13)
 
     def fence():
@@ -172,15 +252,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
+    def timed(fn, steps, warmup):
+        """`warmup` untimed + exactly `steps` timed calls of fn between fences; returns (max-over-ranks seconds,
+        per-rank seconds, last result)."""
+        res = None
+        for _ in range(warmup):
+            res = fn()
         fence()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out, _ = step()
+        for _ in range(steps):
+            res = fn()
         fence()
-        elapsed = time.perf_counter() - t0
+        mine = time.perf_counter() - t0
+        per_rank = [mine]
+        if use_dist:
+            tt = torch.tensor([mine], dtype=torch.float64, device=device)
+            allt = [torch.empty_like(tt) for _ in range(world)]
+            dist.all_gather(allt, tt)
+            per_rank = [float(x.item()) for x in allt]
+        return max(per_rank), per_rank, res
+
+    with torch.no_grad():
+        elapsed, per_rank_s, (out, _) = timed(step, args.steps, args.warmup)
         # Roofline leg: HIP events around every launch of the dominant kernel on its launch stream.
         # The timed steps above interleave mini-batches on two streams, where an event bracket also
         # covers the other stream's kernels; this extra (untimed) step runs the same launches on ONE
@@ -193,19 +286,25 @@ def main():
         pk.ops.set_kernel_timer(None)
         pk.inference.DECODE_STREAMS = streams_saved
         psum = timer.summary().get('cross_attn', dict(launches=0, total_ms=0.0, total_flops=0.0))
+        extra = not args.no_extra
+        # Secondary grid (informational): the other strong-scaling curve's point for this N.
+        other = None
+        if extra:
+            q2 = grid(NUM_SAMPLE_DENSE if world == 1 else NUM_SAMPLE)
+            k2 = max(2, (args.steps + 3) // 4) if world == 1 else args.steps
+            e2, _, _ = timed(lambda: step(q2), k2, 1)
+            lo2, hi2 = pk.distributed.shard_bounds(q2.shape[0], rank, world)
+            other = dict(workload='%s grid of %d queries%s' % (args.kind.upper(), q2.shape[0],
+                                                               ' (%d per GPU)' % (hi2 - lo2) if world > 1 else ''),
+                         steps=k2, ms_per_step=1e3 * e2 / k2, value=q2.shape[0] * k2 / e2, n_gpus=world)
+            del q2
         # Opt-in mode, reported next to the official fp32 number (never as `value`): the attention-logit
         # GEMM on split-bf16 MFMAs (three bf16 products, fp32 accumulate); outputs stay within 1e-6 of
         # the fp32 path (tests/test_gpu_parity.py::test_decoder_with_split_bf16_logits).
         alt = None
-        if not args.no_alt and world == 1:
+        if not args.no_alt and extra and world == 1:
             pk.point_transformer_layer.LOGIT_PRECISION = 'bf16x3'
-            step()
-            fence()
-            ta = time.perf_counter()
-            for _ in range(args.steps):
-                out_alt, _ = step()
-            fence()
-            alt_elapsed = time.perf_counter() - ta
+            alt_elapsed, _, (out_alt, _) = timed(step, args.steps, 1)
             pk.point_transformer_layer.LOGIT_PRECISION = 'f32'
             alt = dict(mode='attention-logit GEMM on bf16x3 split MFMA (fp32 accumulate), all else fp32',
                        ms_per_step=1e3 * alt_elapsed / args.steps, value=n_total * args.steps / alt_elapsed,
@@ -214,19 +313,20 @@ def main():
         # issued on a side stream while step i decodes (distributed.ClipPipeline).  Every step still encodes and
         # decodes in full; K steps contain K encode launches and K decodes.
         pipelined = None
-        if world == 1:          # extra legs only on the single-GPU run: nothing optional may endanger an N > 1 line
+        if extra and world == 1:   # extra legs only on the single-GPU run: nothing optional may endanger an N > 1 line
             pipe = pk.distributed.ClipPipeline(enc, dec, BATCH, inf['color_mode'], inf['predict_segmentation'], 'none', 13)
             pipe.submit(pcl)
-            for _ in range(max(1, args.warmup)):
+
+            def pipe_step():
                 taken = pipe.take()
                 pipe.submit(pcl)
-                out_pipe, _ = pipe.decode(taken, queries)
+                return pipe.decode(taken, queries)
+            for _ in range(max(1, args.warmup)):
+                pipe_step()
             fence()
             tp = time.perf_counter()
             for _ in range(args.steps):
-                taken = pipe.take()
-                pipe.submit(pcl)
-                out_pipe, _ = pipe.decode(taken, queries)
+                out_pipe, _ = pipe_step()
             pipe.take()                                         # the last encode issued inside the timed region
             fence()
             pipe_elapsed = time.perf_counter() - tp
@@ -237,7 +337,7 @@ def main():
         # eval loop makes it -- host point cloud in (H2D), grid generated on the device, encode + decode, split /
         # compress_air on the device, every result array copied back to host numpy (D2H over PCIe).
         host_boundary = None
-        if world == 1:
+        if extra and world == 1:
             reps = 3
             torch.cuda.synchronize()
             th = time.perf_counter()
@@ -251,60 +351,69 @@ def main():
             t_host = (time.perf_counter() - th) / reps
             host_boundary = dict(ms_per_call=1e3 * t_host, value=res['points_query'].shape[0] / t_host,
                                  what='perform_inference with host numpy inputs and outputs (PCIe inclusive)')
-        # encode share, measured separately (informational)
-        torch.cuda.synchronize()
-        te = time.perf_counter()
-        enc(pcl, False)
-        torch.cuda.synchronize()
-        t_encode = time.perf_counter() - te
+        # encode share, measured separately (informational; rank 0 is the rank that encodes)
+        t_encode = None
+        if rank == 0:
+            torch.cuda.synchronize()
+            te = time.perf_counter()
+            enc(pcl, False)
+            torch.cuda.synchronize()
+            t_encode = time.perf_counter() - te
 
-    if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
     ms_per_step = 1e3 * elapsed / args.steps
     value = n_total * args.steps / elapsed
 
     if rank == 0:
         m_abs = pk.distributed.abstract_shape(enc, N_POINTS)[0]
-        calls = -(-(hi - lo) // pk.inference.decode_chunk(BATCH))
-        fl = as_written_flops(hi - lo, calls, m_abs, ia['d_out'])
-        executed = psum['total_flops'] / (psum['total_ms'] * 1e-3) if psum['total_ms'] > 0 else 0.0
-        H, K = 416, 14
+        chunk = pk.inference.decode_chunk(BATCH)
+        calls = -(-(hi - lo) // chunk)
+        fl = as_written_flops(hi - lo, calls, m_abs, ia['d_out'])            # rank 0's share (it also encodes)
+        fl_exec = executed_flops(hi - lo, m_abs, ia['d_out'])
+        t_kernel = psum['total_ms'] * 1e-3
+        executed = psum['total_flops'] / t_kernel if t_kernel > 0 else 0.0
+        H = 416
         as_written_pair = 2.0 * (3 * 32 + 32 * H + 2 * H * H + 2 * H * H)       # FLOP per (query, neighbour)
         executed_pair = 2.0 * (32 * 2 * H + 2 * H * H + 32 * H)
-        achieved = executed * as_written_pair / executed_pair
+        as_written = executed * as_written_pair / executed_pair
+        traffic, traffic_source = pmc_traffic(args.kind)
         line = {
             'metric': '4D query-points/sec (encode+decode) at n_points=14336',
             'value': value, 'unit': 'query-points/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
+            'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
+            'scaling': 'strong' if world > 1 else 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': '%s inference: n_points=%d video_len=%d num_sample=%d (-> %d grid queries'
-                                   '%s) implicit_batch_size=%d, seeded random-init weights'
-                                   % (args.kind.upper(), N_POINTS, VIDEO_LEN, NUM_SAMPLE * world, n_total,
+            'config': {'workload': '%s inference (BASELINE configs[%d]): n_points=%d video_len=%d num_sample=%d (-> %d grid '
+                                   'queries%s) implicit_batch_size=%d, seeded random-init weights'
+                                   % (args.kind.upper(), 1 if world == 1 else 3, N_POINTS, VIDEO_LEN, num_sample, n_total,
                                       ', %d per GPU' % (hi - lo) if world > 1 else '', BATCH),
                        'abstract_points': m_abs, 'outputs_per_query': ia['d_out'],
-                       'parallelism': 'query-sharded x%d, abstract cloud broadcast' % world,
-                       'decode_streams': pk.inference.DECODE_STREAMS,
-                       'decode_chunk': pk.inference.decode_chunk(BATCH)},
+                       'parallelism': 'query-sharded x%d, rank 0 encodes, abstract cloud broadcast (RCCL)' % world
+                                      if world > 1 else 'single GPU',
+                       'scaling_note': 'N = 1 runs configs[1] (534 528 queries); N = 2, 4, 8 run configs[3] (2 125 568 '
+                                       'queries, fixed total -> strong).  The other grid is the secondary leg of each line.',
+                       'rccl_ranks': rccl_ranks, 'per_rank_ms_per_step': [1e3 * t / args.steps for t in per_rank_s],
+                       'decode_streams': pk.inference.DECODE_STREAMS, 'decode_chunk': chunk},
             'roofline': {
-                'bound': 'mfma', 'achieved': achieved / 1e12, 'peak': FP32_MFMA_PEAK / 1e12, 'unit': 'TFLOP/s',
-                'frac': achieved / FP32_MFMA_PEAK,
-                # HBM bytes per full 32256-query launch from the PMC passes committed as profiles/r01_pmc_final.txt:
-                # (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE correction); not re-measured live
-                'traffic': 236.5e6 if args.kind == 'greater' else None,
-                'traffic_source': 'profiles/r01_pmc_final.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)',
+                'bound': 'mfma', 'achieved': executed / 1e12, 'peak': FP32_MFMA_PEAK / 1e12, 'unit': 'TFLOP/s',
+                'frac': executed / FP32_MFMA_PEAK,
+                'achieved_as_written': as_written / 1e12, 'frac_as_written': as_written / FP32_MFMA_PEAK,
+                'traffic': traffic, 'traffic_source': traffic_source,
+                'traffic_over_algorithmic': (traffic / (chunk * (2 * H + H + 14) * 4.0)) if traffic else None,
                 'kernel': 'cross_attn_kernel<13> (fused vector attention: pos-MLP + attn-MLP + softmax + '
                           'aggregate, 14 neighbours, D=416)',
                 'launches': psum['launches'], 'avg_launch_ms': psum['total_ms'] / max(1, psum['launches']),
+                'flop_per_launch_executed': psum['total_flops'] / max(1, psum['launches']),
                 'flop_per_launch_as_written': psum['total_flops'] / max(1, psum['launches'])
-                * as_written_pair / executed_pair,
-                'achieved_executed': executed / 1e12, 'frac_executed': executed / FP32_MFMA_PEAK},
+                * as_written_pair / executed_pair},
             'pipeline': {
+                'executed_tflop_per_step_per_gpu': fl_exec / 1e12,
+                'executed_frac': fl_exec / (ms_per_step * 1e-3) / FP32_MFMA_PEAK,
                 'as_written_tflop_per_step_per_gpu': fl / 1e12,
                 'as_written_fp32_mfma_frac': fl / (ms_per_step * 1e-3) / FP32_MFMA_PEAK,
                 'encode_ms': 1e3 * t_encode},
         }
+        if other is not None:
+            line['config4_single_gpu' if world == 1 else 'strong_config2'] = other
         if alt is not None:
             line['alt_precision'] = alt
         if pipelined is not None:
@@ -312,11 +421,12 @@ def main():
         if host_boundary is not None:
             line['host_boundary'] = host_boundary
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(args.kind, world)
+            line['cpu_baseline'] = cpu_baseline(args.kind)
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

@@ -188,7 +188,8 @@ extern "C" int occ4d_fps_f32(const float* xyz, int64_t stride, int n, int m, int
   // (OCC4D_FPS_THREADS overrides for experiments.)
   // measured: 14336 pts 1024/512/256 threads = 10.7/9.4/15.3 ms; above 56 points per thread only 1024 threads fit
   int threads = n <= 2048 ? 256 : (n <= 56 * 512 ? 512 : 1024);
-  if (const char* e = getenv("OCC4D_FPS_THREADS")) threads = atoi(e);
+  static const int forced_threads = [] { const char* e = getenv("OCC4D_FPS_THREADS"); return e ? atoi(e) : 0; }();   // read once
+  if (forced_threads > 0) threads = forced_threads;
   int rc;
   if (threads == 256) rc = launch_threads<256>(xyz, stride, n, m, out_sorted, out_order, st);
   else if (threads == 512) rc = launch_threads<512>(xyz, stride, n, m, out_sorted, out_order, st);

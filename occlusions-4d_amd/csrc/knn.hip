@@ -81,7 +81,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const float* __restrict_
 #pragma unroll
       for (int s = 0; s < KT; ++s) {
         if (s < k) {
-          out_idx[(int64_t)qi * k + s] = (IdxT)bi[s];
+          out_idx[(int64_t)qi * k + s] = (IdxT)min(bi[s], nd - 1);   // unfilled slot (NaN / inf input): in bounds
           if (out_dist) out_dist[(int64_t)qi * k + s] = bd[s];
         }
       }
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const float* __restrict_
       }
 #pragma unroll
       for (int u = 0; u < TPQ; ++u) head[u] += (u == best_u) ? 1 : 0;
-      out_idx[(int64_t)qi * k + s] = (IdxT)best_i;
+      out_idx[(int64_t)qi * k + s] = (IdxT)min(best_i, nd - 1);
       if (out_dist) out_dist[(int64_t)qi * k + s] = best_d;
     }
   }
@@ -137,7 +137,8 @@ int launch_k(const float* q, int64_t qs, int nq, const float* d, int64_t ds, int
   // sampler's 1-NN filter): 8.1 ms -> 1.15 ms.  Tiny data sets are never split.
   int tpq = 1;
   if (nd >= 256) tpq = (nq / 64 >= 384) ? 4 : 16;
-  if (const char* e = getenv("OCC4D_KNN_TPQ")) tpq = atoi(e);   // experiments
+  static const int forced_tpq = [] { const char* e = getenv("OCC4D_KNN_TPQ"); return e ? atoi(e) : 0; }();   // experiments; read once
+  if (forced_tpq > 0) tpq = forced_tpq;
   if (metric == 0) {
     if (i64) launch_t<KT, 0, int64_t>(tpq, q, qs, nq, d, ds, nd, k, (int64_t*)oi, od, st);
     else launch_t<KT, 0, int32_t>(tpq, q, qs, nq, d, ds, nd, k, (int32_t*)oi, od, st);

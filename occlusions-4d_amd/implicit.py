@@ -18,7 +18,7 @@ from . import geometry  # noqa: F401  (same module graph as the reference)
 from . import modules
 from . import ops
 from . import autograd
-from .point_transformer_layer import needs_grad
+from .point_transformer_layer import needs_grad, weights_epoch
 
 _QUERY_CHUNK = 32768
 
@@ -170,7 +170,7 @@ class LocalPclResnetFC(ResnetFC):
 
     # -- per-scene precompute ---------------------------------------------------------
     def _weights_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.lin_z.parameters())
+        return (weights_epoch(),) + tuple((p.data_ptr(), p._version) for p in self.lin_z.parameters())
 
     def prepare_scene(self, points_abstract, features_global, features_abstract=None):
         """Per-scene tables: abstract xyz / features made contiguous, Z = F @ [Wz_0^loc; ..]^T (M, n_blocks*H),
@@ -230,7 +230,7 @@ class LocalPclResnetFC(ResnetFC):
         if self.local_mode == 'feature':
             output, penult = self._forward_feature(q, sc)
         else:
-            output, penult = self._forward_attention(q, sc, points_abstract)
+            output, penult = self._forward_attention(q, sc, sc['owners'])
         if not no_batch:
             output, penult = output[None], penult[None]
         return (output, penult)

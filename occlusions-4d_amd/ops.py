@@ -84,9 +84,14 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-def _aligned_rows(t, name):
-    """2-D fp32 tensor with 16-byte aligned base and row stride % 4 == 0 (copies if needed)."""
+def _aligned_rows(t, name, k_pad=None):
+    """2-D fp32 tensor with 16-byte aligned base and row stride % 4 == 0 (copies if needed).  `k_pad`: the column
+    count to zero-pad to (the caller decides it ONCE for both operands of a product, so that an aligned strided view
+    with K % 4 != 0 and a freshly padded partner agree on K)."""
     t, ld = _rows(t, name)
+    if k_pad is not None and t.shape[1] != k_pad:
+        t = torch.nn.functional.pad(t, (0, k_pad - t.shape[1]))        # contiguous copy, ld = k_pad
+        ld = k_pad
     if t.data_ptr() % 16 or ld % 4:
         t = t.contiguous()
         if t.shape[1] % 4:
@@ -189,11 +194,13 @@ def fps_auto(xyz, m, start=0):
 def linear(x, w, b=None, relu_in=False, relu_out=False, residual=None, out=None,
            add_rows=None, add_div=1, sub_rows=None, sub_idx=None):
     """y = [relu]( [relu](x) @ w.T + b + add_rows[row // add_div] - sub_rows[sub_idx[row]] ) + residual."""
-    x, ldx = _aligned_rows(_dev(x, name='x'), 'x')
-    w, ldw = _aligned_rows(_dev(w, name='w'), 'w')
+    assert x.dim() == 2 and w.dim() == 2 and w.shape[1] == x.shape[1], \
+        'linear: x is %s but w is %s' % (tuple(x.shape), tuple(w.shape))
+    k4 = (x.shape[1] + 3) // 4 * 4             # K of the kernel: decided once, applied to both operands
+    x, ldx = _aligned_rows(_dev(x, name='x'), 'x', k4)
+    w, ldw = _aligned_rows(_dev(w, name='w'), 'w', k4)
     M, K = x.shape
     N = w.shape[0]
-    assert w.shape[1] == K, 'linear: x is (%d,%d) but w is %s' % (M, K, tuple(w.shape))
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
     y, ldy = _rows(_dev(out, name='out'), 'out')

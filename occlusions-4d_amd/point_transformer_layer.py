@@ -30,6 +30,22 @@ USE_FUSED_ATTENTION = True   # tests flip this to cover the unfused kernel chain
 LOGIT_PRECISION = os.environ.get('OCC4D_LOGIT_PRECISION', 'f32')
 
 
+# Derived-weight caches (merged matrices, per-scene tables, bf16 packs) are keyed on (data_ptr, _version) of the
+# parameters PLUS this epoch.  A parameter's _version does not move when it is updated outside Python's view: a
+# captured hipGraph replay (training.GraphedTrainStep), `p.data.add_()`, a raw-pointer write.  Whoever updates
+# parameters that way calls invalidate_weight_caches(); TrainStep / GraphedTrainStep do after every step.
+_WEIGHTS_EPOCH = [0]
+
+
+def invalidate_weight_caches():
+    """Forces every derived-weight cache of every module to be rebuilt on its next use."""
+    _WEIGHTS_EPOCH[0] += 1
+
+
+def weights_epoch():
+    return _WEIGHTS_EPOCH[0]
+
+
 def needs_grad(module, *tensors):
     """True when the call must be recorded for autograd: the training path (occlusions4d_amd.autograd,
     unfused differentiable kernels in the reference's as-written op order) is taken instead of the
@@ -83,7 +99,7 @@ class PointTransformerLayer(nn.Module):
     # -- derived weights ---------------------------------------------------------------
     def _params_key(self, pre):
         ps = list(self.parameters()) + ([pre.weight, pre.bias] if pre is not None else [])
-        return tuple((p.data_ptr(), p._version) for p in ps)
+        return (weights_epoch(),) + tuple((p.data_ptr(), p._version) for p in ps)
 
     def merged_weights(self, pre=None):
         """fp64-merged matrices of refactoring (i); `pre` is an optional nn.Linear applied to
@@ -113,16 +129,19 @@ class PointTransformerLayer(nn.Module):
         return m
 
     def scene_tables(self, x2, owner=None):
-        """Per-scene tables (W1 Wk) x2 and Wv x2.  Cached while `owner` (the tensor object
-        the caller keeps alive for the scene) and the weights are unchanged -- the
-        reference recomputes them on every forward call."""
-        key = (id(owner), owner._version if owner is not None else None, self._params_key(None))
-        if owner is not None and self._scene is not None and self._scene[0] == key and self._scene[1] is owner:
+        """Per-scene tables (W1 Wk) x2 and Wv x2.  Cached while `owner` (the tensor object, or tuple of
+        tensor objects, the caller keeps alive for the scene), the feature tensor x2's storage / version and the
+        weights are unchanged -- the reference recomputes them on every forward call."""
+        owners = owner if isinstance(owner, tuple) else (owner,)
+        key = (tuple((id(o), None if o is None else o._version) for o in owners),
+               (x2.data_ptr(), x2._version, tuple(x2.shape)), self._params_key(None))
+        if owner is not None and self._scene is not None and self._scene[0] == key \
+                and all(a is b for a, b in zip(self._scene[1], owners)):
             return self._scene[2]
         m = self.merged_weights(None)
         tabs = (ops.linear(x2, m['wk']), ops.linear(x2, self.to_v.weight))
         if owner is not None:
-            self._scene = (key, owner, tabs)   # holds `owner` alive: its address cannot be recycled
+            self._scene = (key, owners, tabs)   # holds the owners alive: their addresses cannot be recycled
         return tabs
 
     # -- forward -----------------------------------------------------------------------

@@ -8,15 +8,16 @@ BCE :175-194), backward through occlusions4d_amd.autograd, all-reduce gradients 
 (one process per GPU, RCCL) instead of nn.DataParallel, clip, AdamW step.
 
 torch supplies the tape, the loss reductions, the optimiser and torch.distributed; every network
-forward and backward kernel is libocc4d.so.  The training-time point sampler
-(utils/geometry.py:578-1105, rank 2 of 8(f)) is not built: query points and their targets are
-inputs of the step.
+forward and backward kernel is libocc4d.so.  Query points and their targets are inputs of the step;
+the training-time point sampler that draws them (utils/geometry.py:578-1105, rank 2 of 8(f)) is
+geometry.GuidedImplicitPointSampler (bench_train.py --sampler runs it inside the step).
 """
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
 from . import ops
+from .point_transformer_layer import invalidate_weight_caches
 
 
 def _masked_mean(values, mask):
@@ -28,43 +29,76 @@ def _masked_mean(values, mask):
     return (values * m).sum() / (m.sum() * (values.numel() // mask.numel()))
 
 
+def squash_for_loss(implicit_output, color_mode):
+    """The pre-loss squashing of the training pipeline (pipeline.py:198-212): density stays a logit (BCE with
+    logits follows); 'rgb' -> sigmoid of channels 1:4, 'rgb_nosigmoid' -> clamp to [0, 1] (so no gradient
+    flows through colours outside [0, 1]), 'hsv' -> clamp of (S, V), 'bins' -> nothing.  Out of place."""
+    if color_mode == 'rgb':
+        mid = torch.sigmoid(implicit_output[..., 1:4])
+    elif color_mode == 'rgb_nosigmoid':
+        mid = torch.clamp(implicit_output[..., 1:4], min=0.0, max=1.0)
+    elif color_mode in ('hsv', 'bins'):
+        raise NotImplementedError("colour losses of color_mode 'hsv' / 'bins' (loss.py:85-149) are not used by "
+                                  'any published configuration')
+    else:
+        raise ValueError('Unknown color_mode: ' + str(color_mode))
+    return torch.cat([implicit_output[..., :1], mid, implicit_output[..., 4:]], dim=-1)
+
+
 def implicit_loss(implicit_output, implicit_target, density_lw=1.0, color_lw=0.0, segmentation_lw=0.0,
-                  tracking_lw=0.0, color_mode='rgb', semantic_classes=13, static_shapes=False):
-    """implicit_output (T,N,G) logits (density, R, G, B, mark_track, segm?); implicit_target (T,N,6) with
-    (density, R, G, B, mark_track, segm).  Per-frame means averaged over frames, weighted sum.
+                  tracking_lw=0.0, color_mode='rgb', semantic_classes=13, static_shapes=False, squashed=False):
+    """loss.MyLosses.per_example + entire_batch (loss.py:200-294) on the RAW decoder outputs.
+
+    implicit_output (T,N,G) or (T,B,N,G) logits (density, R, G, B, mark_track, segm?); implicit_target
+    (T,[B,]N,6) with (density, R, G, B, mark_track, segm).  As the reference: the outputs are squashed first
+    (squash_for_loss, pipeline.py:198-212; skipped when `squashed`), every term is the mean over its supervised
+    points of ONE (example, frame) -- density BCE on all points (:50-64); colour L1 where density >= 0.1 AND
+    colour available, target[..., 1] >= 0 (:72-83); segmentation CE where label >= 0 (:156-173); tracking BCE
+    where density >= 0.1 AND mark_track >= 0 (:175-194) -- the per-(example, frame) values are averaged
+    (:243-250) and summed with their weights (:276-277).
     static_shapes=True computes the masked means by weighting instead of boolean indexing (no host sync, no
     data-dependent shapes): the form GraphedTrainStep captures."""
+    if implicit_output.dim() == 3:
+        implicit_output, implicit_target = implicit_output[:, None], implicit_target[:, None]
+    if not squashed and color_lw > 0.0:
+        implicit_output = squash_for_loss(implicit_output, color_mode)
+    if color_lw > 0.0 and color_mode not in ('rgb', 'rgb_nosigmoid'):
+        raise NotImplementedError("colour loss for color_mode '%s'" % color_mode)
+    track_idx = 4                                        # utils.get_track_idx for rgb / rgb_nosigmoid
     total = implicit_output.new_zeros(())
-    nf = implicit_output.shape[0]
+    (nf, nb) = implicit_output.shape[:2]
+    cells = nf * nb
     for t in range(nf):
-        o, y = implicit_output[t], implicit_target[t]
-        if static_shapes:
+        for b in range(nb):
+            o, y = implicit_output[t, b], implicit_target[t, b]
+            solid = y[:, 0] >= 0.1
             if density_lw > 0.0:
-                total = total + density_lw * F.binary_cross_entropy_with_logits(o[:, 0], y[:, 0]) / nf
+                total = total + density_lw * F.binary_cross_entropy_with_logits(o[:, 0], y[:, 0]) / cells
             if color_lw > 0.0:
-                pred = torch.sigmoid(o[:, 1:4]) if color_mode == 'rgb' else o[:, 1:4]
-                total = total + color_lw * _masked_mean((pred - y[:, 1:4]).abs(), y[:, 0] >= 0.1) / nf
+                keep = solid & (y[:, 1] >= 0.0)
+                if static_shapes:
+                    term = _masked_mean((o[:, 1:4] - y[:, 1:4]).abs(), keep)
+                else:
+                    term = F.l1_loss(o[keep, 1:4], y[keep, 1:4])
+                total = total + color_lw * term / cells
             if segmentation_lw > 0.0:
                 lab = y[:, -1].to(torch.int64)
-                ce = F.cross_entropy(o[:, -semantic_classes:], lab.clamp(min=0), reduction='none')
-                total = total + segmentation_lw * _masked_mean(ce, lab >= 0) / nf
+                keep = lab >= 0
+                if static_shapes:
+                    ce = F.cross_entropy(o[:, -semantic_classes:], lab.clamp(min=0), reduction='none')
+                    term = _masked_mean(ce, keep)
+                else:
+                    term = F.cross_entropy(o[keep][:, -semantic_classes:], lab[keep])
+                total = total + segmentation_lw * term / cells
             if tracking_lw > 0.0:
-                bce = F.binary_cross_entropy_with_logits(o[:, 4], y[:, 4].clamp(min=0.0), reduction='none')
-                total = total + tracking_lw * _masked_mean(bce, (y[:, 0] >= 0.1) & (y[:, 4] >= 0.0)) / nf
-            continue
-        if density_lw > 0.0:
-            total = total + density_lw * F.binary_cross_entropy_with_logits(o[:, 0], y[:, 0]) / nf
-        if color_lw > 0.0:
-            solid = y[:, 0] >= 0.1
-            pred = torch.sigmoid(o[solid, 1:4]) if color_mode == 'rgb' else o[solid, 1:4]
-            total = total + color_lw * F.l1_loss(pred, y[solid, 1:4]) / nf
-        if segmentation_lw > 0.0:
-            lab = y[:, -1].to(torch.int64)
-            keep = lab >= 0
-            total = total + segmentation_lw * F.cross_entropy(o[keep][:, -semantic_classes:], lab[keep]) / nf
-        if tracking_lw > 0.0:
-            keep = (y[:, 0] >= 0.1) & (y[:, 4] >= 0.0)
-            total = total + tracking_lw * F.binary_cross_entropy_with_logits(o[keep, 4], y[keep, 4]) / nf
+                keep = solid & (y[:, 4] >= 0.0)
+                if static_shapes:
+                    bce = F.binary_cross_entropy_with_logits(o[:, track_idx], y[:, 4].clamp(min=0.0),
+                                                             reduction='none')
+                    term = _masked_mean(bce, keep)
+                else:
+                    term = F.binary_cross_entropy_with_logits(o[keep, track_idx], y[keep, 4])
+                total = total + tracking_lw * term / cells
     return total
 
 
@@ -74,6 +108,12 @@ def allreduce_gradients(params, world=None):
     if not (dist.is_available() and dist.is_initialized()):
         return
     world = world or dist.get_world_size()
+    # a parameter without a gradient on THIS rank still takes part (as zeros): every rank must reduce the same
+    # flat layout, and another rank may have produced a gradient for it
+    params = list(params)
+    for p in params:
+        if p.grad is None and p.requires_grad:
+            p.grad = torch.zeros_like(p)
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:
         return
@@ -114,6 +154,7 @@ class TrainStep:
         if self.grad_clip:
             torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
         self.optimizer.step()
+        invalidate_weight_caches()             # merged inference matrices / per-scene tables are stale now
         return loss.detach()
 
 
@@ -154,6 +195,7 @@ class GraphedTrainStep(TrainStep):
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.static_loss = self._eager(*self.static)
+        invalidate_weight_caches()
         return losses
 
     def __call__(self, pcl_input, points_query, implicit_target):
@@ -162,4 +204,7 @@ class GraphedTrainStep(TrainStep):
             if dst is not src:
                 dst.copy_(src)
         self.graph.replay()
+        # the replay updates the parameters in place without touching their _version counters: the derived-weight
+        # caches of the inference path (keyed on _version + this epoch) must not survive it
+        invalidate_weight_caches()
         return self.static_loss

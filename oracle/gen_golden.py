@@ -184,6 +184,55 @@ def main():
         save('g13_sampler_' + case['name'], **{k: v.numpy() for k, v in zip(
             ['solid_input', 'air_input', 'solid_target', 'air_target', 'solid_sbs', 'air_sbs'], res)})
 
+    # G14: training losses.  The REAL pipeline.MyTrainPipeline.handle_frame (pre-loss squashing, pipeline.py:198-212)
+    # and loss.MyLosses.per_example / entire_batch (loss.py:50-294) run on seeded raw decoder outputs: the point
+    # sampler and the implicit network are replaced by stand-ins that hand back the seeded tensors (with the stale
+    # 5-argument / 3-return arity pipeline.py expects), so everything between "raw logits" and "total loss" is the
+    # reference's own code.  The gradient of the total loss w.r.t. the raw logits pins the backward as well.
+    class _Logger:
+        def report_scalar(self, *a, **k):
+            pass
+
+        def warning(self, *a, **k):
+            pass
+    for case in gc.LOSS_CASES:
+        raw_np, target_np = gc.loss_inputs(case)
+        T, B = raw_np.shape[:2]
+        with torch.enable_grad():
+            raw = t(raw_np).clone().requires_grad_(True)
+            target = t(target_np)
+            frame = {'t': 0}
+
+            def sampler(pcl_target, pcl_target_size, valo_ids, num_valo_ids, time_idx):
+                n = raw.shape[2]
+                pts = torch.zeros(B, n, 4)
+                return (pts[:, :n // 2], pts[:, n // 2:], target[time_idx][:, :n // 2], target[time_idx][:, n // 2:],
+                        torch.zeros(B, 1, 5), torch.zeros(B, 1, 5))
+
+            def implicit_net(points_query, pcl_abstract, features_global, features_abstract, flag):
+                return (raw[frame['t']] * 1.0, None, None)
+
+            pipe = ref.pipeline.MyTrainPipeline(
+                [None, implicit_net], sampler, torch.device('cpu'), 'if', _Logger(), False, case['color_lw'],
+                case['density_lw'], case['segmentation_lw'], case['tracking_lw'], case['color_mode'], 13, T, 0,
+                'greater' if case['d_out'] == 5 else 'carla')
+            pipe.set_stage('train')
+            pcl_target = [torch.zeros(B, 4, 11) for _ in range(T)]
+            sizes = [[4] * B for _ in range(T)]       # (per_example only asserts sizes <= M)
+            outs, tgts = [], []
+            for ti in range(T):
+                frame['t'] = ti
+                (_, o, y, _, _) = pipe.handle_frame(ti, pcl_target, sizes, None, None, None, None, None)
+                outs.append(o)
+                tgts.append(y)
+            terms = pipe.losses.per_example(pcl_target, sizes, outs, tgts)
+            (total, l_rgb, l_dens, l_segm, l_track) = pipe.losses.entire_batch(
+                0, *[x.unsqueeze(0) if torch.is_tensor(x) else None for x in terms], None, outs, None)
+            total.backward()
+        save('g14_loss_' + case['name'], total=np.array([total.item()], dtype=np.float64),
+             terms=np.array([float(l_rgb), float(l_dens), float(l_segm), float(l_track)], dtype=np.float64),
+             squashed=torch.stack(outs).detach().numpy()[:, :, ::16], grad=raw.grad.numpy())
+
 
 if __name__ == '__main__':
     main()

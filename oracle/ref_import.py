@@ -23,7 +23,7 @@ def available():
 
 def load():
     """Returns a namespace with the reference modules: model, implicit, modules,
-    point_transformer_layer, geometry, inference."""
+    point_transformer_layer, geometry, inference, loss, pipeline."""
     assert available(), 'reference not mounted'
     from . import cluster
     for name in ['open3d', 'cv2', 'imageio', 'seaborn', 'wandb', 'torchvision',
@@ -43,7 +43,7 @@ def load():
     # the reference's own top-level module names shadow nothing of ours while loading
     saved = {k: sys.modules.pop(k) for k in ['__init__', 'model', 'implicit', 'modules', 'geometry',
                                              'point_transformer_layer', 'inference', 'utils', 'args',
-                                             'data', 'logvis', 'loss'] if k in sys.modules}
+                                             'data', 'logvis', 'loss', 'pipeline'] if k in sys.modules}
     try:
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
@@ -53,16 +53,18 @@ def load():
             import point_transformer_layer as r_ptl
             import geometry as r_geometry
             import inference as r_inference
+            import loss as r_loss
+            import pipeline as r_pipeline
     finally:
         os.chdir(cwd)
         for p in added:
             sys.path.remove(p)
     ns = types.SimpleNamespace(model=r_model, implicit=r_implicit, modules=r_modules,
                                point_transformer_layer=r_ptl, geometry=r_geometry,
-                               inference=r_inference)
+                               inference=r_inference, loss=r_loss, pipeline=r_pipeline)
     # keep the reference modules reachable only through `ns`
     for k in ['model', 'implicit', 'modules', 'geometry', 'point_transformer_layer', 'inference',
-              'utils', 'args', 'data', 'logvis', 'loss', '__init__']:
+              'utils', 'args', 'data', 'logvis', 'loss', 'pipeline', '__init__']:
         sys.modules.pop(k, None)
     sys.modules.update(saved)
     return ns

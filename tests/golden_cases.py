@@ -294,5 +294,41 @@ def sampler_inputs(case):
     return frames, sizes, valo, num_valo
 
 
+# ---------------------------------------------------------------- G14 (training losses, 8(f) rank 1)
+LOSS_CASES = [
+    # the published GREATER training command (README.md:36): rgb_nosigmoid, density + colour + tracking
+    dict(name='greater_nosigmoid', color_mode='rgb_nosigmoid', d_out=5, frames=3, batch=2, n=257, seed=141,
+         density_lw=1.0, color_lw=1.0, segmentation_lw=0.0, tracking_lw=1.0),
+    dict(name='greater_sigmoid', color_mode='rgb', d_out=5, frames=2, batch=1, n=300, seed=142,
+         density_lw=1.0, color_lw=0.5, segmentation_lw=0.0, tracking_lw=0.25),
+    # the published CARLA training command (README.md:41): density + segmentation
+    dict(name='carla_segm', color_mode='rgb', d_out=18, frames=4, batch=1, n=311, seed=143,
+         density_lw=1.0, color_lw=0.0, segmentation_lw=0.6, tracking_lw=0.0),
+    dict(name='carla_all_terms', color_mode='rgb_nosigmoid', d_out=18, frames=2, batch=2, n=200, seed=144,
+         density_lw=0.7, color_lw=0.9, segmentation_lw=0.6, tracking_lw=0.3),
+]
+
+
+def loss_inputs(case):
+    """Raw decoder outputs (T, B, N, G) (logits, colour channels spread beyond [0, 1] so that the clamp of
+    rgb_nosigmoid matters) and targets (T, B, N, 6) = (density, R, G, B, mark_track, segm) with the -1 "not
+    available" markers the data loaders produce: missing colours, untracked points, unlabelled points."""
+    rng = _rng(case['seed'])
+    T, B, N, G = case['frames'], case['batch'], case['n'], case['d_out']
+    raw = rng.normal(scale=1.5, size=(T, B, N, G)).astype(np.float32)
+    dens = (rng.uniform(size=(T, B, N, 1)) < 0.45).astype(np.float32)
+    rgb = rng.uniform(size=(T, B, N, 3)).astype(np.float32)
+    rgb[rng.uniform(size=(T, B, N)) < 0.2] = -1.0                 # colour not available
+    rgb = np.where(dens > 0.5, rgb, 0.0).astype(np.float32)       # air rows carry zeros
+    mark = rng.integers(-1, 2, size=(T, B, N, 1)).astype(np.float32)
+    segm = rng.integers(-1, 13, size=(T, B, N, 1)).astype(np.float32)
+    target = np.concatenate([dens, rgb, mark, segm], axis=-1).astype(np.float32)
+    return raw, target
+
+
+def loss_kwargs(case):
+    return {k: case[k] for k in ('density_lw', 'color_lw', 'segmentation_lw', 'tracking_lw', 'color_mode')}
+
+
 def as_tensor(a):
     return torch.from_numpy(np.ascontiguousarray(a))

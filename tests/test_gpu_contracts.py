@@ -1,0 +1,280 @@
+"""GPU: host-contract checks added in round 2 -- the public `index_points` mirror, derived-weight cache
+invalidation (in-place / graph-replayed parameter updates), the scene cache of the 4-argument decoder form,
+defined behaviour on non-finite coordinates, K-padding of strided views, the training losses against the
+reference-generated G14 vectors, and the two BASELINE configurations no other test runs at full size:
+configs[3] (2 125 568-query grid sharded over 8 ranks) and configs[4] (CARLA training step, n_points 28 672)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+import occlusions4d_amd as pk
+from conftest import load_golden
+from oracle import path as op
+
+pytestmark = pytest.mark.gpu
+T = gc.as_tensor
+
+
+# ---------------------------------------------------------------- E5: index_points (model/point_transformer_layer.py:102-113)
+@pytest.mark.parametrize('shape', [(1, 50, 3, (1, 20, 16)), (2, 37, 36, (2, 11, 12)), (1, 300, 416, (1, 64))])
+def test_index_points_matches_torch_gather(shape):
+    (B, N, Cc, idx_shape) = shape
+    rng = np.random.default_rng(sum(idx_shape) + Cc)
+    pts = torch.from_numpy(rng.normal(size=(B, N, Cc)).astype(np.float32))
+    idx = torch.from_numpy(rng.integers(0, N, size=idx_shape))                       # int64, as kNN_torch returns
+    # the reference's semantics: gather rows along dim 1 for every trailing index position
+    flat = idx.reshape(B, -1)
+    want = torch.gather(pts, 1, flat[:, :, None].expand(-1, -1, Cc)).reshape(*idx_shape, Cc)
+    got = pk.point_transformer_layer.index_points(pts.cuda(), idx.cuda())
+    assert got.shape == want.shape and torch.equal(got.cpu(), want)
+    want_o = op.gather_rows(pts, idx)
+    assert torch.equal(got.cpu(), want_o)
+
+
+# ---------------------------------------------------------------- derived-weight caches
+def _small_nets(kind='greater', n=512, seed=5, train=False):
+    pa, ia, inf = pk.configs.model_args(kind, n)
+    esd, dsd = pk.configs.synthetic_weights(pa, ia, seed)
+    enc = pk.model.PointCompletionNetV3(**pa).cuda()
+    dec = pk.implicit.LocalPclResnetFC(**ia).cuda()
+    enc.load_state_dict(esd)
+    dec.load_state_dict(dsd)
+    (enc.train(), dec.train()) if train else (enc.eval(), dec.eval())
+    return pa, ia, inf, enc, dec
+
+
+def _fresh_copy(ia, dec):
+    fresh = pk.implicit.LocalPclResnetFC(**ia).cuda().eval()
+    fresh.load_state_dict({k: v.detach().clone() for k, v in dec.state_dict().items()})
+    return fresh
+
+
+def test_merged_weight_caches_follow_untracked_parameter_updates():
+    """`p.data.mul_()` does not move p._version: the caches keyed on it alone would serve stale merged
+    matrices.  invalidate_weight_caches() (what TrainStep / GraphedTrainStep call) must rebuild them."""
+    pa, ia, inf, enc, dec = _small_nets()
+    pcl = pk.configs.synthetic_pcl('greater', 512, 4, 6).cuda()
+    np.random.seed(6)
+    q = T(op.sample_query_points(300, inf['min_z'], inf['cube_bounds'], 1, 'greater', 4, 'random')).cuda()
+    with torch.no_grad():
+        ab, fg, _ = enc(pcl, False)
+        out0, _ = dec(q, ab[0], fg[0], None)
+        for name, p in dec.named_parameters():
+            if 'attn_mlp.0' in name or 'to_k' in name or 'lin_z.3' in name:
+                p.data.mul_(1.25)                                          # untracked in-place update
+        pk.point_transformer_layer.invalidate_weight_caches()
+        out1, _ = dec(q, ab[0], fg[0], None)
+        want, _ = _fresh_copy(ia, dec)(q, ab[0].clone(), fg[0].clone(), None)
+    assert float((out1 - out0).abs().max()) > 1e-3                         # the update matters
+    assert torch.equal(out1, want)
+
+
+def test_inference_after_graph_replays_uses_current_weights():
+    """validate, N hipGraph replays (parameters updated inside the graph, no Python), validate again: the second
+    validation must see the new weights (the (data_ptr, _version) key alone missed this)."""
+    kind, n = 'carla', 512
+    pa, ia, inf, enc, dec = _small_nets(kind, n, 52, train=True)
+    pcl = pk.configs.synthetic_pcl(kind, n, 4, 51).cuda()
+    rng = np.random.default_rng(53)
+    q = torch.stack([T(op.sample_query_points(128, inf['min_z'], inf['cube_bounds'], t, kind, 4, 'random'))
+                     for t in range(2)]).cuda()
+    target = torch.from_numpy(np.concatenate(
+        [rng.integers(0, 2, size=(2, 128, 1)), rng.uniform(size=(2, 128, 3)), np.zeros((2, 128, 1)),
+         rng.integers(-1, 13, size=(2, 128, 1))], -1).astype(np.float32)).cuda()
+    qe = q[0]
+
+    def validate():
+        with torch.no_grad():
+            ab, fg, _ = enc(pcl, False)
+            return dec(qe, ab[0], fg[0], None)[0].clone(), ab[0].clone(), fg[0].clone()
+    v0, _, _ = validate()
+    step = pk.training.GraphedTrainStep(enc, dec, lr=5e-3, grad_clip=0.2,
+                                        loss_kwargs=dict(density_lw=1.0, segmentation_lw=0.6))
+    step.capture(pcl, q, target, warmup=1)
+    validate()                                                              # fills the caches between replays
+    for _ in range(3):
+        step(pcl, q, target)
+    v1, ab1, fg1 = validate()
+    with torch.no_grad():
+        want, _ = _fresh_copy(ia, dec)(qe, ab1, fg1, None)
+    assert float((v1 - v0).abs().max()) > 1e-4
+    assert torch.equal(v1, want)
+
+
+def test_scene_cache_sees_new_features_in_the_four_argument_form():
+    """forward(q, points_abstract (M,3), features_global, features_abstract (M,E)) with the SAME xyz tensor and a
+    modified / replaced feature tensor: Kt / Vt of the cross-attention layers must be rebuilt."""
+    pa, ia, inf, enc, dec = _small_nets(seed=9)
+    rng = np.random.default_rng(10)
+    M = 76
+    xyz = torch.from_numpy(rng.uniform(-5, 5, size=(M, 3)).astype(np.float32)).cuda()
+    f1 = torch.from_numpy(rng.normal(size=(M, 288)).astype(np.float32)).cuda()
+    fg = torch.from_numpy(rng.normal(size=(128,)).astype(np.float32)).cuda()
+    q = T(op.sample_query_points(200, inf['min_z'], inf['cube_bounds'], 1, 'greater', 4, 'random')).cuda()
+    with torch.no_grad():
+        a, _ = dec(q, xyz, fg, f1)
+        f1.mul_(-0.5)                                                       # in place
+        b, _ = dec(q, xyz, fg, f1)
+        f2 = (f1 * 3.0).contiguous()                                        # another tensor object
+        c, _ = dec(q, xyz, fg, f2)
+        fresh = _fresh_copy(ia, dec)
+        want_b, _ = fresh(q, xyz.clone(), fg.clone(), f1.clone())
+        want_c, _ = _fresh_copy(ia, dec)(q, xyz.clone(), fg.clone(), f2.clone())
+    assert float((a - b).abs().max()) > 1e-3
+    assert torch.equal(b, want_b) and torch.equal(c, want_c)
+
+
+# ---------------------------------------------------------------- defined behaviour on bad / awkward inputs
+def test_knn_indices_stay_in_bounds_for_non_finite_coordinates():
+    rng = np.random.default_rng(3)
+    data = torch.from_numpy(rng.uniform(-5, 5, size=(700, 3)).astype(np.float32))
+    q = torch.from_numpy(rng.uniform(-5, 5, size=(300, 3)).astype(np.float32))
+    q[5] = float('nan')
+    q[17, 1] = float('inf')
+    data[40] = float('nan')
+    for k, metric in ((14, 0), (8, 1), (1, 1), (16, 0)):
+        idx = pk.ops.knn(q.cuda(), data.cuda(), k, metric=metric).cpu()
+        assert int(idx.min()) >= 0 and int(idx.max()) < 700
+    # and a downstream gather / attention on them does not fault
+    rows = pk.ops.gather_rows(data.cuda(), pk.ops.knn(q.cuda(), data.cuda(), 14, metric=0).reshape(-1))
+    torch.cuda.synchronize()
+    assert rows.shape == (300 * 14, 3)
+
+
+def test_linear_on_aligned_strided_view_with_k_not_multiple_of_4():
+    """pcl[:, :6] of an 8-column tensor: base 16-byte aligned, row stride 8 (% 4 == 0) but K = 6.  The K padding is
+    decided once for both operands (x stayed at K = 6 while w was padded to 8)."""
+    rng = np.random.default_rng(8)
+    full = torch.from_numpy(rng.normal(size=(257, 8)).astype(np.float32)).cuda()
+    w = torch.from_numpy(rng.normal(size=(36, 6)).astype(np.float32)).cuda()
+    b = torch.from_numpy(rng.normal(size=(36,)).astype(np.float32)).cuda()
+    got = pk.ops.linear(full[:, :6], w, b)
+    want = full[:, :6].double() @ w.double().T + b.double()
+    assert float((got.double() - want).abs().max()) < 1e-5
+
+
+# ---------------------------------------------------------------- training losses (G14: produced by the reference's own code)
+@pytest.mark.parametrize('static_shapes', [False, True], ids=['eager', 'static'])
+@pytest.mark.parametrize('case', gc.LOSS_CASES, ids=lambda c: c['name'])
+def test_g14_loss_on_device(case, static_shapes):
+    g = load_golden('g14_loss_' + case['name'])
+    raw_np, target_np = gc.loss_inputs(case)
+    raw = torch.from_numpy(raw_np).cuda().requires_grad_(True)
+    total = pk.training.implicit_loss(raw, torch.from_numpy(target_np).cuda(), static_shapes=static_shapes,
+                                      **gc.loss_kwargs(case))
+    total.backward()
+    assert abs(total.item() - float(g['total'][0])) < 2e-6
+    assert np.abs(raw.grad.cpu().numpy() - g['grad']).max() < 1e-7
+
+
+# ---------------------------------------------------------------- BASELINE configs[3]: dense grid sharded over 8 ranks
+@pytest.fixture(scope='module')
+def dense_scene():
+    kind, n_points = 'greater', 14336
+    pa, ia, inf = pk.configs.model_args(kind, n_points)
+    esd, dsd = pk.configs.synthetic_weights(pa, ia, 1830)
+    pcl = pk.configs.synthetic_pcl(kind, n_points, 12, 1830)
+    enc = pk.model.PointCompletionNetV3(**pa).cuda().eval()
+    dec = pk.implicit.LocalPclResnetFC(**ia).cuda().eval()
+    enc.load_state_dict(esd)
+    dec.load_state_dict(dsd)
+    q = pk.geometry.sample_implicit_points_blind_device(2097152, inf['min_z'], inf['cube_bounds'], 3, kind, 4, 'grid',
+                                                        torch.device('cuda'))
+    with torch.no_grad():
+        ab, fg, _ = enc(pcl.cuda(), False)
+    return dict(ia=ia, inf=inf, dsd=dsd, dec=dec, q=q, ab=ab[0], fg=fg[0])
+
+
+def test_config4_grid_and_shards(dense_scene):
+    n = dense_scene['q'].shape[0]
+    assert n == 2125568                                                      # 2 097 152 -> 2 125 568
+    bounds = [pk.distributed.shard_bounds(n, r, 8) for r in range(8)]
+    assert bounds[0] == (0, 265696) and bounds[7] == (7 * 265696, n)
+    assert all(b[0] == a[1] for a, b in zip(bounds, bounds[1:]))
+
+
+@pytest.mark.parametrize('rank', [0, 7])
+def test_config4_rank_slice_decode(dense_scene, rank):
+    """Rank r's slice of the 2 125 568-query grid exactly as sharded_inference decodes it (32768-query mini-batches
+    on two streams): finite, deterministic, independent of the mini-batch split, and equal to the CPU oracle on a
+    1536-query sample of the slice."""
+    sc = dense_scene
+    dec, inf, q = sc['dec'], sc['inf'], sc['q']
+    lo, hi = pk.distributed.shard_bounds(q.shape[0], rank, 8)
+    codes = pk.inference.squash_codes(dec.d_out, inf['color_mode'], False, 'none', 13)
+
+    def run(batch):
+        out = torch.empty((hi - lo, dec.d_out), dtype=torch.float32, device='cuda')
+        with torch.no_grad():
+            pk.inference.decode_batches(dec, q, lo, hi, batch, sc['ab'], sc['fg'], out)
+        pk.ops.squash(out, codes)
+        return out
+    a = run(32768)
+    assert a.shape == (265696, 5) and torch.isfinite(a).all()
+    assert torch.equal(a, run(32768))                                        # deterministic
+    assert float((a - run(20000)).abs().max()) <= 1e-5                      # split invariant up to fp32 rounding
+    rng = np.random.default_rng(100 + rank)
+    sel = np.sort(rng.choice(hi - lo, size=1536, replace=False))
+    qs = q[lo:hi][torch.from_numpy(sel).cuda()].cpu()
+    with op.stable_ties():
+        ref, _ = op.decoder_forward(sc['dsd'], sc['ia'], qs, sc['ab'].cpu(), sc['fg'].cpu())
+    ref = op.squash_outputs(ref.clone(), inf['color_mode'], False, 'none', 13)
+    assert float((a[torch.from_numpy(sel).cuda()].cpu() - ref).abs().max()) <= 1e-4
+
+
+# ---------------------------------------------------------------- BASELINE configs[4]: CARLA training step at full size
+def test_config5_train_step_full_size():
+    """One TrainStep at n_points 28 672, 4 target frames x (7168 solid + 10035 air) queries, CARLA losses
+    (density 1.0, segmentation 0.6; README.md:41): finite loss, every parameter moves; the gradient of a sampled
+    set of parameters is checked against torch autograd over the CPU oracle on a query subsample (same encoder
+    input, same weights; the subsample keeps the oracle's (n, 14, 832) tensors small)."""
+    kind, n_points, frames, nq = 'carla', 28672, 4, 7168 + 10035
+    pa, ia, inf = pk.configs.model_args(kind, n_points)
+    esd, dsd = pk.configs.synthetic_weights(pa, ia, 77)
+    pcl = pk.configs.synthetic_pcl(kind, n_points, 12, 78)
+    enc = pk.model.PointCompletionNetV3(**pa).cuda().train()
+    dec = pk.implicit.LocalPclResnetFC(**ia).cuda().train()
+    enc.load_state_dict(esd)
+    dec.load_state_dict(dsd)
+    rng = np.random.default_rng(79)
+    np.random.seed(79)
+    q = torch.stack([T(op.sample_query_points(nq, inf['min_z'], inf['cube_bounds'], t, kind, 4, 'random'))
+                     for t in range(frames)])
+    target = torch.from_numpy(np.concatenate(
+        [rng.integers(0, 2, size=(frames, nq, 1)), rng.uniform(size=(frames, nq, 3)), -np.ones((frames, nq, 1)),
+         rng.integers(-1, 13, size=(frames, nq, 1))], -1).astype(np.float32))
+    lkw = dict(density_lw=1.0, color_lw=0.0, segmentation_lw=0.6, tracking_lw=0.0, color_mode='rgb')
+    step = pk.training.TrainStep(enc, dec, lr=1e-3, grad_clip=0.2, loss_kwargs=lkw)
+    assert pk.distributed.abstract_shape(enc, n_points) == (4248, 291)
+    before = {k: v.detach().clone() for k, v in list(enc.named_parameters()) + list(dec.named_parameters())}
+
+    # gradient check on a subsample BEFORE the parameters move (2 frames x 96 queries; decoder + encoder tail)
+    sub = 96
+    qs, ys = q[:2, :sub], target[:2, :sub]
+    loss_s = step.forward_loss(pcl.cuda(), qs.cuda(), ys.cuda())
+    step.optimizer.zero_grad(set_to_none=True)
+    loss_s.backward()
+    esd_r = {k: v.clone().requires_grad_(True) for k, v in esd.items()}
+    dsd_r = {k: v.clone().requires_grad_(True) for k, v in dsd.items()}
+    with op.stable_ties():
+        ab_r, fg_r = op.encoder_forward(esd_r, pa, pcl)
+        outs = [op.decoder_forward(dsd_r, ia, qs[t], ab_r[0], fg_r[0])[0] for t in range(2)]
+    loss_r = pk.training.implicit_loss(torch.stack(outs), ys, **lkw)
+    loss_r.backward()
+    assert abs(loss_s.item() - loss_r.item()) < 1e-4
+    probes = [(dec, dsd_r, n) for n in ('lin_out.weight', 'blocks.5.fc_1.weight', 'pt_blocks.1.layer2.attn_mlp.2.weight',
+                                        'pt_blocks.0.layer2.to_k.weight', 'lin_z.0.weight', 'lin_in.weight')]
+    probes += [(enc, esd_r, n) for n in ('global_mlp.2.weight', 'blocks.6.layer3.weight', 'abstract_skip_mlps.0.weight')]
+    for mod, ref_sd, name in probes:
+        g = dict(mod.named_parameters())[name].grad.detach().cpu().double()
+        r = ref_sd[name].grad.double()
+        rel = float((g - r).norm() / max(1e-12, float(r.norm())))
+        assert rel <= 2e-3, (name, rel)
+
+    loss = step(pcl.cuda(), q.cuda(), target.cuda())
+    torch.cuda.synchronize()
+    pk.ops.check_pending()
+    assert np.isfinite(loss.item()) and 0.1 < loss.item() < 10.0
+    moved = [k for k, v in list(enc.named_parameters()) + list(dec.named_parameters()) if not torch.equal(v, before[k])]
+    assert len(moved) == len(before)

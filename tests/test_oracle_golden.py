@@ -201,3 +201,45 @@ def test_point_sampler_replays_reference_draws(case):
     # sanity of the fixture itself: shares are used (not all regular) when a bias is active
     if case['bias'] != 'none':
         assert g['solid_sbs'][0, 0] < 1.0 or g['air_sbs'][0, 1] > 0.0
+
+
+# ---------------------------------------------------------------- G14: training losses (reference pipeline + loss code)
+@pytest.mark.parametrize('case', gc.LOSS_CASES, ids=lambda c: c['name'])
+def test_g14_oracle_loss_matches_reference(case):
+    from oracle import loss as ol
+    g = load_golden('g14_loss_' + case['name'])
+    raw_np, target_np = gc.loss_inputs(case)
+    raw = torch.from_numpy(raw_np).requires_grad_(True)
+    total, terms = ol.training_loss(raw, torch.from_numpy(target_np), **gc.loss_kwargs(case))
+    total.backward()
+    assert abs(total.item() - float(g['total'][0])) < 1e-6
+    for got, want in zip(terms, g['terms']):
+        assert abs(float(got) - float(want)) < 1e-6
+    assert np.array_equal(ol.squash(raw.detach(), case['color_mode']).numpy()[:, :, ::16], g['squashed'])
+    assert np.abs(raw.grad.numpy() - g['grad']).max() < 1e-8
+
+
+@pytest.mark.parametrize('static_shapes', [False, True], ids=['eager', 'static'])
+@pytest.mark.parametrize('case', gc.LOSS_CASES, ids=lambda c: c['name'])
+def test_g14_product_loss_matches_reference(case, static_shapes):
+    """training.implicit_loss is torch glue (runs on any device); the same check runs on the GPU in
+    tests/test_gpu_training.py.  Value within 1e-6, gradient w.r.t. the raw logits within 1e-7 of the
+    reference's (the static form sums in a different order)."""
+    import occlusions4d_amd as pk
+    g = load_golden('g14_loss_' + case['name'])
+    raw_np, target_np = gc.loss_inputs(case)
+    raw = torch.from_numpy(raw_np).requires_grad_(True)
+    total = pk.training.implicit_loss(raw, torch.from_numpy(target_np), static_shapes=static_shapes,
+                                      **gc.loss_kwargs(case))
+    total.backward()
+    assert abs(total.item() - float(g['total'][0])) < 1e-6
+    assert np.abs(raw.grad.numpy() - g['grad']).max() < 1e-7
+
+
+def test_product_loss_rejects_unpublished_colour_modes():
+    import occlusions4d_amd as pk
+    o, y = torch.zeros(1, 4, 16), torch.zeros(1, 4, 6)
+    with pytest.raises(NotImplementedError):
+        pk.training.implicit_loss(o, y, color_lw=1.0, color_mode='hsv')
+    with pytest.raises(ValueError):
+        pk.training.implicit_loss(o, y, color_lw=1.0, color_mode='nope')
