@@ -195,6 +195,37 @@ int occ4d_interp_weights_f32(const float* dist, int n, int k, float* w, void* st
 int occ4d_interp_add_f32(float* x, int64_t ldx, const float* cvec, const float* table, int64_t ldt,
                          const int32_t* idx, const float* w, int n, int k, int d, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Row-resident fused trunk layers (csrc/trunk.hip), width 416 = d_hidden of every published configuration
+ * (train.py:255-256).  A row tile's activations stay in registers across the layers of a block; weights are
+ * streamed from a STAGE-PACKED copy (the exact LDS image of each 32-channel stage, built once per weight
+ * update by the caller; layout below), fp32 exact on v_mfma_f32_16x16x4_f32.
+ *
+ * occ4d_resblock_f32:  y = x + W1 relu(W0 relu(x) + b0) + b1   -- ResnetBlockFC.forward, model/implicit.py:92-101
+ *   (fc_0, fc_1, identity shortcut), optionally followed by  y += zconst + sum_j zw[:, j] ztab[zidx[:, j], :]
+ *   -- the `x = x + lin_z[i+1](features_query)` of the NEXT block (model/implicit.py:416-417) in the exact-in-R
+ *   form of occ4d_interp_add_f32.  y may alias x.
+ * occ4d_rowlin_f32:  y[:, 0..n_out) = [res +] W [relu](x) + b [+ the same interpolation term], K = 416,
+ *   n_out % 32 == 0 -- the Linear layers around the cross-attention (model/modules.py:61-65: layer1 merged into
+ *   the query projection, layer3 + residual).  res may alias y.
+ *
+ * Packed weights (floats; occ4d_trunk_packed_floats(n_out) = (n_out / 32 + 1) * 13312 of them, the stage after
+ * the last repeats stage 0 so that the kernels prefetch branch-free):
+ *   "rows" packing of an (n_out, 416) weight (w0_packed, occ4d_rowlin's w_packed):
+ *       P[s][(nt * 26 + t) * 256 + (g * 16 + r) * 4 + e] = W[32 s + 16 nt + r][16 t + 4 g + e]
+ *   "cols" packing of the (416, 416) second layer of a residual block (w1_packed):
+ *       P[j][(nt * 2 + tt) * 256 + (g * 16 + r) * 4 + e] = W[16 nt + r][32 j + 16 tt + 4 g + e]
+ *   with r < 16, g < 4, e < 4, t < 26, nt < 2 (rows) / 26 (cols), tt < 2.
+ * x, y, res: 16-byte aligned, row strides % 4 == 0; ztab / zconst / biases 16-byte aligned, ldz % 4 == 0. */
+int occ4d_trunk_width(void);
+int64_t occ4d_trunk_packed_floats(int n_out);
+int occ4d_resblock_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w0_packed, const float* b0,
+                       const float* w1_packed, const float* b1, const float* zconst, const float* ztab, int64_t ldz,
+                       const int32_t* zidx, const float* zw, int kz, int n, void* stream);
+int occ4d_rowlin_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed, const float* b,
+                     int n_out, int relu_in, const float* res, int64_t ldr, const float* zconst, const float* ztab,
+                     int64_t ldz, const int32_t* zidx, const float* zw, int kz, int n, void* stream);
+
 /* K13 post-ops (eval/inference.py:218-243): per channel op code in `ops` (G ints):
  * 0 = identity, 1 = sigmoid, 2 = clamp to [0,1].  In place. */
 int occ4d_squash_f32(float* out, int64_t ld, int n, int g, const int32_t* ops_host, void* stream);

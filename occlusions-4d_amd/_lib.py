@@ -58,6 +58,12 @@ SIGNATURES = {
     'occ4d_posenc_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, _f, C.c_int64, _s]),
     'occ4d_interp_weights_f32': (C.c_int, [_f, C.c_int, C.c_int, _f, _s]),
     'occ4d_interp_add_f32': (C.c_int, [_f, C.c_int64, _f, _f, C.c_int64, _i, _f, C.c_int, C.c_int, C.c_int, _s]),
+    'occ4d_trunk_width': (C.c_int, []),
+    'occ4d_trunk_packed_floats': (C.c_int64, [C.c_int]),
+    'occ4d_resblock_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, _f, _f, _f, _f, _f, C.c_int64, _i, _f, C.c_int,
+                                     C.c_int, _s]),
+    'occ4d_rowlin_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, _f, C.c_int, C.c_int, _f, C.c_int64, _f, _f,
+                                   C.c_int64, _i, _f, C.c_int, C.c_int, _s]),
     'occ4d_squash_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int32), _s]),
     'occ4d_grid_points_f32': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                         C.c_float, C.c_float, _f, _s]),

@@ -18,6 +18,7 @@ from . import geometry  # noqa: F401  (same module graph as the reference)
 from . import modules
 from . import ops
 from . import autograd
+from . import point_transformer_layer as ptl
 from .point_transformer_layer import needs_grad, weights_epoch
 
 _QUERY_CHUNK = 32768
@@ -63,6 +64,11 @@ class ResnetBlockFC(torch.nn.Module):
         return autograd.linear(h, self.fc_1, relu_in=True, residual=xs)
 
     def _run(self, x, inplace=False):
+        if self.shortcut is None and ptl.USE_TRUNK_KERNELS and self.d_in == self.d_hidden == self.d_out:
+            # both layers in one kernel, the (n, d_hidden) intermediate never leaves the registers (csrc/trunk.hip)
+            w0p, w1p = ptl.trunk_pack(self.fc_0.weight), ptl.trunk_pack(self.fc_1.weight, 'cols')
+            if w0p is not None and w1p is not None:
+                return ops.resblock(x, w0p, self.fc_0.bias, w1p, self.fc_1.bias, out=x if inplace else None)
         h = ops.linear(x, self.fc_0.weight, self.fc_0.bias, relu_in=True)
         if self.shortcut is None:
             return ops.linear(h, self.fc_1.weight, self.fc_1.bias, relu_in=True, residual=x,

@@ -40,8 +40,14 @@ class PointTransformerBlock(torch.nn.Module):
         if needs_grad(self, x, x2):
             z = ops.stack_batch([autograd.linear(agg[b], self.layer3, residual=x[b]) for b in range(x.shape[0])])
         else:
-            z = ops.stack_batch([ops.linear(agg[b], self.layer3.weight, self.layer3.bias, residual=x[b])
-                             for b in range(x.shape[0])])
+            w3p = point_transformer_layer.trunk_pack(self.layer3.weight) \
+                if point_transformer_layer.USE_TRUNK_KERNELS and self.d_out == self.d_in else None
+            if w3p is not None:
+                z = ops.stack_batch([ops.rowlin(agg[b], w3p, self.layer3.bias, self.d_out, residual=x[b])
+                                     for b in range(x.shape[0])])
+            else:
+                z = ops.stack_batch([ops.linear(agg[b], self.layer3.weight, self.layer3.bias, residual=x[b])
+                                     for b in range(x.shape[0])])
         return (z, p)
 
 

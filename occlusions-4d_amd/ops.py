@@ -414,6 +414,84 @@ def interp_add(x, cvec, table, idx, w):
     return x
 
 
+TRUNK_WIDTH = 416          # width the row-resident trunk kernels are built for (occ4d_trunk_width)
+
+
+def pack_trunk_rows(w):
+    """(n_out, 416) weight -> stage-packed stream for occ4d_rowlin_f32 / the first layer of occ4d_resblock_f32
+    (include/occ4d.h "rows" packing): per 32-output stage the LDS image of its 52 MFMA fragments; one extra
+    stage (a copy of stage 0) at the end."""
+    w = _dev(w.detach(), name='w')
+    n_out, k = w.shape
+    assert k == TRUNK_WIDTH and n_out % 32 == 0, 'pack_trunk_rows: (%d, %d) is not (32 s, %d)' % (n_out, k, TRUNK_WIDTH)
+    s = n_out // 32
+    p = w.reshape(s, 2, 16, 26, 4, 4).permute(0, 1, 3, 4, 2, 5).reshape(s, -1)      # [s][nt][t][g][r][e]
+    return torch.cat([p, p[:1]], dim=0).contiguous()
+
+
+def pack_trunk_cols(w):
+    """(416, 416) second-layer weight of a residual block -> stage-packed stream ("cols" packing): stage j holds
+    the 32 input columns 32 j .. 32 j + 31 of every output row."""
+    w = _dev(w.detach(), name='w')
+    assert tuple(w.shape) == (TRUNK_WIDTH, TRUNK_WIDTH)
+    p = w.reshape(26, 16, 13, 2, 4, 4).permute(2, 0, 3, 4, 1, 5).reshape(13, -1)    # [j][nt][tt][g][r][e]
+    return torch.cat([p, p[:1]], dim=0).contiguous()
+
+
+def _interp_args(interp, n):
+    """(zconst (416), ztab (M, >= 416) row view, idx (n, k) int32, w (n, k)) -> ctypes argument tuple."""
+    if interp is None:
+        return (None, None, 0, None, None, 0)
+    zconst, ztab, idx, w = interp
+    zt, ldz = _rows(_dev(ztab, name='ztab'), 'ztab')
+    idx = _dev(idx, torch.int32, 'idx')
+    assert zt.shape[1] == TRUNK_WIDTH and idx.is_contiguous() and w.is_contiguous() and idx.shape == w.shape
+    assert idx.shape[0] == n
+    zc = _dev(zconst).contiguous()
+    assert zc.numel() == TRUNK_WIDTH
+    return (_ptr(zc), _ptr(zt), ldz, _ptr(idx), _ptr(_dev(w, name='w')), idx.shape[1], (zc, zt))
+
+
+def resblock(x, w0_packed, b0, w1_packed, b1, out=None, interp=None):
+    """out = x + W1 relu(W0 relu(x) + b0) + b1 [+ interpolation term]: one fused kernel (occ4d_resblock_f32)."""
+    xx, ldx = _rows(_dev(x, name='x'), 'x')
+    n, d = xx.shape
+    assert d == TRUNK_WIDTH
+    if out is None:
+        out = torch.empty((n, d), dtype=torch.float32, device=x.device)
+    o, ldo = _rows(_dev(out, name='out'), 'out')
+    assert o is out and o.shape == (n, d)
+    ia = _interp_args(interp, n)
+    b0c, b1c = _dev(b0).contiguous(), _dev(b1).contiguous()
+    _lib.check(_launch('resblock', dict(n=n), 4.0 * n * d * d, lambda: _lib.lib().occ4d_resblock_f32(
+        _ptr(xx), ldx, _ptr(o), ldo, _ptr(w0_packed), _ptr(b0c), _ptr(w1_packed), _ptr(b1c),
+        ia[0], ia[1], ia[2], ia[3], ia[4], ia[5], n, _stream())))
+    return out
+
+
+def rowlin(x, w_packed, b, n_out, relu_in=False, residual=None, out=None, interp=None):
+    """out (n, n_out) = [residual +] W [relu](x) + b [+ interpolation term], K = 416 (occ4d_rowlin_f32)."""
+    xx, ldx = _rows(_dev(x, name='x'), 'x')
+    n, d = xx.shape
+    assert d == TRUNK_WIDTH and n_out % 32 == 0 and w_packed.numel() == (n_out // 32 + 1) * 13312
+    if out is None:
+        out = torch.empty((n, n_out), dtype=torch.float32, device=x.device)
+    o, ldo = _rows(_dev(out, name='out'), 'out')
+    assert o is out and o.shape == (n, n_out)
+    rr, ldr = (None, 0)
+    if residual is not None:
+        rr, ldr = _rows(_dev(residual, name='residual'), 'residual')
+        assert rr.shape == (n, n_out)
+    ia = _interp_args(interp, n)
+    assert interp is None or n_out == TRUNK_WIDTH
+    bc = _dev(b).contiguous()
+    assert bc.numel() == n_out
+    _lib.check(_launch('rowlin', dict(n=n, n_out=n_out), 2.0 * n * d * n_out, lambda: _lib.lib().occ4d_rowlin_f32(
+        _ptr(xx), ldx, _ptr(o), ldo, _ptr(w_packed), _ptr(bc), n_out, int(relu_in), _ptr(rr), ldr,
+        ia[0], ia[1], ia[2], ia[3], ia[4], ia[5], n, _stream())))
+    return out
+
+
 def squash(out, ops):
     """In-place per-channel post-op; ops: list of G codes (0 identity, 1 sigmoid, 2 clamp[0,1])."""
     o, ld = _rows(_dev(out, name='out'), 'out')

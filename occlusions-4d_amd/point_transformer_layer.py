@@ -25,6 +25,7 @@ from . import ops
 
 _PAIR_CHUNK = 32768      # query rows per pass (bounds the (rows*K, 2D) workspace)
 USE_FUSED_ATTENTION = True   # tests flip this to cover the unfused kernel chain as well
+USE_TRUNK_KERNELS = True     # row-resident fused trunk kernels (csrc/trunk.hip) where the shapes allow; False = generic Linear
 # 'f32' (default): every GEMM exact fp32 on v_mfma_f32_32x32x2_f32.  'bf16x3': the attention-logit GEMM of the
 # fused kernel on split-bf16 MFMAs (occ4d_pt_cross_attn_bf16x3_f32); everything else unchanged.  Opt-in.
 LOGIT_PRECISION = os.environ.get('OCC4D_LOGIT_PRECISION', 'f32')
@@ -44,6 +45,23 @@ def invalidate_weight_caches():
 
 def weights_epoch():
     return _WEIGHTS_EPOCH[0]
+
+
+def trunk_pack(weight, kind='rows'):
+    """Stage-packed copy of a 416-input weight for the row-resident trunk kernels (ops.pack_trunk_rows / _cols),
+    cached on the tensor object while (storage, version, weights epoch) are unchanged; None when the kernels do
+    not apply to this shape."""
+    if weight.shape[1] != ops.TRUNK_WIDTH or weight.shape[0] % 32 != 0 or not weight.is_cuda:
+        return None
+    if kind == 'cols' and weight.shape[0] != ops.TRUNK_WIDTH:
+        return None
+    key = (weights_epoch(), weight.data_ptr(), weight._version, kind)
+    hit = getattr(weight, '_occ4d_trunk_pack', None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    packed = ops.pack_trunk_rows(weight) if kind == 'rows' else ops.pack_trunk_cols(weight)
+    weight._occ4d_trunk_pack = (key, packed)
+    return packed
 
 
 def needs_grad(module, *tensors):
@@ -122,6 +140,7 @@ class PointTransformerLayer(nn.Module):
             wq=wq.float().contiguous(), bq=bq.float().contiguous(),
             wk=(W1 @ self.to_k.weight.detach().to(f64)).float().contiguous(),
             wp=(W1 @ P2).float().contiguous())
+        m['wq_packed'] = trunk_pack(m['wq'])          # (2D, 416) query projection on the row-resident kernel
         if self.attn_mlp[2].weight.shape[1] % 32 == 0:
             m['w2_bf16x3'] = ops.pack_w2_bf16x3(self.attn_mlp[2].weight)
             m['wp_bf16x3'] = ops.pack_w2_bf16x3(m['wp']) if m['wp'].shape[1] == 32 else None
@@ -201,7 +220,12 @@ class PointTransformerLayer(nn.Module):
         for lo in range(0, n, _PAIR_CHUNK):
             hi = min(n, lo + _PAIR_CHUNK)
             idx = ops.knn(pos[lo:hi], pos2, K, metric=0)                        # (c,K) int32
-            aq = aq_all[lo:hi] if aq_all is not None else ops.linear(x[lo:hi], m['wq'], m['bq'])
+            if aq_all is not None:
+                aq = aq_all[lo:hi]
+            elif m.get('wq_packed') is not None and USE_TRUNK_KERNELS:
+                aq = ops.rowlin(x[lo:hi], m['wq_packed'], m['bq'], m['wq'].shape[0])
+            else:
+                aq = ops.linear(x[lo:hi], m['wq'], m['bq'])
             if (self.dim in ops.FUSED_ATTN_DIMS and K <= ops.FUSED_ATTN_MAX_K
                     and self.pos_mlp[0].out_features == 32 and USE_FUSED_ATTENTION):
                 assert LOGIT_PRECISION in ('f32', 'bf16x3'), LOGIT_PRECISION

@@ -1,5 +1,5 @@
 """Small product-path workloads for rocprofv3 runs (GPU box).
-    python profiles/probe.py decode [n_queries] [reps]   one decoder batch, repeated
+    python profiles/probe.py decode [n_queries] [reps] [kind]   one decoder batch, repeated
     python profiles/probe.py encode [reps]               encoder only
     python profiles/probe.py fps                         FPS / kNN micro timings (HIP events)
 """
@@ -43,10 +43,11 @@ def main():
         if mode == 'decode':
             n = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
             reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-            enc, dec, pcl, inf = nets()
+            kind = sys.argv[4] if len(sys.argv) > 4 else 'greater'
+            enc, dec, pcl, inf = nets(kind)
             ab, fg, _ = enc(pcl, False)
             q = torch.from_numpy(pk.geometry.sample_implicit_points_blind_numpy(
-                524288, -1.0, 5.0, 3, 'greater', 4, 'grid')[:n]).cuda()
+                524288, inf['min_z'], inf['cube_bounds'], 3, kind, 4, 'grid')[:n]).cuda()
             ms = timed(lambda: dec(q, ab[0], fg[0], None), reps)
             print('decode %d queries: %.3f ms  -> %.3f M q/s' % (n, ms, n / ms / 1e3))
         elif mode == 'encode':
