@@ -195,6 +195,22 @@ int occ4d_interp_weights_f32(const float* dist, int n, int k, float* w, void* st
 int occ4d_interp_add_f32(float* x, int64_t ldx, const float* cvec, const float* table, int64_t ldt,
                          const int32_t* idx, const float* w, int n, int k, int d, void* stream);
 
+/* Second-generation fused vector attention for d = 416, K <= 14 (csrc/crossattn16.hip): the same contract as
+ * occ4d_pt_cross_attn_f32 (model/point_transformer_layer.py:168-179 with the merged first attn_mlp layer), on
+ * v_mfma_f32_16x16x4_f32 with one wave per 16 pair rows and all 416 channels (no duplicated GEMM1, no spills), weights
+ * DMA-streamed from a stage-packed copy `wstream` of occ4d_pt_cross_attn16_stream_floats() floats:
+ *   27 stages of 56 fragments x 256 floats; stage hb < 26 = hidden units 32 hb .. 32 hb + 31:
+ *     fragment 2 t + nt   (t < 26 channel tiles, nt < 2):  [(g*16 + c)*4 + e] = W2[16 t + c][32 hb + 16 nt + 4 g + e]
+ *     fragment 52 + 2 nt + kh (kh < 2):                    [(g*16 + r)*4 + e] = Wp[32 hb + 16 nt + r][16 kh + 4 e + g]
+ *   stage 26: fragment 2 t + kh:                           [(g*16 + c)*4 + e] = P2[16 t + c][16 kh + 4 e + g];
+ *             floats 52*256 + ch = b2[ch] * log2(e) / sqrt(416), 54*256 + ch = c2[ch] (ch < 416), rest zero
+ * (g < 4, c, r < 16, e < 4; W2, b2 = attn_mlp[2] (416, 832), Wp = W1 P2 (832, 32), P2, c2 = pos_mlp[2] (416, 32)). */
+int64_t occ4d_pt_cross_attn16_stream_floats(void);
+int occ4d_pt_cross_attn16_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t q_stride, const float* apos,
+                              int64_t a_stride, const int32_t* idx, const float* kt, int64_t ld_kt, const float* vt,
+                              int64_t ld_vt, const float* P1, const float* c1, const float* wstream, float* agg,
+                              int64_t ld_agg, int n, int m, int k, int d, float divisor, void* stream);
+
 /* ------------------------------------------------------------------------
  * Row-resident fused trunk layers (csrc/trunk.hip), width 416 = d_hidden of every published configuration
  * (train.py:255-256).  A row tile's activations stay in registers across the layers of a block; weights are

@@ -262,8 +262,11 @@ __global__ __launch_bounds__(512, 2) void resblock_kernel(const TrunkArgs a) {
 __device__ __forceinline__ void rowlin_stage(const TrunkArgs& a, int s, const float* __restrict__ frag, const f32x4* xr,
                                              int row, int rowc, int g) {
   const int c0 = 32 * s + 4 * g;
-  f32x4 o0 = *reinterpret_cast<const f32x4*>(a.b0 + c0);
-  f32x4 o1 = *reinterpret_cast<const f32x4*>(a.b0 + c0 + 16);
+  // bias / residual: compiler-tracked global loads issued AFTER this stage's DMA and consumed at the END of the stage
+  // (the hardware's vmcnt is in order: consuming them earlier would wait for the DMA as well)
+  const f32x4 bz0 = *reinterpret_cast<const f32x4*>(a.b0 + c0);
+  const f32x4 bz1 = *reinterpret_cast<const f32x4*>(a.b0 + c0 + 16);
+  f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
   f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f};
   if (a.res) {
     r0 = *reinterpret_cast<const f32x4*>(a.res + (int64_t)rowc * a.ldr + c0);
@@ -284,8 +287,8 @@ __device__ __forceinline__ void rowlin_stage(const TrunkArgs& a, int s, const fl
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  o0.x += r0.x; o0.y += r0.y; o0.z += r0.z; o0.w += r0.w;
-  o1.x += r1.x; o1.y += r1.y; o1.z += r1.z; o1.w += r1.w;
+  o0.x += bz0.x + r0.x; o0.y += bz0.y + r0.y; o0.z += bz0.z + r0.z; o0.w += bz0.w + r0.w;
+  o1.x += bz1.x + r1.x; o1.y += bz1.y + r1.y; o1.z += bz1.z + r1.z; o1.w += bz1.w + r1.w;
   if (a.ztab) {
     const f32x4 ca = *reinterpret_cast<const f32x4*>(a.zconst + c0);
     const f32x4 cb = *reinterpret_cast<const f32x4*>(a.zconst + c0 + 16);

@@ -336,6 +336,52 @@ def pt_cross_attn(aq, qpos, apos, idx, kt, vt, P1, c1, wp, w2, b2, p2, c2, out=N
     return out
 
 
+def pack_attn16_stream(w2, b2, wp, p2, c2):
+    """Stage-packed weight stream of occ4d_pt_cross_attn16_f32 (layout in include/occ4d.h): w2 (416, 832), b2 (416)
+    = attn_mlp[2]; wp (832, 32) = W1 P2 (merged); p2 (416, 32), c2 (416) = pos_mlp[2] -> (27, 56 * 256) fp32."""
+    w2, b2, wp, p2, c2 = (_dev(t.detach(), name='w') for t in (w2, b2, wp, p2, c2))
+    d = p2.shape[0]
+    assert d == 416 and tuple(w2.shape) == (d, 2 * d) and tuple(wp.shape) == (2 * d, 32) and p2.shape[1] == 32
+    nt, nhb = d // 16, 2 * d // 32
+    a = w2.reshape(nt, 16, nhb, 2, 4, 4).permute(2, 0, 3, 4, 1, 5).reshape(nhb, 2 * nt * 256)   # [hb][t][nt][g][c][e]
+    b = wp.reshape(nhb, 2, 16, 2, 4, 4).permute(0, 1, 3, 5, 2, 4).reshape(nhb, 4 * 256)         # [hb][nt][kh][g][r][e]
+    c = p2.reshape(nt, 16, 2, 4, 4).permute(0, 2, 4, 1, 3).reshape(1, 2 * nt * 256)             # [t][kh][g][c][e]
+    tail = torch.zeros((1, 4 * 256), dtype=torch.float32, device=c.device)
+    # attn_mlp[2].bias pre-scaled into the kernel's log2-domain logits: (acc + b2) / sqrt(d) * log2(e)
+    scale = float(torch.tensor(math.log2(math.e), dtype=torch.float64) / math.sqrt(d))
+    tail[0, :d] = (b2.double() * scale).float()
+    tail[0, 512:512 + d] = c2
+    last = torch.cat([c, tail], dim=1)
+    out = torch.cat([torch.cat([a, b], dim=1), last], dim=0).contiguous()
+    assert out.numel() == _lib.lib().occ4d_pt_cross_attn16_stream_floats()
+    return out
+
+
+def pt_cross_attn16(aq, qpos, apos, idx, kt, vt, P1, c1, wstream, out=None):
+    """Fused vector attention, d = 416 (occ4d_pt_cross_attn16_f32): agg (n, 416)."""
+    aq, ld_aq = _aligned_rows(_dev(aq, name='aq'), 'aq')
+    kt, ld_kt = _aligned_rows(_dev(kt, name='kt'), 'kt')
+    vt, ld_vt = _rows(_dev(vt, name='vt'), 'vt')
+    qp, qs = _rows(_dev(qpos, name='qpos'), 'qpos')
+    ap, as_ = _rows(_dev(apos, name='apos'), 'apos')
+    idx = _dev(idx, torch.int32, 'idx')
+    n, k = idx.shape
+    d = vt.shape[1]
+    assert idx.is_contiguous() and aq.shape == (n, 2 * d) and kt.shape[1] == 2 * d and qp.shape[0] == n
+    ws = [_dev(t).contiguous() for t in (P1, c1)]
+    assert ws[0].shape == (32, 3) and wstream.is_contiguous()
+    if out is None:
+        out = torch.empty((n, d), dtype=torch.float32, device=aq.device)
+    o, ldo = _rows(out, 'out')
+    assert o is out and o.shape == (n, d)
+    divisor = float(torch.tensor(math.sqrt(d), dtype=torch.float32))
+    flops = 2.0 * n * k * (32 * 2 * d + 2 * d * d + 32 * d)      # executed, useful (same count as pt_cross_attn)
+    _lib.check(_launch('cross_attn', dict(n=n, k=k, d=d), flops, lambda: _lib.lib().occ4d_pt_cross_attn16_f32(
+        _ptr(aq), ld_aq, _ptr(qp), qs, _ptr(ap), as_, _ptr(idx), _ptr(kt), ld_kt, _ptr(vt), ld_vt,
+        _ptr(ws[0]), _ptr(ws[1]), _ptr(wstream), _ptr(o), ldo, n, kt.shape[0], k, d, divisor, _stream())))
+    return out
+
+
 def layernorm(x, gamma, beta, eps=1e-5, relu=False, out=None):
     x, ldx = _rows(_dev(x, name='x'), 'x')
     n, d = x.shape

@@ -25,6 +25,7 @@ from . import ops
 
 _PAIR_CHUNK = 32768      # query rows per pass (bounds the (rows*K, 2D) workspace)
 USE_FUSED_ATTENTION = True   # tests flip this to cover the unfused kernel chain as well
+USE_ATTN16 = True            # d = 416: second-generation fused attention kernel (csrc/crossattn16.hip); False = crossattn.hip
 USE_TRUNK_KERNELS = True     # row-resident fused trunk kernels (csrc/trunk.hip) where the shapes allow; False = generic Linear
 # 'f32' (default): every GEMM exact fp32 on v_mfma_f32_32x32x2_f32.  'bf16x3': the attention-logit GEMM of the
 # fused kernel on split-bf16 MFMAs (occ4d_pt_cross_attn_bf16x3_f32); everything else unchanged.  Opt-in.
@@ -141,6 +142,9 @@ class PointTransformerLayer(nn.Module):
             wk=(W1 @ self.to_k.weight.detach().to(f64)).float().contiguous(),
             wp=(W1 @ P2).float().contiguous())
         m['wq_packed'] = trunk_pack(m['wq'])          # (2D, 416) query projection on the row-resident kernel
+        if self.dim == 416 and self.pos_mlp[0].out_features == 32 and self.attn_mlp[2].weight.is_cuda:
+            m['attn16_stream'] = ops.pack_attn16_stream(self.attn_mlp[2].weight, self.attn_mlp[2].bias, m['wp'],
+                                                             self.pos_mlp[2].weight, self.pos_mlp[2].bias)
         if self.attn_mlp[2].weight.shape[1] % 32 == 0:
             m['w2_bf16x3'] = ops.pack_w2_bf16x3(self.attn_mlp[2].weight)
             m['wp_bf16x3'] = ops.pack_w2_bf16x3(m['wp']) if m['wp'].shape[1] == 32 else None
@@ -229,6 +233,9 @@ class PointTransformerLayer(nn.Module):
             if (self.dim in ops.FUSED_ATTN_DIMS and K <= ops.FUSED_ATTN_MAX_K
                     and self.pos_mlp[0].out_features == 32 and USE_FUSED_ATTENTION):
                 assert LOGIT_PRECISION in ('f32', 'bf16x3'), LOGIT_PRECISION
+                if LOGIT_PRECISION == 'f32' and USE_ATTN16 and m.get('attn16_stream') is not None:
+                    ops.pt_cross_attn16(aq, pos[lo:hi], pos2, idx, kt, vt, P1, c1, m['attn16_stream'], out=agg[lo:hi])
+                    continue
                 ops.pt_cross_attn(aq, pos[lo:hi], pos2, idx, kt, vt, P1, c1, m['wp'], W2, b2, P2, c2,
                                   out=agg[lo:hi],
                                   w2_packed=m['w2_bf16x3'] if LOGIT_PRECISION == 'bf16x3' else None,

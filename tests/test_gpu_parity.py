@@ -254,10 +254,16 @@ def test_perform_inference(pk, case):
 # ------------------------------------------------------------------ fused vs unfused attention
 @pytest.mark.parametrize('k,n,dim,dim2', [(14, 1003, 416, 288), (13, 100, 416, 288), (12, 9, 416, 288),
                                           (8, 37, 416, 288), (7, 500, 416, 288), (3, 64, 416, 288),
-                                          (1, 10, 416, 288), (14, 531, 288, 288), (5, 1, 416, 288)])
-def test_fused_attention_matches_unfused_chain(pk, k, n, dim, dim2):
-    """The fused kernel (9 queries x 14 rows packed per workgroup, masked slots for k < 14, ragged
-    tail for n % 9 != 0) against the unfused kernel chain on the same inputs."""
+                                          (1, 10, 416, 288), (14, 531, 288, 288), (5, 1, 416, 288),
+                                          (14, 8, 416, 288), (14, 10, 416, 288), (14, 17, 416, 288), (14, 18, 416, 288),
+                                          (14, 19, 416, 288), (11, 2, 416, 288), (2, 4000, 416, 288)])
+@pytest.mark.parametrize('generation', ['attn16', 'first'])
+def test_fused_attention_matches_unfused_chain(pk, k, n, dim, dim2, generation):
+    """The fused kernels (9 queries x 14 rows packed per workgroup, masked slots for k < 14, ragged
+    tail for n % 9 != 0) against the unfused kernel chain on the same inputs: the 16 x 16 MFMA kernel
+    (crossattn16.hip, d = 416) and the first-generation 32 x 32 kernel (crossattn.hip, d = 288 / 416)."""
+    if generation == 'attn16' and dim != 416:
+        pytest.skip('crossattn16.hip is built for d = 416')
     rng = np.random.default_rng(1000 * k + n)
     m = 76
     x = rng.normal(size=(n, dim)).astype(np.float32)
@@ -270,12 +276,14 @@ def test_fused_attention_matches_unfused_chain(pk, k, n, dim, dim2):
     layer.load_state_dict(sd)
     args = (dev(x)[None], dev(pos)[None], dev(x2)[None], dev(pos2)[None])
     with torch.no_grad():
-        fused = layer(*args)[0]
-        ptl.USE_FUSED_ATTENTION = False
+        ptl.USE_ATTN16 = generation == 'attn16'
         try:
+            fused = layer(*args)[0]
+            ptl.USE_FUSED_ATTENTION = False
             chain = layer(*args)[0]
         finally:
             ptl.USE_FUSED_ATTENTION = True
+            ptl.USE_ATTN16 = True
     assert torch.isfinite(fused).all()
     close(fused, chain, 2e-5)
 
