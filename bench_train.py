@@ -29,6 +29,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--no-checkpoint', action='store_true', help='store the attention pair tensors (round-1 path) instead of recomputing them in backward')
     ap.add_argument('--graph', action='store_true', help='replay the step as one captured hipGraph (GraphedTrainStep)')
     ap.add_argument('--sampler', action='store_true',
                     help='draw the supervision points inside the step with GuidedImplicitPointSampler '
@@ -43,6 +44,7 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=device)
+    pk.point_transformer_layer.CHECKPOINT_ATTENTION = not args.no_checkpoint
     pa, ia, inf = pk.configs.model_args('carla', N_POINTS)
     esd, dsd = pk.configs.synthetic_weights(pa, ia, SEED)
     enc = pk.model.PointCompletionNetV3(**pa).to(device).train()
@@ -123,7 +125,7 @@ def main():
             'metric': 'training step (BASELINE config 5: CARLA-4D, batch 1/GPU, n_points=28672, 4 x 17203 queries)',
             'value': world * args.steps / elapsed, 'unit': 'examples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'dtype': 'f32', 'data': 'synthetic', 'losses': losses, 'sampler_ms_per_step': sampler_ms, 'graph': bool(args.graph),
+            'scaling': 'weak', 'dtype': 'f32', 'data': 'synthetic', 'losses': losses, 'sampler_ms_per_step': sampler_ms, 'graph': bool(args.graph), 'attention_backward': 'stored pair tensors' if args.no_checkpoint else 'recompute in backward (chunked)',
             'peak_mem_gb': torch.cuda.max_memory_allocated() / 2 ** 30}), flush=True)
     if world > 1:
         dist.destroy_process_group()

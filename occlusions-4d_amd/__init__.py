@@ -12,6 +12,7 @@ from . import _lib  # noqa: F401
 from . import ops  # noqa: F401
 from . import autograd  # noqa: F401
 from . import point_transformer_layer, modules, model, geometry, implicit, inference, distributed, training  # noqa: F401
+from . import evaluation  # noqa: F401
 
 __all__ = ['configs', 'ops', 'point_transformer_layer', 'modules', 'model', 'geometry', 'implicit',
-           'inference', 'distributed', 'autograd', 'training']
+           'inference', 'distributed', 'autograd', 'training', 'evaluation']

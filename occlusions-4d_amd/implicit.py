@@ -255,13 +255,17 @@ class LocalPclResnetFC(ResnetFC):
         for lo in range(0, n, _QUERY_CHUNK):
             q = q_all[lo:lo + _QUERY_CHUNK]
             idx8, w8 = self._interp(q, sc)
+            # every cross-attention layer attends from the same query xyz to the same abstract xyz with the same K:
+            # one kNN_torch (model/point_transformer_layer.py:167) serves them all
+            idx_att = ops.knn(q[:, :3], xyz, self.cross_attn_neighbors, metric=0)[None] if self.use_pt_inds else None
             x = self._embed(q)
             for i in range(self.n_blocks):
                 ops.interp_add(x, sc['zconst'][i * H:(i + 1) * H], sc['ztab'][:, i * H:(i + 1) * H], idx8, w8)
                 x = self.blocks[i]._run(x, inplace=True)
                 if i in self.use_pt_inds:
                     blk = self.pt_blocks[self.use_pt_inds[i]]
-                    x = blk(x[None], q[None, :, :3], x2=feats[None], p2=xyz[None], scene_owner=owner)[0][0]
+                    x = blk(x[None], q[None, :, :3], x2=feats[None], p2=xyz[None], scene_owner=owner,
+                            knn_idx=idx_att)[0][0]
             if single:
                 pen = x
             else:
@@ -310,14 +314,18 @@ class LocalPclResnetFC(ResnetFC):
         f_local = autograd.InterpFn.apply(fa, idx8, w8)                                   # (n, E)
         f_query = torch.cat([fg[None, :].expand(n, dg), f_local], dim=-1)                 # (n, D)
         x = autograd.linear(ops.posenc(q, self.pos_encoding_freqs, 0.1), self.lin_in)
-        qxyz = q[:, :3]
+        qxyz = q[:, :3].detach()
+        idx_att = None
         for i in range(self.n_blocks):
             x = autograd.linear(f_query, self.lin_z[i], residual=x)
             x = self.blocks[i]._run_train(x)
             if i in self.use_pt_inds:
                 blk = self.pt_blocks[self.use_pt_inds[i]]
                 y = autograd.linear(x, blk.layer1)
-                agg = blk.layer2.forward_train(y, qxyz, fa, pa)
+                if idx_att is None:       # one kNN_torch for all cross-attention layers (same xyz on both sides, same K)
+                    idx_att = ops.knn(qxyz, pa, self.cross_attn_neighbors, metric=0)
+                agg = blk.layer2._forward(y[None], qxyz[None], fa[None], pa[None], pre=None, scene_owner=None,
+                                          knn_idx=idx_att[None])[0]
                 x = autograd.linear(agg, blk.layer3, residual=x)
         output = autograd.linear(x, self.lin_out, relu_in=True)
         penult = x

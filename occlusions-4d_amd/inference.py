@@ -87,10 +87,14 @@ def perform_inference(pcl_input, pcl_input_sem, pcl_target_frame, networks, devi
                       sample_implicit=True, num_sample=16384, point_sample_mode='random',
                       batch_size=1024, predict_segmentation=False, track_mode='none',
                       point_occupancy_radius=0.2, semantic_classes=13,
-                      density_threshold=0.5, data_kind='', cube_mode=4, compress_air=False):
+                      density_threshold=0.5, data_kind='', cube_mode=4, compress_air=False,
+                      encoded=None, return_encoded=False):
     """One encode of the input point-cloud video + decode of all query points of one output
     frame.  Returns dict(output_solid, output_air, pcl_abstract, features_global,
-    implicit_output, points_query) of float32 numpy arrays."""
+    implicit_output, points_query) of float32 numpy arrays.
+    Extensions (keyword only, default = the reference's behaviour): `encoded` = the (pcl_abstract, features_global)
+    device tensors of an earlier call on the same input cloud (the reference's eval loop re-encodes the clip for every
+    output frame, eval/test.py:67-86); `return_encoded` adds them to the result as '_encoded'."""
     assert task == 'if'
     assert sample_implicit
     output_track_idx = get_track_idx(color_mode)
@@ -124,7 +128,8 @@ def perform_inference(pcl_input, pcl_input_sem, pcl_target_frame, networks, devi
             if inst_id >= 0:                  # mark the instance to follow in the input cloud (:190-193)
                 pcl_input[..., -1] = (pcl_input_sem[..., input_inst_idx] == inst_id)
             res = infer_device(pcl_input, queries_dev, pcl_net, implicit_net, batch_size, color_mode,
-                               predict_segmentation, track_mode, semantic_classes)
+                               predict_segmentation, track_mode, semantic_classes,
+                               encoded=encoded if inst_id < 0 else None)
             output_dev = res['implicit_output']
             all_output.append(output_dev.cpu().numpy())
             all_abstract.append(res['pcl_abstract'].cpu().numpy() if res['pcl_abstract'] is not None else None)
@@ -148,6 +153,8 @@ def perform_inference(pcl_input, pcl_input_sem, pcl_target_frame, networks, devi
     ops.check_pending()                      # cooperative-FPS status words (everything above has completed)
     result = dict(output_solid=solid, output_air=air, pcl_abstract=pcl_abstract,
                   features_global=features_global, implicit_output=implicit_output, points_query=points_query)
+    if return_encoded:
+        result['_encoded'] = (res['pcl_abstract'], res['features_global'])
     if gt_available:
         solid_mask = implicit_output[..., 0] >= density_threshold
         gt_solid, gt_air = points_nngt[solid_mask], points_nngt[~solid_mask]
@@ -186,14 +193,17 @@ def multi_track_merge(track_instance_ids, pcl_abstract, features_global, implici
 
 
 def infer_device(pcl_input, points_query, pcl_net, implicit_net, batch_size, color_mode,
-                 predict_segmentation=False, track_mode='none', semantic_classes=13):
+                 predict_segmentation=False, track_mode='none', semantic_classes=13, encoded=None):
     """Device-resident core of perform_inference: encode once, decode every mini-batch, squash.
     All tensors are CUDA; returns CUDA tensors (implicit_output (N,G), pcl_abstract (M,3+E),
     features_global (D))."""
-    (pcl_abstract, features_global, _) = pcl_net(pcl_input, False)
-    if pcl_abstract is not None:
-        pcl_abstract = pcl_abstract.squeeze(0)
-    features_global = features_global.squeeze(0)
+    if encoded is not None:
+        (pcl_abstract, features_global) = encoded
+    else:
+        (pcl_abstract, features_global, _) = pcl_net(pcl_input, False)
+        if pcl_abstract is not None:
+            pcl_abstract = pcl_abstract.squeeze(0)
+        features_global = features_global.squeeze(0)
     n = points_query.shape[0]
     out = torch.empty((n, implicit_net.d_out), dtype=torch.float32, device=points_query.device)
     decode_batches(implicit_net, points_query, 0, n, batch_size, pcl_abstract, features_global, out)

@@ -65,6 +65,82 @@ def trunk_pack(weight, kind='rows'):
     return packed
 
 
+CHECKPOINT_ATTENTION = True   # training: cross-attention layers recompute their pair tensors in backward (below)
+_CHECKPOINT_CHUNK = 4096      # queries per recompute chunk in backward: bounds the (chunk * K, 2D) workspace
+
+
+class _CheckpointedAttention(torch.autograd.Function):
+    """Training-time vector attention without stored pair tensors ("recompute-in-backward to
+    avoid storing (N_q, K, 832)").  forward = the fused inference kernel: nothing of size (N*K, .) is written.
+    backward walks the queries in chunks and, per chunk, recomputes the layer in its MERGED form (refactoring (i) of
+    DESIGN.md 4: the per-pair first GEMM has K = 32 instead of K = D) on the differentiable kernels, back-propagates
+    the chunk's output gradient and adds up the gradients of the merged matrices / key-value tables; one small
+    autograd pass then carries those to the original parameters (the merged matrices are differentiable fp64
+    products of them).  Against the stored-activation path this removes the per-pair W1 GEMMs of forward and
+    backward as well as the stored (N*K, 2D) tensors."""
+
+    calls = 0        # (tests: how many layers went through this path)
+
+    @staticmethod
+    def forward(ctx, layer, x, pos, x2, pos2, idx, *params):
+        _CheckpointedAttention.calls += 1
+        with torch.no_grad():
+            agg = layer._forward_one(x, pos, x2, pos2, None, None, knn_idx=idx)
+        ctx.layer = layer
+        ctx.save_for_backward(x, pos, x2, pos2, idx)
+        return agg
+
+    @staticmethod
+    def backward(ctx, g):
+        layer = ctx.layer
+        (x, pos, x2, pos2, idx) = ctx.saved_tensors
+        L = autograd.LinearFn.apply
+        f64 = torch.float64
+        g = g.contiguous()
+        P1, c1 = layer.pos_mlp[0].weight, layer.pos_mlp[0].bias
+        P2, c2 = layer.pos_mlp[2].weight, layer.pos_mlp[2].bias
+        W1, b1 = layer.attn_mlp[0].weight, layer.attn_mlp[0].bias
+        W2, b2 = layer.attn_mlp[2].weight, layer.attn_mlp[2].bias
+        Wq, Wk, Wv = layer.to_q.weight, layer.to_k.weight, layer.to_v.weight
+        with torch.enable_grad():
+            # merged matrices as differentiable functions of the parameters (fp64 products, rounded once)
+            W1d = W1.to(f64)
+            merged = [(W1d @ Wq.to(f64)).float(), (W1d @ c2.to(f64) + b1.to(f64)).float(),
+                      (W1d @ Wk.to(f64)).float(), (W1d @ P2.to(f64)).float()]
+            wq_l, bq_l, wk_l, wp_l = (m.detach().requires_grad_(True) for m in merged)
+            x2d = x2.detach().requires_grad_(True)
+            kt = L(x2d, wk_l, None, False, False, None)                    # (M, 2D), once per backward
+            vt = L(x2d, Wv, None, False, False, None)                      # (M, D)
+            kt_l, vt_l = kt.detach().requires_grad_(True), vt.detach().requires_grad_(True)
+            leaves = [kt_l, vt_l, wq_l, bq_l, wp_l, P1, c1, P2, c2, W2, b2]
+            sums = [torch.zeros_like(t) for t in leaves]
+            gx = torch.empty_like(x)
+            for lo in range(0, x.shape[0], _CHECKPOINT_CHUNK):
+                hi = min(x.shape[0], lo + _CHECKPOINT_CHUNK)
+                xc = x[lo:hi].detach().requires_grad_(True)
+                ic = idx[lo:hi].contiguous()
+                aq = L(xc, wq_l, bq_l, False, False, None)                                      # (c, 2D)
+                r = autograd.PosHiddenFn.apply(pos[lo:hi].contiguous(), pos2, ic, P1, c1)      # (c*K, 32)
+                a = autograd.AttnInFn.apply(aq, kt_l, L(r, wp_l, None, False, False, None), ic) # aq_i - kt_j + Wp r
+                logits = L(a, W2, b2, True, False, None)                                        # W2 relu(.) + b2
+                pe = L(r, P2, c2, False, False, None)
+                out = autograd.SoftmaxAggFn.apply(logits, vt_l, pe, ic)
+                grads = torch.autograd.grad(out, [xc] + leaves, g[lo:hi])
+                gx[lo:hi] = grads[0]
+                for acc, gr in zip(sums, grads[1:]):
+                    acc += gr
+            (g_kt, g_vt, g_wq, g_bq, g_wp, g_P1, g_c1, g_P2, g_c2, g_W2, g_b2) = sums
+            # key / value tables -> abstract features, Wk' and Wv
+            (gx2a, g_wk) = torch.autograd.grad(kt, [x2d, wk_l], g_kt)
+            (gx2b, g_Wv) = torch.autograd.grad(vt, [x2d, Wv], g_vt)
+            # merged matrices -> original parameters
+            (d_W1, d_b1, d_Wq, d_Wk, d_P2, d_c2) = torch.autograd.grad(
+                merged, [W1, b1, Wq, Wk, P2, c2], [g_wq, g_bq, g_wk, g_wp], allow_unused=True)
+        by_param = {id(Wq): d_Wq, id(Wk): d_Wk, id(Wv): g_Wv, id(P1): g_P1, id(c1): g_c1,
+                    id(P2): g_P2 + d_P2, id(c2): g_c2 + d_c2, id(W1): d_W1, id(b1): d_b1, id(W2): g_W2, id(b2): g_b2}
+        return (None, gx, None, gx2a + gx2b, None, None) + tuple(by_param[id(p)] for p in layer.parameters())
+
+
 def needs_grad(module, *tensors):
     """True when the call must be recorded for autograd: the training path (occlusions4d_amd.autograd,
     unfused differentiable kernels in the reference's as-written op order) is taken instead of the
@@ -172,11 +248,18 @@ class PointTransformerLayer(nn.Module):
         """x (B,N,D), pos (B,N,3) [, x2 (B,M,D2), pos2 (B,M,3)] -> agg (B,N,D)."""
         return self._forward(x, pos, x2, pos2, pre=None, scene_owner=None)
 
-    def _forward(self, x, pos, x2, pos2, pre, scene_owner):
+    def _forward(self, x, pos, x2, pos2, pre, scene_owner, knn_idx=None):
         if needs_grad(self, x, x2) or (pre is not None and needs_grad(pre)):
             out = []
             for b in range(x.shape[0]):
                 y = x[b] if pre is None else autograd.linear(x[b], pre)
+                if (CHECKPOINT_ATTENTION and x2 is not None and self.dim in ops.FUSED_ATTN_DIMS
+                        and self.num_neighbors <= ops.FUSED_ATTN_MAX_K and self.pos_mlp[0].out_features == 32):
+                    idx = knn_idx[b] if knn_idx is not None else ops.knn(pos[b].detach(), pos2[b].detach(),
+                                                                          self.num_neighbors, metric=0)
+                    out.append(_CheckpointedAttention.apply(self, y, pos[b].detach(), x2[b], pos2[b].detach(), idx,
+                                                            *self.parameters()))
+                    continue
                 out.append(self.forward_train(y, pos[b], None if x2 is None else x2[b],
                                               None if pos2 is None else pos2[b]))
             return ops.stack_batch(out)
@@ -184,15 +267,18 @@ class PointTransformerLayer(nn.Module):
         for b in range(x.shape[0]):
             xb2 = None if x2 is None else x2[b]
             pb2 = None if pos2 is None else pos2[b]
-            out.append(self._forward_one(x[b], pos[b], xb2, pb2, pre, scene_owner))
+            out.append(self._forward_one(x[b], pos[b], xb2, pb2, pre, scene_owner,
+                                         None if knn_idx is None else knn_idx[b]))
         return ops.stack_batch(out)
 
-    def forward_train(self, x, pos, x2=None, pos2=None):
-        """Differentiable forward for one cloud, as written in the reference (:167-179): x (N,D)."""
+    def forward_train(self, x, pos, x2=None, pos2=None, idx=None):
+        """Differentiable forward for one cloud, as written in the reference (:167-179): x (N,D).  `idx`: the
+        (N,K) int32 neighbour lists when the caller already has them."""
         K = self.num_neighbors
         if x2 is None:
             x2, pos2 = x, pos
-        idx = ops.knn(pos.detach(), pos2.detach(), K, metric=0)
+        if idx is None:
+            idx = ops.knn(pos.detach(), pos2.detach(), K, metric=0)
         q = autograd.linear(x, self.to_q)
         kf = autograd.linear(x2, self.to_k)
         vf = autograd.linear(x2, self.to_v)
@@ -203,7 +289,7 @@ class PointTransformerLayer(nn.Module):
         logits = autograd.linear(h, self.attn_mlp[2])
         return autograd.SoftmaxAggFn.apply(logits, vf, pe, idx)
 
-    def _forward_one(self, x, pos, x2, pos2, pre, scene_owner):
+    def _forward_one(self, x, pos, x2, pos2, pre, scene_owner, knn_idx=None):
         K = self.num_neighbors
         if x2 is None:
             # self-attention: queries, keys and values all come from the (post-`pre`) features
@@ -223,7 +309,10 @@ class PointTransformerLayer(nn.Module):
         W2, b2 = self.attn_mlp[2].weight, self.attn_mlp[2].bias
         for lo in range(0, n, _PAIR_CHUNK):
             hi = min(n, lo + _PAIR_CHUNK)
-            idx = ops.knn(pos[lo:hi], pos2, K, metric=0)                        # (c,K) int32
+            if knn_idx is not None:      # the caller already has kNN_torch(pos, pos2, K) (shared by the decoder's layers)
+                idx = knn_idx[lo:hi]
+            else:
+                idx = ops.knn(pos[lo:hi], pos2, K, metric=0)                    # (c,K) int32
             if aq_all is not None:
                 aq = aq_all[lo:hi]
             elif m.get('wq_packed') is not None and USE_TRUNK_KERNELS:

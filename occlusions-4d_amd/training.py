@@ -170,6 +170,16 @@ class GraphedTrainStep(TrainStep):
         self.graph = None
 
     def _eager(self, pcl_input, points_query, implicit_target):
+        # (the recompute-in-backward attention Function drives a nested autograd pass that the stream capture does
+        # not accept; a captured step has static memory anyway, so it keeps the stored-activation path)
+        from . import point_transformer_layer as ptl
+        saved, ptl.CHECKPOINT_ATTENTION = ptl.CHECKPOINT_ATTENTION, False
+        try:
+            return self._eager_step(pcl_input, points_query, implicit_target)
+        finally:
+            ptl.CHECKPOINT_ATTENTION = saved
+
+    def _eager_step(self, pcl_input, points_query, implicit_target):
         loss = self.forward_loss(pcl_input, points_query, implicit_target)
         loss.backward()
         allreduce_gradients(self.params)

@@ -100,6 +100,38 @@ def test_pt_layer_gradients_strict(case):
     check_grads(layer, rsd)
 
 
+@pytest.mark.parametrize('chunk', [17, 4096])
+def test_checkpointed_attention_gradients_strict(chunk):
+    """Cross-attention through the recompute-in-backward Function (fused forward kernel, chunked recomputation of
+    the as-written chain in backward): same strict criterion as the stored-activation path, several chunks."""
+    case = gc.PTL_CASES[2]
+    assert 'dim2' in case
+    x, pos, x2, pos2, sd = gc.ptl_inputs(case)
+    rng = np.random.default_rng(3)
+    go = torch.from_numpy(rng.normal(size=(x.shape[0], case['dim'])).astype(np.float32))
+    rsd = {k: v.clone().double().requires_grad_(True) for k, v in sd.items()}
+    xr, x2r = T(x).double().requires_grad_(True), T(x2).double().requires_grad_(True)
+    agg_r = op.pt_layer(rsd, xr[None], T(pos).double()[None], x2=x2r[None], pos2=T(pos2).double()[None],
+                        num_neighbors=case['k'])[0]
+    (agg_r * go.double()).sum().backward()
+    ptl = pk.point_transformer_layer
+    layer = ptl.PointTransformerLayer(case['dim'], num_neighbors=case['k'], dim2=case['dim2']).cuda()
+    layer.load_state_dict(sd)
+    xg, x2g = T(x).cuda().requires_grad_(True), T(x2).cuda().requires_grad_(True)
+    saved = ptl._CHECKPOINT_CHUNK
+    ptl._CHECKPOINT_CHUNK = chunk
+    try:
+        before = ptl._CheckpointedAttention.calls
+        agg = layer(xg[None], T(pos).cuda()[None], x2g[None], T(pos2).cuda()[None])[0]
+        assert ptl._CheckpointedAttention.calls == before + 1
+        (agg * go.cuda()).sum().backward()
+    finally:
+        ptl._CHECKPOINT_CHUNK = saved
+    assert rel_err(agg, agg_r) < 1e-5
+    assert rel_err(xg.grad, xr.grad) <= REL and rel_err(x2g.grad, x2r.grad) <= REL
+    check_grads(layer, rsd)
+
+
 def test_chained_blocks_gradients_strict():
     case = gc.PTB_CASES[1]
     x, pos, x2, pos2, sd = gc.ptb_inputs(case)
@@ -176,6 +208,7 @@ def test_end_to_end_training_step_gradients():
     pcl = pk.configs.synthetic_pcl(kind, n, 4, 31)
     esd, dsd = pk.configs.synthetic_weights(pa, ia, 32)
     rng = np.random.default_rng(33)
+    np.random.seed(1210)          # (the oracle sampler draws from numpy's global generator)
     q = T(op.sample_query_points(64, inf['min_z'], inf['cube_bounds'], 1, kind, 4, 'random'))
     target = torch.from_numpy(np.concatenate([rng.integers(0, 2, size=(64, 1)), rng.uniform(size=(64, 3)),
                                               np.zeros((64, 1)), rng.integers(-1, 13, size=(64, 1))], 1).astype(np.float32))
@@ -211,6 +244,7 @@ def test_train_step_reduces_loss():
     enc.load_state_dict(esd)
     dec.load_state_dict(dsd)
     rng = np.random.default_rng(43)
+    np.random.seed(1245)          # (the oracle sampler draws from numpy's global generator)
     q = torch.stack([T(op.sample_query_points(128, inf['min_z'], inf['cube_bounds'], t, kind, 4, 'random'))
                      for t in range(2)]).cuda()
     target = torch.from_numpy(np.concatenate(
@@ -234,6 +268,7 @@ def test_graphed_train_step_matches_eager():
     pcl = pk.configs.synthetic_pcl(kind, n, 4, 51).cuda()
     esd, dsd = pk.configs.synthetic_weights(dict(pa), ia, 52)
     rng = np.random.default_rng(53)
+    np.random.seed(1268)          # (the oracle sampler draws from numpy's global generator)
     q = torch.stack([T(op.sample_query_points(128, inf['min_z'], inf['cube_bounds'], t, kind, 4, 'random'))
                      for t in range(2)]).cuda()
     target = torch.from_numpy(np.concatenate(
