@@ -25,7 +25,7 @@ grid on one GPU) and `strong_config2` on the N > 1 lines (the 534 528-query grid
 where the serial 13 ms encode is the Amdahl term).
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel = cross_attn_kernel<13> (fused vector attention, 14
+  roofline      the dominant kernel = cross_attn16_kernel (fused vector attention, 14
                 neighbours, D = 416), timed with HIP events on its launch stream.  achieved / frac
                 = the FLOP the kernel EXECUTES (after the exact-in-R refactoring of DESIGN.md 4,
                 counted once: 2 * 14 * (32*832 + 832*416 + 32*416) per query) / time, against the
@@ -399,8 +399,8 @@ def main():
                 'achieved_as_written': as_written / 1e12, 'frac_as_written': as_written / FP32_MFMA_PEAK,
                 'traffic': traffic, 'traffic_source': traffic_source,
                 'traffic_over_algorithmic': (traffic / (chunk * (2 * H + H + 14) * 4.0)) if traffic else None,
-                'kernel': 'cross_attn_kernel<13> (fused vector attention: pos-MLP + attn-MLP + softmax + '
-                          'aggregate, 14 neighbours, D=416)',
+                'kernel': 'cross_attn16_kernel (csrc/crossattn16.hip: fused vector attention = pos-MLP + attn-MLP + softmax '
+                          '+ aggregate, 14 neighbours, D=416, v_mfma_f32_16x16x4_f32)',
                 'launches': psum['launches'], 'avg_launch_ms': psum['total_ms'] / max(1, psum['launches']),
                 'flop_per_launch_executed': psum['total_flops'] / max(1, psum['launches']),
                 'flop_per_launch_as_written': psum['total_flops'] / max(1, psum['launches'])

@@ -174,9 +174,6 @@ __global__ __launch_bounds__(512, 2) void resblock_kernel(const TrunkArgs a) {
 #pragma clang loop unroll(disable)
   for (int j = 0; j < TNS; ++j) {
     // ---- stage A: h = relu(W0[32 j .. 32 j + 32, :] relu(x) + b0); meanwhile W1's chunk j lands in bufB
-#ifndef OCC4D_TR_NODMA
-    dma_stage(a.w1p + (int64_t)j * STAGE_FLOATS, bufB, wave, lane);
-#endif
     f32x4 h0 = *reinterpret_cast<const f32x4*>(s_b0 + 32 * j + 4 * g);
     f32x4 h1 = *reinterpret_cast<const f32x4*>(s_b0 + 32 * j + 16 + 4 * g);
     {
@@ -187,6 +184,11 @@ __global__ __launch_bounds__(512, 2) void resblock_kernel(const TrunkArgs a) {
       f32x4 wb = *reinterpret_cast<const f32x4*>(fa + TKG * FRAG_FLOATS);
 #pragma unroll
       for (int t = 0; t < TKG; ++t) {
+#ifndef OCC4D_TR_NODMA
+        // the other buffer's DMA is issued a few groups into the stage, between MFMAs (right after the barrier its
+        // issue slots delayed both waves of the SIMD at once, with the matrix pipe idle)
+        if (t == 2) dma_stage(a.w1p + (int64_t)j * STAGE_FLOATS, bufB, wave, lane);
+#endif
         const f32x4 ca = wa, cb = wb;
         if (t + 1 < TKG) {
           wa = *reinterpret_cast<const f32x4*>(fa + (t + 1) * FRAG_FLOATS);
@@ -206,9 +208,6 @@ __global__ __launch_bounds__(512, 2) void resblock_kernel(const TrunkArgs a) {
 #endif
     STAMP(1)
     // ---- stage B: yacc += W1[:, 32 j .. 32 j + 32] h; meanwhile W0's chunk j + 1 lands in bufA
-#ifndef OCC4D_TR_NODMA
-    dma_stage(a.w0p + (int64_t)(j + 1) * STAGE_FLOATS, bufA, wave, lane);
-#endif
     {
       // group (p, tt): output tiles 2 p and 2 p + 1, hidden half tt; same fenced pipeline
       f32x4 wa = *reinterpret_cast<const f32x4*>(fb);
@@ -216,6 +215,9 @@ __global__ __launch_bounds__(512, 2) void resblock_kernel(const TrunkArgs a) {
 #pragma unroll
       for (int q = 0; q < TKG; ++q) {
         const int p = q >> 1, tt = q & 1;
+#ifndef OCC4D_TR_NODMA
+        if (q == 2) dma_stage(a.w0p + (int64_t)(j + 1) * STAGE_FLOATS, bufA, wave, lane);
+#endif
         const f32x4 ca = wa, cb = wb;
         if (q + 1 < TKG) {
           const int pn = (q + 1) >> 1, tn = (q + 1) & 1;
@@ -260,7 +262,8 @@ __global__ __launch_bounds__(512, 2) void resblock_kernel(const TrunkArgs a) {
 // ---------------------------------------------------------------------------------------------------
 // y[:, 0 .. 32 S) = [res +] W [relu](x) + b  [+ interpolation term], K = 416, one stage per 32 output channels
 __device__ __forceinline__ void rowlin_stage(const TrunkArgs& a, int s, const float* __restrict__ frag, const f32x4* xr,
-                                             int row, int rowc, int g) {
+                                             int row, int rowc, int g, const float* next_src, const float* next_dst,
+                                             int wave, int lane) {
   const int c0 = 32 * s + 4 * g;
   // bias / residual: compiler-tracked global loads issued AFTER this stage's DMA and consumed at the END of the stage
   // (the hardware's vmcnt is in order: consuming them earlier would wait for the DMA as well)
@@ -277,6 +280,7 @@ __device__ __forceinline__ void rowlin_stage(const TrunkArgs& a, int s, const fl
     f32x4 wb = *reinterpret_cast<const f32x4*>(frag + TKG * FRAG_FLOATS);
 #pragma unroll
     for (int t = 0; t < TKG; ++t) {
+      if (t == 2) dma_stage(next_src, next_dst, wave, lane);     // a few groups in, between MFMAs (see resblock_kernel)
       const f32x4 ca = wa, cb = wb;
       if (t + 1 < TKG) {
         wa = *reinterpret_cast<const f32x4*>(frag + (t + 1) * FRAG_FLOATS);
@@ -332,14 +336,11 @@ __global__ __launch_bounds__(512, 2) void rowlin_kernel(const TrunkArgs a) {
   // the packed stream carries n_stages + 1 stages (the last repeats stage 0): prefetching is branch-free
 #pragma clang loop unroll(disable)
   for (int s = 0; s < a.n_stages; s += 2) {
-    dma_stage(a.w0p + (int64_t)(s + 1) * STAGE_FLOATS, bufB, wave, lane);
-    rowlin_stage(a, s, bufA + lane * 4, xr, row, rowc, g);
+    rowlin_stage(a, s, bufA + lane * 4, xr, row, rowc, g, a.w0p + (int64_t)(s + 1) * STAGE_FLOATS, bufB, wave, lane);
     dma_wait();
     __syncthreads();
-    if (s + 1 < a.n_stages) {
-      dma_stage(a.w0p + (int64_t)(s + 2) * STAGE_FLOATS, bufA, wave, lane);
-      rowlin_stage(a, s + 1, bufB + lane * 4, xr, row, rowc, g);
-    }
+    if (s + 1 < a.n_stages)
+      rowlin_stage(a, s + 1, bufB + lane * 4, xr, row, rowc, g, a.w0p + (int64_t)(s + 2) * STAGE_FLOATS, bufA, wave, lane);
     dma_wait();
     __syncthreads();
   }

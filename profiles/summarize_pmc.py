@@ -13,7 +13,7 @@ import os
 import sys
 from collections import defaultdict
 
-WANT = ('cross_attn_kernel', 'resblock_kernel', 'rowlin_kernel', 'linear_kernel<13', 'interp_add', 'knn_kernel')
+WANT = ('cross_attn16_kernel', 'cross_attn_kernel', 'resblock_kernel', 'rowlin_kernel', 'linear_kernel<13', 'interp_add', 'knn_kernel')
 
 
 def short(name):
@@ -65,14 +65,15 @@ def main():
         if os.path.exists(path):
             with open(path) as f:
                 rec = json.load(f)
-        ca = [k for k in out if 'cross_attn_kernel<13' in k and '_hbm' in out[k]]
+        ca = [k for k in out if ('cross_attn16_kernel' in k or 'cross_attn_kernel<13' in k) and '_hbm' in out[k]]
+        ca.sort(key=lambda k: 'cross_attn16' not in k)
         if ca:
             v = out[ca[0]]
             rec[kind] = dict(hbm_bytes_per_launch=v['_hbm'][0], fetch_size_kib=v['FETCH_SIZE'][0],
                              write_size_kib=v['WRITE_SIZE'][0], dispatches=v['FETCH_SIZE'][1],
                              source='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/run_pmc.sh) of '
-                                    'cross_attn_kernel<13,false> on one %s decode chunk; (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B'
-                                    % kind)
+                                    '%s on one %s decode chunk (32256 queries); (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B'
+                                    % (ca[0], kind))
             with open(path, 'w') as f:
                 json.dump(rec, f, indent=1)
             print('wrote', path)
