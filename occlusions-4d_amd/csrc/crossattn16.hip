@@ -70,6 +70,15 @@ __device__ __forceinline__ void dma_stage16(const float* __restrict__ src, const
                  : "=&s"(keep) : "v"(g), "s"(d) : "memory");
   }
 }
+// the i-th of this wave's 7 fragments of a stage (fragment wave + 8 i)
+__device__ __forceinline__ void dma_frag16(const float* __restrict__ src, const float* dst, int wave, int lane, int i) {
+  const int c = wave + 8 * i;
+  const float* g = src + c * AFRAG + lane * 4;
+  const unsigned d = __builtin_amdgcn_readfirstlane(lds_addr16(dst) + (unsigned)c * (AFRAG * 4));
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(d) : "memory");
+}
 __device__ __forceinline__ void dma_wait16() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // 8 MFMAs on two accumulators, alternating (A operands a0 / a1 share the B fragment element-wise or vice versa)
@@ -170,71 +179,76 @@ __global__ __launch_bounds__(512, 2) void cross_attn16_kernel(const Attn16Args a
   dma_wait16();
   __syncthreads();
 
-  // One hidden block per iteration; two iterations per loop trip so that the LDS buffers are compile-time objects.
-  auto block = [&](const int hb, const float* __restrict__ cur, const float* nxt) {
-    // Order matters for the hardware's in-order vmcnt: the gathered Aq / Kt slices (compiler-tracked loads, issued one
-    // block ago) are consumed FIRST, then the DMA of the next stage is issued, then the next slices.  The compiler
-    // does not see the DMA: had it been issued before this use, the compiler's "all but my newest loads" wait would
-    // make the wave sit out the DMA's full latency at the top of every block.
-    f32x4 h0 = {ia0.x - ik0.x, ia0.y - ik0.y, ia0.z - ik0.z, ia0.w - ik0.w};
-    f32x4 h1 = {ia1.x - ik1.x, ia1.y - ik1.y, ia1.z - ik1.z, ia1.w - ik1.w};
+  // ---- hidden-block loop.  A block is 28 groups of 8 MFMAs behind a fenced fragment pipeline: the two ds_read_b128 of
+  // group i + 1 are issued before the MFMAs of group i and nothing is scheduled across the fences.  Groups 0, 1:
+  // GEMM1 (Wp fragments 52 + 2 nt + kh); groups 2 .. 27: GEMM2, group (p, nt) = channel tiles 2 p, 2 p + 1, hidden
+  // half nt (W2 fragments 2 t + nt).
+  f32x4 h0, h1, wa, wb;
+  auto frag_a = [](int gq) { return gq == 0 ? 52 : gq == 1 ? 53 : 4 * ((gq - 2) >> 1) + ((gq - 2) & 1); };
+  auto frag_b = [](int gq) { return gq == 0 ? 54 : gq == 1 ? 55 : 4 * ((gq - 2) >> 1) + 2 + ((gq - 2) & 1); };
+  // Order matters for the hardware's in-order vmcnt: the gathered Aq / Kt slices (compiler-tracked loads, issued one
+  // block ago) are consumed FIRST, before any DMA of this block is issued.  The compiler does not see the DMA: had one
+  // been issued before this use, the compiler's "all but my newest loads" wait would make the wave sit out the DMA's
+  // full latency at the top of every block.
+  auto begin_block = [&](const float* __restrict__ cur) {
+    h0 = f32x4{ia0.x - ik0.x, ia0.y - ik0.y, ia0.z - ik0.z, ia0.w - ik0.w};
+    h1 = f32x4{ia1.x - ik1.x, ia1.y - ik1.y, ia1.z - ik1.z, ia1.w - ik1.w};
+    wa = *reinterpret_cast<const f32x4*>(cur + lane * 4 + 52 * AFRAG);
+    wb = *reinterpret_cast<const f32x4*>(cur + lane * 4 + 54 * AFRAG);
     __builtin_amdgcn_sched_barrier(0);
-    // the packed stream has AHB + 1 stages: "prefetch stage hb + 1" is branch-free (the last one brings P2)
-    dma_stage16(a.wstream + (int64_t)(hb + 1) * ASTAGE, nxt, wave, lane);
-    {
-      const int hn = hb + 1 < AHB ? hb + 1 : hb;     // (clamped: the last block re-reads its own slices)
-      ia0 = *reinterpret_cast<const f32x4*>(aq_row + 32 * hn);
-      ia1 = *reinterpret_cast<const f32x4*>(aq_row + 32 * hn + 16);
-      ik0 = *reinterpret_cast<const f32x4*>(kt_row + 32 * hn);
-      ik1 = *reinterpret_cast<const f32x4*>(kt_row + 32 * hn + 16);
-    }
+  };
+  // The block's 11 vector-memory instructions per wave (4 gathered Aq / Kt slices of the next block, 7 DMA fragments of
+  // the next stage; the packed stream has AHB + 1 stages, so "stage hb + 1" is branch-free and the last one brings P2)
+  // are SPREAD over the MFMA groups, one every other group.  Issued back to back at the top of the block, the eight
+  // waves' 88 KB queued up in the CU's single vector-memory path (64 B / clk) and every wave's instruction stream --
+  // MFMAs included -- sat behind its own stalled VMEM issue: measured 3.0 % (DMA) + 3.4 % (gathers) of the loop.
+  // Gathers first (consumed at the next block's top, after the DMA has been waited for anyway), the last DMA
+  // fragment 5 groups before the barrier.
+  auto groups = [&](const int hb, const float* __restrict__ cur, const float* nxt) {
     const float* f = cur + lane * 4;
-    // fragment pipeline over 28 groups of 8 MFMAs: the two ds_read_b128 of group i + 1 are issued before the MFMAs of
-    // group i; nothing is scheduled across the fences.  Groups 0, 1: GEMM1 (Wp fragments 52 .. 55: (nt, kh) =
-    // 52 + 2 nt + kh); groups 2 .. 27: GEMM2, group (p, nt): channel tiles 2 p, 2 p + 1, hidden half nt.
-    f32x4 wa = *reinterpret_cast<const f32x4*>(f + 52 * AFRAG);      // Wp (nt 0, kh 0)
-    f32x4 wb = *reinterpret_cast<const f32x4*>(f + 54 * AFRAG);      // Wp (nt 1, kh 0)
-    {
-      const f32x4 ca = wa, cb = wb;
-      wa = *reinterpret_cast<const f32x4*>(f + 53 * AFRAG);          // (nt 0, kh 1)
-      wb = *reinterpret_cast<const f32x4*>(f + 55 * AFRAG);          // (nt 1, kh 1)
-      __builtin_amdgcn_sched_barrier(0);
-      mm_ba(ca, cb, r_lo, h0, h1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    {
-      const f32x4 ca = wa, cb = wb;
-      wa = *reinterpret_cast<const f32x4*>(f);                       // W2 (tile 0, nt 0)
-      wb = *reinterpret_cast<const f32x4*>(f + 2 * AFRAG);           // W2 (tile 1, nt 0)
-      __builtin_amdgcn_sched_barrier(0);
-      mm_ba(ca, cb, r_hi, h0, h1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    h0.x = fmaxf(h0.x, 0.f); h0.y = fmaxf(h0.y, 0.f); h0.z = fmaxf(h0.z, 0.f); h0.w = fmaxf(h0.w, 0.f);
-    h1.x = fmaxf(h1.x, 0.f); h1.y = fmaxf(h1.y, 0.f); h1.z = fmaxf(h1.z, 0.f); h1.w = fmaxf(h1.w, 0.f);
+    const int hn = hb + 1 < AHB ? hb + 1 : hb;       // (clamped: the last block re-reads its own slices)
+    const float* nsrc = a.wstream + (int64_t)(hb + 1) * ASTAGE;
 #pragma unroll
-    for (int q = 0; q < ATD; ++q) {
-      const int p = q >> 1, nt = q & 1;
+    for (int gq = 0; gq < 28; ++gq) {
       const f32x4 ca = wa, cb = wb;
-      if (q + 1 < ATD) {
-        const int pn = (q + 1) >> 1, nn = (q + 1) & 1;
-        wa = *reinterpret_cast<const f32x4*>(f + (4 * pn + nn) * AFRAG);          // tile 2 pn, hidden half nn
-        wb = *reinterpret_cast<const f32x4*>(f + (4 * pn + 2 + nn) * AFRAG);      // tile 2 pn + 1
+      if (gq + 1 < 28) {
+        wa = *reinterpret_cast<const f32x4*>(f + frag_a(gq + 1) * AFRAG);
+        wb = *reinterpret_cast<const f32x4*>(f + frag_b(gq + 1) * AFRAG);
       }
+#ifndef OCC4D_CA16_ABL_NOGATHER
+      if (gq == 1) ia0 = *reinterpret_cast<const f32x4*>(aq_row + 32 * hn);
+      if (gq == 3) ia1 = *reinterpret_cast<const f32x4*>(aq_row + 32 * hn + 16);
+      if (gq == 5) ik0 = *reinterpret_cast<const f32x4*>(kt_row + 32 * hn);
+      if (gq == 7) ik1 = *reinterpret_cast<const f32x4*>(kt_row + 32 * hn + 16);
+#endif
+#ifndef OCC4D_CA16_ABL_NODMA
+      if (gq >= 9 && gq <= 21 && (gq & 1)) dma_frag16(nsrc, nxt, wave, lane, (gq - 9) >> 1);
+#endif
       __builtin_amdgcn_sched_barrier(0);
-      mm_ab(nt ? h1 : h0, ca, cb, acc[2 * p], acc[2 * p + 1]);
+      if (gq == 0) mm_ba(ca, cb, r_lo, h0, h1);
+      else if (gq == 1) mm_ba(ca, cb, r_hi, h0, h1);
+      else mm_ab(((gq - 2) & 1) ? h1 : h0, ca, cb, acc[2 * ((gq - 2) >> 1)], acc[2 * ((gq - 2) >> 1) + 1]);
       __builtin_amdgcn_sched_barrier(0);
+      if (gq == 1) {
+        h0.x = fmaxf(h0.x, 0.f); h0.y = fmaxf(h0.y, 0.f); h0.z = fmaxf(h0.z, 0.f); h0.w = fmaxf(h0.w, 0.f);
+        h1.x = fmaxf(h1.x, 0.f); h1.y = fmaxf(h1.y, 0.f); h1.z = fmaxf(h1.z, 0.f); h1.w = fmaxf(h1.w, 0.f);
+      }
     }
-    dma_wait16();
-    __syncthreads();
   };
 #ifdef OCC4D_CA16_STAMP
   const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
 #endif
+  // two blocks per loop trip so that the LDS buffers are compile-time objects; one barrier per block
 #pragma clang loop unroll(disable)
   for (int hb = 0; hb < AHB; hb += 2) {
-    block(hb, buf0, buf1);
-    block(hb + 1, buf1, buf0);
+    begin_block(buf0);
+    groups(hb, buf0, buf1);
+    dma_wait16();
+    __syncthreads();
+    begin_block(buf1);
+    groups(hb + 1, buf1, buf0);
+    dma_wait16();
+    __syncthreads();
   }
 #ifdef OCC4D_CA16_STAMP
   const unsigned long long ts2 = __builtin_amdgcn_s_memtime();

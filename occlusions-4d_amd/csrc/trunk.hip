@@ -77,6 +77,18 @@ __device__ __forceinline__ void dma_stage(const float* __restrict__ src, const f
   }
 }
 
+// the i-th of this wave's (up to 7) fragments of a stage: fragment wave + 8 i (i = 6 exists for waves 0-3 only)
+__device__ __forceinline__ void dma_frag(const float* __restrict__ src, const float* dst, int wave, int lane, int i) {
+  const int c = wave + 8 * i;                         // wave-uniform
+  if (c < STAGE_FRAGS) {
+    const float* g = src + c * FRAG_FLOATS + lane * 4;
+    const unsigned d = __builtin_amdgcn_readfirstlane(lds_addr(dst) + (unsigned)c * (FRAG_FLOATS * 4));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(d) : "memory");
+  }
+}
+
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ f32x4 mfma4(const f32x4 w, const f32x4 v, f32x4 acc) {
@@ -185,9 +197,10 @@ __global__ __launch_bounds__(512, 2) void resblock_kernel(const TrunkArgs a) {
 #pragma unroll
       for (int t = 0; t < TKG; ++t) {
 #ifndef OCC4D_TR_NODMA
-        // the other buffer's DMA is issued a few groups into the stage, between MFMAs (right after the barrier its
-        // issue slots delayed both waves of the SIMD at once, with the matrix pipe idle)
-        if (t == 2) dma_stage(a.w1p + (int64_t)j * STAGE_FLOATS, bufB, wave, lane);
+        // the other buffer's DMA, one fragment every third group, between MFMAs: issued back to back right after the
+        // barrier, the eight waves' 52 KB queued up in the CU's single vector-memory path and every wave's
+        // instruction stream -- MFMAs included -- sat behind its own stalled VMEM issue
+        if (t >= 2 && t <= 20 && (t - 2) % 3 == 0) dma_frag(a.w1p + (int64_t)j * STAGE_FLOATS, bufB, wave, lane, (t - 2) / 3);
 #endif
         const f32x4 ca = wa, cb = wb;
         if (t + 1 < TKG) {
@@ -216,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void resblock_kernel(const TrunkArgs a) {
       for (int q = 0; q < TKG; ++q) {
         const int p = q >> 1, tt = q & 1;
 #ifndef OCC4D_TR_NODMA
-        if (q == 2) dma_stage(a.w0p + (int64_t)(j + 1) * STAGE_FLOATS, bufA, wave, lane);
+        if (q >= 2 && q <= 20 && (q - 2) % 3 == 0) dma_frag(a.w0p + (int64_t)(j + 1) * STAGE_FLOATS, bufA, wave, lane, (q - 2) / 3);
 #endif
         const f32x4 ca = wa, cb = wb;
         if (q + 1 < TKG) {
@@ -280,7 +293,7 @@ __device__ __forceinline__ void rowlin_stage(const TrunkArgs& a, int s, const fl
     f32x4 wb = *reinterpret_cast<const f32x4*>(frag + TKG * FRAG_FLOATS);
 #pragma unroll
     for (int t = 0; t < TKG; ++t) {
-      if (t == 2) dma_stage(next_src, next_dst, wave, lane);     // a few groups in, between MFMAs (see resblock_kernel)
+      if (t >= 2 && t <= 20 && (t - 2) % 3 == 0) dma_frag(next_src, next_dst, wave, lane, (t - 2) / 3);   // (see resblock_kernel)
       const f32x4 ca = wa, cb = wb;
       if (t + 1 < TKG) {
         wa = *reinterpret_cast<const f32x4*>(frag + (t + 1) * FRAG_FLOATS);
