@@ -288,8 +288,13 @@ __global__ __launch_bounds__(512, 2) void cross_attn16_kernel(const Attn16Args a
     for (int i = 0; i < NTH; ++i) pe[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float vq[3][4];
     auto loadV = [&](int t, float* V) {
+#ifndef OCC4D_CA16_ABL_NOV
 #pragma unroll
       for (int i = 0; i < 4; ++i) V[i] = a.vt[(int64_t)jrow[i] * a.ld_vt + 16 * t + c];
+#else
+#pragma unroll
+      for (int i = 0; i < 4; ++i) V[i] = (float)(jrow[i] + t);
+#endif
     };
     loadV(T0, vq[0]);
     loadV(T0 + 1, vq[1]);
