@@ -69,6 +69,18 @@ CHECKPOINT_ATTENTION = True   # training: cross-attention layers recompute their
 _CHECKPOINT_CHUNK = 4096      # queries per recompute chunk in backward: bounds the (chunk * K, 2D) workspace
 
 
+def _grad_or_none(outputs, inputs, grad_outputs):
+    """torch.autograd.grad over the inputs that require grad; None for the others (frozen parameters)."""
+    if torch.is_tensor(outputs):
+        outputs, grad_outputs = [outputs], [grad_outputs]
+    pairs = [(o, g) for o, g in zip(outputs, grad_outputs) if o.requires_grad]
+    live = [t for t in inputs if t.requires_grad]
+    if not pairs or not live:
+        return tuple(None for _ in inputs)
+    got = iter(torch.autograd.grad([o for o, _ in pairs], live, [g for _, g in pairs], allow_unused=True))
+    return tuple(next(got) if t.requires_grad else None for t in inputs)
+
+
 class _CheckpointedAttention(torch.autograd.Function):
     """Training-time vector attention without stored pair tensors ("recompute-in-backward to
     avoid storing (N_q, K, 832)").  forward = the fused inference kernel: nothing of size (N*K, .) is written.
@@ -112,7 +124,9 @@ class _CheckpointedAttention(torch.autograd.Function):
             kt = L(x2d, wk_l, None, False, False, None)                    # (M, 2D), once per backward
             vt = L(x2d, Wv, None, False, False, None)                      # (M, D)
             kt_l, vt_l = kt.detach().requires_grad_(True), vt.detach().requires_grad_(True)
-            leaves = [kt_l, vt_l, wq_l, bq_l, wp_l, P1, c1, P2, c2, W2, b2]
+            # (detached leaf copies, so that frozen parameters do not break the per-chunk autograd.grad)
+            P1, c1, P2l, c2l, W2, b2 = (t.detach().requires_grad_(True) for t in (P1, c1, P2, c2, W2, b2))
+            leaves = [kt_l, vt_l, wq_l, bq_l, wp_l, P1, c1, P2l, c2l, W2, b2]
             sums = [torch.zeros_like(t) for t in leaves]
             gx = torch.empty_like(x)
             for lo in range(0, x.shape[0], _CHECKPOINT_CHUNK):
@@ -123,7 +137,7 @@ class _CheckpointedAttention(torch.autograd.Function):
                 r = autograd.PosHiddenFn.apply(pos[lo:hi].contiguous(), pos2, ic, P1, c1)      # (c*K, 32)
                 a = autograd.AttnInFn.apply(aq, kt_l, L(r, wp_l, None, False, False, None), ic) # aq_i - kt_j + Wp r
                 logits = L(a, W2, b2, True, False, None)                                        # W2 relu(.) + b2
-                pe = L(r, P2, c2, False, False, None)
+                pe = L(r, P2l, c2l, False, False, None)
                 out = autograd.SoftmaxAggFn.apply(logits, vt_l, pe, ic)
                 grads = torch.autograd.grad(out, [xc] + leaves, g[lo:hi])
                 gx[lo:hi] = grads[0]
@@ -132,12 +146,14 @@ class _CheckpointedAttention(torch.autograd.Function):
             (g_kt, g_vt, g_wq, g_bq, g_wp, g_P1, g_c1, g_P2, g_c2, g_W2, g_b2) = sums
             # key / value tables -> abstract features, Wk' and Wv
             (gx2a, g_wk) = torch.autograd.grad(kt, [x2d, wk_l], g_kt)
-            (gx2b, g_Wv) = torch.autograd.grad(vt, [x2d, Wv], g_vt)
-            # merged matrices -> original parameters
-            (d_W1, d_b1, d_Wq, d_Wk, d_P2, d_c2) = torch.autograd.grad(
-                merged, [W1, b1, Wq, Wk, P2, c2], [g_wq, g_bq, g_wk, g_wp], allow_unused=True)
-        by_param = {id(Wq): d_Wq, id(Wk): d_Wk, id(Wv): g_Wv, id(P1): g_P1, id(c1): g_c1,
-                    id(P2): g_P2 + d_P2, id(c2): g_c2 + d_c2, id(W1): d_W1, id(b1): d_b1, id(W2): g_W2, id(b2): g_b2}
+            (gx2b, g_Wv) = _grad_or_none(vt, [x2d, Wv], g_vt)
+            # merged matrices -> original parameters (frozen ones are skipped: autograd.grad rejects them)
+            (d_W1, d_b1, d_Wq, d_Wk, d_P2, d_c2) = _grad_or_none(merged, [W1, b1, Wq, Wk, P2, c2], [g_wq, g_bq, g_wk, g_wp])
+        add = lambda u, v: u if v is None else (v if u is None else u + v)   # noqa: E731
+        lp, la = layer.pos_mlp, layer.attn_mlp
+        by_param = {id(Wq): d_Wq, id(Wk): d_Wk, id(Wv): g_Wv, id(lp[0].weight): g_P1, id(lp[0].bias): g_c1,
+                    id(P2): add(g_P2, d_P2), id(c2): add(g_c2, d_c2), id(W1): d_W1, id(b1): d_b1,
+                    id(la[2].weight): g_W2, id(la[2].bias): g_b2}
         return (None, gx, None, gx2a + gx2b, None, None) + tuple(by_param[id(p)] for p in layer.parameters())
 
 

@@ -132,6 +132,33 @@ def test_checkpointed_attention_gradients_strict(chunk):
     check_grads(layer, rsd)
 
 
+def test_checkpointed_attention_with_frozen_parameters():
+    """Frozen parameters (requires_grad False) get no gradient and do not disturb the others."""
+    case = gc.PTL_CASES[2]
+    x, pos, x2, pos2, sd = gc.ptl_inputs(case)
+    go = torch.from_numpy(np.random.default_rng(4).normal(size=(x.shape[0], case['dim'])).astype(np.float32)).cuda()
+    ptl = pk.point_transformer_layer
+
+    def run(freeze):
+        layer = ptl.PointTransformerLayer(case['dim'], num_neighbors=case['k'], dim2=case['dim2']).cuda()
+        layer.load_state_dict(sd)
+        for name, p in layer.named_parameters():
+            if any(name.startswith(f) for f in freeze):
+                p.requires_grad_(False)
+        xg, x2g = T(x).cuda().requires_grad_(True), T(x2).cuda().requires_grad_(True)
+        agg = layer(xg[None], T(pos).cuda()[None], x2g[None], T(pos2).cuda()[None])[0]
+        (agg * go).sum().backward()
+        return layer, xg.grad, x2g.grad
+    full, gx, gx2 = run(())
+    part, hx, hx2 = run(('to_v', 'attn_mlp.0', 'pos_mlp.2.bias'))
+    assert rel_err(hx, gx) < 1e-6 and rel_err(hx2, gx2) < 1e-6
+    for (name, p), (_, q) in zip(part.named_parameters(), full.named_parameters()):
+        if name.startswith(('to_v', 'attn_mlp.0', 'pos_mlp.2.bias')):
+            assert p.grad is None
+        else:
+            assert rel_err(p.grad, q.grad) < 1e-6, name
+
+
 def test_chained_blocks_gradients_strict():
     case = gc.PTB_CASES[1]
     x, pos, x2, pos2, sd = gc.ptb_inputs(case)
