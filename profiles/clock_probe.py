@@ -42,6 +42,19 @@ def main():
         fn, flop = (lambda: pk.ops.resblock(x, p0, b, p1, b, out=y)), 4.0 * n * H * H
     elif what == 'linear':
         fn, flop = (lambda: pk.ops.linear(x, w0, b, relu_in=True, out=y)), 2.0 * n * H * H
+    elif what == 'attn':
+        d, k, m = 416, 14, 531
+        T = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32)).cuda()   # noqa: E731
+        aq, kt, vt = T(rng.normal(size=(n, 2 * d))), T(rng.normal(size=(m, 2 * d))), T(rng.normal(size=(m, d)))
+        qpos, apos = T(rng.uniform(-5, 5, size=(n, 3))), T(rng.uniform(-5, 5, size=(m, 3)))
+        idx = pk.ops.knn(qpos, apos, k, metric=0)
+        P1, c1 = T(rng.normal(size=(32, 3))), T(rng.normal(size=(32,)))
+        wp, w2 = T(0.1 * rng.normal(size=(2 * d, 32))), T(0.03 * rng.normal(size=(d, 2 * d)))
+        b2, p2, c2 = T(rng.normal(size=(d,))), T(0.1 * rng.normal(size=(d, 32))), T(rng.normal(size=(d,)))
+        stream = pk.ops.pack_attn16_stream(w2, b2, wp, p2, c2)
+        out = torch.empty((n, d), device='cuda')
+        fn = lambda: pk.ops.pt_cross_attn16(aq, qpos, apos, idx, kt, vt, P1, c1, stream, out=out)   # noqa: E731
+        flop = 2.0 * n * k * (32 * 2 * d + 2 * d * d + 32 * d)
     elif what == 'micro':
         exe = '/tmp/mfma_issue'
         subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', os.path.join(os.path.dirname(__file__), 'micro',
@@ -60,10 +73,10 @@ def main():
             subprocess.run([exe], stdout=subprocess.DEVNULL)
     else:
         while time.time() - t0 < secs:
-            for _ in range(200):
+            for _ in range(50 if what == 'attn' else 200):
                 fn()
             torch.cuda.synchronize()
-            launches += 200
+            launches += 50 if what == 'attn' else 200
     dt = time.time() - t0
     stop.set()
     th.join()
