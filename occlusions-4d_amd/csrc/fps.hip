@@ -47,7 +47,6 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
   constexpr int PP = PPT / 2;
   constexpr int NW = T / 64;
   __shared__ u64 s_key[2][NW];
-  __shared__ float s_p[2][NW][4];
   __shared__ unsigned s_flags[FLAG_WORDS];
   __shared__ int s_cnt[T];
 
@@ -78,37 +77,39 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
 
   int par = 0;
   for (int it = 1; it < m; ++it) {
-    float bd = -1.f, bx = 0.f, by = 0.f, bz = 0.f;
-    unsigned bi = 0xffffffffu;
     const f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
+    // (1) running-min update + the thread's maximum (value only: min / max, no selects)
+    f32x2 bd2 = {-1.f, -1.f};
 #pragma unroll
     for (int u = 0; u < PP; ++u) {
       const f32x2 dx = px[u] - c2x, dy = py[u] - c2y, dz = pz[u] - c2z;
       const f32x2 d = (dx * dx + dy * dy) + dz * dz;          // -ffp-contract=off: no FMA
-#pragma unroll
-      for (int v = 0; v < 2; ++v) {
-        const float old = md[u][v];
-        const float nv = d[v] < old ? d[v] : old;              // dead slots: old = -1 stays
-        md[u][v] = nv;
-        // the candidate's xyz travel with it (a wave-uniform "switch on the winner's slot" after
-        // the reduction was measured slower: hipcc lowers it to a longer v_cndmask chain)
-        const bool better = nv > bd;                            // strict: slots ascend in index
-        bd = better ? nv : bd;
-        bi = better ? (unsigned)(t + T * (2 * u + v)) : bi;
-        bx = better ? px[u][v] : bx;
-        by = better ? py[u][v] : by;
-        bz = better ? pz[u][v] : bz;
-      }
+      // (d is never NaN for finite input; dead slots hold -1 and stay: min(d, -1) = -1)
+      md[u] = f32x2{fminf(d[0], md[u][0]), fminf(d[1], md[u][1])};
+      bd2 = f32x2{fmaxf(bd2[0], md[u][0]), fmaxf(bd2[1], md[u][1])};
     }
+    const float bd = fmaxf(bd2[0], bd2[1]);
     // bd >= 0 for live candidates, so its bit pattern orders like the float; dead lanes map to 0.
     const unsigned dbits = bd >= 0.f ? __float_as_uint(bd) + 1u : 0u;
     const unsigned wmax = wave_reduce_u32<true>(dbits);
-    const unsigned cand = (dbits == wmax) ? bi : 0xffffffffu;
-    const unsigned wmin = wave_reduce_u32<false>(cand);
-    if (dbits == wmax && bi == wmin) {  // exactly one lane per wave (or a dead wave: bi = ~0)
-      s_key[par][wave] = ((u64)wmax << 32) | (u64)(0xffffffffu - wmin);
-      s_p[par][wave][0] = bx; s_p[par][wave][1] = by; s_p[par][wave][2] = bz;
+    // (2) the wave's lowest INDEX among the points at that maximum (index = t + T slot: lowest slot first, then the
+    // lowest lane): one compare per slot into a wave-wide ballot, the search over the ballots is scalar work.  (The
+    // sequential "better than the best so far" scan with its index / xyz selects was 60 % of the step's VALU work.)
+    const float wv = __uint_as_float(wmax - 1u);               // the maximum as a float (unused when wmax == 0)
+    unsigned long long hit = 0ull;
+    int hslot = 0;
+#pragma unroll
+    for (int u = PP - 1; u >= 0; --u) {
+#pragma unroll
+      for (int v = 1; v >= 0; --v) {
+        const unsigned long long m = __ballot(md[u][v] == wv);
+        hit = m ? m : hit;                                      // descending slots: the last assignment is the lowest slot
+        hslot = m ? 2 * u + v : hslot;
+      }
     }
+    const unsigned wmin = (wmax != 0u && hit != 0ull)
+                              ? (unsigned)((t & ~63) + (int)__builtin_ctzll(hit) + T * hslot) : 0xffffffffu;
+    if ((t & 63) == 0) s_key[par][wave] = ((u64)wmax << 32) | (u64)(0xffffffffu - wmin);   // (wave-uniform values)
     __syncthreads();
     u64 k[NW];
 #pragma unroll
@@ -117,9 +118,11 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     for (int span = NW / 2; span > 0; span >>= 1)
 #pragma unroll
       for (int w = 0; w < span; ++w) k[w] = k[w] > k[w + span] ? k[w] : k[w + span];
-    const unsigned gi = 0xffffffffu - (unsigned)(k[0] & 0xffffffffu);
-    const int gw = (int)((gi % T) >> 6);
-    cx = s_p[par][gw][0]; cy = s_p[par][gw][1]; cz = s_p[par][gw][2];
+    const unsigned gi = __builtin_amdgcn_readfirstlane(0xffffffffu - (unsigned)(k[0] & 0xffffffffu));
+    {
+      const float* pw = xyz + (int64_t)min(gi, (unsigned)(n - 1)) * stride;     // wave-uniform address: scalar loads
+      cx = pw[0]; cy = pw[1]; cz = pw[2];
+    }
     if (t == 0) {
       s_flags[gi >> 5] |= 1u << (gi & 31);
       if (out_order) out_order[it] = (int)gi;
