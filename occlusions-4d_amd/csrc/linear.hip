@@ -308,11 +308,23 @@ extern "C" int occ4d_linear_f32(const occ4d_linear_args* args, void* stream) {
   if (a.M == 0) return OCC4D_OK;
   hipStream_t st = (hipStream_t)stream;
   const int n = a.N;
-  if (n <= 32) return launch<1>(a, st);
-  if (n <= 64) return launch<2>(a, st);
-  if (n <= 96) return launch<3>(a, st);
-  if (n <= 128) return launch<4>(a, st);
-  if (n <= 160) return launch<5>(a, st);
-  if (n <= 288) return launch<9>(a, st);
-  return launch<13>(a, st);
+  // Column tiles per workgroup: as many as cover N (one A fragment feeds NT MFMAs) -- unless the launch would leave
+  // most of the 256 CUs idle: the encoder's last levels are (531 .. 1593) x 288 GEMMs, 5-13 row tiles; with all 288
+  // columns in one workgroup they ran 60-75 us each on 5 CUs, on the critical path behind the last FPS.  Fewer columns
+  // per workgroup = more, shorter workgroups; the k order of every output element is unchanged (bit-identical).
+  static const int kNT[7] = {13, 9, 5, 4, 3, 2, 1};
+  int pick = 6;
+  for (int i = 6; i >= 0; --i)
+    if (32 * kNT[i] >= n || i == 0) { pick = i; break; }          // smallest NT that covers N (or 13)
+  const int row_tiles = occ4d::cdiv(a.M, BM);
+  while (pick < 6 && row_tiles * occ4d::cdiv(n, 32 * kNT[pick]) < 128) ++pick;
+  switch (kNT[pick]) {
+    case 1: return launch<1>(a, st);
+    case 2: return launch<2>(a, st);
+    case 3: return launch<3>(a, st);
+    case 4: return launch<4>(a, st);
+    case 5: return launch<5>(a, st);
+    case 9: return launch<9>(a, st);
+    default: return launch<13>(a, st);
+  }
 }

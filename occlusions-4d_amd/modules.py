@@ -70,20 +70,25 @@ class DownTransition(torch.nn.Module):
         else:
             raise ValueError()
 
-    def geometry(self, p):
-        """Feature-independent half of forward() for ONE cloud p (N,3): farthest-point subset
-        (ascending indices), its coordinates and the knn_k nearest full-cloud points of every
-        sampled point.  Depends on coordinates only, so the encoder runs the three levels of this
-        chain (the FPS steps are one long dependent chain on a single CU) on a side stream,
-        concurrently with the attention / Linear kernels (model.py)."""
+    def sample(self, p):
+        """Farthest-point subset of ONE cloud p (N,3): (ascending indices (n_new) int32, their coordinates (n_new,3)).
+        Depends on coordinates only: the encoder runs the three levels of this dependent chain (the FPS steps are
+        one long chain on a single CU) back to back on a side stream (model.py)."""
         n_new = int(np.ceil(p.shape[0] / self.factor))
         # torch_cluster draws the first sample at random when random_start (training default); the reference
         # forces False at test time (eval/inference.py:59).  The draw uses torch's global CPU generator.
         start = int(torch.randint(p.shape[0], (1,)).item()) if self.fps_random_start else 0
         inds = ops.fps_auto(p, n_new, start=start)                     # ascending int32
-        p_sub = ops.gather_rows(p, inds)                               # (n_new,3)
-        nn_idx = ops.knn(p_sub, p, self.knn_k, metric=0)               # (n_new,k)
-        return (inds, p_sub, nn_idx)
+        return (inds, ops.gather_rows(p, inds))                        # (n_new), (n_new,3)
+
+    def neighbours(self, p_sub, p):
+        """The knn_k nearest full-cloud points of every sampled point: (n_new,k) int32."""
+        return ops.knn(p_sub, p, self.knn_k, metric=0)
+
+    def geometry(self, p):
+        """Feature-independent half of forward() for ONE cloud p (N,3): (inds, p_sub, nn_idx)."""
+        (inds, p_sub) = self.sample(p)
+        return (inds, p_sub, self.neighbours(p_sub, p))
 
     def forward(self, x, p, geometry=None):
         """x (B,N,d_in), p (B,N,3) -> (z (B,ceil(N/factor),d_out), p_sub (B,ceil(N/factor),3)).

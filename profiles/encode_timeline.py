@@ -1,0 +1,30 @@
+"""Timeline of one encode from a rocprofv3 --kernel-trace CSV (profiles/probe.py encode N): per kernel start / end
+relative to the first kernel of the LAST encode, stream (queue) and gaps.
+Usage: python profiles/encode_timeline.py <kernel_trace.csv> [n_encodes_in_trace]"""
+import csv
+import sys
+
+
+def main():
+    rows = list(csv.DictReader(open(sys.argv[1])))
+    n_enc = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    # one encode = everything from one fps_kernel<28 (level 0) launch's neighbourhood to the next; split on level-0 FPS
+    starts = [i for i, r in enumerate(rows) if 'fps_kernel<28' in r['Kernel_Name']]
+    assert len(starts) >= 2, 'need at least two encodes in the trace'
+    # an encode begins a few kernels before its level-0 FPS: take the first kernel after the previous encode's last one
+    a = starts[-1]
+    while a > 0 and int(rows[a]['Start_Timestamp']) - int(rows[a - 1]['End_Timestamp']) < 200000:
+        a -= 1
+    seg = rows[a:]
+    t0 = int(seg[0]['Start_Timestamp'])
+    end = max(int(r['End_Timestamp']) for r in seg)
+    print('last encode: %d kernels, %.3f ms from first start to last end' % (len(seg), (end - t0) / 1e6))
+    for r in seg:
+        name = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:44]
+        s, e = (int(r['Start_Timestamp']) - t0) / 1e3, (int(r['End_Timestamp']) - t0) / 1e3
+        print('%9.1f %9.1f us  %8.1f us  q%-3s %s' % (s, e, e - s, r.get('Queue_Id', '?'), name))
+
+
+if __name__ == '__main__':
+    main()
