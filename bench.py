@@ -155,7 +155,7 @@ def self_launch(n_gpus):
     import socket
     import subprocess
     have = torch.cuda.device_count()
-    if have < n_gpus:
+    if have < n_gpus and os.environ.get('OCC4D_BENCH_SHARE_GPU') != '1':
         print('bench.py: --gpus %d needs %d visible GPUs, this machine has %d' % (n_gpus, n_gpus, have), file=sys.stderr)
         return 2
     with socket.socket() as sk:
@@ -204,12 +204,19 @@ def main():
         print('bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d)' % (args.gpus, world, args.gpus),
               file=sys.stderr)
         return 2
-    if torch.cuda.device_count() <= local_rank:
-        print('bench.py: rank %d needs GPU %d, only %d visible' % (rank, local_rank, torch.cuda.device_count()),
+    # Harness self-test only (tests/test_gpu_bench_multirank.py): OCC4D_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and
+    # OCC4D_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device), so that the complete N > 1 code
+    # path -- sharding, broadcast, per-rank timing exchange, both grids -- runs on a 1-GPU box.  Timings of such a
+    # run mean nothing and the line says so.
+    share_gpu = os.environ.get('OCC4D_BENCH_SHARE_GPU') == '1'
+    backend = os.environ.get('OCC4D_BENCH_BACKEND', 'nccl')
+    dev_index = 0 if share_gpu else local_rank
+    if torch.cuda.device_count() <= dev_index:
+        print('bench.py: rank %d needs GPU %d, only %d visible' % (rank, dev_index, torch.cuda.device_count()),
               file=sys.stderr)
         return 2
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     use_dist = world > 1 or os.environ.get('OCC4D_FORCE_DIST') == '1'   # (1-rank RCCL: smoke test of the N > 1 path)
     rccl_ranks = 1
     if use_dist:
@@ -217,7 +224,10 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', str(rank))
         os.environ.setdefault('WORLD_SIZE', str(world))
-        dist.init_process_group('nccl', device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
         ones = torch.ones((), device=device)
         dist.all_reduce(ones)                   # the ranks RCCL really connected
         rccl_ranks = int(ones.item())
@@ -391,7 +401,9 @@ def main():
                                       if world > 1 else 'single GPU',
                        'scaling_note': 'N = 1 runs configs[1] (534 528 queries); N = 2, 4, 8 run configs[3] (2 125 568 '
                                        'queries, fixed total -> strong).  The other grid is the secondary leg of each line.',
-                       'rccl_ranks': rccl_ranks, 'per_rank_ms_per_step': [1e3 * t / args.steps for t in per_rank_s],
+                       'rccl_ranks': rccl_ranks, 'backend': ('rccl' if backend == 'nccl' else backend) if use_dist else None,
+                       'ranks_share_one_gpu': share_gpu or None,
+                       'per_rank_ms_per_step': [1e3 * t / args.steps for t in per_rank_s],
                        'decode_streams': pk.inference.DECODE_STREAMS, 'decode_chunk': chunk},
             'roofline': {
                 'bound': 'mfma', 'achieved': executed / 1e12, 'peak': FP32_MFMA_PEAK / 1e12, 'unit': 'TFLOP/s',

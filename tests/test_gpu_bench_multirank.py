@@ -1,0 +1,44 @@
+"""GPU: the N > 1 code path of bench.py end to end on a 1-GPU box.  Two ranks share GPU 0 and talk over gloo (RCCL
+refuses two ranks on one device): self-launch from a bare shell, rank discovery, rank 0 encodes + broadcast, the
+configs[3] grid sharded over the ranks, per-rank timing exchange, the secondary configs[1] grid, ONE JSON line from
+rank 0.  Timings of such a run mean nothing; what is checked is that the harness the driver will launch on 8 GPUs
+runs and reports the right workload."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_on_one_gpu():
+    env = dict(os.environ, OCC4D_BENCH_SHARE_GPU='1', OCC4D_BENCH_BACKEND='gloo')
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1',
+                           '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, proc.stdout[-2000:]                    # rank 0 only
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['steps'] == 1
+    cfg = d['config']
+    assert 'configs[3]' in cfg['workload'] and '2125568 grid queries, 1062784 per GPU' in cfg['workload']
+    assert cfg['rccl_ranks'] == 2 and cfg['backend'] == 'gloo' and cfg['ranks_share_one_gpu'] is True
+    assert len(cfg['per_rank_ms_per_step']) == 2 and all(t > 0 for t in cfg['per_rank_ms_per_step'])
+    assert abs(d['value'] - 2125568 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
+    s2 = d['strong_config2']
+    assert s2['n_gpus'] == 2 and '534528 queries (267264 per GPU)' in s2['workload']
+    assert 0.0 < d['roofline']['frac'] <= 1.0 and d['roofline']['launches'] > 0
+    assert 'cpu_baseline' not in d and 'alt_precision' not in d    # single-GPU legs stay off the N > 1 line
+
+
+def test_bench_refuses_a_mismatched_launch():
+    """--gpus 2 under a 1-rank launcher environment: a clear message and exit code 2, not an assert."""
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, capture_output=True,
+                          text=True, timeout=300)
+    assert proc.returncode == 2 and 'WORLD_SIZE=1' in proc.stderr
