@@ -3,10 +3,18 @@
 // point.  The m - 1 dependent argmax steps are why this is a single-CU kernel: a grid barrier
 // costs more than a whole step does (MI355X_MICROARCH.md, barrier-xcd row).
 //
-// Per step: packed-fp32 distance update of the thread's points, per-thread best, two DPP wave
-// reductions (max distance bits, then min index among the maxima), the wave winner publishes
-// (key, xyz) to LDS, one barrier, every thread picks the block winner with a max tree over the
-// per-wave 64-bit keys (distance bits << 32 | ~index : larger distance first, then lower index).
+// Per step (cycle accounting: profiles/stamp_fps.py):
+//   1. packed-fp32 distance update of the thread's points; running mins are kept as bit patterns (>= +0 or exactly
+//      -1.0f for padding: those order like signed integers, so v_min_i32 / v_max_i32 need no canonicalize), per-group
+//      maxima (groups of GS consecutive slots) and the thread's maximum;
+//   2. wave maximum on the DPP network (fused v_max_i32_dpp);
+//   3. the wave's lowest INDEX at that maximum (index = t + T slot: lowest slot first, then the lowest lane), found
+//      hierarchically: one compare + ballot per GROUP, then one per slot of the lowest hit group (the slots of a
+//      wave-uniform group are read with a GPR-indexed v_mov: the running mins live in one register tuple);
+//   4. the winner's coordinates come out of the register tuples the same way (uniform slot, v_readlane of the lane):
+//      re-loading xyz[winner] from global memory after the barrier cost 650 .. 870 cycles of every step;
+//   5. the wave publishes (key, xyz) to LDS, one barrier, every wave picks the block winner with a max tree over the
+//      64-bit keys (distance bits << 32 | ~index << 8 | wave: larger distance first, then the lower index).
 //
 // Arithmetic pinned to oracle/cluster.py: d = ((dx*dx + dy*dy) + dz*dz) (no FMA:
 // -ffp-contract=off), running min, first (lowest-index) argmax.
@@ -21,51 +29,60 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int FLAG_WORDS = 1024;  // selection bitmask, n <= 32768
 
-// wave64 all-lanes -> lane 63 reduction on the DPP network (no LDS traffic).
-template <bool IS_MAX>
-__device__ __forceinline__ unsigned wave_reduce_u32(unsigned v) {
-#define OCC4D_DPP_STEP(ctrl, rmask)                                                        \
-  {                                                                                        \
-    unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xf, false); \
-    v = IS_MAX ? max(v, o) : min(v, o);                                                    \
-  }
-  OCC4D_DPP_STEP(0xB1, 0xf)   // quad_perm [1,0,3,2]
-  OCC4D_DPP_STEP(0x4E, 0xf)   // quad_perm [2,3,0,1]
-  OCC4D_DPP_STEP(0x141, 0xf)  // row_half_mirror
-  OCC4D_DPP_STEP(0x140, 0xf)  // row_mirror      -> every lane holds its row's result
-  OCC4D_DPP_STEP(0x142, 0xa)  // row_bcast15 into rows 1,3
-  OCC4D_DPP_STEP(0x143, 0xc)  // row_bcast31 into rows 2,3 -> lane 63 holds the wave result
+// wave64 signed-max reduction on the DPP network, one fused v_max_i32_dpp per step (the compiler's update_dpp
+// lowering is mov + mov_dpp + max); s_nop 1 = the VALU-write -> DPP-read hazard.  Returned wave-uniform.
+__device__ __forceinline__ int wave_max_i32(int v) {
+#define OCC4D_DPP_STEP(ctrl) asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 " ctrl : "+v"(v));
+  OCC4D_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+  OCC4D_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+  OCC4D_DPP_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
+  OCC4D_DPP_STEP("row_mirror row_mask:0xf bank_mask:0xf")     // every lane holds its row's result
+  OCC4D_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")   // into rows 1, 3
+  OCC4D_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")   // into rows 2, 3: lane 63 holds the wave result
 #undef OCC4D_DPP_STEP
-  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
-// PPT (even) points per thread as PPT/2 float2 pairs -> v_pk_add_f32 / v_pk_mul_f32.
+// The thread's coordinates and running mins live in ONE register tuple each (ext_vector of VL elements, VL >= PPT a
+// tuple size the register file has: 2, 8, 16, 32), so that "slot s" with a wave-uniform s is a GPR-indexed v_mov
+// (s_set_gpr_idx_on) instead of a branch tree over the slots.
+template <typename E, int VL> struct vec_of { typedef E type __attribute__((ext_vector_type(VL))); };
+constexpr int tuple_len(int ppt) { return ppt <= 2 ? 2 : ppt <= 8 ? 8 : ppt <= 16 ? 16 : 32; }
+
+// PPT (even) points per thread; pairs of slots -> v_pk_add_f32 / v_pk_mul_f32.
 template <int PPT, int T>
 __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, int64_t stride, int n, int m,
                                                 int32_t* __restrict__ out_sorted, int32_t* __restrict__ out_order) {
   static_assert(PPT % 2 == 0, "PPT must be even");
-  constexpr int PP = PPT / 2;
   constexpr int NW = T / 64;
+  constexpr int NV = PPT <= 32 ? 1 : 2;                 // 56 points per thread: two tuples of 28 (in 32)
+  constexpr int PV = PPT / NV;                          // slots per tuple
+  constexpr int VL = tuple_len(PV);
+  constexpr int GS = PPT % 4 == 0 ? 4 : 2;              // slots per group
+  constexpr int NG = PPT / GS;
+  static_assert(PV % GS == 0, "a group never straddles the two tuples");
+  typedef typename vec_of<float, VL>::type fvec;
+  typedef typename vec_of<int, VL>::type ivec;
   __shared__ u64 s_key[2][NW];
+  __shared__ float4 s_c[2][NW];
   __shared__ unsigned s_flags[FLAG_WORDS];
   __shared__ int s_cnt[T];
 
   const int t = threadIdx.x;
   const int wave = t >> 6;
-  f32x2 px[PP], py[PP], pz[PP], md[PP];
+  fvec px[NV], py[NV], pz[NV];
+  ivec md[NV];                                          // running min-distances (bit patterns)
 #pragma unroll
-  for (int u = 0; u < PP; ++u) {
-#pragma unroll
-    for (int v = 0; v < 2; ++v) {
-      const int i = t + T * (2 * u + v);
-      float x = 0.f, y = 0.f, z = 0.f, d0 = -1.f;   // d0 = -1: never wins (live running mins are >= 0)
-      if (i < n) {
-        const float* p = xyz + (int64_t)i * stride;
-        x = p[0]; y = p[1]; z = p[2];
-        d0 = __builtin_inff();
-      }
-      px[u][v] = x; py[u][v] = y; pz[u][v] = z; md[u][v] = d0;
+  for (int s = 0; s < PPT; ++s) {
+    const int i = t + T * s;
+    float x = 0.f, y = 0.f, z = 0.f, d0 = -1.f;         // d0 = -1: never wins, never changes (min(d, -1) = -1)
+    if (i < n) {
+      const float* p = xyz + (int64_t)i * stride;
+      x = p[0]; y = p[1]; z = p[2];
+      d0 = __builtin_inff();
     }
+    px[s / PV][s % PV] = x; py[s / PV][s % PV] = y; pz[s / PV][s % PV] = z;
+    md[s / PV][s % PV] = __float_as_int(d0);
   }
   for (int w = t; w < FLAG_WORDS; w += T) s_flags[w] = 0u;
   __syncthreads();
@@ -75,61 +92,107 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     if (out_order) out_order[0] = 0;
   }
 
+#ifdef OCC4D_FPS_STAMP
+  // per-wave cycle accounting (debug build): [0] distance update, [1] wave max + index search + winner coordinates,
+  // [2] publish + barrier, [3] block winner
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#define STAMP(i) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tacc[i] += tn - tprev; tprev = tn; }
+#else
+#define STAMP(i)
+#endif
   int par = 0;
   for (int it = 1; it < m; ++it) {
     const f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
-    // (1) running-min update + the thread's maximum (value only: min / max, no selects)
-    f32x2 bd2 = {-1.f, -1.f};
+    // (1) running-min update, group maxima, the thread's maximum
+    int gm[NG];
 #pragma unroll
-    for (int u = 0; u < PP; ++u) {
-      const f32x2 dx = px[u] - c2x, dy = py[u] - c2y, dz = pz[u] - c2z;
-      const f32x2 d = (dx * dx + dy * dy) + dz * dz;          // -ffp-contract=off: no FMA
-      // (d is never NaN for finite input; dead slots hold -1 and stay: min(d, -1) = -1)
-      md[u] = f32x2{fminf(d[0], md[u][0]), fminf(d[1], md[u][1])};
-      bd2 = f32x2{fmaxf(bd2[0], md[u][0]), fmaxf(bd2[1], md[u][1])};
+    for (int g = 0; g < NG; ++g) {
+      int top = (int)0x80000000;
+#pragma unroll
+      for (int s = g * GS; s < (g + 1) * GS; s += 2) {
+        const int q = s / PV, e = s % PV;
+        const f32x2 dx = f32x2{px[q][e], px[q][e + 1]} - c2x;
+        const f32x2 dy = f32x2{py[q][e], py[q][e + 1]} - c2y;
+        const f32x2 dz = f32x2{pz[q][e], pz[q][e + 1]} - c2z;
+        const f32x2 d = (dx * dx + dy * dy) + dz * dz;          // -ffp-contract=off: no FMA; d >= +0 for finite input
+        md[q][e] = min(__float_as_int(d[0]), md[q][e]);
+        md[q][e + 1] = min(__float_as_int(d[1]), md[q][e + 1]);
+        top = max(top, max(md[q][e], md[q][e + 1]));            // (v_max3_i32)
+      }
+      gm[g] = top;
     }
-    const float bd = fmaxf(bd2[0], bd2[1]);
-    // bd >= 0 for live candidates, so its bit pattern orders like the float; dead lanes map to 0.
-    const unsigned dbits = bd >= 0.f ? __float_as_uint(bd) + 1u : 0u;
-    const unsigned wmax = wave_reduce_u32<true>(dbits);
-    // (2) the wave's lowest INDEX among the points at that maximum (index = t + T slot: lowest slot first, then the
-    // lowest lane): one compare per slot into a wave-wide ballot, the search over the ballots is scalar work.  (The
-    // sequential "better than the best so far" scan with its index / xyz selects was 60 % of the step's VALU work.)
-    const float wv = __uint_as_float(wmax - 1u);               // the maximum as a float (unused when wmax == 0)
+    int bd = gm[0];
+#pragma unroll
+    for (int g = 1; g < NG; ++g) bd = max(bd, gm[g]);
+    STAMP(0)
+    // (2) wave maximum; < 0 = the wave holds padding only
+    const int wtop = wave_max_i32(bd);
+    // (3) lowest slot, then lowest lane, at the maximum.  Descending loops: the last assignment is the lowest.
+    int hgroup = 0;
+#pragma unroll
+    for (int g = NG - 1; g >= 0; --g) hgroup = __ballot(gm[g] == wtop) ? g : hgroup;
     unsigned long long hit = 0ull;
     int hslot = 0;
 #pragma unroll
-    for (int u = PP - 1; u >= 0; --u) {
-#pragma unroll
-      for (int v = 1; v >= 0; --v) {
-        const unsigned long long m = __ballot(md[u][v] == wv);
-        hit = m ? m : hit;                                      // descending slots: the last assignment is the lowest slot
-        hslot = m ? 2 * u + v : hslot;
-      }
+    for (int s = GS - 1; s >= 0; --s) {
+      const int slot = hgroup * GS + s;
+      const int val = (NV == 1 || slot < PV) ? md[0][slot % PV] : md[NV - 1][slot - PV];     // (uniform register index)
+      const unsigned long long mk = __ballot(val == wtop);
+      hit = mk ? mk : hit;
+      hslot = mk ? slot : hslot;
     }
-    const unsigned wmin = (wmax != 0u && hit != 0ull)
-                              ? (unsigned)((t & ~63) + (int)__builtin_ctzll(hit) + T * hslot) : 0xffffffffu;
-    if ((t & 63) == 0) s_key[par][wave] = ((u64)wmax << 32) | (u64)(0xffffffffu - wmin);   // (wave-uniform values)
+    const int hlane = (int)__builtin_ctzll(hit | (1ull << 63));
+    const unsigned wmin = (unsigned)((t & ~63) + hlane + T * hslot);
+    // (4) the candidate's coordinates: slot hslot of every lane, then lane hlane of that
+    float vx, vy, vz;
+    if (NV == 1 || hslot < PV) {
+      vx = px[0][hslot % PV]; vy = py[0][hslot % PV]; vz = pz[0][hslot % PV];
+    } else {
+      vx = px[NV - 1][hslot - PV]; vy = py[NV - 1][hslot - PV]; vz = pz[NV - 1][hslot - PV];
+    }
+    const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vx), hlane));
+    const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vy), hlane));
+    const float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vz), hlane));
+    STAMP(1)
+    // (5) key: distance bits + 1 (0 = the wave holds padding only: loses against every real candidate, whatever its
+    // low word says), then the LOWER index, then the wave (indices are unique)
+    if ((t & 63) == 0) {   // (wave-uniform values)
+      s_key[par][wave] = ((u64)(unsigned)max(wtop + 1, 0) << 32) | (u64)((0x7fff00u | (unsigned)wave) - ((wmin & 0x7fffu) << 8));
+      s_c[par][wave] = float4{wx, wy, wz, 0.f};
+    }
     __syncthreads();
+    STAMP(2)
     u64 k[NW];
 #pragma unroll
     for (int w = 0; w < NW; ++w) k[w] = s_key[par][w];
+    const float4 mine = s_c[par][t & (NW - 1)];              // lane l holds wave l % NW's candidate
 #pragma unroll
     for (int span = NW / 2; span > 0; span >>= 1)
 #pragma unroll
       for (int w = 0; w < span; ++w) k[w] = k[w] > k[w + span] ? k[w] : k[w + span];
-    const unsigned gi = __builtin_amdgcn_readfirstlane(0xffffffffu - (unsigned)(k[0] & 0xffffffffu));
-    {
-      const float* pw = xyz + (int64_t)min(gi, (unsigned)(n - 1)) * stride;     // wave-uniform address: scalar loads
-      cx = pw[0]; cy = pw[1]; cz = pw[2];
-    }
+    const unsigned low = __builtin_amdgcn_readfirstlane((unsigned)(k[0] & 0xffffffffu));
+    const unsigned gi = 0x7fffu - (low >> 8);
+    const int ww = (int)(low & 0xffu);
+    cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.x), ww));
+    cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.y), ww));
+    cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.z), ww));
+    STAMP(3)
     if (t == 0) {
-      s_flags[gi >> 5] |= 1u << (gi & 31);
-      if (out_order) out_order[it] = (int)gi;
+      const unsigned g = min(gi, (unsigned)(n - 1));
+      s_flags[g >> 5] |= 1u << (g & 31);
+      if (out_order) out_order[it] = (int)g;
     }
     par ^= 1;
   }
   __syncthreads();
+#ifdef OCC4D_FPS_STAMP
+  if ((t & 63) == 0 && out_order) {   // debug build: out_order has 8 * NW * 2 spare ints behind the (even-rounded) m entries
+    unsigned long long* o = (unsigned long long*)(out_order + ((m + 1) & ~1)) + wave * 8;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[i] = tacc[i];
+  }
+#endif
 
   // stream-compact the selection mask into ascending indices: each thread owns a contiguous
   // chunk of mask words; chunk totals are scanned serially (executed once, T <= 1024 adds)
@@ -189,9 +252,15 @@ extern "C" int occ4d_fps_f32(const float* xyz, int64_t stride, int n, int m, int
   hipStream_t st = (hipStream_t)stream;
   // Threads per workgroup: fewer waves = cheaper per-step reduce/broadcast, more points per thread.
   // (OCC4D_FPS_THREADS overrides for experiments.)
-  // measured: 14336 pts 1024/512/256 threads = 10.7/9.4/15.3 ms; above 56 points per thread only 1024 threads fit
-  int threads = n <= 2048 ? 256 : (n <= 56 * 512 ? 512 : 1024);
+  // measured (profiles/time_fps.py): 4779 pts 256 / 512 threads = 0.76 / 0.90 us per step, 9558 pts 1.38 / 1.16,
+  // 14336 pts 1.39 / 1.34 / 1.78 (1024); above 56 points per thread only 1024 threads fit
   static const int forced_threads = [] { const char* e = getenv("OCC4D_FPS_THREADS"); return e ? atoi(e) : 0; }();   // read once
+  // 9600 .. 16384 points: the spatially pruned kernel (fps_bucket.hip), same indices.  OCC4D_FPS_PRUNE=0 keeps the
+  // exhaustive kernel below (experiments: profiles/time_fps.py, profiles/stamp_fps.py).
+  static const int prune = [] { const char* e = getenv("OCC4D_FPS_PRUNE"); return e ? atoi(e) : 1; }();
+  if (prune && forced_threads <= 0 && occ4d::fps_bucket_launch(xyz, stride, n, m, out_sorted, out_order, st) == 0)
+    return occ4d::check_launch("occ4d_fps_f32");
+  int threads = n <= 28 * 256 ? 256 : (n <= 56 * 512 ? 512 : 1024);
   if (forced_threads > 0) threads = forced_threads;
   int rc;
   if (threads == 256) rc = launch_threads<256>(xyz, stride, n, m, out_sorted, out_order, st);

@@ -1,0 +1,107 @@
+"""The spatially pruned single-workgroup FPS (csrc/fps_bucket.hip, 9600 .. 16384 points) selects exactly what the
+reference's greedy scan selects: same order, lowest index on ties (oracle/cluster.py restates torch_cluster.fps,
+which the reference's DownTransition calls: model/point_transformer/modules.py:67-80).  The pruning reorders the points
+along a Morton curve and skips whole buckets, so the cases here stress what that could break: exact ties (lattice
+points, duplicates), degenerate boxes (planar / collinear / all-equal clouds), padding buckets (n not a multiple of
+2048), strided rows, and the cooperative multi-workgroup kernel (an independent exhaustive implementation) as a second
+reference at sizes where the numpy oracle is slow."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def pk():
+    import importlib
+    return importlib.import_module('occlusions-4d_amd')
+
+
+def _oracle_order(p, m):
+    p = p.astype(np.float32)
+
+    def sq(i):
+        d = p - p[i]
+        return (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+    order = [0]
+    mind = sq(0)
+    for _ in range(1, m):
+        nxt = int(np.argmax(mind))            # first (lowest-index) maximum
+        order.append(nxt)
+        mind = np.minimum(mind, sq(nxt))
+    return np.array(order, dtype=np.int32)
+
+
+def _cloud(kind, n, rng):
+    if kind == 'uniform':
+        return rng.uniform(-5, 5, size=(n, 3))
+    if kind == 'lattice':                      # integer lattice with repeats: almost every step is a tie
+        return rng.integers(0, 12, size=(n, 3)).astype(np.float64)
+    if kind == 'half_lattice':                 # ties between distinct points at fractional coordinates
+        return rng.integers(-40, 40, size=(n, 3)) * 0.125
+    if kind == 'planar':                       # zero-extent axis: Morton scale 0 on z
+        p = rng.uniform(-3, 3, size=(n, 3))
+        p[:, 2] = 1.5
+        return p
+    if kind == 'line':
+        p = np.zeros((n, 3))
+        p[:, 0] = rng.uniform(-100, 100, size=n)
+        return p
+    if kind == 'clusters':                     # far-apart tight clusters + duplicates + zero padding rows
+        c = rng.uniform(-50, 50, size=(7, 3))
+        p = c[rng.integers(0, 7, size=n)] + rng.normal(scale=0.01, size=(n, 3))
+        p[100:400] = p[1000:1300]
+        p[-50:] = 0.0
+        return p
+    if kind == 'all_equal':
+        return np.full((n, 3), 0.25)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize('kind,n,m', [
+    ('uniform', 9600, 3200), ('uniform', 10241, 10241), ('uniform', 12289, 900), ('uniform', 14336, 4779),
+    ('uniform', 14337, 1200), ('uniform', 16384, 2000), ('uniform', 15361, 900),
+    ('lattice', 9700, 2500), ('lattice', 14336, 3000), ('half_lattice', 10000, 2400), ('planar', 11000, 1700),
+    ('line', 9601, 1400), ('clusters', 12000, 2000), ('all_equal', 9800, 50),
+    # below the pruned kernel's range: the exhaustive kernel, 256 and 512 threads
+    ('uniform', 2049, 683), ('uniform', 3000, 3000), ('uniform', 7168, 1000), ('uniform', 7169, 1000),
+    ('uniform', 9558, 3186), ('lattice', 2500, 2500), ('half_lattice', 7000, 2400), ('all_equal', 2100, 50)])
+def test_pruned_fps_matches_the_greedy_scan(pk, kind, n, m):
+    rng = np.random.default_rng(n * 7 + m)
+    p = _cloud(kind, n, rng).astype(np.float32)
+    sel, order = pk.ops.fps(torch.from_numpy(p).cuda(), m, return_order=True)
+    ref = _oracle_order(p, m)
+    got = order.cpu().numpy()
+    assert np.array_equal(got, ref), (kind, n, m, int(np.argmax(got != ref)))
+    expect_sorted = np.unique(ref)             # (duplicates in `ref` only once all distances are 0)
+    assert np.array_equal(sel.cpu().numpy()[:expect_sorted.size], expect_sorted.astype(np.int32))
+
+
+def test_pruned_fps_against_the_cooperative_kernel_random(pk):
+    rng = np.random.default_rng(2718)
+    kinds = ['uniform', 'lattice', 'half_lattice', 'planar', 'clusters']
+    for trial in range(12):
+        n = int(rng.integers(2049, 16385)) if trial % 3 == 0 else int(rng.integers(9600, 16385))
+        m = int(rng.integers(n // 8, n // 2))
+        p = torch.from_numpy(_cloud(kinds[trial % len(kinds)], n, rng).astype(np.float32)).cuda()
+        a, ao = pk.ops.fps(p, m, return_order=True)
+        b, bo = pk.ops.fps_coop(p, m, start=0, n_workgroups=int(rng.choice([2, 4, 7])), return_order=True)
+        assert torch.equal(ao, bo), (trial, n, m, int((ao != bo).nonzero()[0]))
+        distinct = torch.unique(ao).numel()        # (repeats only once every remaining distance is 0: lattice clouds)
+        assert torch.equal(a[:distinct], b[:distinct])
+
+
+def test_pruned_fps_strided_rows_and_model_clouds(pk):
+    """xyz columns of the (N, 8) point-cloud rows (row stride 8), the encoder's three levels."""
+    pcl = pk.configs.synthetic_pcl('greater', 14336, 12)[0].cuda()
+    level = pcl[:, :3]
+    for m in (4779, 1593, 531):
+        a, ao = pk.ops.fps(level, m, return_order=True)
+        b, bo = pk.ops.fps(level.contiguous(), m, return_order=True)
+        assert torch.equal(ao, bo) and torch.equal(a, b)
+        if level.shape[0] > 2048:
+            c, co = pk.ops.fps_coop(level.contiguous(), m, start=0, n_workgroups=2, return_order=True)
+            assert torch.equal(ao, co)
+        assert torch.equal(a, torch.sort(ao)[0].to(a.dtype))
+        level = level[a.long()]
