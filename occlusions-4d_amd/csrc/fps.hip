@@ -47,7 +47,7 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 // tuple size the register file has: 2, 8, 16, 32), so that "slot s" with a wave-uniform s is a GPR-indexed v_mov
 // (s_set_gpr_idx_on) instead of a branch tree over the slots.
 template <typename E, int VL> struct vec_of { typedef E type __attribute__((ext_vector_type(VL))); };
-constexpr int tuple_len(int ppt) { return ppt <= 2 ? 2 : ppt <= 8 ? 8 : ppt <= 16 ? 16 : 32; }
+constexpr int tuple_len(int ppt) { return ppt <= 16 ? 16 : 32; }   // (tuples of 8 are indexed with a compare-select chain instead)
 
 // PPT (even) points per thread; pairs of slots -> v_pk_add_f32 / v_pk_mul_f32.
 template <int PPT, int T>
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     STAMP(3)
     if (t == 0) {
       const unsigned g = min(gi, (unsigned)(n - 1));
-      s_flags[g >> 5] |= 1u << (g & 31);
+      atomicOr(&s_flags[g >> 5], 1u << (g & 31));    // (ds_or_b32 without return: thread 0 does not wait for it)
       if (out_order) out_order[it] = (int)g;
     }
     par ^= 1;

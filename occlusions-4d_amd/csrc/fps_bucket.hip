@@ -356,7 +356,7 @@ __global__ __launch_bounds__(T) void fps_bucket_kernel(const float* __restrict__
     STAMP(5)
     if (t == 0) {
       const unsigned g = min(gi, (unsigned)(n - 1));
-      s_flags[g >> 5] |= 1u << (g & 31);
+      atomicOr(&s_flags[g >> 5], 1u << (g & 31));    // (ds_or_b32 without return: thread 0 does not wait for it)
       if (out_order) out_order[it] = (int)g;
     }
     par ^= 1;

@@ -28,10 +28,11 @@ def main():
     fn = lib.occ4d_fps_f32
     fn.restype = C.c_int
     fn.argtypes = pk._lib.SIGNATURES['occ4d_fps_f32'][1]
-    names = ['box test', 'bucket updates', 'wave max', 'candidate', 'publish+barrier', 'block winner']
-    if os.environ.get('OCC4D_FPS_PRUNE') == '0':
-        names = ['distance update', 'wave max + index', 'publish+barrier', 'block winner', 'winner xyz (scalar loads)', '-']
+    names = ['box test', 'bucket updates', 'wave max', 'index + coordinates', 'publish+barrier', 'block winner']
+    exhaustive_names = ['distance update', 'wave max + index + coordinates', 'publish+barrier', 'block winner', '-', '-']
+    pruned_names = names
     for n, m in sizes:
+        names = exhaustive_names if (os.environ.get('OCC4D_FPS_PRUNE') == '0' or n < 9600) else pruned_names
         level = pk.configs.synthetic_pcl('greater', n, 12)[0].cuda()[:, :3].contiguous()
         sel = torch.empty(m, dtype=torch.int32, device='cuda')
         order = torch.zeros(m + 2 + 8 * 16 * 2, dtype=torch.int32, device='cuda')
@@ -47,7 +48,9 @@ def main():
         st = order[s0:s0 + 128].cpu().numpy().view(np.int64).reshape(-1, 8)[:8, :6].astype(np.float64) / (m - 1)
         print('n=%d m=%d: %.3f ms, %.3f us/step; cycles per step (mean over steps), per wave:' %
               (n, m, e0.elapsed_time(e1), 1e3 * e0.elapsed_time(e1) / m))
-        for w in range(8):
+        nw = 4 if (n <= 7168 and (os.environ.get('OCC4D_FPS_PRUNE') == '0' or n < 9600)) else 8
+        st = st[:nw]
+        for w in range(nw):
             print('  wave %d: ' % w + '  '.join('%s %.0f' % (names[i], st[w, i]) for i in range(6)) +
                   '  total %.0f' % st[w].sum())
         print('  mean  : ' + '  '.join('%s %.0f' % (names[i], st[:, i].mean()) for i in range(6)) +
