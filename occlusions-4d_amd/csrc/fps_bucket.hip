@@ -226,7 +226,7 @@ __global__ __launch_bounds__(T) void fps_bucket_kernel(const float* __restrict__
   for (int g = 0; g < NB; ++g) gm[g] = max(max(md[4 * g], md[4 * g + 1]), max(md[4 * g + 2], md[4 * g + 3]));
   float cx = xyz[0], cy = xyz[1], cz = xyz[2];
   if (t == 0) {
-    s_flags[0] = 1u;
+    out_sorted[0] = 0;                              // (out_sorted carries the picks in selection order until the end)
     if (out_order) out_order[0] = 0;
   }
 
@@ -355,8 +355,11 @@ __global__ __launch_bounds__(T) void fps_bucket_kernel(const float* __restrict__
     cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.z), ww));
     STAMP(5)
     if (t == 0) {
+      // The pick goes to global memory only (fire-and-forget stores): an LDS flag update here put a full LDS round
+      // trip in front of wave 0's next step (the loop header waits for lgkmcnt(0)), and wave 0 is the wave the
+      // others then wait for at the barrier.  The selection mask is rebuilt from out_sorted after the loop.
       const unsigned g = min(gi, (unsigned)(n - 1));
-      atomicOr(&s_flags[g >> 5], 1u << (g & 31));    // (ds_or_b32 without return: thread 0 does not wait for it)
+      out_sorted[it] = (int)g;
       if (out_order) out_order[it] = (int)g;
     }
     par ^= 1;
@@ -370,7 +373,13 @@ __global__ __launch_bounds__(T) void fps_bucket_kernel(const float* __restrict__
   }
 #endif
 
-  // stream-compact the selection mask into ascending indices
+  // selection mask from the picks (written by thread 0 of this workgroup: __syncthreads orders them), then
+  // stream-compact it into ascending indices
+  for (int i = t; i < m; i += T) {
+    const unsigned g = (unsigned)out_sorted[i];
+    atomicOr(&s_flags[g >> 5], 1u << (g & 31));
+  }
+  __syncthreads();
   constexpr int CH = FLAG_WORDS / T;
   static_assert(CH >= 1, "T <= FLAG_WORDS");
   int cnt = 0;
