@@ -60,11 +60,19 @@ int occ4d_knn_f32(const float* query, int64_t q_stride, int n_query,
  * random_start=False, model/modules.py:133-135): start at index 0, then
  * repeatedly the first argmax of the running min of ((dx*dx+dy*dy)+dz*dz).
  * One workgroup, register-resident points.  n <= 32768, 1 <= m <= n.
+ * 9600 <= n <= 16384 runs the spatially pruned kernel (csrc/fps_bucket.hip): same picks, ties included.
  * out_sorted: (m) int32 selected indices in ASCENDING order (the reference sorts
  * them, :135);  out_order: (m) int32 in selection order, or NULL.
+ * When the cloud holds fewer than m distinct points the greedy rule re-picks (distance 0, lowest index):
+ * out_order records every pick, out_sorted holds the distinct ones in its first entries and the rest is
+ * unspecified.
  */
 int occ4d_fps_f32(const float* xyz, int64_t stride, int n, int m,
                   int32_t* out_sorted, int32_t* out_order, void* stream);
+/* The same with the first sample at index `start` (torch_cluster's random_start=True, the reference's training default
+ * model/modules.py:133, draws it; the caller passes the draw). */
+int occ4d_fps_start_f32(const float* xyz, int64_t stride, int n, int m, int start,
+                        int32_t* out_sorted, int32_t* out_order, void* stream);
 
 /* The same sampling over up to 16 cooperating workgroups (n <= 262144): the dataloader's reduction of
  * a whole clip to n_points (utils/geometry.py:353-364, torch_cluster.fps on ~172 K points) and the

@@ -36,6 +36,7 @@ SIGNATURES = {
     'occ4d_knn_f32': (C.c_int, [_f, C.c_int64, C.c_int, _f, C.c_int64, C.c_int, C.c_int, C.c_int, _i, C.c_int,
                                 _f, _s]),
     'occ4d_fps_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, _i, _i, _s]),
+    'occ4d_fps_start_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, C.c_int, _i, _i, _s]),
     'occ4d_fps_coop_workspace_bytes': (C.c_int64, []),
     'occ4d_fps_coop_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _i, _i, _s, _s]),
     'occ4d_linear_f32': (C.c_int, [C.POINTER(LinearArgs), _s]),

@@ -33,7 +33,7 @@ inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // Below ~9600 points the exhaustive kernel wins: the step is then bound by its serial argmax chain, not by the distance
 // updates the pruning saves (profiles/time_fps.py: 9558 points 3.61 vs 3.68 ms, 4779 points 1.80 vs 1.22 ms).
 constexpr int FPS_BUCKET_MIN_POINTS = 9600;
-int fps_bucket_launch(const float* xyz, int64_t stride, int n, int m, int32_t* out_sorted, int32_t* out_order,
-                      hipStream_t stream);
+int fps_bucket_launch(const float* xyz, int64_t stride, int n, int m, int start, int32_t* out_sorted,
+                      int32_t* out_order, hipStream_t stream);
 
 }  // namespace occ4d

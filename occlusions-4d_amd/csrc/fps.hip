@@ -52,7 +52,8 @@ constexpr int tuple_len(int ppt) { return ppt <= 16 ? 16 : 32; }   // (tuples of
 // PPT (even) points per thread; pairs of slots -> v_pk_add_f32 / v_pk_mul_f32.
 template <int PPT, int T>
 __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, int64_t stride, int n, int m,
-                                                int32_t* __restrict__ out_sorted, int32_t* __restrict__ out_order) {
+                                                int start, int32_t* __restrict__ out_sorted,
+                                                int32_t* __restrict__ out_order) {
   static_assert(PPT % 2 == 0, "PPT must be even");
   constexpr int NW = T / 64;
   constexpr int NV = PPT <= 32 ? 1 : 2;                 // 56 points per thread: two tuples of 28 (in 32)
@@ -86,10 +87,11 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
   }
   for (int w = t; w < FLAG_WORDS; w += T) s_flags[w] = 0u;
   __syncthreads();
-  float cx = xyz[0], cy = xyz[1], cz = xyz[2];
+  const float* first = xyz + (int64_t)start * stride;
+  float cx = first[0], cy = first[1], cz = first[2];
   if (t == 0) {
-    out_sorted[0] = 0;                              // (out_sorted carries the picks in selection order until the end)
-    if (out_order) out_order[0] = 0;
+    out_sorted[0] = start;                          // (out_sorted carries the picks in selection order until the end)
+    if (out_order) out_order[0] = start;
   }
 
 #ifdef OCC4D_FPS_STAMP
@@ -234,9 +236,9 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
 }
 
 template <int T>
-int launch_threads(const float* xyz, int64_t stride, int n, int m, int32_t* os, int32_t* oo, hipStream_t st) {
+int launch_threads(const float* xyz, int64_t stride, int n, int m, int start, int32_t* os, int32_t* oo, hipStream_t st) {
   const int ppt = occ4d::cdiv(n, T);
-#define OCC4D_FPS(P) fps_kernel<P, T><<<1, T, 0, st>>>(xyz, stride, n, m, os, oo)
+#define OCC4D_FPS(P) fps_kernel<P, T><<<1, T, 0, st>>>(xyz, stride, n, m, start, os, oo)
   if (ppt <= 2) OCC4D_FPS(2);
   else if (ppt <= 6) OCC4D_FPS(6);
   else if (ppt <= 10) OCC4D_FPS(10);
@@ -254,9 +256,15 @@ int launch_threads(const float* xyz, int64_t stride, int n, int m, int32_t* os, 
 
 extern "C" int occ4d_fps_f32(const float* xyz, int64_t stride, int n, int m, int32_t* out_sorted,
                              int32_t* out_order, void* stream) {
+  return occ4d_fps_start_f32(xyz, stride, n, m, 0, out_sorted, out_order, stream);
+}
+
+extern "C" int occ4d_fps_start_f32(const float* xyz, int64_t stride, int n, int m, int start, int32_t* out_sorted,
+                                   int32_t* out_order, void* stream) {
   OCC4D_REQUIRE(xyz && out_sorted, "occ4d_fps_f32: null pointer");
   OCC4D_REQUIRE(n >= 1 && n <= 32768, "occ4d_fps_f32: n=%d outside [1,32768]", n);
   OCC4D_REQUIRE(m >= 1 && m <= n, "occ4d_fps_f32: m=%d outside [1,n=%d]", m, n);
+  OCC4D_REQUIRE(start >= 0 && start < n, "occ4d_fps_f32: start=%d outside [0,n=%d)", start, n);
   OCC4D_REQUIRE(stride >= 3, "occ4d_fps_f32: stride=%lld < 3", (long long)stride);
   hipStream_t st = (hipStream_t)stream;
   // Threads per workgroup: fewer waves = cheaper per-step reduce/broadcast, more points per thread.
@@ -267,14 +275,14 @@ extern "C" int occ4d_fps_f32(const float* xyz, int64_t stride, int n, int m, int
   // 9600 .. 16384 points: the spatially pruned kernel (fps_bucket.hip), same indices.  OCC4D_FPS_PRUNE=0 keeps the
   // exhaustive kernel below (experiments: profiles/time_fps.py, profiles/stamp_fps.py).
   static const int prune = [] { const char* e = getenv("OCC4D_FPS_PRUNE"); return e ? atoi(e) : 1; }();
-  if (prune && forced_threads <= 0 && occ4d::fps_bucket_launch(xyz, stride, n, m, out_sorted, out_order, st) == 0)
+  if (prune && forced_threads <= 0 && occ4d::fps_bucket_launch(xyz, stride, n, m, start, out_sorted, out_order, st) == 0)
     return occ4d::check_launch("occ4d_fps_f32");
   int threads = n <= 28 * 256 ? 256 : (n <= 56 * 512 ? 512 : 1024);
   if (forced_threads > 0) threads = forced_threads;
   int rc;
-  if (threads == 256) rc = launch_threads<256>(xyz, stride, n, m, out_sorted, out_order, st);
-  else if (threads == 512) rc = launch_threads<512>(xyz, stride, n, m, out_sorted, out_order, st);
-  else rc = launch_threads<1024>(xyz, stride, n, m, out_sorted, out_order, st);
+  if (threads == 256) rc = launch_threads<256>(xyz, stride, n, m, start, out_sorted, out_order, st);
+  else if (threads == 512) rc = launch_threads<512>(xyz, stride, n, m, start, out_sorted, out_order, st);
+  else rc = launch_threads<1024>(xyz, stride, n, m, start, out_sorted, out_order, st);
   OCC4D_REQUIRE(rc == 0, "occ4d_fps_f32: n=%d does not fit %d threads", n, threads);
   return occ4d::check_launch("occ4d_fps_f32");
 }

@@ -87,7 +87,7 @@ __device__ __forceinline__ float block_reduce(float v, bool is_max, float* s_red
 // NB buckets of 256 points per wave (four per lane), T threads.
 template <int NB, int T>
 __global__ __launch_bounds__(T) void fps_bucket_kernel(const float* __restrict__ xyz, int64_t stride, int n, int m,
-                                                       int32_t* __restrict__ out_sorted,
+                                                       int start, int32_t* __restrict__ out_sorted,
                                                        int32_t* __restrict__ out_order) {
   static_assert(NB >= 1 && NB <= 8, "buckets per wave: at most 8 (32 slots per lane)");
   constexpr int NW = T / 64;
@@ -224,10 +224,11 @@ __global__ __launch_bounds__(T) void fps_bucket_kernel(const float* __restrict__
   int gm[NB];                                    // the lane's maximum over a bucket's four slots
 #pragma unroll
   for (int g = 0; g < NB; ++g) gm[g] = max(max(md[4 * g], md[4 * g + 1]), max(md[4 * g + 2], md[4 * g + 3]));
-  float cx = xyz[0], cy = xyz[1], cz = xyz[2];
+  const float* first = xyz + (int64_t)start * stride;
+  float cx = first[0], cy = first[1], cz = first[2];
   if (t == 0) {
-    out_sorted[0] = 0;                              // (out_sorted carries the picks in selection order until the end)
-    if (out_order) out_order[0] = 0;
+    out_sorted[0] = start;                          // (out_sorted carries the picks in selection order until the end)
+    if (out_order) out_order[0] = start;
   }
 
 #ifdef OCC4D_FPSB_STAMP
@@ -414,11 +415,12 @@ __global__ __launch_bounds__(T) void fps_bucket_kernel(const float* __restrict__
 namespace occ4d {
 
 // FPS_BUCKET_MIN_POINTS <= n <= 16384.  Returns -1 when n is outside that range.
-int fps_bucket_launch(const float* xyz, int64_t stride, int n, int m, int32_t* os, int32_t* oo, hipStream_t st) {
+int fps_bucket_launch(const float* xyz, int64_t stride, int n, int m, int start, int32_t* os, int32_t* oo,
+                      hipStream_t st) {
   if (n < FPS_BUCKET_MIN_POINTS || n > 16384) return -1;
   constexpr int T = 512;
   const int nb = cdiv(n, 256 * (T / 64));
-#define OCC4D_FPSB(B) fps_bucket_kernel<B, T><<<1, T, 0, st>>>(xyz, stride, n, m, os, oo)
+#define OCC4D_FPSB(B) fps_bucket_kernel<B, T><<<1, T, 0, st>>>(xyz, stride, n, m, start, os, oo)
   if (nb <= 5) OCC4D_FPSB(5);
   else if (nb <= 6) OCC4D_FPSB(6);
   else if (nb <= 7) OCC4D_FPSB(7);

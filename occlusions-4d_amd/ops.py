@@ -118,12 +118,14 @@ def knn(query, data, k, metric=0, return_dist=False, int64=False):
     return (idx, dist) if return_dist else idx
 
 
-def fps(xyz, m, return_order=False):
-    """xyz (N,>=3) -> ascending int32 indices (m) of the farthest-point sample."""
+def fps(xyz, m, return_order=False, start=0):
+    """xyz (N,>=3), N <= 32768 -> ascending int32 indices (m) of the farthest-point sample that begins at `start`
+    [, the selection order (m)]: one workgroup, the cloud in registers."""
     p, ps = _rows(_dev(xyz, name='xyz'), 'xyz')
     out = torch.empty((m,), dtype=torch.int32, device=p.device)
     order = torch.empty((m,), dtype=torch.int32, device=p.device) if return_order else None
-    _lib.check(_lib.lib().occ4d_fps_f32(_ptr(p), ps, p.shape[0], m, _ptr(out), _ptr(order), _stream()))
+    _lib.check(_lib.lib().occ4d_fps_start_f32(_ptr(p), ps, p.shape[0], m, int(start), _ptr(out), _ptr(order),
+                                              _stream()))
     return (out, order) if return_order else out
 
 
@@ -177,18 +179,21 @@ def check_pending(wait=True):
         raise RuntimeError(_FPS_TIMEOUT)
 
 
-FPS_COOP_MIN_POINTS = 16385     # measured (profiles/time_fps.py): 4779 pts single 1.05 vs coop 1.5 us/step;
-                                # 14336: 1.95 vs 1.74 alone but no gain inside the encoder; 28672: 4.40 vs 1.89
+FPS_COOP_MIN_POINTS = 28673     # measured (profiles/time_fps.py, r02_fps_time.txt): one workgroup 1.17 us / step at
+                                # 14336 points (cooperative: 1.74 at best), 2.12 at 28672 (cooperative 2.03 .. 2.16).
+                                # Up to 28672 points (56 per lane at 512 threads) the single workgroup is as fast and
+                                # does not depend on several workgroups being co-resident -- which matters when the
+                                # chain is prefetched under another step's backward (model.prefetch_geometry)
 
 
 def fps_auto(xyz, m, start=0):
     """Ascending FPS indices with the faster kernel for the cloud size: one workgroup with the cloud in registers
-    (fps) below FPS_COOP_MIN_POINTS points and start 0, the cooperative multi-workgroup kernel otherwise."""
+    (fps) below FPS_COOP_MIN_POINTS points, the cooperative multi-workgroup kernel above (the dataloader's whole
+    clips)."""
     n = xyz.shape[0]
-    if start == 0 and n < FPS_COOP_MIN_POINTS:
-        return fps(xyz, m)
-    wgs = -(-n // 4096) if n <= 16384 else 16
-    return fps_coop(xyz, m, start=start, n_workgroups=wgs, check=False)
+    if n < FPS_COOP_MIN_POINTS:
+        return fps(xyz, m, start=start)
+    return fps_coop(xyz, m, start=start, n_workgroups=16, check=False)
 
 
 def linear(x, w, b=None, relu_in=False, relu_out=False, residual=None, out=None,

@@ -277,7 +277,8 @@ class PointTransformerLayer(nn.Module):
                                                             *self.parameters()))
                     continue
                 out.append(self.forward_train(y, pos[b], None if x2 is None else x2[b],
-                                              None if pos2 is None else pos2[b]))
+                                              None if pos2 is None else pos2[b],
+                                              idx=None if knn_idx is None else knn_idx[b]))
             return ops.stack_batch(out)
         out = []
         for b in range(x.shape[0]):

@@ -145,10 +145,15 @@ class TrainStep:
                 for t in range(points_query.shape[0])]
         return implicit_loss(torch.stack(outs), implicit_target, **self.loss_kwargs)
 
-    def __call__(self, pcl_input, points_query, implicit_target):
+    def __call__(self, pcl_input, points_query, implicit_target, next_pcl_input=None):
+        """`next_pcl_input` (optional): the NEXT step's point cloud, already resident.  Its farthest-point chain and
+        kNNs (coordinates only, no weights) are issued on the encoder's geometry stream as soon as this step's forward
+        is launched, so they run under this step's backward (PointCompletionNetV3.prefetch_geometry)."""
         ops.check_pending(wait=False)          # status of earlier steps' cooperative FPS launches (no stall)
         self.optimizer.zero_grad(set_to_none=True)
         loss = self.forward_loss(pcl_input, points_query, implicit_target)
+        if next_pcl_input is not None:
+            self.pcl_net.prefetch_geometry(next_pcl_input)
         loss.backward()
         allreduce_gradients(self.params)
         if self.grad_clip:

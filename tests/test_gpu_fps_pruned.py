@@ -105,3 +105,27 @@ def test_pruned_fps_strided_rows_and_model_clouds(pk):
             assert torch.equal(ao, co)
         assert torch.equal(a, torch.sort(ao)[0].to(a.dtype))
         level = level[a.long()]
+
+
+@pytest.mark.parametrize('n,m,start', [(100, 34, 99), (2048, 683, 17), (4779, 1593, 4778), (9558, 1000, 5000),
+                                        (14336, 2000, 7001), (16384, 900, 16383), (28672, 600, 12345)])
+def test_single_workgroup_fps_with_a_start_index(pk, n, m, start):
+    """occ4d_fps_start_f32 (random_start=True passes its draw): every single-workgroup kernel (256 / 512 threads,
+    pruned) against the greedy scan begun at `start`."""
+    rng = np.random.default_rng(n + start)
+    p = _cloud('uniform' if n % 2 else 'half_lattice', n, rng).astype(np.float32)
+    sel, order = pk.ops.fps(torch.from_numpy(p).cuda(), m, return_order=True, start=start)
+
+    def sq(i):
+        d = p - p[i]
+        return (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+    ref = [start]
+    mind = sq(start)
+    for _ in range(1, m):
+        nxt = int(np.argmax(mind))
+        ref.append(nxt)
+        mind = np.minimum(mind, sq(nxt))
+    assert np.array_equal(order.cpu().numpy(), np.array(ref, dtype=np.int32))
+    assert np.array_equal(sel.cpu().numpy(), np.sort(np.array(ref, dtype=np.int32)))
+    with pytest.raises(AssertionError):
+        pk.ops.fps(torch.from_numpy(p).cuda(), m, start=n)

@@ -287,6 +287,69 @@ def test_train_step_reduces_loss():
     assert len(moved) == len(before)
 
 
+def test_geometry_prefetch_is_used_and_changes_nothing():
+    """prefetch_geometry(pcl) runs the FPS chain and every encoder kNN ahead of forward(pcl): the forward that picks
+    them up returns the same bits (inference and training paths), consumes the prefetch exactly once, ignores one
+    made for another tensor or an older version of this one, and a TrainStep fed `next_pcl_input` follows the same
+    loss trajectory as one that is not."""
+    kind, n = 'carla', 2048
+    pa, ia, inf = pk.configs.model_args(kind, n)
+    pcl = pk.configs.synthetic_pcl(kind, n, 4, 61).cuda()
+    esd, dsd = pk.configs.synthetic_weights(dict(pa), ia, 62)
+    enc = pk.model.PointCompletionNetV3(**pa).cuda().eval()
+    enc.load_state_dict(esd)
+    calls = {'fps': 0, 'knn': 0}
+    real_fps, real_knn = pk.ops.fps_auto, pk.ops.knn
+
+    def counting(name, fn):
+        def wrapped(*a, **k):
+            calls[name] += 1
+            return fn(*a, **k)
+        return wrapped
+    pk.ops.fps_auto, pk.ops.knn = counting('fps', real_fps), counting('knn', real_knn)
+    try:
+        with torch.no_grad():
+            ref, ref_g, _ = enc(pcl, False)
+            per_forward = dict(calls)
+            assert per_forward['fps'] >= 2 and per_forward['knn'] >= 4
+            enc.prefetch_geometry(pcl)
+            assert calls == {k: 2 * v for k, v in per_forward.items()}          # all of it ran in the prefetch ...
+            out, out_g, _ = enc(pcl, False)
+            assert calls == {k: 2 * v for k, v in per_forward.items()}          # ... and none of it in the forward
+            assert torch.equal(out, ref) and torch.equal(out_g, ref_g)
+            assert enc._prefetched is None                                       # consumed
+            out, _, _ = enc(pcl, False)                                          # (next forward computes its own)
+            assert calls == {k: 3 * v for k, v in per_forward.items()} and torch.equal(out, ref)
+            enc.prefetch_geometry(pcl.clone())                                   # another tensor: ignored, dropped
+            out, _, _ = enc(pcl, False)
+            assert calls == {k: 5 * v for k, v in per_forward.items()} and torch.equal(out, ref)
+            enc.prefetch_geometry(pcl)
+            pcl.add_(0.0)                                                        # a newer version of this tensor
+            out, _, _ = enc(pcl, False)
+            assert calls == {k: 7 * v for k, v in per_forward.items()} and torch.equal(out, ref)
+    finally:
+        pk.ops.fps_auto, pk.ops.knn = real_fps, real_knn
+
+    rng = np.random.default_rng(63)
+    np.random.seed(1301)          # (the oracle sampler draws from numpy's global generator)
+    q = torch.stack([T(op.sample_query_points(128, inf['min_z'], inf['cube_bounds'], t, kind, 4, 'random'))
+                     for t in range(2)]).cuda()
+    target = torch.from_numpy(np.concatenate(
+        [rng.integers(0, 2, size=(2, 128, 1)), rng.uniform(size=(2, 128, 3)), np.zeros((2, 128, 1)),
+         rng.integers(-1, 13, size=(2, 128, 1))], -1).astype(np.float32)).cuda()
+    traj = []
+    for prefetch in (False, True):
+        e = pk.model.PointCompletionNetV3(**pa).cuda().train()
+        d = pk.implicit.LocalPclResnetFC(**ia).cuda().train()
+        e.load_state_dict(esd)
+        d.load_state_dict(dsd)
+        step = pk.training.TrainStep(e, d, lr=2e-4, grad_clip=0.2, loss_kwargs=dict(density_lw=1.0, segmentation_lw=0.6))
+        traj.append([float(step(pcl, q, target, next_pcl_input=pcl if prefetch else None)) for _ in range(4)])
+        assert (e._prefetched is not None) == prefetch
+    # (the backward pass accumulates with atomics: two runs agree to rounding, not to the bit)
+    assert np.allclose(traj[0], traj[1], rtol=1e-4, atol=0), traj
+
+
 def test_graphed_train_step_matches_eager():
     """GraphedTrainStep (one captured hipGraph per step, masked-mean losses, capturable AdamW) follows the same
     loss trajectory as the eager TrainStep from the same initial state on the same batch."""
