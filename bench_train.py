@@ -30,6 +30,7 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--no-checkpoint', action='store_true', help='store the attention pair tensors (round-1 path) instead of recomputing them in backward')
+    ap.add_argument('--per-frame', action='store_true', help='decode the target frames one after the other (the reference\'s loop) instead of in one batched decoder call')
     ap.add_argument('--no-prefetch', action='store_true', help='do not prefetch the next step\'s FPS chain / kNNs under this step\'s backward')
     ap.add_argument('--graph', action='store_true', help='replay the step as one captured hipGraph (GraphedTrainStep)')
     ap.add_argument('--sampler', action='store_true',
@@ -64,7 +65,9 @@ def main():
     lkw = dict(density_lw=1.0, segmentation_lw=0.6)
     if args.graph:
         assert not args.sampler, 'the guided sampler draws on the host: it cannot be part of a captured step'
-        step = pk.training.GraphedTrainStep(enc, dec, lr=1e-3, grad_clip=0.2, loss_kwargs=lkw)
+        step = pk.training.GraphedTrainStep(enc, dec, lr=1e-3, grad_clip=0.2, loss_kwargs=lkw,
+                                            external_geometry=not args.no_prefetch)
+        step.batch_frames = not args.per_frame
         step.capture(pcl, q, target)
     else:
         step = pk.training.TrainStep(enc, dec, lr=1e-3, grad_clip=0.2, loss_kwargs=lkw)
@@ -76,9 +79,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # the next batch's geometry is prefetched under this step's backward (eager steps only: a captured graph replays
-    # its own geometry); the synthetic bench feeds the same resident cloud every step
-    nxt = {} if (args.graph or args.no_prefetch) else {'next_pcl_input': pcl}
+    step.batch_frames = not args.per_frame
+    # the next batch's geometry is prefetched under this step's backward / replay; the synthetic bench feeds the same
+    # resident cloud every step
+    nxt = {} if args.no_prefetch else {'next_pcl_input': pcl}
     sampler_ms = None
     if args.sampler:
         frames, sizes, valo, num_valo = pk.configs.synthetic_target_frames('carla', 57344, FRAMES, SEED + 200 + rank)
@@ -129,7 +133,7 @@ def main():
             'metric': 'training step (BASELINE config 5: CARLA-4D, batch 1/GPU, n_points=28672, 4 x 17203 queries)',
             'value': world * args.steps / elapsed, 'unit': 'examples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'dtype': 'f32', 'data': 'synthetic', 'losses': losses, 'sampler_ms_per_step': sampler_ms, 'graph': bool(args.graph), 'geometry_prefetch': bool(nxt), 'attention_backward': 'stored pair tensors' if args.no_checkpoint else 'recompute in backward (chunked)',
+            'scaling': 'weak', 'dtype': 'f32', 'data': 'synthetic', 'losses': losses, 'sampler_ms_per_step': sampler_ms, 'graph': bool(args.graph), 'geometry_prefetch': bool(nxt), 'frames_batched': bool(step.batch_frames), 'attention_backward': 'stored pair tensors' if args.no_checkpoint else 'recompute in backward (chunked)',
             'peak_mem_gb': torch.cuda.max_memory_allocated() / 2 ** 30}), flush=True)
     if world > 1:
         dist.destroy_process_group()

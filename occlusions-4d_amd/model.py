@@ -51,17 +51,21 @@ class PointCompletionNetV3(torch.nn.Module):
                  for lv in range(abstract_levels - 1)])
         self.blocks = torch.nn.ModuleList(blocks)
 
-    def _geometry_chain(self, pos, full=False):
+    def _geometry_chain(self, pos, full=False, ready=None):
         """FPS -> sub-cloud of every DownTransition, for all levels, enqueued on a side stream: they depend on
         coordinates only, and the FPS steps are a ~10 ms single-CU dependent chain that would otherwise serialise the
         whole encode.  Returns {block index: (per-batch geometry, clouds, event)}; the main stream waits on the event
         right before the block needs it.  full=True (prefetch_geometry) also runs every kNN of the encoder there: the
-        pooling neighbours of the DownTransitions and the self-kNN of the PointTransformerBlocks."""
+        pooling neighbours of the DownTransitions and the self-kNN of the PointTransformerBlocks.  `ready`: an event
+        after which `pos` is complete; without it the side stream waits for everything queued on the current stream."""
         main = torch.cuda.current_stream()
         if self._geom_stream is None:
             self._geom_stream = torch.cuda.Stream()
         side = self._geom_stream
-        side.wait_stream(main)
+        if ready is not None:
+            side.wait_event(ready)
+        else:
+            side.wait_stream(main)
         out = {}
         with torch.cuda.stream(side):
             cur = [pos[b].contiguous() for b in range(pos.shape[0])]
@@ -89,16 +93,24 @@ class PointCompletionNetV3(torch.nn.Module):
                     out[i] = (idx, cur, ev)
         return out
 
-    def prefetch_geometry(self, pcl):
+    def prefetch_geometry(self, pcl, ready=None):
         """Issues the coordinate-only part of forward(pcl) -- the FPS chain and every kNN of the encoder -- NOW, on the
         geometry stream; the next forward() called with this very tensor (same storage, same version) picks the
         results up instead of computing them.  A training loop calls it for batch i + 1 once batch i's forward is
         launched (training.TrainStep does, given `next_pcl_input`): the 23 ms FPS chain of a 28672-point cloud then runs
         under batch i's backward instead of in front of batch i + 1's forward -- the reference hides the same work in
         its dataloader workers (utils/geometry.py:353-364).  With fps_random_start the start indices are drawn from
-        torch's CPU generator at this call rather than inside forward()."""
+        torch's CPU generator at this call rather than inside forward().  `ready` (optional torch.cuda.Event): `pcl` is
+        complete once it has fired; by default the geometry stream waits for all work queued on the current stream.
+        Returns the geometry (also kept for the next forward)."""
         pos = pcl[..., :3].detach()
-        self._prefetched = ((pcl.data_ptr(), pcl._version, tuple(pcl.shape)), self._geometry_chain(pos, full=True))
+        geom = self._geometry_chain(pos, full=True, ready=ready)
+        self._prefetched = (self.geometry_key(pcl), geom)
+        return geom
+
+    @staticmethod
+    def geometry_key(pcl):
+        return (pcl.data_ptr(), pcl._version, tuple(pcl.shape))
 
     _prefetched = None
 
@@ -120,20 +132,22 @@ class PointCompletionNetV3(torch.nn.Module):
         skips = []
         x_global = None
         pre, self._prefetched = self._prefetched, None
-        if pre is not None and pre[0] == (pcl.data_ptr(), pcl._version, tuple(pcl.shape)):
+        if pre is not None and pre[0] == self.geometry_key(pcl):
             geom = pre[1]
         else:
             geom = self._geometry_chain(pos)
         for i, block in enumerate(self.blocks):
             if isinstance(block, modules.DownTransition):
                 g, clouds, ev = geom[i]
-                torch.cuda.current_stream().wait_event(ev)
+                if ev is not None:
+                    torch.cuda.current_stream().wait_event(ev)
                 if len(g[0]) == 2:
                     g = [(inds, p_sub, block.neighbours(p_sub, c)) for (inds, p_sub), c in zip(g, clouds)]
                 (x, pos) = block(x, pos, geometry=g)
             elif i in geom:
                 idx, _, ev = geom[i]
-                torch.cuda.current_stream().wait_event(ev)
+                if ev is not None:
+                    torch.cuda.current_stream().wait_event(ev)
                 (x, pos) = block(x, pos, knn_idx=idx)
             else:
                 (x, pos) = block(x, pos)

@@ -350,9 +350,42 @@ def test_geometry_prefetch_is_used_and_changes_nothing():
     assert np.allclose(traj[0], traj[1], rtol=1e-4, atol=0), traj
 
 
-def test_graphed_train_step_matches_eager():
+def test_batched_frames_equal_the_per_frame_loop():
+    """TrainStep.batch_frames (all target frames through one decoder call) against the reference's per-frame loop:
+    same loss, same gradients (to rounding: the weight gradients sum the same products in another order)."""
+    kind, n = 'carla', 512
+    pa, ia, inf = pk.configs.model_args(kind, n)
+    pcl = pk.configs.synthetic_pcl(kind, n, 4, 71).cuda()
+    esd, dsd = pk.configs.synthetic_weights(dict(pa), ia, 72)
+    rng = np.random.default_rng(73)
+    np.random.seed(1333)          # (the oracle sampler draws from numpy's global generator)
+    q = torch.stack([T(op.sample_query_points(96, inf['min_z'], inf['cube_bounds'], t, kind, 4, 'random'))
+                     for t in range(3)]).cuda()
+    target = torch.from_numpy(np.concatenate(
+        [rng.integers(0, 2, size=(3, 96, 1)), rng.uniform(size=(3, 96, 3)), np.zeros((3, 96, 1)),
+         rng.integers(-1, 13, size=(3, 96, 1))], -1).astype(np.float32)).cuda()
+    res = []
+    for batched in (False, True):
+        e = pk.model.PointCompletionNetV3(**pa).cuda().train()
+        d = pk.implicit.LocalPclResnetFC(**ia).cuda().train()
+        e.load_state_dict(esd)
+        d.load_state_dict(dsd)
+        step = pk.training.TrainStep(e, d, loss_kwargs=dict(density_lw=1.0, segmentation_lw=0.6))
+        step.batch_frames = batched
+        loss = step.forward_loss(pcl, q, target)
+        loss.backward()
+        res.append((float(loss), {k: v.grad.clone() for k, v in list(e.named_parameters()) + list(d.named_parameters())}))
+    assert abs(res[0][0] - res[1][0]) <= 2e-6 * abs(res[0][0])
+    for k, g in res[0][1].items():
+        assert rel_err(res[1][1][k], g) <= 1e-4 or float(g.abs().max()) < 1e-7, k
+
+
+@pytest.mark.parametrize('mode', ['external', 'external_prefetch', 'new_cloud_each_step', 'captured'])
+def test_graphed_train_step_matches_eager(mode):
     """GraphedTrainStep (one captured hipGraph per step, masked-mean losses, capturable AdamW) follows the same
-    loss trajectory as the eager TrainStep from the same initial state on the same batch."""
+    loss trajectory as the eager TrainStep from the same initial state on the same batch -- with the encoder's FPS /
+    kNN geometry outside the graph (computed per step, or prefetched under the previous replay, also when every step
+    brings another cloud) and captured inside it."""
     kind, n = 'carla', 512
     pa, ia, inf = pk.configs.model_args(kind, n)
     pcl = pk.configs.synthetic_pcl(kind, n, 4, 51).cuda()
@@ -372,13 +405,22 @@ def test_graphed_train_step_matches_eager():
         enc.load_state_dict(esd)
         dec.load_state_dict(dsd)
         return enc, dec
+    clouds = [pcl] * 6
+    if mode == 'new_cloud_each_step':      # steps 3 .. 6 see other clouds: the graph must read THEIR geometry
+        clouds = [pcl, pcl] + [pk.configs.synthetic_pcl(kind, n, 4, 54 + i).cuda() for i in range(4)]
     enc_e, dec_e = nets()
     eager = pk.training.TrainStep(enc_e, dec_e, lr=2e-4, grad_clip=0.2, loss_kwargs=lkw)
-    ref = [float(eager(pcl, q, target)) for _ in range(6)]
+    ref = [float(eager(c, q, target)) for c in clouds]
     enc_g, dec_g = nets()
-    graphed = pk.training.GraphedTrainStep(enc_g, dec_g, lr=2e-4, grad_clip=0.2, loss_kwargs=lkw)
+    graphed = pk.training.GraphedTrainStep(enc_g, dec_g, lr=2e-4, grad_clip=0.2, loss_kwargs=lkw,
+                                           external_geometry=mode != 'captured')
     got = [float(v) for v in graphed.capture(pcl, q, target, warmup=2)]      # steps 1, 2 (eager, on a side stream)
-    got += [float(graphed(pcl, q, target)) for _ in range(4)]                 # steps 3 .. 6 (graph replays)
+    for i in range(2, 6):                                                     # steps 3 .. 6 (graph replays)
+        nxt = clouds[i + 1] if (mode in ('external_prefetch', 'new_cloud_each_step') and i + 1 < 6) else None
+        got.append(float(graphed(clouds[i], q, target, next_pcl_input=nxt) if mode != 'captured'
+                         else graphed(clouds[i], q, target)))
+    if mode == 'new_cloud_each_step':
+        assert len(set(round(v, 4) for v in ref[2:])) > 1                     # (the clouds do differ)
     assert np.allclose(got, ref, rtol=2e-3, atol=2e-4), (got, ref)
     w_e = torch.cat([p.detach().reshape(-1) for p in eager.params])
     w_g = torch.cat([p.detach().reshape(-1) for p in graphed.params])
