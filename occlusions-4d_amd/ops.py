@@ -298,8 +298,11 @@ def pack_w2_bf16x3(w2):
     w2 = w2.detach().float()
     hi = w2.bfloat16()
     lo = (w2 - hi.float()).bfloat16()
-    perm = torch.tensor([16 * t + 8 * (j >> 2) + 4 * half + (j & 3)
-                         for t in range(2) for half in range(2) for j in range(8)], device=w2.device)
+    # position 16 t + 8 half + j  <-  hidden 16 t + 8 (j >> 2) + 4 half + (j & 3); built with device arithmetic (a
+    # host list copied to the device is not allowed while a stream is being captured)
+    i = torch.arange(32, device=w2.device)
+    t_, half, j = i // 16, (i // 8) % 2, i % 8
+    perm = 16 * t_ + 8 * (j // 4) + 4 * half + (j % 4)
     hi = hi.view(d, h2 // 32, 32)[:, :, perm]
     lo = lo.view(d, h2 // 32, 32)[:, :, perm]
     packed = torch.cat([hi, lo], dim=2).contiguous()            # (d, blocks, 64) bf16 = 128 B per block

@@ -210,7 +210,7 @@ class PointTransformerLayer(nn.Module):
     # -- derived weights ---------------------------------------------------------------
     def _params_key(self, pre):
         ps = list(self.parameters()) + ([pre.weight, pre.bias] if pre is not None else [])
-        return (weights_epoch(),) + tuple((p.data_ptr(), p._version) for p in ps)
+        return (weights_epoch(), LOGIT_PRECISION) + tuple((p.data_ptr(), p._version) for p in ps)
 
     def merged_weights(self, pre=None):
         """fp64-merged matrices of refactoring (i); `pre` is an optional nn.Linear applied to
@@ -237,7 +237,8 @@ class PointTransformerLayer(nn.Module):
         if self.dim == 416 and self.pos_mlp[0].out_features == 32 and self.attn_mlp[2].weight.is_cuda:
             m['attn16_stream'] = ops.pack_attn16_stream(self.attn_mlp[2].weight, self.attn_mlp[2].bias, m['wp'],
                                                              self.pos_mlp[2].weight, self.pos_mlp[2].bias)
-        if self.attn_mlp[2].weight.shape[1] % 32 == 0:
+        m['w2_bf16x3'] = m['wp_bf16x3'] = None
+        if LOGIT_PRECISION == 'bf16x3' and self.attn_mlp[2].weight.shape[1] % 32 == 0:     # (opt-in mode only)
             m['w2_bf16x3'] = ops.pack_w2_bf16x3(self.attn_mlp[2].weight)
             m['wp_bf16x3'] = ops.pack_w2_bf16x3(m['wp']) if m['wp'].shape[1] == 32 else None
         self._merged[pre is not None] = (key, m)

@@ -216,16 +216,6 @@ class GraphedTrainStep(TrainStep):
                 dst.copy_(src)
 
     def _eager(self, pcl_input, points_query, implicit_target):
-        # (the recompute-in-backward attention Function drives a nested autograd pass that the stream capture does
-        # not accept; a captured step has static memory anyway, so it keeps the stored-activation path)
-        from . import point_transformer_layer as ptl
-        saved, ptl.CHECKPOINT_ATTENTION = ptl.CHECKPOINT_ATTENTION, False
-        try:
-            return self._eager_step(pcl_input, points_query, implicit_target)
-        finally:
-            ptl.CHECKPOINT_ATTENTION = saved
-
-    def _eager_step(self, pcl_input, points_query, implicit_target):
         loss = self.forward_loss(pcl_input, points_query, implicit_target)
         loss.backward()
         allreduce_gradients(self.params)
@@ -254,7 +244,8 @@ class GraphedTrainStep(TrainStep):
             self._geom_static = {i: (g, None, None) for i, (g, _, _) in geom.items()}
             self.pcl_net._prefetched = None
         self.optimizer.zero_grad(set_to_none=True)
-        self.graph = torch.cuda.CUDAGraph()
+        invalidate_weight_caches()      # derived weights must be recomputed INSIDE the capture (as graph nodes), not
+        self.graph = torch.cuda.CUDAGraph()                                       # taken from the warm-up's cache
         with torch.cuda.graph(self.graph):
             if self.external_geometry:      # the captured forward reads the static index buffers (no events: same stream)
                 self.pcl_net._prefetched = (self.pcl_net.geometry_key(self.static[0]), self._geom_static)

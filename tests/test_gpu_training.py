@@ -380,12 +380,13 @@ def test_batched_frames_equal_the_per_frame_loop():
         assert rel_err(res[1][1][k], g) <= 1e-4 or float(g.abs().max()) < 1e-7, k
 
 
-@pytest.mark.parametrize('mode', ['external', 'external_prefetch', 'new_cloud_each_step', 'captured'])
+@pytest.mark.parametrize('mode', ['external', 'external_prefetch', 'new_cloud_each_step', 'captured', 'stored'])
 def test_graphed_train_step_matches_eager(mode):
     """GraphedTrainStep (one captured hipGraph per step, masked-mean losses, capturable AdamW) follows the same
     loss trajectory as the eager TrainStep from the same initial state on the same batch -- with the encoder's FPS /
     kNN geometry outside the graph (computed per step, or prefetched under the previous replay, also when every step
-    brings another cloud) and captured inside it."""
+    brings another cloud) and captured inside it; the attention pair tensors recomputed in backward inside the graph
+    (default) or stored ('stored')."""
     kind, n = 'carla', 512
     pa, ia, inf = pk.configs.model_args(kind, n)
     pcl = pk.configs.synthetic_pcl(kind, n, 4, 51).cuda()
@@ -406,6 +407,9 @@ def test_graphed_train_step_matches_eager(mode):
         dec.load_state_dict(dsd)
         return enc, dec
     clouds = [pcl] * 6
+    saved_ckpt = pk.point_transformer_layer.CHECKPOINT_ATTENTION
+    pk.point_transformer_layer.CHECKPOINT_ATTENTION = mode != 'stored'
+    calls0 = pk.point_transformer_layer._CheckpointedAttention.calls
     if mode == 'new_cloud_each_step':      # steps 3 .. 6 see other clouds: the graph must read THEIR geometry
         clouds = [pcl, pcl] + [pk.configs.synthetic_pcl(kind, n, 4, 54 + i).cuda() for i in range(4)]
     enc_e, dec_e = nets()
@@ -419,6 +423,8 @@ def test_graphed_train_step_matches_eager(mode):
         nxt = clouds[i + 1] if (mode in ('external_prefetch', 'new_cloud_each_step') and i + 1 < 6) else None
         got.append(float(graphed(clouds[i], q, target, next_pcl_input=nxt) if mode != 'captured'
                          else graphed(clouds[i], q, target)))
+    pk.point_transformer_layer.CHECKPOINT_ATTENTION = saved_ckpt
+    assert (pk.point_transformer_layer._CheckpointedAttention.calls > calls0) == (mode != 'stored')
     if mode == 'new_cloud_each_step':
         assert len(set(round(v, 4) for v in ref[2:])) > 1                     # (the clouds do differ)
     assert np.allclose(got, ref, rtol=2e-3, atol=2e-4), (got, ref)
