@@ -66,7 +66,11 @@ def trunk_pack(weight, kind='rows'):
 
 
 CHECKPOINT_ATTENTION = True   # training: cross-attention layers recompute their pair tensors in backward (below)
-_CHECKPOINT_CHUNK = 4096      # queries per recompute chunk in backward: bounds the (chunk * K, 2D) workspace
+# queries per recompute chunk in backward: bounds the (chunk * K, 2D) workspace.  Measured on BASELINE config 5
+# (bench_train.py, ms per step eager / replayed, peak memory): 4096: 184 / 179, 4.4 GB; 8192: 173 / 170, 5.2 GB;
+# 16384: - / 161, 6.9 GB; 32768: 159 / 157, 10.2 GB (stored pair tensors: 167 / 163, 24.2 GB) -- small chunks run the
+# pair GEMMs at 57 K rows and repeat the accumulation of every weight gradient per chunk.
+_CHECKPOINT_CHUNK = int(os.environ.get('OCC4D_CHECKPOINT_CHUNK', '32768'))
 
 
 def _grad_or_none(outputs, inputs, grad_outputs):
