@@ -183,6 +183,25 @@ def test_weight_gradient_random(pk):
         assert np.array_equal(pk.ops.relu_mask(C(g[:, :min(N, K)]), C(x[:, :min(N, K)])).cpu().numpy(), ref_mask)
 
 
+@pytest.mark.parametrize('M,N,K', [(4096, 416, 64), (5003, 416, 832), (40001, 832, 128), (70000, 416, 832), (4097, 832, 64)])
+def test_weight_gradient_training_shapes(pk, M, N, K):
+    """The weight-gradient GEMM at the decoder's widths with many rows (the shapes that carry a training step's FLOPs),
+    ragged M, bias gradient, relu on the x operand and accumulation into an existing gradient, against fp64."""
+    rng = np.random.default_rng(M + N + K)
+    g = rng.normal(size=(M, N)).astype(np.float32)
+    x = rng.normal(size=(M, K)).astype(np.float32)
+    for relu_x, bias in ((False, True), (True, False)):
+        res = pk.ops.linear_wgrad(C(g), C(x), bias=bias, relu_x=relu_x)
+        dw, db = res if bias else (res, None)
+        xr = np.maximum(x, 0) if relu_x else x
+        assert _rel(dw, g.astype(np.float64).T @ xr.astype(np.float64)) <= 3e-6
+        if bias:
+            assert _rel(db, g.astype(np.float64).sum(axis=0)) <= 3e-6
+    acc = torch.ones((N, K), device='cuda')
+    pk.ops.linear_wgrad(C(g), C(x), out=acc, accumulate=True)
+    assert _rel(acc, 1.0 + g.astype(np.float64).T @ x.astype(np.float64)) <= 3e-6
+
+
 def test_scatter_and_pool_gradients_random(pk):
     rng = np.random.default_rng(37)
     for trial in range(12):
