@@ -22,7 +22,7 @@ the total work is the same for N = 2, 4, 8 -> "scaling": "strong".  value = tota
 max-over-ranks time.  Each line also carries the other grid as a secondary leg, so that both
 strong-scaling curves have all their points: `config4_single_gpu` on the N = 1 line (the 2 M
 grid on one GPU) and `strong_config2` on the N > 1 lines (the 534 528-query grid split N ways,
-where the serial 13 ms encode is the Amdahl term).
+where the serial 7.6 ms encode is the Amdahl term).
 
 Extra objects on the JSON line:
   roofline      the dominant kernel = cross_attn16_kernel (fused vector attention, 14
