@@ -29,7 +29,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--no-checkpoint', action='store_true', help='store the attention pair tensors (round-1 path) instead of recomputing them in backward')
+    ap.add_argument('--no-checkpoint', action='store_true', help='store the attention pair tensors (merged form; OCC4D_STORED_ATTENTION_FORM=as_written for the round-1 path) instead of recomputing them in backward')
     ap.add_argument('--per-frame', action='store_true', help='decode the target frames one after the other (the reference\'s loop) instead of in one batched decoder call')
     ap.add_argument('--no-prefetch', action='store_true', help='do not prefetch the next step\'s FPS chain / kNNs under this step\'s backward')
     ap.add_argument('--graph', action='store_true', help='replay the step as one captured hipGraph (GraphedTrainStep)')
@@ -133,7 +133,7 @@ def main():
             'metric': 'training step (BASELINE config 5: CARLA-4D, batch 1/GPU, n_points=28672, 4 x 17203 queries)',
             'value': world * args.steps / elapsed, 'unit': 'examples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'dtype': 'f32', 'data': 'synthetic', 'losses': losses, 'sampler_ms_per_step': sampler_ms, 'graph': bool(args.graph), 'geometry_prefetch': bool(nxt), 'frames_batched': bool(step.batch_frames), 'attention_backward': 'stored pair tensors' if args.no_checkpoint else 'recompute in backward (chunked)',
+            'scaling': 'weak', 'dtype': 'f32', 'data': 'synthetic', 'losses': losses, 'sampler_ms_per_step': sampler_ms, 'graph': bool(args.graph), 'geometry_prefetch': bool(nxt), 'frames_batched': bool(step.batch_frames), 'attention_backward': ('stored pair tensors (%s form)' % pk.point_transformer_layer.STORED_ATTENTION_FORM) if args.no_checkpoint else 'recompute in backward (chunks of %d queries)' % pk.point_transformer_layer._CHECKPOINT_CHUNK,
             'peak_mem_gb': torch.cuda.max_memory_allocated() / 2 ** 30}), flush=True)
     if world > 1:
         dist.destroy_process_group()

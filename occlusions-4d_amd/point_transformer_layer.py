@@ -66,6 +66,9 @@ def trunk_pack(weight, kind='rows'):
 
 
 CHECKPOINT_ATTENTION = True   # training: cross-attention layers recompute their pair tensors in backward (below)
+# training with CHECKPOINT_ATTENTION off: 'merged' stores the pair tensors of the MERGED form (forward_train_merged: the
+# per-pair first GEMM has K = 32), 'as_written' those of the reference's op order (forward_train)
+STORED_ATTENTION_FORM = os.environ.get('OCC4D_STORED_ATTENTION_FORM', 'merged')
 # queries per recompute chunk in backward: bounds the (chunk * K, 2D) workspace.  Measured on BASELINE config 5
 # (bench_train.py, ms per step eager / replayed, peak memory): 4096: 184 / 179, 4.4 GB; 8192: 173 / 170, 5.2 GB;
 # 16384: - / 161, 6.9 GB; 32768: 159 / 157, 10.2 GB (stored pair tensors: 167 / 163, 24.2 GB) -- small chunks run the
@@ -281,6 +284,11 @@ class PointTransformerLayer(nn.Module):
                     out.append(_CheckpointedAttention.apply(self, y, pos[b].detach(), x2[b], pos2[b].detach(), idx,
                                                             *self.parameters()))
                     continue
+                if (STORED_ATTENTION_FORM == 'merged' and x2 is not None and self.pos_mlp[0].out_features == 32
+                        and self.attn_mlp[0].in_features == self.dim):
+                    out.append(self.forward_train_merged(y, pos[b].detach(), x2[b], pos2[b].detach(),
+                                                         idx=None if knn_idx is None else knn_idx[b]))
+                    continue
                 out.append(self.forward_train(y, pos[b], None if x2 is None else x2[b],
                                               None if pos2 is None else pos2[b],
                                               idx=None if knn_idx is None else knn_idx[b]))
@@ -292,6 +300,34 @@ class PointTransformerLayer(nn.Module):
             out.append(self._forward_one(x[b], pos[b], xb2, pb2, pre, scene_owner,
                                          None if knn_idx is None else knn_idx[b]))
         return ops.stack_batch(out)
+
+    def forward_train_merged(self, x, pos, x2, pos2, idx=None):
+        """Differentiable cross-attention for one cloud in the MERGED form of DESIGN.md 4 (i): the query / key halves of
+        attn_mlp[0] become per-point tables (W1 Wq) x + (W1 c2 + b1) and (W1 Wk) x2, the positional half a K = 32 GEMM
+        on the pair hidden units, so that the only per-pair GEMM with a wide contraction is attn_mlp[2].  The merged
+        matrices are differentiable fp64 products of the parameters (rounded once); every pair tensor is stored for
+        backward.  Same ops as the recompute path (_CheckpointedAttention.backward), without the second forward."""
+        L = autograd.LinearFn.apply
+        f64 = torch.float64
+        if idx is None:
+            idx = ops.knn(pos, pos2, self.num_neighbors, metric=0)
+        P1, c1 = self.pos_mlp[0].weight, self.pos_mlp[0].bias
+        P2, c2 = self.pos_mlp[2].weight, self.pos_mlp[2].bias
+        W1, b1 = self.attn_mlp[0].weight, self.attn_mlp[0].bias
+        W2, b2 = self.attn_mlp[2].weight, self.attn_mlp[2].bias
+        W1d = W1.to(f64)
+        wq = (W1d @ self.to_q.weight.to(f64)).float()
+        bq = (W1d @ c2.to(f64) + b1.to(f64)).float()
+        wk = (W1d @ self.to_k.weight.to(f64)).float()
+        wp = (W1d @ P2.to(f64)).float()
+        kt = L(x2, wk, None, False, False, None)                       # (M, 2D)
+        vt = L(x2, self.to_v.weight, None, False, False, None)         # (M, D)
+        aq = L(x, wq, bq, False, False, None)                          # (N, 2D)
+        r = autograd.PosHiddenFn.apply(pos, pos2, idx, P1, c1)         # (N*K, 32)
+        a = autograd.AttnInFn.apply(aq, kt, L(r, wp, None, False, False, None), idx)    # aq_i - kt_j + Wp r
+        logits = L(a, W2, b2, True, False, None)                       # W2 relu(.) + b2
+        pe = L(r, P2, c2, False, False, None)
+        return autograd.SoftmaxAggFn.apply(logits, vt, pe, idx)
 
     def forward_train(self, x, pos, x2=None, pos2=None, idx=None):
         """Differentiable forward for one cloud, as written in the reference (:167-179): x (N,D).  `idx`: the

@@ -132,6 +132,44 @@ def test_checkpointed_attention_gradients_strict(chunk):
     check_grads(layer, rsd)
 
 
+@pytest.mark.parametrize('form', ['merged', 'as_written'])
+def test_stored_attention_gradients_strict(form):
+    """Cross-attention with stored pair tensors (CHECKPOINT_ATTENTION off), in the merged form (default) and in the
+    reference's op order: the layer entry point picks the form, same strict criterion."""
+    case = gc.PTL_CASES[2]
+    x, pos, x2, pos2, sd = gc.ptl_inputs(case)
+    rng = np.random.default_rng(4)
+    go = torch.from_numpy(rng.normal(size=(x.shape[0], case['dim'])).astype(np.float32))
+    rsd = {k: v.clone().double().requires_grad_(True) for k, v in sd.items()}
+    xr, x2r = T(x).double().requires_grad_(True), T(x2).double().requires_grad_(True)
+    agg_r = op.pt_layer(rsd, xr[None], T(pos).double()[None], x2=x2r[None], pos2=T(pos2).double()[None],
+                        num_neighbors=case['k'])[0]
+    (agg_r * go.double()).sum().backward()
+    ptl = pk.point_transformer_layer
+    layer = ptl.PointTransformerLayer(case['dim'], num_neighbors=case['k'], dim2=case['dim2']).cuda()
+    layer.load_state_dict(sd)
+    xg, x2g = T(x).cuda().requires_grad_(True), T(x2).cuda().requires_grad_(True)
+    saved = (ptl.CHECKPOINT_ATTENTION, ptl.STORED_ATTENTION_FORM)
+    ptl.CHECKPOINT_ATTENTION, ptl.STORED_ATTENTION_FORM = False, form
+    calls = {'merged': 0}
+    real = layer.forward_train_merged
+
+    def counted(*a, **k):
+        calls['merged'] += 1
+        return real(*a, **k)
+    layer.forward_train_merged = counted
+    try:
+        before = ptl._CheckpointedAttention.calls
+        agg = layer(xg[None], T(pos).cuda()[None], x2g[None], T(pos2).cuda()[None])[0]
+        assert ptl._CheckpointedAttention.calls == before and calls['merged'] == (1 if form == 'merged' else 0)
+        (agg * go.cuda()).sum().backward()
+    finally:
+        ptl.CHECKPOINT_ATTENTION, ptl.STORED_ATTENTION_FORM = saved
+    assert rel_err(agg, agg_r) < 1e-5
+    assert rel_err(xg.grad, xr.grad) <= REL and rel_err(x2g.grad, x2r.grad) <= REL
+    check_grads(layer, rsd)
+
+
 def test_checkpointed_attention_with_frozen_parameters():
     """Frozen parameters (requires_grad False) get no gradient and do not disturb the others."""
     case = gc.PTL_CASES[2]
