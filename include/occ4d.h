@@ -219,6 +219,28 @@ int occ4d_pt_cross_attn16_f32(const float* aq, int64_t ld_aq, const float* qpos,
                               int64_t ld_vt, const float* P1, const float* c1, const float* wstream, float* agg,
                               int64_t ld_agg, int n, int m, int k, int d, float divisor, void* stream);
 
+/* Third-generation fused vector attention for d = 416, K <= 14 (csrc/crossattn16p.hip): the same contract and the same
+ * MFMA chain as occ4d_pt_cross_attn16_f32, restructured so that TWO independent 4-wave workgroups share a CU out of
+ * phase (one's softmax epilogue / prologue / barrier waits run under the other's MFMA stream): a workgroup handles its
+ * 9 queries in two passes of 64 pair rows over stages of 16 hidden units.  `wstream` holds
+ * occ4d_pt_cross_attn16p_stream_floats() floats: 54 stages of 28 fragments x 256 floats;
+ *   stage s < 52 = hidden units 16 s .. 16 s + 15:
+ *     fragment t (t < 26 channel tiles):   [(g*16 + c)*4 + e] = W2[16 t + c][16 s + 4 g + e]
+ *     fragment 26 + kh (kh < 2):           [(g*16 + r)*4 + e] = Wp[16 s + r][16 kh + 4 e + g]
+ *   stage 52: fragment 2 t + kh (t < 14):        [(g*16 + c)*4 + e] = P2[16 t + c][16 kh + 4 e + g]
+ *   stage 53: fragment 2 (t - 14) + kh (14 <= t < 26): the same for the remaining tiles; the last 4 fragments zero
+ * (g < 4, c, r < 16, e < 4; matrices as for occ4d_pt_cross_attn16_f32).  Two biases are not in the stream:
+ * attn_mlp[2].bias is constant over the neighbour axis the softmax normalises over and cancels exactly; pos_mlp[2].bias
+ * c2 must come folded into the value table: vt[j] = Wv f_j + c2 (the kernel adds P2 r_ij to it).
+ * skew: phase offset given once to the later-placed workgroup of every CU in the first dispatch round, in units of
+ * s_sleep(127) (about 8 K shader cycles); 0 = none.  Performance only -- results do not depend on it. */
+int64_t occ4d_pt_cross_attn16p_stream_floats(void);
+int occ4d_pt_cross_attn16p_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t q_stride, const float* apos,
+                               int64_t a_stride, const int32_t* idx, const float* kt, int64_t ld_kt, const float* vt,
+                               int64_t ld_vt, const float* P1, const float* c1, const float* wstream,
+                               float* agg, int64_t ld_agg, int n, int m, int k, int d, float divisor, int skew,
+                               void* stream);
+
 /* ------------------------------------------------------------------------
  * Row-resident fused trunk layers (csrc/trunk.hip), width 416 = d_hidden of every published configuration
  * (train.py:255-256).  A row tile's activations stay in registers across the layers of a block; weights are

@@ -20,6 +20,10 @@ OBJDIR = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libocc4d.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-I' + INCLUDE, '-I' + CSRC]
 FLAGS += os.environ.get('OCC4D_HIPCC_EXTRA', '').split()      # experiments only (e.g. -DOCC4D_CA_NO_XCD_MAP)
+# per-file flags.  -fno-honor-nans: fmaxf() on MFMA / lane-swap results otherwise gets a canonicalising v_max v, v, v
+# in front of every maximum, and in these kernels every VALU instruction costs matrix time (profiles/micro/
+# valu_beside_mfma.hip).  The kernels' masking uses infinities (still honoured), never NaNs.
+FILE_FLAGS = {'crossattn16p.hip': ['-fno-honor-nans']}
 
 
 def _hipcc():
@@ -47,7 +51,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(OBJDIR, src[:-4] + '.o')
         objs.append(obj)
         if force or _stale(obj, [os.path.join(CSRC, src)] + headers):
-            jobs.append([_hipcc()] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj])
+            jobs.append([_hipcc()] + FLAGS + FILE_FLAGS.get(src, []) + ['-c', os.path.join(CSRC, src), '-o', obj])
 
     def run(cmd):
         if verbose:

@@ -238,6 +238,7 @@ __global__ __launch_bounds__(512, 2) void cross_attn16_kernel(const Attn16Args a
 #ifdef OCC4D_CA16_STAMP
   const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
 #endif
+  asm volatile("; OCC4D_MARK loop");
   // two blocks per loop trip so that the LDS buffers are compile-time objects; one barrier per block
 #pragma clang loop unroll(disable)
   for (int hb = 0; hb < AHB; hb += 2) {
@@ -253,6 +254,7 @@ __global__ __launch_bounds__(512, 2) void cross_attn16_kernel(const Attn16Args a
 #ifdef OCC4D_CA16_STAMP
   const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
 #endif
+  asm volatile("; OCC4D_MARK epilogue");
   // buf0 now holds P2's fragments (stage AHB); buf1 is free: the 9th query's partial softmax (3 x 7 x D floats)
 
   // ---- epilogue.  C/D rows of this lane: 4 g + reg; rows 0-13 = neighbours of query q0 + wave, rows 14, 15 (g = 3,

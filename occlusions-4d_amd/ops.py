@@ -4,6 +4,7 @@ torch is plumbing here (device memory + streams); all arithmetic happens in
 libocc4d.so.  CPU tensors are rejected -- there is no fallback path."""
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -387,6 +388,55 @@ def pt_cross_attn16(aq, qpos, apos, idx, kt, vt, P1, c1, wstream, out=None):
     _lib.check(_launch('cross_attn', dict(n=n, k=k, d=d), flops, lambda: _lib.lib().occ4d_pt_cross_attn16_f32(
         _ptr(aq), ld_aq, _ptr(qp), qs, _ptr(ap), as_, _ptr(idx), _ptr(kt), ld_kt, _ptr(vt), ld_vt,
         _ptr(ws[0]), _ptr(ws[1]), _ptr(wstream), _ptr(o), ldo, n, kt.shape[0], k, d, divisor, _stream())))
+    return out
+
+
+ATTN16P_SKEW = int(os.environ.get('OCC4D_CA16P_SKEW', '6'))   # phase offset of the paired workgroups (units of s_sleep(127))
+
+
+def pack_attn16p_stream(w2, b2, wp, p2, c2):
+    """Stage-packed weight stream of occ4d_pt_cross_attn16p_f32 (layout in include/occ4d.h): w2 (416, 832), b2 (416)
+    = attn_mlp[2]; wp (832, 32) = W1 P2 (merged); p2 (416, 32), c2 (416) = pos_mlp[2] -> (54, 28 * 256) fp32."""
+    w2, b2, wp, p2, c2 = (_dev(t.detach(), name='w') for t in (w2, b2, wp, p2, c2))
+    d = p2.shape[0]
+    assert d == 416 and tuple(w2.shape) == (d, 2 * d) and tuple(wp.shape) == (2 * d, 32) and p2.shape[1] == 32
+    nt, ns = d // 16, 2 * d // 16
+    a = w2.reshape(nt, 16, ns, 4, 4).permute(2, 0, 3, 1, 4).reshape(ns, nt * 256)        # [s][t][g][c][e]
+    b = wp.reshape(ns, 16, 2, 4, 4).permute(0, 2, 4, 1, 3).reshape(ns, 2 * 256)          # [s][kh][g][r][e]
+    c = p2.reshape(nt, 16, 2, 4, 4).permute(0, 2, 4, 1, 3).reshape(nt, 2 * 256)          # [t][kh][g][c][e]
+    # b2 / c2 are not part of the stream: b2 cancels in the softmax over the neighbours, c2 comes folded into the
+    # value table the kernel is given (vt + c2, see pt_cross_attn16p)
+    tail = torch.zeros((1, 4 * 256), dtype=torch.float32, device=c.device)
+    out = torch.cat([torch.cat([a, b], dim=1), c[:14].reshape(1, -1),
+                     torch.cat([c[14:].reshape(1, -1), tail], dim=1)], dim=0).contiguous()
+    assert out.numel() == _lib.lib().occ4d_pt_cross_attn16p_stream_floats()
+    return out
+
+
+def pt_cross_attn16p(aq, qpos, apos, idx, kt, vt, P1, c1, wstream, out=None, skew=None):
+    """Fused vector attention, d = 416, paired workgroups (occ4d_pt_cross_attn16p_f32): agg (n, 416).
+    `vt` is the value table WITH pos_mlp[2].bias folded in (Wv f + c2), one row per abstract point."""
+    aq, ld_aq = _aligned_rows(_dev(aq, name='aq'), 'aq')
+    kt, ld_kt = _aligned_rows(_dev(kt, name='kt'), 'kt')
+    vt, ld_vt = _rows(_dev(vt, name='vt'), 'vt')
+    qp, qs = _rows(_dev(qpos, name='qpos'), 'qpos')
+    ap, as_ = _rows(_dev(apos, name='apos'), 'apos')
+    idx = _dev(idx, torch.int32, 'idx')
+    n, k = idx.shape
+    d = vt.shape[1]
+    assert idx.is_contiguous() and aq.shape == (n, 2 * d) and kt.shape[1] == 2 * d and qp.shape[0] == n
+    ws = [_dev(t).contiguous() for t in (P1, c1)]
+    assert ws[0].shape == (32, 3) and wstream.is_contiguous()
+    if out is None:
+        out = torch.empty((n, d), dtype=torch.float32, device=aq.device)
+    o, ldo = _rows(out, 'out')
+    assert o is out and o.shape == (n, d)
+    divisor = float(torch.tensor(math.sqrt(d), dtype=torch.float32))
+    flops = 2.0 * n * k * (32 * 2 * d + 2 * d * d + 32 * d)      # executed, useful (same count as pt_cross_attn)
+    sk = ATTN16P_SKEW if skew is None else int(skew)
+    _lib.check(_launch('cross_attn', dict(n=n, k=k, d=d), flops, lambda: _lib.lib().occ4d_pt_cross_attn16p_f32(
+        _ptr(aq), ld_aq, _ptr(qp), qs, _ptr(ap), as_, _ptr(idx), _ptr(kt), ld_kt, _ptr(vt), ld_vt,
+        _ptr(ws[0]), _ptr(ws[1]), _ptr(wstream), _ptr(o), ldo, n, kt.shape[0], k, d, divisor, sk, _stream())))
     return out
 
 

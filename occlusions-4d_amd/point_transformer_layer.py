@@ -26,6 +26,8 @@ from . import ops
 _PAIR_CHUNK = 32768      # query rows per pass (bounds the (rows*K, 2D) workspace)
 USE_FUSED_ATTENTION = True   # tests flip this to cover the unfused kernel chain as well
 USE_ATTN16 = True            # d = 416: second-generation fused attention kernel (csrc/crossattn16.hip); False = crossattn.hip
+# d = 416: third generation, two 4-wave workgroups per CU out of phase (csrc/crossattn16p.hip); off = crossattn16.hip
+USE_ATTN16P = os.environ.get('OCC4D_ATTN16P', '1') != '0'
 USE_TRUNK_KERNELS = True     # row-resident fused trunk kernels (csrc/trunk.hip) where the shapes allow; False = generic Linear
 # 'f32' (default): every GEMM exact fp32 on v_mfma_f32_32x32x2_f32.  'bf16x3': the attention-logit GEMM of the
 # fused kernel on split-bf16 MFMAs (occ4d_pt_cross_attn_bf16x3_f32); everything else unchanged.  Opt-in.
@@ -217,7 +219,7 @@ class PointTransformerLayer(nn.Module):
     # -- derived weights ---------------------------------------------------------------
     def _params_key(self, pre):
         ps = list(self.parameters()) + ([pre.weight, pre.bias] if pre is not None else [])
-        return (weights_epoch(), LOGIT_PRECISION) + tuple((p.data_ptr(), p._version) for p in ps)
+        return (weights_epoch(), LOGIT_PRECISION, USE_ATTN16P) + tuple((p.data_ptr(), p._version) for p in ps)
 
     def merged_weights(self, pre=None):
         """fp64-merged matrices of refactoring (i); `pre` is an optional nn.Linear applied to
@@ -242,8 +244,9 @@ class PointTransformerLayer(nn.Module):
             wp=(W1 @ P2).float().contiguous())
         m['wq_packed'] = trunk_pack(m['wq'])          # (2D, 416) query projection on the row-resident kernel
         if self.dim == 416 and self.pos_mlp[0].out_features == 32 and self.attn_mlp[2].weight.is_cuda:
-            m['attn16_stream'] = ops.pack_attn16_stream(self.attn_mlp[2].weight, self.attn_mlp[2].bias, m['wp'],
-                                                             self.pos_mlp[2].weight, self.pos_mlp[2].bias)
+            pack = ops.pack_attn16p_stream if USE_ATTN16P else ops.pack_attn16_stream
+            m['attn16p' if USE_ATTN16P else 'attn16_stream'] = pack(
+                self.attn_mlp[2].weight, self.attn_mlp[2].bias, m['wp'], self.pos_mlp[2].weight, self.pos_mlp[2].bias)
         m['w2_bf16x3'] = m['wp_bf16x3'] = None
         if LOGIT_PRECISION == 'bf16x3' and self.attn_mlp[2].weight.shape[1] % 32 == 0:     # (opt-in mode only)
             m['w2_bf16x3'] = ops.pack_w2_bf16x3(self.attn_mlp[2].weight)
@@ -262,7 +265,10 @@ class PointTransformerLayer(nn.Module):
                 and all(a is b for a, b in zip(self._scene[1], owners)):
             return self._scene[2]
         m = self.merged_weights(None)
-        tabs = (ops.linear(x2, m['wk']), ops.linear(x2, self.to_v.weight))
+        # third entry: the value table with pos_mlp[2].bias folded in (v_j + pe_ij = (Wv f_j + c2) + P2 r_ij), which
+        # is what the paired-workgroup kernel reads (its GEMM3 then starts from 0: no VALU instruction for the bias)
+        tabs = (ops.linear(x2, m['wk']), ops.linear(x2, self.to_v.weight),
+                ops.linear(x2, self.to_v.weight, self.pos_mlp[2].bias))
         if owner is not None:
             self._scene = (key, owners, tabs)   # holds the owners alive: their addresses cannot be recycled
         return tabs
@@ -354,11 +360,12 @@ class PointTransformerLayer(nn.Module):
             y = x if pre is None else ops.linear(x, pre.weight, pre.bias)
             m = self.merged_weights(None)
             kt, vt = ops.linear(y, m['wk']), ops.linear(y, self.to_v.weight)
+            vtc = ops.linear(y, self.to_v.weight, self.pos_mlp[2].bias) if m.get('attn16p') is not None else None
             aq_all = ops.linear(y, m['wq'], m['bq'])
             pos2 = pos
         else:
             m = self.merged_weights(pre)
-            kt, vt = self.scene_tables(x2, owner=scene_owner)
+            kt, vt, vtc = self.scene_tables(x2, owner=scene_owner)
             aq_all = None
         n = x.shape[0]
         agg = torch.empty((n, self.dim), dtype=torch.float32, device=x.device)
@@ -380,6 +387,9 @@ class PointTransformerLayer(nn.Module):
             if (self.dim in ops.FUSED_ATTN_DIMS and K <= ops.FUSED_ATTN_MAX_K
                     and self.pos_mlp[0].out_features == 32 and USE_FUSED_ATTENTION):
                 assert LOGIT_PRECISION in ('f32', 'bf16x3'), LOGIT_PRECISION
+                if LOGIT_PRECISION == 'f32' and USE_ATTN16 and USE_ATTN16P and m.get('attn16p') is not None:
+                    ops.pt_cross_attn16p(aq, pos[lo:hi], pos2, idx, kt, vtc, P1, c1, m['attn16p'], out=agg[lo:hi])
+                    continue
                 if LOGIT_PRECISION == 'f32' and USE_ATTN16 and m.get('attn16_stream') is not None:
                     ops.pt_cross_attn16(aq, pos[lo:hi], pos2, idx, kt, vt, P1, c1, m['attn16_stream'], out=agg[lo:hi])
                     continue

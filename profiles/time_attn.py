@@ -40,9 +40,18 @@ def main():
     t_old = timeit(lambda: pk.ops.pt_cross_attn(aq, qpos, apos, idx, kt, vt, P1, c1, wp, w2, b2, p2, c2, out=out_a))
     t_new = timeit(lambda: pk.ops.pt_cross_attn16(aq, qpos, apos, idx, kt, vt, P1, c1, stream, out=out_b))
     print('n = %d queries, m = %d abstract points, k = %d' % (n, m, k))
-    for name, ms in (('crossattn.hip   (32x32x2, 2 channel groups)', t_old), ('crossattn16.hip (16x16x4, row-owning waves)', t_new)):
+    rows = [('crossattn.hip   (32x32x2, 2 channel groups)', t_old), ('crossattn16.hip (16x16x4, row-owning waves)', t_new)]
+    stream_p = pk.ops.pack_attn16p_stream(w2, b2, wp, p2, c2)
+    out_c = torch.empty((n, d), device='cuda')
+    vtc = vt + c2          # the paired kernel reads the value table with pos_mlp[2].bias folded in
+    skews = [int(v) for v in os.environ.get('SKEWS', '0,2,4,6,8,12,16,24').split(',')]
+    for sk in skews:
+        t = timeit(lambda: pk.ops.pt_cross_attn16p(aq, qpos, apos, idx, kt, vtc, P1, c1, stream_p, out=out_c, skew=sk))
+        rows.append(('crossattn16p.hip (paired workgroups), skew %2d' % sk, t))
+    for name, ms in rows:
         print('%-46s %8.3f ms  %6.1f TFLOP/s executed  %.3f of fp32 MFMA peak' % (name, ms, flop / ms / 1e9, flop / ms / 1e9 / 157.3))
-    print('max |difference| between the two kernels: %.3g' % float((out_a - out_b).abs().max()))
+    print('max |difference| crossattn vs crossattn16: %.3g' % float((out_a - out_b).abs().max()))
+    print('max |difference| crossattn16 vs crossattn16p: %.3g' % float((out_b - out_c).abs().max()))
 
 
 if __name__ == '__main__':

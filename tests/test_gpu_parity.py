@@ -257,13 +257,14 @@ def test_perform_inference(pk, case):
                                           (1, 10, 416, 288), (14, 531, 288, 288), (5, 1, 416, 288),
                                           (14, 8, 416, 288), (14, 10, 416, 288), (14, 17, 416, 288), (14, 18, 416, 288),
                                           (14, 19, 416, 288), (11, 2, 416, 288), (2, 4000, 416, 288)])
-@pytest.mark.parametrize('generation', ['attn16', 'first'])
+@pytest.mark.parametrize('generation', ['attn16p', 'attn16', 'first'])
 def test_fused_attention_matches_unfused_chain(pk, k, n, dim, dim2, generation):
     """The fused kernels (9 queries x 14 rows packed per workgroup, masked slots for k < 14, ragged
-    tail for n % 9 != 0) against the unfused kernel chain on the same inputs: the 16 x 16 MFMA kernel
-    (crossattn16.hip, d = 416) and the first-generation 32 x 32 kernel (crossattn.hip, d = 288 / 416)."""
-    if generation == 'attn16' and dim != 416:
-        pytest.skip('crossattn16.hip is built for d = 416')
+    tail for n % 9 != 0) against the unfused kernel chain on the same inputs: the paired-workgroup 16 x 16
+    MFMA kernel (crossattn16p.hip, d = 416), its one-workgroup-per-CU predecessor (crossattn16.hip) and the
+    first-generation 32 x 32 kernel (crossattn.hip, d = 288 / 416)."""
+    if generation != 'first' and dim != 416:
+        pytest.skip('crossattn16*.hip are built for d = 416')
     rng = np.random.default_rng(1000 * k + n)
     m = 76
     x = rng.normal(size=(n, dim)).astype(np.float32)
@@ -276,7 +277,8 @@ def test_fused_attention_matches_unfused_chain(pk, k, n, dim, dim2, generation):
     layer.load_state_dict(sd)
     args = (dev(x)[None], dev(pos)[None], dev(x2)[None], dev(pos2)[None])
     with torch.no_grad():
-        ptl.USE_ATTN16 = generation == 'attn16'
+        ptl.USE_ATTN16 = generation != 'first'
+        old_p, ptl.USE_ATTN16P = ptl.USE_ATTN16P, generation == 'attn16p'
         try:
             fused = layer(*args)[0]
             ptl.USE_FUSED_ATTENTION = False
@@ -284,6 +286,7 @@ def test_fused_attention_matches_unfused_chain(pk, k, n, dim, dim2, generation):
         finally:
             ptl.USE_FUSED_ATTENTION = True
             ptl.USE_ATTN16 = True
+            ptl.USE_ATTN16P = old_p
     assert torch.isfinite(fused).all()
     close(fused, chain, 2e-5)
 
