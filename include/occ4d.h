@@ -272,6 +272,57 @@ int occ4d_rowlin_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const f
                      int n_out, int relu_in, const float* res, int64_t ldr, const float* zconst, const float* ztab,
                      int64_t ldz, const int32_t* zidx, const float* zw, int kz, int n, void* stream);
 
+/* Half-CU re-cut of the two kernels above (csrc/trunk4.hip): the same contracts, arithmetic and register layout, with
+ * 4-wave workgroups of 64 rows and 26 KB stages of 16 channels, so that two workgroups -- of these kernels, of
+ * occ4d_pt_cross_attn16p_f32, or of whatever the other decode stream runs -- share a CU and one's memory phases sit
+ * under the other's MFMA stream.  occ4d_rowlin4_f32 takes n_out % 16 == 0.
+ * Packed weights (floats; occ4d_trunk4_packed_floats(n_out) = (n_out / 16 + 1) * 6656 of them, the stage after the
+ * last repeats stage 0):
+ *   "rows" packing of an (n_out, 416) weight:   P[s][t * 256 + (g * 16 + r) * 4 + e] = W[16 s + r][16 t + 4 g + e]
+ *   "cols" packing of the (416, 416) second layer of a residual block:
+ *                                               P[j][nt * 256 + (g * 16 + r) * 4 + e] = W[16 nt + r][16 j + 4 g + e]
+ *   with r < 16, g < 4, e < 4, t, nt, j < 26. */
+int64_t occ4d_trunk4_packed_floats(int n_out);
+int occ4d_resblock4_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w0_packed, const float* b0,
+                        const float* w1_packed, const float* b1, const float* zconst, const float* ztab, int64_t ldz,
+                        const int32_t* zidx, const float* zw, int kz, int n, void* stream);
+int occ4d_rowlin4_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed, const float* b,
+                      int n_out, int relu_in, const float* res, int64_t ldr, const float* zconst, const float* ztab,
+                      int64_t ldz, const int32_t* zidx, const float* zw, int kz, int n, void* stream);
+
+/* Trunk chain (csrc/trunk4.hip): a short program of row-tile operations run with the (n, 416) activation RESIDENT IN
+ * REGISTERS between them -- the decoder trunk between two cross-attention layers (model/implicit.py:411-425: per block
+ * `x = x + lin_z[i](features_query)`, `x = blocks[i](x)`, then the query projection of the next PointTransformerBlock
+ * or lin_out) as one kernel instead of one kernel per layer with an HBM round trip of the activation between them.
+ *   v = x rows;  then for every op in order:
+ *     OCC4D_CHAIN_INTERP    v += zconst[zoff ..] + sum_j zw[:, j] ztab[zidx[:, j], zoff ..]   (occ4d_interp_add_f32)
+ *     OCC4D_CHAIN_RESBLOCK  v = v + W1 relu(W0 relu(v) + b0) + b1                              (occ4d_resblock4_f32)
+ *     OCC4D_CHAIN_LINEAR    dst[:, 0 .. n_cols) = W [relu](v) + b0   (flags & 1 = relu; v unchanged)
+ *     OCC4D_CHAIN_STORE     dst[:, 0 .. 416) = v
+ * wstream: the weight stages of all operations in execution order, 6656 floats each, in the packings of
+ * occ4d_resblock4_f32 / occ4d_rowlin4_f32: a RESBLOCK contributes 52 stages (W0 "rows" stage 0, W1 "cols" stage 0,
+ * W0 stage 1, ...), a LINEAR n_stages "rows" stages (n_stages even: pad with a zero stage; b0 padded to 16 * n_stages
+ * floats), plus ONE padding stage at the very end; n_stream_stages = that total.  skew as for
+ * occ4d_pt_cross_attn16p_f32.  At most OCC4D_CHAIN_MAX_OPS operations. */
+enum { OCC4D_CHAIN_INTERP = 1, OCC4D_CHAIN_RESBLOCK = 2, OCC4D_CHAIN_LINEAR = 3, OCC4D_CHAIN_STORE = 4 };
+#define OCC4D_CHAIN_MAX_OPS 12
+typedef struct occ4d_chain_op {
+  int32_t kind, n_stages, flags, n_cols;
+  const float* b0;
+  const float* b1;
+  float* dst;
+  int64_t ld_dst;
+  int32_t zoff, reserved;
+} occ4d_chain_op;
+typedef struct occ4d_chain_args {
+  const float* x; int64_t ldx;
+  const float* wstream; int64_t n_stream_stages;
+  const float* zconst; const float* ztab; int64_t ldz; const int32_t* zidx; const float* zw; int32_t kz;
+  int32_t n, n_ops, skew;
+  occ4d_chain_op ops[OCC4D_CHAIN_MAX_OPS];
+} occ4d_chain_args;
+int occ4d_trunk_chain_f32(const occ4d_chain_args* args, void* stream);
+
 /* K13 post-ops (eval/inference.py:218-243): per channel op code in `ops` (G ints):
  * 0 = identity, 1 = sigmoid, 2 = clamp to [0,1].  In place. */
 int occ4d_squash_f32(float* out, int64_t ld, int n, int g, const int32_t* ops_host, void* stream);

@@ -29,6 +29,25 @@ class LinearArgs(C.Structure):
     ]
 
 
+CHAIN_INTERP, CHAIN_RESBLOCK, CHAIN_LINEAR, CHAIN_STORE = 1, 2, 3, 4
+CHAIN_MAX_OPS = 12
+
+
+class ChainOp(C.Structure):
+    """occ4d_chain_op (include/occ4d.h)."""
+    _fields_ = [('kind', C.c_int32), ('n_stages', C.c_int32), ('flags', C.c_int32), ('n_cols', C.c_int32),
+                ('b0', C.c_void_p), ('b1', C.c_void_p), ('dst', C.c_void_p), ('ld_dst', C.c_int64),
+                ('zoff', C.c_int32), ('reserved', C.c_int32)]
+
+
+class ChainArgs(C.Structure):
+    """occ4d_chain_args (include/occ4d.h)."""
+    _fields_ = [('x', C.c_void_p), ('ldx', C.c_int64), ('wstream', C.c_void_p), ('n_stream_stages', C.c_int64),
+                ('zconst', C.c_void_p), ('ztab', C.c_void_p), ('ldz', C.c_int64), ('zidx', C.c_void_p),
+                ('zw', C.c_void_p), ('kz', C.c_int32), ('n', C.c_int32), ('n_ops', C.c_int32), ('skew', C.c_int32),
+                ('ops', ChainOp * CHAIN_MAX_OPS)]
+
+
 # name -> (restype, argtypes): every symbol include/occ4d.h declares
 SIGNATURES = {
     'occ4d_abi_version': (C.c_int, []),
@@ -73,6 +92,12 @@ SIGNATURES = {
                                      C.c_int, _s]),
     'occ4d_rowlin_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, _f, C.c_int, C.c_int, _f, C.c_int64, _f, _f,
                                    C.c_int64, _i, _f, C.c_int, C.c_int, _s]),
+    'occ4d_trunk4_packed_floats': (C.c_int64, [C.c_int]),
+    'occ4d_resblock4_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, _f, _f, _f, _f, _f, C.c_int64, _i, _f, C.c_int,
+                                      C.c_int, _s]),
+    'occ4d_rowlin4_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, _f, C.c_int, C.c_int, _f, C.c_int64, _f, _f,
+                                    C.c_int64, _i, _f, C.c_int, C.c_int, _s]),
+    'occ4d_trunk_chain_f32': (C.c_int, [C.POINTER(ChainArgs), _s]),
     'occ4d_squash_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int32), _s]),
     'occ4d_grid_points_f32': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                         C.c_float, C.c_float, _f, _s]),

@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256, 2) void cross_attn16p_kernel(const Attn16pArgs
 #ifdef OCC4D_CA16P_STAMP
   unsigned long long ts[8];
   ts[0] = __builtin_amdgcn_s_memtime();
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
   const unsigned lane16 = lane * 16;
   dma_stage_p(a.wstream, buf0, wave, lane16);
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void cross_attn16p_kernel(const Attn16pArgs
     unsigned long long* o = (unsigned long long*)(a.agg + (int64_t)(a.N + blockIdx.x) * a.ld_agg) + 10 * wave;
     for (int i = 0; i < 8; ++i) o[i] = ts[i];
     o[8] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
-    o[9] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);   // XCC_ID
+    o[9] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) | ((__builtin_amdgcn_s_memrealtime() - rt0) << 8);   // XCC_ID, 100 MHz ticks
   }
 #endif
 }

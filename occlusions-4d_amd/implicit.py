@@ -241,6 +241,68 @@ class LocalPclResnetFC(ResnetFC):
             output, penult = output[None], penult[None]
         return (output, penult)
 
+    # -- trunk chains (occ4d_trunk_chain_f32): the blocks between two cross-attention layers as one kernel -----------
+    def _chain_plan(self):
+        """Segments of the trunk for local_mode 'attention': consecutive residual blocks up to (and including the query
+        projection of) the next PointTransformerBlock, or up to lin_out; per segment the flat weight stream and the
+        stage counts.  Cached while the parameters (storage, version, weights epoch) are unchanged; None when the
+        row-resident kernels do not apply to this configuration."""
+        if not (ptl.USE_TRUNK_KERNELS and ptl.USE_TRUNK4 and ptl.USE_TRUNK_CHAIN and self.d_hidden == ops.TRUNK_WIDTH
+                and self.d_latent > 0 and all(b.shortcut is None and b.d_hidden == self.d_hidden for b in self.blocks)
+                and self.lin_out.weight.is_cuda):
+            return None
+        key = (weights_epoch(), ptl.USE_ATTN16P) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        hit = getattr(self, '_chain_cache', None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        plan, first = [], 0
+        for i in range(self.n_blocks):
+            last = i == self.n_blocks - 1
+            if i not in self.use_pt_inds and not last:
+                continue
+            blocks = list(range(first, i + 1))
+            first = i + 1
+            if 2 * len(blocks) + 2 > 12:          # (OCC4D_CHAIN_MAX_OPS)
+                return None
+            parts = [('resblock', self.blocks[j].fc_0.weight, self.blocks[j].fc_1.weight) for j in blocks]
+            seg = dict(blocks=blocks, pt=self.use_pt_inds.get(i), tail=False)
+            if seg['pt'] is not None:
+                blk = self.pt_blocks[seg['pt']]
+                m = blk.layer2.merged_weights(blk.layer1)
+                if m['wq'].shape[1] != ops.TRUNK_WIDTH:
+                    return None
+                parts.append(('linear', m['wq']))
+                seg['n_aq'], seg['bias'] = m['wq'].shape[0], m['bq']
+                plan.append(seg)
+                if last:                            # a cross-attention layer after the last block: lin_out on its own
+                    plan.append(dict(blocks=[], pt=None, tail=True))
+                    parts_tail = [('linear', self.lin_out.weight)]
+                    plan[-1]['stream'], plan[-1]['counts'] = ops.pack_chain_stream(parts_tail)
+                    plan[-1]['bias'] = ops.pad_bias(self.lin_out.bias, plan[-1]['counts'][-1])
+            else:
+                parts.append(('linear', self.lin_out.weight))
+                seg['tail'], seg['bias'] = True, self.lin_out.bias
+                plan.append(seg)
+            seg['stream'], seg['counts'] = ops.pack_chain_stream(parts)
+            seg['bias'] = ops.pad_bias(seg['bias'], seg['counts'][-1])
+        self._chain_cache = (key, plan)
+        return plan
+
+    def _run_chain(self, seg, x, interp, out_rows, aq=None):
+        """One segment on the rows of x (in place): returns x (also the penultimate activation after the tail)."""
+        H = self.d_hidden
+        prog = []
+        for j in seg['blocks']:
+            prog += [('interp', j * H), ('resblock', self.blocks[j].fc_0.bias, self.blocks[j].fc_1.bias)]
+        ns = seg['counts'][-1]
+        if seg['tail']:
+            prog += [('store', x)] if seg['blocks'] else []
+            prog.append(('linear', seg['bias'], ns, self.d_out, True, out_rows))
+        else:
+            prog += [('linear', seg['bias'], ns, seg['n_aq'], False, aq), ('store', x)]
+        ops.trunk_chain(x, seg['stream'], prog, interp=interp if seg['blocks'] else None)
+        return x
+
     def _interp(self, q, sc):
         idx, dist = ops.knn(q, sc['xyz'], self.num_local_features, metric=1, return_dist=True)
         return idx, ops.interp_weights(dist)
@@ -259,6 +321,25 @@ class LocalPclResnetFC(ResnetFC):
             # one kNN_torch (model/point_transformer_layer.py:167) serves them all
             idx_att = ops.knn(q[:, :3], xyz, self.cross_attn_neighbors, metric=0)[None] if self.use_pt_inds else None
             x = self._embed(q)
+            plan = self._chain_plan()
+            if plan is not None:
+                # the trunk between two cross-attention layers is one kernel: [x += lin_z term; block] ..., then the merged
+                # query projection of the next PointTransformerBlock (or lin_out) while the rows are still in registers
+                interp = (sc['zconst'], sc['ztab'], idx8, w8)
+                for seg in plan:
+                    aq = None
+                    if seg['pt'] is not None:
+                        aq = torch.empty((x.shape[0], seg['n_aq']), dtype=torch.float32, device=x.device)
+                    self._run_chain(seg, x, interp, out[lo:lo + _QUERY_CHUNK], aq)
+                    if seg['pt'] is not None:
+                        blk = self.pt_blocks[seg['pt']]
+                        x = blk(x[None], q[None, :, :3], x2=feats[None], p2=xyz[None], scene_owner=owner,
+                                knn_idx=idx_att, aq_pre=aq[None])[0][0]
+                if single:
+                    pen = x
+                else:
+                    pen[lo:lo + _QUERY_CHUNK] = x
+                continue
             for i in range(self.n_blocks):
                 ops.interp_add(x, sc['zconst'][i * H:(i + 1) * H], sc['ztab'][:, i * H:(i + 1) * H], idx8, w8)
                 x = self.blocks[i]._run(x, inplace=True)

@@ -28,16 +28,18 @@ class PointTransformerBlock(torch.nn.Module):
             dim2=d_hidden_abstract)
         self.layer3 = torch.nn.Linear(d_hidden, d_out)
 
-    def forward(self, x, p, x2=None, p2=None, scene_owner=None, knn_idx=None):
+    def forward(self, x, p, x2=None, p2=None, scene_owner=None, knn_idx=None, aq_pre=None):
         """x (B,N,d_in), p (B,N,3) [, x2 (B,M,E), p2 (B,M,3)] -> (z (B,N,d_out), p).
         `scene_owner` (extension, optional): tensor object identifying the abstract cloud so
         its key/value tables are computed once per scene instead of once per call.  `knn_idx` (extension, optional):
-        (B,N,num_neighbors) int32 result of kNN_torch(p, p2) when the caller already has it."""
+        (B,N,num_neighbors) int32 result of kNN_torch(p, p2) when the caller already has it.  `aq_pre` (extension,
+        optional): (B,N,2 d_hidden) merged query projection of layer1 + layer2 when the caller already has it."""
         assert x.shape[:2] == p.shape[:2]
         if x2 is not None:
             assert x2.shape[:2] == p2.shape[:2]
         # layer1 is folded into the query-side merged matrix (cross) or applied once (self)
-        agg = self.layer2._forward(x, p, x2, p2, pre=self.layer1, scene_owner=scene_owner, knn_idx=knn_idx)
+        agg = self.layer2._forward(x, p, x2, p2, pre=self.layer1, scene_owner=scene_owner, knn_idx=knn_idx,
+                                   aq_pre=aq_pre)
         if needs_grad(self, x, x2):
             z = ops.stack_batch([autograd.linear(agg[b], self.layer3, residual=x[b]) for b in range(x.shape[0])])
         else:

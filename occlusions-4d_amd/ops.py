@@ -542,6 +542,25 @@ def pack_trunk_cols(w):
     return torch.cat([p, p[:1]], dim=0).contiguous()
 
 
+def pack_trunk4_rows(w):
+    """(n_out, 416) weight -> stage-packed stream of the half-CU trunk kernels (include/occ4d.h, csrc/trunk4.hip):
+    per 16-output stage the LDS image of its 26 MFMA fragments; one extra stage (a copy of stage 0) at the end."""
+    w = _dev(w.detach(), name='w')
+    n_out, k = w.shape
+    assert k == TRUNK_WIDTH and n_out % 16 == 0, 'pack_trunk4_rows: (%d, %d) is not (16 s, %d)' % (n_out, k, TRUNK_WIDTH)
+    p = w.reshape(n_out // 16, 16, 26, 4, 4).permute(0, 2, 3, 1, 4).reshape(n_out // 16, -1)      # [s][t][g][r][e]
+    return torch.cat([p, p[:1]], dim=0).contiguous()
+
+
+def pack_trunk4_cols(w):
+    """(416, 416) second-layer weight of a residual block -> "cols" packing of csrc/trunk4.hip: stage j holds the 16
+    input columns 16 j .. 16 j + 15 of every output row."""
+    w = _dev(w.detach(), name='w')
+    assert tuple(w.shape) == (TRUNK_WIDTH, TRUNK_WIDTH)
+    p = w.reshape(26, 16, 26, 4, 4).permute(2, 0, 3, 1, 4).reshape(26, -1)                          # [j][nt][g][r][e]
+    return torch.cat([p, p[:1]], dim=0).contiguous()
+
+
 def _interp_args(interp, n):
     """(zconst (416), ztab (M, >= 416) row view, idx (n, k) int32, w (n, k)) -> ctypes argument tuple."""
     if interp is None:
@@ -567,7 +586,12 @@ def resblock(x, w0_packed, b0, w1_packed, b1, out=None, interp=None):
     assert o is out and o.shape == (n, d)
     ia = _interp_args(interp, n)
     b0c, b1c = _dev(b0).contiguous(), _dev(b1).contiguous()
-    _lib.check(_launch('resblock', dict(n=n), 4.0 * n * d * d, lambda: _lib.lib().occ4d_resblock_f32(
+    # the packing tells the kernel generation: 27 stages of 6656 floats = csrc/trunk4.hip, 14 of 13312 = csrc/trunk.hip
+    half_cu = w0_packed is not None and w0_packed.numel() == 27 * 6656
+    assert w0_packed is None or w1_packed is None or (
+        w1_packed.numel() == w0_packed.numel() and (half_cu or w0_packed.numel() == 14 * 13312))
+    fn = _lib.lib().occ4d_resblock4_f32 if half_cu else _lib.lib().occ4d_resblock_f32
+    _lib.check(_launch('resblock', dict(n=n), 4.0 * n * d * d, lambda: fn(
         _ptr(xx), ldx, _ptr(o), ldo, _ptr(w0_packed), _ptr(b0c), _ptr(w1_packed), _ptr(b1c),
         ia[0], ia[1], ia[2], ia[3], ia[4], ia[5], n, _stream())))
     return out
@@ -577,7 +601,8 @@ def rowlin(x, w_packed, b, n_out, relu_in=False, residual=None, out=None, interp
     """out (n, n_out) = [residual +] W [relu](x) + b [+ interpolation term], K = 416 (occ4d_rowlin_f32)."""
     xx, ldx = _rows(_dev(x, name='x'), 'x')
     n, d = xx.shape
-    assert d == TRUNK_WIDTH and n_out % 32 == 0 and w_packed.numel() == (n_out // 32 + 1) * 13312
+    half_cu = n_out % 16 == 0 and w_packed.numel() == (n_out // 16 + 1) * 6656      # csrc/trunk4.hip packing
+    assert d == TRUNK_WIDTH and (half_cu or (n_out % 32 == 0 and w_packed.numel() == (n_out // 32 + 1) * 13312))
     if out is None:
         out = torch.empty((n, n_out), dtype=torch.float32, device=x.device)
     o, ldo = _rows(_dev(out, name='out'), 'out')
@@ -590,10 +615,99 @@ def rowlin(x, w_packed, b, n_out, relu_in=False, residual=None, out=None, interp
     assert interp is None or n_out == TRUNK_WIDTH
     bc = _dev(b).contiguous()
     assert bc.numel() == n_out
-    _lib.check(_launch('rowlin', dict(n=n, n_out=n_out), 2.0 * n * d * n_out, lambda: _lib.lib().occ4d_rowlin_f32(
+    fn = _lib.lib().occ4d_rowlin4_f32 if half_cu else _lib.lib().occ4d_rowlin_f32
+    _lib.check(_launch('rowlin', dict(n=n, n_out=n_out), 2.0 * n * d * n_out, lambda: fn(
         _ptr(xx), ldx, _ptr(o), ldo, _ptr(w_packed), _ptr(bc), n_out, int(relu_in), _ptr(rr), ldr,
         ia[0], ia[1], ia[2], ia[3], ia[4], ia[5], n, _stream())))
     return out
+
+
+CHAIN_SKEW = int(os.environ.get('OCC4D_CHAIN_SKEW', '2'))   # phase offset of a CU's two workgroups (units of s_sleep(127))
+
+
+def pack_chain_stream(parts):
+    """Flat weight stream of occ4d_trunk_chain_f32 (include/occ4d.h): the 26 KB stages of every operation in execution
+    order.  parts: ('resblock', W0 (416, 416), W1 (416, 416)) -> 52 stages, W0 "rows" / W1 "cols" stages interleaved;
+    ('linear', W (n_out, 416)) -> "rows" stages of W zero-padded to an even stage count.  Returns (stream
+    (S + 1, 6656), [stage count of each part])."""
+    chunks, counts = [], []
+    for part in parts:
+        if part[0] == 'resblock':
+            a = pack_trunk4_rows(part[1])[:-1]              # (26, 6656)
+            b = pack_trunk4_cols(part[2])[:-1]
+            chunks.append(torch.stack([a, b], dim=1).reshape(52, -1))
+            counts.append(52)
+        elif part[0] == 'linear':
+            w = _dev(part[1].detach(), name='w')
+            n_out = w.shape[0]
+            n_pad = 32 * ((n_out + 31) // 32)
+            if n_pad != n_out:
+                w = torch.cat([w, w.new_zeros((n_pad - n_out, w.shape[1]))], dim=0)
+            chunks.append(pack_trunk4_rows(w)[:-1])
+            counts.append(n_pad // 16)
+        else:
+            raise ValueError(part[0])
+    flat = torch.cat(chunks, dim=0)
+    return torch.cat([flat, flat[:1]], dim=0).contiguous(), counts
+
+
+def pad_bias(b, n_stages):
+    """Bias of a chain Linear padded with zeros to 16 * n_stages floats."""
+    b = _dev(b.detach(), name='bias').contiguous()
+    n = 16 * n_stages
+    return b if b.numel() == n else torch.cat([b, b.new_zeros((n - b.numel(),))])
+
+
+def trunk_chain(x, stream, program, interp=None, skew=None):
+    """One launch of occ4d_trunk_chain_f32 on the rows of x (n, 416).  program: list of
+    ('interp', zoff) | ('resblock', b0, b1) | ('linear', b0_padded, n_stages, n_cols, relu, dst) | ('store', dst);
+    interp = (zconst (>= zoff + 416), ztab (M, >= zoff + 416) rows, idx (n, k) int32, w (n, k)) for the 'interp' ops;
+    stream / stage counts from pack_chain_stream in the same order."""
+    xx, ldx = _rows(_dev(x, name='x'), 'x')
+    n, d = xx.shape
+    assert d == TRUNK_WIDTH and 1 <= len(program) <= _lib.CHAIN_MAX_OPS and stream.is_contiguous()
+    args = _lib.ChainArgs()
+    args.x, args.ldx, args.wstream, args.n_stream_stages = _ptr(xx), ldx, _ptr(stream), stream.shape[0]
+    keep = [xx, stream]
+    if interp is not None:
+        zconst, ztab, idx, w = interp
+        zt, ldz = _rows(_dev(ztab, name='ztab'), 'ztab')
+        idx = _dev(idx, torch.int32, 'idx')
+        w = _dev(w, name='w')
+        zc = _dev(zconst).contiguous()
+        assert idx.is_contiguous() and w.is_contiguous() and idx.shape == w.shape and idx.shape[0] == n
+        args.zconst, args.ztab, args.ldz, args.zidx, args.zw, args.kz = _ptr(zc), _ptr(zt), ldz, _ptr(idx), _ptr(w), idx.shape[1]
+        keep += [zc, zt, idx, w]
+    flops = 0.0
+    for i, op in enumerate(program):
+        o = args.ops[i]
+        if op[0] == 'interp':
+            assert interp is not None
+            o.kind, o.zoff = _lib.CHAIN_INTERP, int(op[1])
+        elif op[0] == 'resblock':
+            b0, b1 = _dev(op[1]).contiguous(), _dev(op[2]).contiguous()
+            o.kind, o.b0, o.b1 = _lib.CHAIN_RESBLOCK, _ptr(b0), _ptr(b1)
+            keep += [b0, b1]
+            flops += 4.0 * n * d * d
+        elif op[0] == 'linear':
+            _, b0, n_stages, n_cols, relu, dst = op
+            dd, ldd = _rows(_dev(dst, name='dst'), 'dst')
+            assert dd is dst and dst.shape == (n, n_cols) and b0.numel() == 16 * n_stages
+            o.kind, o.b0, o.n_stages, o.n_cols, o.flags = _lib.CHAIN_LINEAR, _ptr(b0), int(n_stages), int(n_cols), int(bool(relu))
+            o.dst, o.ld_dst = _ptr(dd), ldd
+            keep += [b0, dd]
+            flops += 2.0 * n * d * n_cols
+        elif op[0] == 'store':
+            dd, ldd = _rows(_dev(op[1], name='dst'), 'dst')
+            assert dd is op[1] and dd.shape == (n, d)
+            o.kind, o.dst, o.ld_dst = _lib.CHAIN_STORE, _ptr(dd), ldd
+            keep.append(dd)
+        else:
+            raise ValueError(op[0])
+    args.n, args.n_ops, args.skew = n, len(program), CHAIN_SKEW if skew is None else int(skew)
+    _lib.check(_launch('trunk_chain', dict(n=n, ops=len(program)), flops,
+                       lambda: _lib.lib().occ4d_trunk_chain_f32(C.byref(args), _stream())))
+    return keep
 
 
 def squash(out, ops):

@@ -28,7 +28,15 @@ USE_FUSED_ATTENTION = True   # tests flip this to cover the unfused kernel chain
 USE_ATTN16 = True            # d = 416: second-generation fused attention kernel (csrc/crossattn16.hip); False = crossattn.hip
 # d = 416: third generation, two 4-wave workgroups per CU out of phase (csrc/crossattn16p.hip); off = crossattn16.hip
 USE_ATTN16P = os.environ.get('OCC4D_ATTN16P', '1') != '0'
-USE_TRUNK_KERNELS = True     # row-resident fused trunk kernels (csrc/trunk.hip) where the shapes allow; False = generic Linear
+USE_TRUNK_KERNELS = True     # row-resident fused trunk kernels (csrc/trunk*.hip) where the shapes allow; False = generic Linear
+# Opt-in variants, both measured SLOWER end to end than the default (csrc/trunk.hip, one 8-wave workgroup per CU) and
+# kept as tested alternatives (bench.py, 20 steps, 2 decode streams: default 122.5-122.8 ms / step; OCC4D_TRUNK4=1
+# 123.7; OCC4D_TRUNK4=1 OCC4D_TRUNK_CHAIN=1 123.8-124.4):
+# half-CU re-cut of the trunk kernels (csrc/trunk4.hip: 4-wave workgroups, two per CU)
+USE_TRUNK4 = os.environ.get('OCC4D_TRUNK4', '0') != '0'
+# decoder trunk between two cross-attention layers as ONE kernel with the activation resident in registers
+# (occ4d_trunk_chain_f32, csrc/trunk4.hip; needs USE_TRUNK4); off = one kernel per layer
+USE_TRUNK_CHAIN = os.environ.get('OCC4D_TRUNK_CHAIN', '0') != '0'
 # 'f32' (default): every GEMM exact fp32 on v_mfma_f32_32x32x2_f32.  'bf16x3': the attention-logit GEMM of the
 # fused kernel on split-bf16 MFMAs (occ4d_pt_cross_attn_bf16x3_f32); everything else unchanged.  Opt-in.
 LOGIT_PRECISION = os.environ.get('OCC4D_LOGIT_PRECISION', 'f32')
@@ -58,11 +66,14 @@ def trunk_pack(weight, kind='rows'):
         return None
     if kind == 'cols' and weight.shape[0] != ops.TRUNK_WIDTH:
         return None
-    key = (weights_epoch(), weight.data_ptr(), weight._version, kind)
+    key = (weights_epoch(), weight.data_ptr(), weight._version, kind, USE_TRUNK4)
     hit = getattr(weight, '_occ4d_trunk_pack', None)
     if hit is not None and hit[0] == key:
         return hit[1]
-    packed = ops.pack_trunk_rows(weight) if kind == 'rows' else ops.pack_trunk_cols(weight)
+    if USE_TRUNK4:
+        packed = ops.pack_trunk4_rows(weight) if kind == 'rows' else ops.pack_trunk4_cols(weight)
+    else:
+        packed = ops.pack_trunk_rows(weight) if kind == 'rows' else ops.pack_trunk_cols(weight)
     weight._occ4d_trunk_pack = (key, packed)
     return packed
 
@@ -219,7 +230,7 @@ class PointTransformerLayer(nn.Module):
     # -- derived weights ---------------------------------------------------------------
     def _params_key(self, pre):
         ps = list(self.parameters()) + ([pre.weight, pre.bias] if pre is not None else [])
-        return (weights_epoch(), LOGIT_PRECISION, USE_ATTN16P) + tuple((p.data_ptr(), p._version) for p in ps)
+        return (weights_epoch(), LOGIT_PRECISION, USE_ATTN16P, USE_TRUNK4) + tuple((p.data_ptr(), p._version) for p in ps)
 
     def merged_weights(self, pre=None):
         """fp64-merged matrices of refactoring (i); `pre` is an optional nn.Linear applied to
@@ -278,7 +289,7 @@ class PointTransformerLayer(nn.Module):
         """x (B,N,D), pos (B,N,3) [, x2 (B,M,D2), pos2 (B,M,3)] -> agg (B,N,D)."""
         return self._forward(x, pos, x2, pos2, pre=None, scene_owner=None)
 
-    def _forward(self, x, pos, x2, pos2, pre, scene_owner, knn_idx=None):
+    def _forward(self, x, pos, x2, pos2, pre, scene_owner, knn_idx=None, aq_pre=None):
         if needs_grad(self, x, x2) or (pre is not None and needs_grad(pre)):
             out = []
             for b in range(x.shape[0]):
@@ -304,7 +315,8 @@ class PointTransformerLayer(nn.Module):
             xb2 = None if x2 is None else x2[b]
             pb2 = None if pos2 is None else pos2[b]
             out.append(self._forward_one(x[b], pos[b], xb2, pb2, pre, scene_owner,
-                                         None if knn_idx is None else knn_idx[b]))
+                                         None if knn_idx is None else knn_idx[b],
+                                         None if aq_pre is None else aq_pre[b]))
         return ops.stack_batch(out)
 
     def forward_train_merged(self, x, pos, x2, pos2, idx=None):
@@ -353,7 +365,9 @@ class PointTransformerLayer(nn.Module):
         logits = autograd.linear(h, self.attn_mlp[2])
         return autograd.SoftmaxAggFn.apply(logits, vf, pe, idx)
 
-    def _forward_one(self, x, pos, x2, pos2, pre, scene_owner, knn_idx=None):
+    def _forward_one(self, x, pos, x2, pos2, pre, scene_owner, knn_idx=None, aq_pre=None):
+        """`aq_pre` (n, 2D): the merged query projection (W1 Wq L1) x + bias when the caller already has it (the decoder's
+        trunk chain writes it while the activation is still in registers)."""
         K = self.num_neighbors
         if x2 is None:
             # self-attention: queries, keys and values all come from the (post-`pre`) features
@@ -378,7 +392,9 @@ class PointTransformerLayer(nn.Module):
                 idx = knn_idx[lo:hi]
             else:
                 idx = ops.knn(pos[lo:hi], pos2, K, metric=0)                    # (c,K) int32
-            if aq_all is not None:
+            if aq_pre is not None:
+                aq = aq_pre[lo:hi]
+            elif aq_all is not None:
                 aq = aq_all[lo:hi]
             elif m.get('wq_packed') is not None and USE_TRUNK_KERNELS:
                 aq = ops.rowlin(x[lo:hi], m['wq_packed'], m['bq'], m['wq'].shape[0])

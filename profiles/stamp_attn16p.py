@@ -56,6 +56,7 @@ def main():
     ts = raw[:, :, :8].astype(np.int64)
     hw = raw[:, :, 8].astype(np.int64)
     xcc = raw[:, :, 9].astype(np.int64) & 15
+    rt = (raw[:, :, 9].astype(np.int64) >> 8).astype(np.float64)      # s_memrealtime (100 MHz) ticks of the workgroup
     t0 = ts[:, :, 0].min()
     ts = ts - t0
     print('kernel %.3f ms, skew %d; span of the stamps %.0f cycles' % (e0.elapsed_time(e1), skew, ts[:, :, 7].max()))
@@ -66,6 +67,7 @@ def main():
     for nm, sg in zip(names, seg):
         print('  %-14s mean %9.0f  (%.1f %% of a workgroup)  first round %9.0f  later rounds %9.0f'
               % (nm, sg.mean(), 100 * sg.mean() / tot.mean(), sg[:512].mean(), sg[512:].mean()))
+    print('  shader clock: %.0f cycles in %.1f us of s_memrealtime -> %.3f GHz' % (tot.mean(), rt.mean() / 100.0, tot.mean() / (rt.mean() * 10.0)))
     print('  workgroup total mean %.0f cycles; ideal MFMA time of a workgroup sharing its SIMDs with one other: '
           '2 passes x 6032 MFMAs x 32 cycles x 2 = %d' % (tot.mean(), 2 * 6032 * 64))
     wave_id, simd, cu, sh, se = hw & 15, (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7

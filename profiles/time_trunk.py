@@ -39,6 +39,8 @@ def main():
     w8 = torch.from_numpy(rng.uniform(size=(n, 8)).astype(np.float32)).cuda()
     p0, p1, pq = pk.ops.pack_trunk_rows(ws[0]), pk.ops.pack_trunk_cols(ws[1]), pk.ops.pack_trunk_rows(wq)
     p3 = pk.ops.pack_trunk_rows(ws[1])
+    h0, h1, hq, h3 = (pk.ops.pack_trunk4_rows(ws[0]), pk.ops.pack_trunk4_cols(ws[1]), pk.ops.pack_trunk4_rows(wq),
+                      pk.ops.pack_trunk4_rows(ws[1]))
     interp = (zc[H:2 * H], ztab[:, H:2 * H], idx, w8)
     y = torch.empty_like(x)
     aq = torch.empty((n, 2 * H), device='cuda')
@@ -64,6 +66,12 @@ def main():
         ('rowlin 416 -> 416 + residual', timeit(lambda: pk.ops.rowlin(x, p3, bs[1], H, residual=y, out=y)), flop / 2),
         ('rowlin 416 -> 416 + residual + interpolation term',
          timeit(lambda: pk.ops.rowlin(x, p3, bs[1], H, residual=y, out=y, interp=interp)), flop / 2),
+        ('HALF-CU resblock fused', timeit(lambda: pk.ops.resblock(x, h0, bs[0], h1, bs[1], out=y)), flop),
+        ('HALF-CU resblock fused + interpolation term', timeit(lambda: pk.ops.resblock(x, h0, bs[0], h1, bs[1], out=y, interp=interp)), flop),
+        ('HALF-CU rowlin 416 -> 832', timeit(lambda: pk.ops.rowlin(x, hq, bq, 2 * H, out=aq)), flop),
+        ('HALF-CU rowlin 416 -> 416 + residual', timeit(lambda: pk.ops.rowlin(x, h3, bs[1], H, residual=y, out=y)), flop / 2),
+        ('HALF-CU rowlin 416 -> 416 + residual + interpolation term',
+         timeit(lambda: pk.ops.rowlin(x, h3, bs[1], H, residual=y, out=y, interp=interp)), flop / 2),
         ('interp_add alone', timeit(lambda: pk.ops.interp_add(y, interp[0], interp[1], idx, w8)), 0.0),
     ]
     print('rows = %d' % n)
@@ -71,5 +79,51 @@ def main():
         print('%-52s %9.1f us  %7.1f TFLOP/s  %5.3f of fp32 MFMA peak' % (name, us, fl / us / 1e6, fl / us / 1e6 / 157.3))
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and not (len(sys.argv) > 1 and sys.argv[1] == 'chain'):
     main()
+
+
+def chain_main():
+    """The trunk chain kernel against the per-layer kernels it replaces: python profiles/time_trunk.py chain [rows]"""
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 32256
+    rng = np.random.default_rng(0)
+    T = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32)).cuda()   # noqa: E731
+    x = T(rng.normal(size=(n, H)))
+    blocks = [((T(0.05 * rng.normal(size=(H, H))), T(0.1 * rng.normal(size=(H,)))),
+               (T(0.05 * rng.normal(size=(H, H))), T(0.1 * rng.normal(size=(H,))))) for _ in range(3)]
+    wq, bq = T(0.05 * rng.normal(size=(2 * H, H))), T(0.1 * rng.normal(size=(2 * H,)))
+    ztab, zc = T(rng.normal(size=(531, 6 * H))), T(rng.normal(size=(6 * H,)))
+    idx = torch.from_numpy(rng.integers(0, 531, size=(n, 8)).astype(np.int32)).cuda()
+    w8 = T(rng.uniform(size=(n, 8)))
+    aq = torch.empty((n, 2 * H), device='cuda')
+    packs = [(pk.ops.pack_trunk4_rows(b[0][0]), pk.ops.pack_trunk4_cols(b[1][0])) for b in blocks]
+    pq = pk.ops.pack_trunk4_rows(wq)
+
+    def separate(nb, with_interp=True):
+        for i in range(nb):
+            if with_interp:
+                pk.ops.interp_add(x, zc[i * H:(i + 1) * H], ztab[:, i * H:(i + 1) * H], idx, w8)
+            pk.ops.resblock(x, packs[i][0], blocks[i][0][1], packs[i][1], blocks[i][1][1], out=x)
+        pk.ops.rowlin(x, pq, bq, 2 * H, out=aq)
+
+    print('rows = %d' % n)
+    for nb in (1, 2, 3):
+        stream, counts = pk.ops.pack_chain_stream([('resblock', blocks[i][0][0], blocks[i][1][0]) for i in range(nb)] + [('linear', wq)])
+        bqp = pk.ops.pad_bias(bq, counts[-1])
+        for with_interp in (True, False):
+            prog = []
+            for i in range(nb):
+                prog += ([('interp', i * H)] if with_interp else []) + [('resblock', blocks[i][0][1], blocks[i][1][1])]
+            prog += [('linear', bqp, counts[-1], 2 * H, False, aq), ('store', x)]
+            flop = (4.0 * nb + 4.0) * n * H * H
+            for skew in (0, 2, 4, 8):
+                us = timeit(lambda: pk.ops.trunk_chain(x, stream, prog, interp=(zc, ztab, idx, w8) if with_interp else None, skew=skew))
+                print('chain %d x [%sresblock] + linear 832, skew %d: %8.1f us  %.3f of fp32 MFMA peak' % (
+                    nb, 'interp + ' if with_interp else '', skew, us, flop / us / 1e6 / 157.3))
+            us = timeit(lambda: separate(nb, with_interp))
+            print('separate kernels (%d x [%sresblock4] + rowlin4 832):      %8.1f us  %.3f of fp32 MFMA peak' % (
+                nb, 'interp_add + ' if with_interp else '', us, flop / us / 1e6 / 157.3))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'chain':
+    chain_main()

@@ -194,6 +194,43 @@ def test_decoder(pk, case):
     assert out_b.shape == (1,) + tuple(out.shape) and torch.equal(out_b[0], out)
 
 
+@pytest.mark.parametrize('variant', ['trunk4', 'trunk4+chain', 'attn16', 'generic_trunk'])
+@pytest.mark.parametrize('case', gc.DEC_CASES, ids=lambda c: c['name'])
+def test_decoder_kernel_variants(pk, case, variant):
+    """The opt-in / fallback kernel selections of the decoder against the same golden vectors (G8): half-CU trunk kernels
+    (csrc/trunk4.hip), the trunk chain kernel (occ4d_trunk_chain_f32), the second-generation attention kernel
+    (csrc/crossattn16.hip) and the generic Linear kernels in place of the row-resident ones."""
+    ptl = pk.point_transformer_layer
+    old = (ptl.USE_TRUNK4, ptl.USE_TRUNK_CHAIN, ptl.USE_ATTN16P, ptl.USE_TRUNK_KERNELS)
+    ptl.USE_TRUNK4 = variant.startswith('trunk4')
+    ptl.USE_TRUNK_CHAIN = variant == 'trunk4+chain'
+    ptl.USE_ATTN16P = variant != 'attn16'
+    ptl.USE_TRUNK_KERNELS = variant != 'generic_trunk'
+    try:
+        q, abstract, fglob, ia, sd = gc.dec_inputs(case)
+        net = pk.implicit.LocalPclResnetFC(**ia).cuda().eval()
+        net.load_state_dict(sd)
+        launches = []
+
+        class Spy:                       # (the hook bench.py's roofline leg uses: ops.set_kernel_timer)
+            @staticmethod
+            def want(name, **shape):
+                launches.append(name)
+                return False
+        pk.ops.set_kernel_timer(Spy)
+        with torch.no_grad():
+            out, pen = net(dev(q), dev(abstract), dev(fglob), None)
+    finally:
+        pk.ops.set_kernel_timer(None)
+        (ptl.USE_TRUNK4, ptl.USE_TRUNK_CHAIN, ptl.USE_ATTN16P, ptl.USE_TRUNK_KERNELS) = old
+    g = load_golden('g8_dec_' + case['name'])
+    close(out, g['output'])
+    close(pen[:, ::8], g['penult'])
+    if ia.get('local_mode', 'attention') == 'attention' and ia.get('d_hidden') == 416:
+        assert ('trunk_chain' in launches) == (variant == 'trunk4+chain')
+        assert ('resblock' in launches) == (variant in ('trunk4', 'attn16'))
+
+
 def test_decoder_batch_split_invariance(pk):
     """A query's result must not depend on which mini-batch it travels in (beyond fp32 rounding)."""
     case = gc.DEC_CASES[1]

@@ -47,9 +47,36 @@ def test_packing_layouts():
     assert pk._lib.lib().occ4d_trunk_packed_floats(416) == p[:14].size and pk._lib.lib().occ4d_trunk_width() == H
 
 
-@pytest.mark.parametrize('n', [1, 15, 16, 17, 129, 1000, 4099])
+def test_packing_layouts_half_cu():
+    rng = np.random.default_rng(0)
+    w = torch.from_numpy(rng.normal(size=(832, H)).astype(np.float32)).cuda()
+    p = pk.ops.pack_trunk4_rows(w).cpu().numpy().reshape(53, 26, 64, 4)
+    wn = w.cpu().numpy()
+    for (s, t, g, r, e) in [(0, 0, 0, 0, 0), (7, 25, 3, 15, 3), (51, 7, 2, 9, 1), (23, 13, 1, 4, 2)]:
+        assert p[s, t, g * 16 + r, e] == wn[16 * s + r, 16 * t + 4 * g + e]
+    assert np.array_equal(p[52], p[0])
+    w1 = torch.from_numpy(rng.normal(size=(H, H)).astype(np.float32)).cuda()
+    q = pk.ops.pack_trunk4_cols(w1).cpu().numpy().reshape(27, 26, 64, 4)
+    w1n = w1.cpu().numpy()
+    for (j, nt, g, r, e) in [(0, 0, 0, 0, 0), (25, 25, 3, 15, 3), (11, 13, 2, 7, 1)]:
+        assert q[j, nt, g * 16 + r, e] == w1n[16 * nt + r, 16 * j + 4 * g + e]
+    assert pk._lib.lib().occ4d_trunk4_packed_floats(416) == q.size
+
+
+GENERATIONS = {'half_cu': ('pack_trunk4_rows', 'pack_trunk4_cols'), 'full_cu': ('pack_trunk_rows', 'pack_trunk_cols')}
+
+
+@pytest.fixture(params=sorted(GENERATIONS))
+def packers(request):
+    """(rows packer, cols packer) of csrc/trunk4.hip (4-wave workgroups, two per CU) and of csrc/trunk.hip"""
+    rows, cols = GENERATIONS[request.param]
+    return getattr(pk.ops, rows), getattr(pk.ops, cols)
+
+
+@pytest.mark.parametrize('n', [1, 15, 16, 17, 63, 64, 65, 129, 1000, 4099])
 @pytest.mark.parametrize('with_interp', [False, True])
-def test_resblock_matches_fp64(n, with_interp):
+def test_resblock_matches_fp64(n, with_interp, packers):
+    pack_rows, pack_cols = packers
     rng = np.random.default_rng(n + 7 * with_interp)
     x = torch.from_numpy(rng.normal(size=(n, H)).astype(np.float32)).cuda()
     w0, b0 = _weights(rng, H)
@@ -62,11 +89,11 @@ def test_resblock_matches_fp64(n, with_interp):
     xd = x.double()
     hd = torch.relu(xd) @ w0.double().T + b0.double()
     want = xd + torch.relu(hd) @ w1.double().T + b1.double() + extra
-    got = pk.ops.resblock(x, pk.ops.pack_trunk_rows(w0), b0, pk.ops.pack_trunk_cols(w1), b1, interp=interp)
+    got = pk.ops.resblock(x, pack_rows(w0), b0, pack_cols(w1), b1, interp=interp)
     assert float((got.double() - want).abs().max()) < 2e-5
     # in place, and identical to the out-of-place result
     x2 = x.clone()
-    pk.ops.resblock(x2, pk.ops.pack_trunk_rows(w0), b0, pk.ops.pack_trunk_cols(w1), b1, out=x2, interp=interp)
+    pk.ops.resblock(x2, pack_rows(w0), b0, pack_cols(w1), b1, out=x2, interp=interp)
     assert torch.equal(x2, got)
     # the generic chain it replaces agrees to fp32 rounding
     h = pk.ops.linear(x, w0, b0, relu_in=True)
@@ -79,7 +106,8 @@ def test_resblock_matches_fp64(n, with_interp):
 @pytest.mark.parametrize('n', [1, 16, 250, 3000])
 @pytest.mark.parametrize('cfg', [dict(n_out=832), dict(n_out=416, relu_in=True), dict(n_out=416, residual=True),
                                  dict(n_out=416, residual=True, interp=True), dict(n_out=32)])
-def test_rowlin_matches_fp64(n, cfg):
+def test_rowlin_matches_fp64(n, cfg, packers):
+    pack_rows = packers[0]
     rng = np.random.default_rng(n + cfg['n_out'])
     x = torch.from_numpy(rng.normal(size=(n, H)).astype(np.float32)).cuda()
     w, b = _weights(rng, cfg['n_out'])
@@ -94,7 +122,7 @@ def test_rowlin_matches_fp64(n, cfg):
         interp = (zconst[H:2 * H], ztab[:, H:2 * H], idx, wi)
         want = want + _interp_ref(ztab, zconst, idx, wi, 1)
     out = res.clone() if res is not None else None           # res aliases out (x += layer3(agg) in place)
-    got = pk.ops.rowlin(x, pk.ops.pack_trunk_rows(w), b, cfg['n_out'], relu_in=bool(cfg.get('relu_in')),
+    got = pk.ops.rowlin(x, pack_rows(w), b, cfg['n_out'], relu_in=bool(cfg.get('relu_in')),
                         residual=out, out=out, interp=interp)
     assert float((got.double() - want).abs().max()) < 2e-5
 
@@ -120,3 +148,78 @@ def test_empty_batch():
     x = torch.zeros((0, H), device='cuda')
     assert pk.ops.resblock(x, pk.ops.pack_trunk_rows(w0), b0, pk.ops.pack_trunk_cols(w0), b0).shape == (0, H)
     assert pk.ops.rowlin(x, pk.ops.pack_trunk_rows(w0), b0, H).shape == (0, H)
+    assert pk.ops.resblock(x, pk.ops.pack_trunk4_rows(w0), b0, pk.ops.pack_trunk4_cols(w0), b0).shape == (0, H)
+    assert pk.ops.rowlin(x, pk.ops.pack_trunk4_rows(w0), b0, H).shape == (0, H)
+    rc = pk._lib.lib().occ4d_rowlin4_f32(None, 416, None, 416, None, None, 416, 0, None, 0, None, None, 0, None, None, 0, 8, None)
+    assert rc == pk._lib.EINVAL
+
+
+@pytest.mark.parametrize('n', [1, 63, 64, 65, 700, 4099])
+@pytest.mark.parametrize('g_out', [5, 18])
+def test_trunk_chain_matches_fp64(n, g_out):
+    """occ4d_trunk_chain_f32: [interp -> resblock] x 3 -> Linear 416 -> 832 to memory -> store, and
+    interp -> resblock -> store -> relu Linear 416 -> G (G not a multiple of 4: element-wise stores), against fp64 torch
+    and against the one-kernel-per-layer path on the same inputs."""
+    rng = np.random.default_rng(n + g_out)
+    x = torch.from_numpy(rng.normal(size=(n, H)).astype(np.float32)).cuda()
+    blocks = [(_weights(rng, H), _weights(rng, H)) for _ in range(4)]
+    wq, bq = _weights(rng, 2 * H)
+    wo, bo = _weights(rng, g_out)
+    ztab, zconst, idx, w = _interp(rng, n)
+    # --- fp64 reference
+    v = x.double()
+    for i in range(3):
+        v = v + _interp_ref(ztab, zconst, idx, w, i)
+        (w0, b0), (w1, b1) = blocks[i]
+        v = v + torch.relu(torch.relu(v) @ w0.double().T + b0.double()) @ w1.double().T + b1.double()
+    aq_want = v @ wq.double().T + bq.double()
+    x3_want = v
+    v = v + _interp_ref(ztab, zconst, idx, w, 3)
+    (w0, b0), (w1, b1) = blocks[3]
+    v = v + torch.relu(torch.relu(v) @ w0.double().T + b0.double()) @ w1.double().T + b1.double()
+    out_want = torch.relu(v) @ wo.double().T + bo.double()
+    # --- chain 1
+    stream, counts = pk.ops.pack_chain_stream([('resblock', blocks[i][0][0], blocks[i][1][0]) for i in range(3)] + [('linear', wq)])
+    assert counts == [52, 52, 52, 52] and stream.shape == (209, 6656)
+    aq = torch.empty((n, 2 * H), device='cuda')
+    xs = x.clone()
+    prog = []
+    for i in range(3):
+        prog += [('interp', i * H), ('resblock', blocks[i][0][1], blocks[i][1][1])]
+    prog += [('linear', pk.ops.pad_bias(bq, counts[3]), counts[3], 2 * H, False, aq), ('store', xs)]
+    pk.ops.trunk_chain(xs, stream, prog, interp=(zconst, ztab, idx, w))
+    assert float((xs.double() - x3_want).abs().max()) < 5e-5
+    assert float((aq.double() - aq_want).abs().max()) < 5e-5
+    # --- chain 2: the tail of the decoder (penult stored, then lin_out on relu(penult))
+    stream2, counts2 = pk.ops.pack_chain_stream([('resblock', blocks[3][0][0], blocks[3][1][0]), ('linear', wo)])
+    assert counts2 == [52, 2]
+    out = torch.empty((n, g_out), device='cuda')
+    pen = torch.empty_like(xs)
+    pk.ops.trunk_chain(xs, stream2, [('interp', 3 * H), ('resblock', blocks[3][0][1], blocks[3][1][1]), ('store', pen),
+                                     ('linear', pk.ops.pad_bias(bo, 2), 2, g_out, True, out)],
+                       interp=(zconst, ztab, idx, w))
+    assert float((pen.double() - v).abs().max()) < 5e-5
+    assert float((out.double() - out_want).abs().max()) < 5e-5
+    # --- the per-layer kernels on the same inputs agree to fp32 rounding
+    y = x.clone()
+    for i in range(3):
+        pk.ops.interp_add(y, zconst[i * H:(i + 1) * H], ztab[:, i * H:(i + 1) * H], idx, w)
+        (w0, b0), (w1, b1) = blocks[i]
+        y = pk.ops.resblock(y, pk.ops.pack_trunk4_rows(w0), b0, pk.ops.pack_trunk4_cols(w1), b1)
+    assert float((y - xs).abs().max()) < 2e-5
+    assert float((pk.ops.rowlin(y, pk.ops.pack_trunk4_rows(wq), bq, 2 * H) - aq).abs().max()) < 2e-5
+
+
+def test_trunk_chain_rejects_bad_programs():
+    x = torch.zeros((8, H), device='cuda')
+    w = torch.zeros((H, H), device='cuda')
+    b = torch.zeros((H,), device='cuda')
+    stream, _ = pk.ops.pack_chain_stream([('resblock', w, w)])
+    with pytest.raises(AssertionError):      # stream too short for the program
+        pk.ops.trunk_chain(x, stream, [('resblock', b, b), ('resblock', b, b), ('store', x)])
+    with pytest.raises(AssertionError):      # interpolation op without tables
+        pk.ops.trunk_chain(x, stream, [('interp', 0), ('resblock', b, b)])
+    args = pk._lib.ChainArgs()
+    args.n, args.n_ops = 8, 0
+    import ctypes
+    assert pk._lib.lib().occ4d_trunk_chain_f32(ctypes.byref(args), None) == pk._lib.EINVAL
