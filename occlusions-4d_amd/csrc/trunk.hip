@@ -62,31 +62,25 @@ __device__ __forceinline__ unsigned lds_addr(const float* p) {
 // for the reads issued just before it (a full LDS round trip per 8 MFMAs; measured: a wave running alone kept the
 // matrix pipe 65 % busy).  The asm is invisible to that bookkeeping; the stage protocol supplies the ordering:
 // dma_wait() (s_waitcnt vmcnt(0)) + barrier before anybody reads the buffer, barrier before it is overwritten.
+// (round 3: scalar fragment address + one constant lane offset -- no VALU address arithmetic: on gfx950 the fp32 MFMAs
+// and the plain VALU share the SIMD's vector issue, profiles/micro/valu_beside_mfma.hip)
+__device__ __forceinline__ void dma_one(const float* __restrict__ src_frag, unsigned lds_dst, int lane) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"((unsigned)lane * 16u), "s"(lds_dst), "s"(src_frag) : "memory");
+}
 __device__ __forceinline__ void dma_stage(const float* __restrict__ src, const float* dst, int wave, int lane) {
-  const unsigned dst0 = lds_addr(dst);
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
     const int c = wave + 8 * i;                       // wave-uniform
-    if (c < STAGE_FRAGS) {
-      const float* g = src + c * FRAG_FLOATS + lane * 4;
-      const unsigned d = __builtin_amdgcn_readfirstlane(dst0 + (unsigned)c * (FRAG_FLOATS * 4));
-      unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(g), "s"(d) : "memory");
-    }
+    if (c < STAGE_FRAGS) dma_one(src + c * FRAG_FLOATS, lds_addr(dst) + (unsigned)c * (FRAG_FLOATS * 4), lane);
   }
 }
 
 // the i-th of this wave's (up to 7) fragments of a stage: fragment wave + 8 i (i = 6 exists for waves 0-3 only)
 __device__ __forceinline__ void dma_frag(const float* __restrict__ src, const float* dst, int wave, int lane, int i) {
   const int c = wave + 8 * i;                         // wave-uniform
-  if (c < STAGE_FRAGS) {
-    const float* g = src + c * FRAG_FLOATS + lane * 4;
-    const unsigned d = __builtin_amdgcn_readfirstlane(lds_addr(dst) + (unsigned)c * (FRAG_FLOATS * 4));
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(d) : "memory");
-  }
+  if (c < STAGE_FRAGS) dma_one(src + c * FRAG_FLOATS, lds_addr(dst) + (unsigned)c * (FRAG_FLOATS * 4), lane);
 }
 
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -182,6 +176,7 @@ __global__ __launch_bounds__(512, 2) void resblock_kernel(const TrunkArgs a) {
 #else
 #define STAMP(i)
 #endif
+  asm volatile("; OCC4D_MARK loop");
   // the packed W0 stream carries TNS + 1 stages (the last repeats stage 0), so "prefetch stage j + 1" is branch-free
 #pragma clang loop unroll(disable)
   for (int j = 0; j < TNS; ++j) {
@@ -249,6 +244,7 @@ __global__ __launch_bounds__(512, 2) void resblock_kernel(const TrunkArgs a) {
 #endif
     STAMP(3)
   }
+  asm volatile("; OCC4D_MARK epilogue");
 #ifdef OCC4D_TR_STAMP
   if (lane == 0 && a.zw) {     // debug build: a.zw doubles as the stamp buffer (5 x u64 per wave)
     unsigned long long* o = (unsigned long long*)a.zw + (size_t)(blockIdx.x * 8 + wave) * 6;
