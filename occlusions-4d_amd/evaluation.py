@@ -13,7 +13,7 @@ parser defines; here it is an explicit argument, defaul
 
 One difference that does not change results: the reference re-encodes the same input cloud for every output frame
 (:67-86); the encode is deterministic, so it is done once per clip and shared (``reuse_encode=False`` restores the
-per-frame encode).
+per-frame encode; it is also what happens, automatically, for an encoder built with fps_random_start=True).
 """
 import os
 import pickle
@@ -29,6 +29,11 @@ def evaluate_clip(batch, networks, device, args, data_kind, logger=None, save_gt
     batch['meta_data']['pcl_target_size'] (list of (1,) tensors), as the reference's test data loader yields them
     (data/data_greater.py:593-606, data/data_carla.py:651-661).  args: namespace with the test_args fields used
     below (args.py:311-410).  Returns pcl_all (list over output frames of tuples of numpy arrays)."""
+    # One encode per clip is only equivalent to the reference's encode per output frame when the encode is
+    # deterministic: a network built with fps_random_start=True (the constructor default; the reference's test path
+    # builds its networks with False, eval/inference.py:59) draws a new FPS start per call, so it is re-encoded per frame.
+    if reuse_encode and any(getattr(m, 'fps_random_start', False) for m in networks[0].modules()):
+        reuse_encode = False
     pcl_input = batch['pcl_input']
     pcl_input_numpy = pcl_input[0].detach().cpu().numpy()
     pcl_input_sem_numpy = batch['pcl_input_sem'][0].detach().cpu().numpy()

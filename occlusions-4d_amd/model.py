@@ -69,6 +69,10 @@ class PointCompletionNetV3(torch.nn.Module):
         out = {}
         with torch.cuda.stream(side):
             cur = [pos[b].contiguous() for b in range(pos.shape[0])]
+            for c in cur:
+                # allocated on the side stream, read by the pooling kNN on the main stream: without this the block
+                # could be recycled by a later side-stream allocation while that kNN is still queued
+                c.record_stream(main)
             for i, block in enumerate(self.blocks):
                 if isinstance(block, modules.DownTransition):
                     # only the FPS subsets chain on the side stream; the down-kNN of a level (which the next level's
@@ -105,7 +109,9 @@ class PointCompletionNetV3(torch.nn.Module):
         Returns the geometry (also kept for the next forward)."""
         pos = pcl[..., :3].detach()
         geom = self._geometry_chain(pos, full=True, ready=ready)
-        self._prefetched = (self.geometry_key(pcl), geom)
+        # the tensor OBJECT is kept (alive, so its address cannot be recycled by another cloud) next to the
+        # (storage, version, shape) key; forward() requires both to match
+        self._prefetched = (self.geometry_key(pcl), geom, pcl)
         return geom
 
     @staticmethod
@@ -132,7 +138,7 @@ class PointCompletionNetV3(torch.nn.Module):
         skips = []
         x_global = None
         pre, self._prefetched = self._prefetched, None
-        if pre is not None and pre[0] == self.geometry_key(pcl):
+        if pre is not None and pre[2] is pcl and pre[0] == self.geometry_key(pcl):
             geom = pre[1]
         else:
             geom = self._geometry_chain(pos)

@@ -62,8 +62,12 @@ def implicit_loss(implicit_output, implicit_target, density_lw=1.0, color_lw=0.0
         implicit_output, implicit_target = implicit_output[:, None], implicit_target[:, None]
     if not squashed and color_lw > 0.0:
         implicit_output = squash_for_loss(implicit_output, color_mode)
-    if color_lw > 0.0 and color_mode not in ('rgb', 'rgb_nosigmoid'):
-        raise NotImplementedError("colour loss for color_mode '%s'" % color_mode)
+    if (color_lw > 0.0 or tracking_lw > 0.0) and color_mode not in ('rgb', 'rgb_nosigmoid'):
+        # the tracking logit sits behind the colour channels (utils.get_track_idx): channel 4 for the three-channel
+        # colour modes only; 'hsv' / 'bins' (4 / 3 * bins colour channels) are not used by any published configuration
+        if color_mode in ('hsv', 'bins'):
+            raise NotImplementedError("colour / tracking losses for color_mode '%s'" % color_mode)
+        raise ValueError('Unknown color_mode: ' + str(color_mode))
     track_idx = 4                                        # utils.get_track_idx for rgb / rgb_nosigmoid
     total = implicit_output.new_zeros(())
     (nf, nb) = implicit_output.shape[:2]
@@ -102,19 +106,40 @@ def implicit_loss(implicit_output, implicit_target, density_lw=1.0, color_lw=0.0
     return total
 
 
+_PARTICIPATION = {}      # parameter list (ids) -> which of them some rank produced a gradient for, last eager step
+
+
 def allreduce_gradients(params, world=None):
     """Average gradients over ranks with ONE flat all-reduce (28.8 MB for the 7.21 M parameters:
     latency/bandwidth of a single bucket; xGMI is point to point, so few large messages)."""
     if not (dist.is_available() and dist.is_initialized()):
         return
     world = world or dist.get_world_size()
-    # a parameter without a gradient on THIS rank still takes part (as zeros): every rank must reduce the same
-    # flat layout, and another rank may have produced a gradient for it
-    params = list(params)
-    for p in params:
-        if p.grad is None and p.requires_grad:
-            p.grad = torch.zeros_like(p)
-    grads = [p.grad for p in params if p.grad is not None]
+    params = [p for p in params if p.requires_grad]
+    if not params:
+        return
+    # Which parameters take part is agreed first (one small MAX all-reduce of a has-gradient mask): a parameter
+    # without a gradient on THIS rank must still be reduced (as zeros) when another rank produced one -- every rank
+    # reduces the same flat layout -- but one that NO rank used keeps grad = None, so that the optimiser skips it
+    # (no weight decay, no moment update), exactly as in a single-process run and as under the reference's
+    # nn.DataParallel (train.py:305).
+    # The agreement needs one host read, which a stream capture forbids: a captured step (GraphedTrainStep) reuses the
+    # agreement of the eager warm-up steps that precede every capture -- all ranks are capturing (or not) at the same
+    # point of the program, so they take the same branch.
+    key = tuple(id(p) for p in params)
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        used = _PARTICIPATION.get(key) or [True] * len(params)
+    else:
+        has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], device=params[0].device)
+        dist.all_reduce(has, op=dist.ReduceOp.MAX)
+        used = [bool(v) for v in has.tolist()]
+        _PARTICIPATION[key] = used
+    grads = []
+    for p, u in zip(params, used):
+        if u:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            grads.append(p.grad)
     if not grads:
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
@@ -206,7 +231,7 @@ class GraphedTrainStep(TrainStep):
         otherwise computed now."""
         key = self.pcl_net.geometry_key(pcl_input)
         nxt, self._geom_next = self._geom_next, None
-        geom = nxt[1] if (nxt is not None and nxt[0] == key) else \
+        geom = nxt[1] if (nxt is not None and nxt[2] is pcl_input and nxt[0] == key) else \
             self.pcl_net._geometry_chain(pcl_input[..., :3].detach(), full=True)
         self.pcl_net._prefetched = None
         cur = torch.cuda.current_stream()
@@ -248,7 +273,7 @@ class GraphedTrainStep(TrainStep):
         self.graph = torch.cuda.CUDAGraph()                                       # taken from the warm-up's cache
         with torch.cuda.graph(self.graph):
             if self.external_geometry:      # the captured forward reads the static index buffers (no events: same stream)
-                self.pcl_net._prefetched = (self.pcl_net.geometry_key(self.static[0]), self._geom_static)
+                self.pcl_net._prefetched = (self.pcl_net.geometry_key(self.static[0]), self._geom_static, self.static[0])
             self.static_loss = self._eager(*self.static)
         invalidate_weight_caches()
         return losses
@@ -267,8 +292,9 @@ class GraphedTrainStep(TrainStep):
                 dst.copy_(src)
         self.graph.replay()
         if ready is not None:
+            # (key, geometry, the tensor object: held alive so that its address cannot be recycled by another cloud)
             self._geom_next = (self.pcl_net.geometry_key(next_pcl_input),
-                               self.pcl_net.prefetch_geometry(next_pcl_input, ready=ready))
+                               self.pcl_net.prefetch_geometry(next_pcl_input, ready=ready), next_pcl_input)
             self.pcl_net._prefetched = None     # (kept here, not for an eager forward)
         # the replay updates the parameters in place without touching their _version counters: the derived-weight
         # caches of the inference path (keyed on _version + this epoch) must not survive it

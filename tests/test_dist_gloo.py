@@ -136,13 +136,14 @@ def _grad_worker(rank, world, port, ret):
                   torch.nn.Parameter(torch.zeros(2, 2))]
         params[0].grad = torch.full((5, 3), float(rank + 1))
         params[1].grad = torch.arange(7, dtype=torch.float32) * (rank + 1)
-        # params[2] has a gradient on rank 1 only, params[3] on no rank: every rank must still reduce the same flat
-        # layout (missing gradients take part as zeros)
+        # params[2] has a gradient on rank 1 only: rank 0 takes part with zeros (every rank reduces the same flat
+        # layout).  params[3] has a gradient on NO rank: it must keep grad = None, so that the optimiser skips it as in a
+        # single-process run (no weight decay / moment update for an unused parameter)
         params.append(torch.nn.Parameter(torch.zeros(3)))
         if rank == 1:
             params[2].grad = torch.full((2, 2), 4.0)
         pk.training.allreduce_gradients(params)
-        ret[rank] = [p.grad.clone() for p in params]
+        ret[rank] = [None if p.grad is None else p.grad.clone() for p in params]
     finally:
         dist.destroy_process_group()
 
@@ -163,4 +164,4 @@ def test_gradient_allreduce_averages_over_ranks():
         assert torch.allclose(out[r][0], torch.full((5, 3), 1.5))
         assert torch.allclose(out[r][1], torch.arange(7, dtype=torch.float32) * 1.5)
         assert torch.allclose(out[r][2], torch.full((2, 2), 2.0))
-        assert torch.equal(out[r][3], torch.zeros(3))
+        assert out[r][3] is None

@@ -104,3 +104,50 @@ def test_synthetic_inputs_are_deterministic_and_tie_free():
     w1 = pk.configs.fill_state_dict({'l.weight': (4, 8), 'l.bias': (4,)}, 3)
     w2 = pk.configs.fill_state_dict({'l.weight': (4, 8), 'l.bias': (4,)}, 3)
     assert all(torch.equal(w1[k], w2[k]) for k in w1) and w1['l.weight'].abs().max() <= 1 / np.sqrt(8)
+
+
+def test_tracking_loss_rejects_colour_modes_with_another_channel_layout():
+    """training.implicit_loss reads the tracking logit at channel 4, which is where utils.get_track_idx puts it for
+    the three-channel colour modes only: 'hsv' / 'bins' must not silently read a colour logit."""
+    import occlusions4d_amd as pk
+    out, tgt = torch.zeros((1, 8, 5)), torch.zeros((1, 8, 6))
+    tgt[..., 0] = 1.0                  # (every point solid: the tracking term has supervised points)
+    for mode in ('hsv', 'bins'):
+        with pytest.raises(NotImplementedError):
+            pk.training.implicit_loss(out, tgt, density_lw=1.0, color_lw=0.0, tracking_lw=0.5, color_mode=mode)
+    with pytest.raises(ValueError):
+        pk.training.implicit_loss(out, tgt, density_lw=1.0, tracking_lw=0.5, color_mode='nonsense')
+    assert torch.isfinite(pk.training.implicit_loss(out, tgt, density_lw=1.0, tracking_lw=0.5, color_mode='rgb'))
+
+
+def test_evaluate_clip_shares_the_encode_only_when_it_is_deterministic(monkeypatch):
+    """evaluation.evaluate_clip: one encode per clip for a deterministic encoder; an encoder built with
+    fps_random_start=True is re-encoded for every output frame, as eval/test.py:67-86 does."""
+    import types
+    import numpy as np
+    import occlusions4d_amd as pk
+    seen = []
+
+    def fake(pcl_input, sem, target, networks, device, mode, *a, encoded=None, return_encoded=False, **kw):
+        seen.append(encoded)
+        res = dict(pcl_abstract=np.zeros((2, 4), np.float32), output_solid=np.zeros((1, 9), np.float32),
+                   output_air=np.zeros((1, 5), np.float32), points_query=np.zeros((2, 4), np.float32))
+        if return_encoded:
+            res['_encoded'] = ('abstract', 'global')
+        return res
+    monkeypatch.setattr(pk.inference, 'perform_inference', fake)
+    args = types.SimpleNamespace(track_mode='none', min_z=-1.0, cr_cube_bounds=5.0, color_mode='rgb', sample_implicit=True,
+                                 num_sample=8, point_sample_mode='grid', implicit_batch_size=8, segmentation_lw=0.0,
+                                 point_occupancy_radius=0.2, semantic_classes=13, density_threshold=0.5, cube_mode=4)
+    batch = dict(pcl_input=torch.zeros((1, 4, 8)), pcl_input_sem=torch.zeros((1, 4, 1)),
+                 pcl_target=[torch.zeros((1, 3, 9)) for _ in range(3)], meta_data=dict(pcl_target_size=[3, 3, 3]))
+
+    class Enc(torch.nn.Module):
+        def __init__(self, random_start):
+            super().__init__()
+            self.down = torch.nn.Module()
+            self.down.fps_random_start = random_start
+    for random_start, want in ((False, [None, ('abstract', 'global'), ('abstract', 'global')]), (True, [None, None, None])):
+        del seen[:]
+        out = pk.evaluation.evaluate_clip(batch, [Enc(random_start), None], 'cpu', args, 'greater')
+        assert len(out) == 3 and seen == want
