@@ -6,7 +6,13 @@ gradient all-reduce on RCCL.  Separate from bench.py (whose single JSON line is 
 inference metric): prints one JSON line with the step time.
 
     python bench_train.py [--steps K --warmup W]            (1 GPU)
+    python bench_train.py --gpus N                           (re-launches itself as N ranks on 127.0.0.1)
     python -m torch.distributed.run --nproc-per-node N bench_train.py --gpus N
+
+The line carries, next to the step time: `roofline` (executed FLOP of the step -- summed over every GEMM / fused
+kernel launch of one step -- and the as-written FLOP of forward + backward, over the step time and the fp32 MFMA
+peak; the kernel with the largest total time and its average launch duration from HIP events on the launch stream),
+`rccl_ranks`, the per-rank step times and the time of the gradient all-reduce alone.
 """
 import argparse
 import json
@@ -22,6 +28,69 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import occlusions4d_amd as pk  # noqa: E402
 
 N_POINTS, FRAMES, QUERIES, SEED = 28672, 4, 17203, 1830
+PEAK_F32_MFMA = 157.3      # TFLOP/s, MI355X fp32 matrix peak (MI355X_MICROARCH.md)
+
+
+def self_launch(n_gpus):
+    """`python bench_train.py --gpus N` from a bare shell: re-run this command line as N ranks under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1).  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n_gpus and os.environ.get('OCC4D_BENCH_SHARE_GPU') != '1':
+        print('bench_train.py: --gpus %d needs %d visible GPUs, this machine has %d' % (n_gpus, n_gpus, have),
+              file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % n_gpus,
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.call(cmd, env=env)
+
+
+def as_written_flops(pa, ia, n_points, n_queries, n_abstract):
+    """Matmul FLOP (2 MAC) of ONE forward pass as the reference writes it (SURVEY.md 8(d) closed forms: per query
+    F_query, per decoder call F_call = L 2 (2 E H) M, encoder proportional to n_points), and 3 x that for
+    forward + backward (data and weight gradients)."""
+    H, E, P, B, L, K, Kloc = 416, 288, 68, 6, 2, 14, 8
+    G = ia['d_out']
+    f_query = 2 * (P * H + B * 3 * H * H + L * (3 * H * H + K * (3 * 32 + 32 * H + 2 * H * H + 2 * H * H) + K * H)
+                   + H * G + Kloc * E)
+    f_call = L * 2 * (2 * E * H) * n_abstract
+    f_enc = 18.48e9 * n_points / 14336.0          # (abstract_levels = 2; [probe] of SURVEY.md 8(d))
+    fwd = f_query * n_queries + f_call + f_enc
+    return 3.0 * fwd
+
+
+class StepCounter:
+    """ops.set_kernel_timer hook: HIP events around every reported launch (GEMMs and fused kernels carry their FLOP)
+    of one step, on the launch stream."""
+
+    def __init__(self):
+        self.events = []
+
+    def want(self, name, **shape):
+        return True
+
+    def launch(self, name, flops, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn()
+        e1.record()
+        self.events.append((name, e0, e1, float(flops)))
+        return rc
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b, f in self.events:
+            d = out.setdefault(name, dict(launches=0, total_ms=0.0, total_flops=0.0))
+            d['launches'] += 1
+            d['total_ms'] += a.elapsed_time(b)
+            d['total_flops'] += f
+        return out
 
 
 def main():
@@ -37,15 +106,40 @@ def main():
                     help='draw the supervision points inside the step with GuidedImplicitPointSampler '
                          '(57344-point target frames, bias low_moving_vehped_sembal) instead of fixed synthetic queries')
     args = ap.parse_args()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        return self_launch(args.gpus)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
-    if world > 1:
+    if world != args.gpus:
+        print('bench_train.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d)'
+              % (args.gpus, world, args.gpus), file=sys.stderr)
+        return 2
+    # Harness self-test only (tests/test_gpu_bench_multirank.py): OCC4D_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and
+    # OCC4D_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device); timings of such a run mean nothing.
+    share_gpu = os.environ.get('OCC4D_BENCH_SHARE_GPU') == '1'
+    backend = os.environ.get('OCC4D_BENCH_BACKEND', 'nccl')
+    dev_index = 0 if share_gpu else local_rank
+    if torch.cuda.device_count() <= dev_index:
+        print('bench_train.py: rank %d needs GPU %d, only %d visible' % (rank, dev_index, torch.cuda.device_count()),
+              file=sys.stderr)
+        return 2
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
+    use_dist = world > 1 or os.environ.get('OCC4D_FORCE_DIST') == '1'   # (1-rank RCCL: smoke test of the N > 1 path)
+    rccl_ranks = 1
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        os.environ.setdefault('MASTER_PORT', '29534')
+        os.environ.setdefault('RANK', str(rank))
+        os.environ.setdefault('WORLD_SIZE', str(world))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
+        ones = torch.ones((), device=device)
+        dist.all_reduce(ones)                   # the ranks RCCL really connected
+        rccl_ranks = int(ones.item())
     pk.point_transformer_layer.CHECKPOINT_ATTENTION = not args.no_checkpoint
     pa, ia, inf = pk.configs.model_args('carla', N_POINTS)
     esd, dsd = pk.configs.synthetic_weights(pa, ia, SEED)
@@ -75,7 +169,7 @@ def main():
     def fence():
         torch.cuda.synchronize()
         pk.ops.check_pending()     # cooperative-FPS status words: a timed-out launch voids the run
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -124,20 +218,66 @@ def main():
     elapsed = time.perf_counter() - t0
     if args.sampler:
         sampler_ms = 1e3 * sampler_time[0] / args.steps
-    if world > 1:
+    per_rank = [elapsed]
+    if use_dist:
         tm = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        elapsed = float(tm.item())
+        allt = [torch.empty_like(tm) for _ in range(world)]
+        dist.all_gather(allt, tm)
+        per_rank = [float(x.item()) for x in allt]
+        elapsed = max(per_rank)
+    # the gradient all-reduce alone (one flat 28.8 MB bucket): the gradients of the last step are still there
+    allreduce_ms = None
+    if use_dist and not args.graph:
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            pk.training.allreduce_gradients(step.params)
+        fence()
+        allreduce_ms = 1e3 * (time.perf_counter() - t1) / 3
+    # roofline leg: one more (untimed) step with HIP events around every reported launch
+    roof = None
+    if not args.graph:
+        counter = StepCounter()
+        pk.ops.set_kernel_timer(counter)
+        run_step()
+        pk.ops.set_kernel_timer(None)
+        summ = counter.summary()
+        fence()
+        executed = sum(v['total_flops'] for v in summ.values())
+        top = max(summ.items(), key=lambda kv: kv[1]['total_ms']) if summ else None
+        m_abs = pk.distributed.abstract_shape(enc, N_POINTS)[0]
+        written = as_written_flops(pa, ia, N_POINTS, FRAMES * QUERIES, m_abs)
+        sec = elapsed / args.steps
+        roof = dict(bound='mfma', peak=PEAK_F32_MFMA, unit='TFLOP/s',
+                    achieved=executed / sec / 1e12, frac=executed / sec / 1e12 / PEAK_F32_MFMA,
+                    achieved_as_written=written / sec / 1e12, frac_as_written=written / sec / 1e12 / PEAK_F32_MFMA,
+                    executed_tflop_per_step=executed / 1e12, as_written_tflop_per_step=written / 1e12,
+                    note='executed = sum of the FLOP of every GEMM / fused-kernel launch of one step (forward, data and '
+                         'weight gradients, recompute); as written = 3 x the reference forward count (SURVEY.md 8(d))',
+                    kernels={k: dict(launches=v['launches'], total_ms=v['total_ms'],
+                                     avg_launch_ms=v['total_ms'] / max(1, v['launches']),
+                                     tflops=v['total_flops'] / max(v['total_ms'], 1e-9) / 1e9)
+                             for k, v in sorted(summ.items(), key=lambda kv: -kv[1]['total_ms'])},
+                    dominant=None if top is None else top[0])
     if rank == 0:
         print(json.dumps({
             'metric': 'training step (BASELINE config 5: CARLA-4D, batch 1/GPU, n_points=28672, 4 x 17203 queries)',
             'value': world * args.steps / elapsed, 'unit': 'examples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'dtype': 'f32', 'data': 'synthetic', 'losses': losses, 'sampler_ms_per_step': sampler_ms, 'graph': bool(args.graph), 'geometry_prefetch': bool(nxt), 'frames_batched': bool(step.batch_frames), 'attention_backward': ('stored pair tensors (%s form)' % pk.point_transformer_layer.STORED_ATTENTION_FORM) if args.no_checkpoint else 'recompute in backward (chunks of %d queries)' % pk.point_transformer_layer._CHECKPOINT_CHUNK,
-            'peak_mem_gb': torch.cuda.max_memory_allocated() / 2 ** 30}), flush=True)
-    if world > 1:
+            'peak_mem_gb': torch.cuda.max_memory_allocated() / 2 ** 30,
+            'roofline': roof,
+            'config': {'workload': 'CARLA-4D training step (BASELINE configs[4]): batch 1 per GPU, n_points=%d, %d x %d '
+                                   'supervision queries, density + segmentation losses, AdamW, clip 0.2' % (N_POINTS, FRAMES, QUERIES),
+                       'parallelism': 'single GPU' if world == 1 else 'dp%d (one process per GPU, one flat gradient all-reduce)' % world,
+                       'rccl_ranks': rccl_ranks, 'backend': backend if use_dist else None,
+                       'ranks_share_one_gpu': share_gpu if use_dist else None,
+                       'per_rank_ms_per_step': [1e3 * t / args.steps for t in per_rank],
+                       'allreduce_ms': allreduce_ms}}), flush=True)
+    if use_dist:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

@@ -819,9 +819,10 @@ def linear_wgrad(g, x, out=None, accumulate=False, bias=False, relu_x=False):
     dw = out if direct else torch.empty((n4, k4), dtype=torch.float32, device=g.device)
     db = torch.empty((n4,), dtype=torch.float32, device=g.device) if bias else None
     assert not (bias and accumulate), 'linear_wgrad: bias gradient with accumulate is not supported'
-    _lib.check(_lib.lib().occ4d_linear_wgrad_bias_f32(_ptr(g), n4, _ptr(x), k4, M, n4, k4, int(relu_x), _ptr(dw),
-                                                      _ptr(db), int(accumulate and direct), _ptr(ws), splits.value,
-                                                      _stream()))
+    _lib.check(_launch('wgrad', dict(M=M, K=K, N=N), 2.0 * M * K * N,
+                       lambda: _lib.lib().occ4d_linear_wgrad_bias_f32(
+                           _ptr(g), n4, _ptr(x), k4, M, n4, k4, int(relu_x), _ptr(dw), _ptr(db),
+                           int(accumulate and direct), _ptr(ws), splits.value, _stream())))
     if bias:
         db = db[:N]
     if direct:
