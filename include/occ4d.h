@@ -399,6 +399,22 @@ int occ4d_pt_pos_hidden_bwd_f32(const float* pos, int64_t ps, const float* pos2,
 int occ4d_interp_bwd_f32(const float* dy, int64_t ldy, const int32_t* idx, const float* w, int n, int k, int d,
                          float* dtable, int64_t ldt, void* stream);
 /* out = alpha*a + beta*b (b may be NULL);  out[i,:] = scale*vec  (mean backward) */
+/* Deterministic (fixed summation order) counterparts of the atomic reductions above, selected by the host in its
+ * deterministic mode (occlusions-4d_amd/ops.py: DETERMINISTIC): gradients are then bit-identical from run to run and
+ * between an eager step and its hipGraph replay.
+ * segment_gather_sum: out[r][c] = scale * sum_{t in [offsets[r], offsets[r+1])} (weights ? weights[order[t]] : 1)
+ *   * src[(order[t] / div) * lds + c]: `order` = the pair indices sorted (stably) by target row, offsets (n_out + 1)
+ *   = the segment bounds.  Serves scatter_add_rows (div 1), the value-table gradient of softmax_agg_bwd (src = its
+ *   per-pair dpe output; occ4d_pt_softmax_agg_bwd_f32 accepts dv = NULL) and interp_bwd (div = k, weights = w).
+ * pos_hidden_bwd_det: occ4d_pt_pos_hidden_bwd_f32 with the block partials written to `workspace`
+ *   (occ4d_pt_pos_hidden_bwd_det_workspace floats) and added up in a fixed order. */
+int occ4d_segment_gather_sum_f32(const float* src, int64_t lds, const int32_t* order, const int32_t* offsets,
+                                 const float* weights, int div, int n_out, int d, float scale, float* out, int64_t ldo,
+                                 void* stream);
+int occ4d_pt_pos_hidden_bwd_det_workspace(int n, int k, int h, int64_t* floats);
+int occ4d_pt_pos_hidden_bwd_det_f32(const float* pos, int64_t ps, const float* pos2, int64_t p2s, const int32_t* idx,
+                                    int n, int k, int h, const float* r, const float* gr, float* dP1, float* dc1,
+                                    float* workspace, void* stream);
 int occ4d_axpby_f32(const float* a, int64_t lda, float alpha, const float* b, int64_t ldb, float beta, int n, int d,
                     float* out, int64_t ldo, void* stream);
 int occ4d_broadcast_rows_f32(const float* vec, float scale, int n, int d, float* out, int64_t ldo, void* stream);

@@ -181,6 +181,59 @@ __global__ __launch_bounds__(TPB) void scatter_add_rows_kernel(const float* __re
   atomicAdd(out + (int64_t)idx[i] * ldo + c, scale * src[i * lds + c]);
 }
 
+// Deterministic counterpart of the atomic scatters (training.DETERMINISTIC / ops.DETERMINISTIC): the (source, target)
+// pairs come pre-sorted by target (stable: original order inside a segment), one thread per (target row, channel) adds
+// its segment in that fixed order:
+//   out[r][c] = scale * sum_{t in [off[r], off[r + 1])} (w ? w[order[t]] : 1) * src[(order[t] / div) * lds + c]
+__global__ __launch_bounds__(TPB) void segment_gather_sum_kernel(const float* __restrict__ src, int64_t lds,
+                                                                 const int32_t* __restrict__ order,
+                                                                 const int32_t* __restrict__ off,
+                                                                 const float* __restrict__ w, int div, int64_t total, int d,
+                                                                 float scale, float* __restrict__ out, int64_t ldo) {
+  const int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)(e % d);
+  const int64_t r = e / d;
+  float s = 0.f;
+  for (int t = off[r]; t < off[r + 1]; ++t) {
+    const int p = order[t];
+    const float v = src[(int64_t)(p / div) * lds + c];
+    s += w ? w[p] * v : v;
+  }
+  out[r * ldo + c] = scale * s;
+}
+
+// pos_hidden_bwd with the block partials written out (blocks x 4 slices x h x 4 floats) instead of atomics ...
+__global__ __launch_bounds__(TPB) void pos_hidden_bwd_partials_kernel(const float* __restrict__ pos, int64_t ps,
+                                                                      const float* __restrict__ pos2, int64_t p2s,
+                                                                      const int32_t* __restrict__ idx, int64_t npairs, int k,
+                                                                      int h, const float* __restrict__ r,
+                                                                      const float* __restrict__ gr, float* __restrict__ ws) {
+  const int m = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  float ax = 0.f, ay = 0.f, az = 0.f, ac = 0.f;
+  if (m < h) {
+    for (int64_t p = (int64_t)blockIdx.x * 4 + sl; p < npairs; p += (int64_t)gridDim.x * 4) {
+      const float gv = r[p * h + m] > 0.f ? gr[p * h + m] : 0.f;
+      const float* a = pos + (p / k) * ps;
+      const float* b = pos2 + (int64_t)idx[p] * p2s;
+      ax += gv * (a[0] - b[0]); ay += gv * (a[1] - b[1]); az += gv * (a[2] - b[2]); ac += gv;
+    }
+    float* o = ws + (((int64_t)blockIdx.x * 4 + sl) * h + m) * 4;
+    o[0] = ax; o[1] = ay; o[2] = az; o[3] = ac;
+  }
+}
+// ... and added up in a fixed order: thread = (hidden unit, component)
+__global__ void pos_hidden_bwd_reduce_kernel(const float* __restrict__ ws, int parts, int h, float* __restrict__ dP1,
+                                             float* __restrict__ dc1) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 4 * h) return;
+  const int m = e >> 2, comp = e & 3;
+  float s = 0.f;
+  for (int q = 0; q < parts; ++q) s += ws[((int64_t)q * h + m) * 4 + comp];
+  if (comp < 3) dP1[3 * m + comp] = s;
+  else dc1[m] = s;
+}
+
 // out[i][c] = sum_{j<k} src[i*k + j][c]
 __global__ __launch_bounds__(TPB) void segment_sum_kernel(const float* __restrict__ src, int64_t total, int k, int d,
                                                           float* __restrict__ out, int64_t ldo) {
@@ -293,7 +346,7 @@ __global__ __launch_bounds__(TPB) void softmax_agg_bwd_kernel(const float* __res
       const float dval = a[j] * go;
       dlogits[p * d + c] = a[j] * (val[j] * go - dot) / divisor;
       if (dpe) dpe[p * d + c] = dval;
-      atomicAdd(dv + (int64_t)idx[p] * lddv + c, dval);
+      if (dv) atomicAdd(dv + (int64_t)idx[p] * lddv + c, dval);
     }
 }
 
@@ -468,7 +521,7 @@ int occ4d_layernorm_bwd_f32(const float* x, int64_t ldx, const float* gamma, con
 int occ4d_pt_softmax_agg_bwd_f32(const float* logits, const float* v, int64_t ldv, const float* pe,
                                  const int32_t* idx, int n, int k, int d, float divisor, const float* dagg,
                                  int64_t ldda, float* dlogits, float* dpe, float* dv, int64_t lddv, void* stream) {
-  OCC4D_REQUIRE(logits && v && idx && dagg && dlogits && dv, "occ4d_pt_softmax_agg_bwd_f32: null pointer");
+  OCC4D_REQUIRE(logits && v && idx && dagg && dlogits && (dv || dpe), "occ4d_pt_softmax_agg_bwd_f32: null pointer");
   OCC4D_REQUIRE(n >= 0 && k >= 1 && k <= 16 && d >= 1 && divisor > 0.f, "occ4d_pt_softmax_agg_bwd_f32: bad sizes");
   const int64_t total = (int64_t)n * d;
   if (!total) return OCC4D_OK;
@@ -497,6 +550,41 @@ int occ4d_interp_bwd_f32(const float* dy, int64_t ldy, const int32_t* idx, const
   if (!total) return OCC4D_OK;
   interp_bwd_kernel<<<grid1d(total), TPB, 0, (hipStream_t)stream>>>(dy, ldy, idx, w, total, k, d, dtable, ldt);
   return occ4d::check_launch("occ4d_interp_bwd_f32");
+}
+
+int occ4d_segment_gather_sum_f32(const float* src, int64_t lds, const int32_t* order, const int32_t* offsets,
+                                 const float* weights, int div, int n_out, int d, float scale, float* out, int64_t ldo,
+                                 void* stream) {
+  OCC4D_REQUIRE(src && order && offsets && out && n_out >= 0 && d >= 1 && div >= 1 && lds >= d && ldo >= d,
+                "occ4d_segment_gather_sum_f32: bad arguments");
+  const int64_t total = (int64_t)n_out * d;
+  if (!total) return OCC4D_OK;
+  segment_gather_sum_kernel<<<grid1d(total), TPB, 0, (hipStream_t)stream>>>(src, lds, order, offsets, weights, div, total,
+                                                                            d, scale, out, ldo);
+  return occ4d::check_launch("occ4d_segment_gather_sum_f32");
+}
+
+int occ4d_pt_pos_hidden_bwd_det_workspace(int n, int k, int h, int64_t* floats) {
+  OCC4D_REQUIRE(floats && n >= 0 && k >= 1 && h >= 1 && h <= 64, "occ4d_pt_pos_hidden_bwd_det_workspace: bad arguments");
+  const int64_t want = ((int64_t)n * k + 3) / 4;
+  const int64_t blocks = want < 1024 ? (want > 0 ? want : 1) : 1024;
+  *floats = blocks * 4 * h * 4;
+  return OCC4D_OK;
+}
+
+int occ4d_pt_pos_hidden_bwd_det_f32(const float* pos, int64_t ps, const float* pos2, int64_t p2s, const int32_t* idx,
+                                    int n, int k, int h, const float* r, const float* gr, float* dP1, float* dc1,
+                                    float* workspace, void* stream) {
+  OCC4D_REQUIRE(pos && pos2 && idx && r && gr && dP1 && dc1 && workspace, "occ4d_pt_pos_hidden_bwd_det_f32: null pointer");
+  OCC4D_REQUIRE(n >= 0 && k >= 1 && h >= 1 && h <= 64, "occ4d_pt_pos_hidden_bwd_det_f32: need h <= 64");
+  const int64_t npairs = (int64_t)n * k;
+  if (!npairs) return OCC4D_OK;
+  const int64_t want = (npairs + 3) / 4;
+  const int blocks = (int)(want < 1024 ? want : 1024);
+  pos_hidden_bwd_partials_kernel<<<blocks, TPB, 0, (hipStream_t)stream>>>(pos, ps, pos2, p2s, idx, npairs, k, h, r, gr,
+                                                                          workspace);
+  pos_hidden_bwd_reduce_kernel<<<occ4d::cdiv(4 * h, 64), 64, 0, (hipStream_t)stream>>>(workspace, blocks * 4, h, dP1, dc1);
+  return occ4d::check_launch("occ4d_pt_pos_hidden_bwd_det_f32");
 }
 
 int occ4d_axpby_f32(const float* a, int64_t lda, float alpha, const float* b, int64_t ldb, float beta, int n, int d,

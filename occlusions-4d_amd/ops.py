@@ -858,11 +858,67 @@ def relu_mask(g, ref):
     return out
 
 
+# Deterministic mode of the backward pass.  The default scatters / small vector gradients accumulate with fp32 atomics
+# (order-dependent rounding, ~1e-7 relative: fine for SGD, but two runs -- or an eager step and its hipGraph replay --
+# are not bit-identical).  With DETERMINISTIC on, every such reduction runs in a fixed order: index scatters through a
+# stable sort by target row + one thread per (target row, channel) adding its segment in order
+# (occ4d_segment_gather_sum_f32), the pos-MLP and LayerNorm parameter gradients through fixed-order two-stage sums.
+DETERMINISTIC = os.environ.get('OCC4D_DETERMINISTIC', '0') != '0'
+
+
+class deterministic:
+    """with ops.deterministic(): ... -> fixed-order reductions in every backward kernel."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global DETERMINISTIC
+        self._old, DETERMINISTIC = DETERMINISTIC, self.on
+
+    def __exit__(self, *exc):
+        global DETERMINISTIC
+        DETERMINISTIC = self._old
+
+
+_SEGMENTS = []       # a few recent (key, idx tensor, order, offsets): one neighbour list serves several scatters
+
+
+def _segments(idx_flat, n_out):
+    """Pair indices sorted stably by target row (int32) and the (n_out + 1) segment bounds."""
+    key = (idx_flat.data_ptr(), idx_flat._version, idx_flat.numel(), n_out)
+    for k, keep, order, off in _SEGMENTS:
+        if k == key and keep is idx_flat:
+            return order, off
+    order = torch.argsort(idx_flat.long(), stable=True).to(torch.int32)
+    counts = torch.bincount(idx_flat.long(), minlength=n_out)
+    off = torch.zeros((n_out + 1,), dtype=torch.int32, device=idx_flat.device)
+    off[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    _SEGMENTS.append((key, idx_flat, order, off))
+    del _SEGMENTS[:-4]
+    return order, off
+
+
+def segment_gather_sum(src, idx_flat, n_out, scale=1.0, weights=None, div=1):
+    """out[r] = scale * sum over the pairs p with idx_flat[p] == r, in pair order, of [weights[p] *] src[p // div]."""
+    src, lds = _rows(_dev(src, name='src'), 'src')
+    order, off = _segments(idx_flat, n_out)
+    d = src.shape[1]
+    out = torch.empty((n_out, d), dtype=torch.float32, device=src.device)
+    wv = None if weights is None else _cont(weights, 'weights').view(-1)
+    assert idx_flat.numel() == src.shape[0] * div and (wv is None or wv.numel() == idx_flat.numel())
+    _lib.check(_lib.lib().occ4d_segment_gather_sum_f32(_ptr(src), lds, _ptr(order), _ptr(off), _ptr(wv), int(div),
+                                                       n_out, d, float(scale), _ptr(out), d, _stream()))
+    return out
+
+
 def scatter_add_rows(src, idx, n_out, scale=1.0):
     src, lds = _rows(_dev(src, name='src'), 'src')
     idx = _dev(idx, torch.int32, 'idx').contiguous().view(-1)
     n, d = src.shape
     assert idx.numel() == n
+    if DETERMINISTIC:
+        return segment_gather_sum(src, idx, n_out, scale=scale)
     out = torch.zeros((n_out, d), dtype=torch.float32, device=src.device)
     _lib.check(_lib.lib().occ4d_scatter_add_rows_f32(_ptr(src), lds, _ptr(idx), n, d, float(scale), _ptr(out), d,
                                                      _stream()))
@@ -884,6 +940,13 @@ def maxpool_gather_bwd(y, idx, dz):
     idx = _dev(idx, torch.int32, 'idx')
     n_out, k = idx.shape
     d = y.shape[1]
+    if DETERMINISTIC:
+        # element-wise scatter (the target row differs per channel): first argmax over the k neighbours, then the
+        # (n_out * d) elements of dz summed per target element in a fixed order
+        best = y[idx.long()].argmax(dim=1)                                  # (n_out, d): first maximum (torch rule)
+        target = (torch.gather(idx.long(), 1, best) * d + torch.arange(d, device=y.device)).view(-1).to(torch.int32)
+        flat = segment_gather_sum(dz.contiguous().view(-1, 1), target, y.shape[0] * d)
+        return flat.view(y.shape[0], d)
     dy = torch.zeros_like(y, memory_format=torch.contiguous_format)
     _lib.check(_lib.lib().occ4d_maxpool_gather_bwd_f32(_ptr(y), ldy, _ptr(idx), n_out, k, d, _ptr(dz), ldz, _ptr(dy), d,
                                                        _stream()))
@@ -895,6 +958,13 @@ def layernorm_bwd(x, gamma, g, eps):
     g, ldg = _rows(_dev(g, name='g'), 'g')
     n, d = x.shape
     dx = torch.empty((n, d), dtype=torch.float32, device=x.device)
+    if DETERMINISTIC:
+        # the kernel gives dx; the two parameter gradients are plain column sums, taken by torch's (fixed-tree) reduction
+        _lib.check(_lib.lib().occ4d_layernorm_bwd_f32(_ptr(x), ldx, _ptr(_cont(gamma)), _ptr(g), ldg, float(eps), n, d,
+                                                      _ptr(dx), d, None, None, _stream()))
+        mu = x.mean(dim=1, keepdim=True)
+        xh = (x - mu) * torch.rsqrt(((x - mu) ** 2).mean(dim=1, keepdim=True) + eps)
+        return dx, (g * xh).sum(dim=0), g.sum(dim=0)
     dgamma = torch.zeros((d,), dtype=torch.float32, device=x.device)
     dbeta = torch.zeros((d,), dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().occ4d_layernorm_bwd_f32(_ptr(x), ldx, _ptr(_cont(gamma)), _ptr(g), ldg, float(eps), n, d,
@@ -910,11 +980,20 @@ def pt_softmax_agg_bwd(logits, v, pe, idx, dagg):
     d = logits.shape[1]
     pe = _cont(pe, 'pe') if pe is not None else None
     dlogits = torch.empty_like(logits)
+    divisor = float(torch.tensor(math.sqrt(d), dtype=torch.float32))
+    idx32 = _dev(idx, torch.int32)
+    if DETERMINISTIC:
+        # the per-pair value gradients (the kernel's dpe output) are kept and summed per abstract point in pair order
+        dval = torch.empty_like(logits)
+        _lib.check(_lib.lib().occ4d_pt_softmax_agg_bwd_f32(_ptr(logits), _ptr(v), ldv, _ptr(pe), _ptr(idx32), n, k, d,
+                                                           divisor, _ptr(dagg), ldda, _ptr(dlogits), _ptr(dval), None, d,
+                                                           _stream()))
+        dv = segment_gather_sum(dval, idx32.contiguous().view(-1), v.shape[0])
+        return dlogits, (dval if pe is not None else None), dv
     dpe = torch.empty_like(logits) if pe is not None else None
     dv = torch.zeros((v.shape[0], d), dtype=torch.float32, device=logits.device)
-    divisor = float(torch.tensor(math.sqrt(d), dtype=torch.float32))
     _lib.check(_lib.lib().occ4d_pt_softmax_agg_bwd_f32(_ptr(logits), _ptr(v), ldv, _ptr(pe),
-                                                       _ptr(_dev(idx, torch.int32)), n, k, d, divisor, _ptr(dagg), ldda,
+                                                       _ptr(idx32), n, k, d, divisor, _ptr(dagg), ldda,
                                                        _ptr(dlogits), _ptr(dpe), _ptr(dv), d, _stream()))
     return dlogits, dpe, dv
 
@@ -928,6 +1007,14 @@ def pt_pos_hidden_bwd(pos, pos2, idx, r, gr):
     h = r.shape[1]
     dP1 = torch.zeros((h, 3), dtype=torch.float32, device=r.device)
     dc1 = torch.zeros((h,), dtype=torch.float32, device=r.device)
+    if DETERMINISTIC:
+        floats = C.c_int64(0)
+        _lib.check(_lib.lib().occ4d_pt_pos_hidden_bwd_det_workspace(n, k, h, C.byref(floats)))
+        ws = torch.empty((floats.value,), dtype=torch.float32, device=r.device)
+        _lib.check(_lib.lib().occ4d_pt_pos_hidden_bwd_det_f32(_ptr(p), ps, _ptr(p2), p2s, _ptr(_dev(idx, torch.int32)), n, k,
+                                                              h, _ptr(r), _ptr(gr), _ptr(dP1), _ptr(dc1), _ptr(ws),
+                                                              _stream()))
+        return dP1, dc1
     _lib.check(_lib.lib().occ4d_pt_pos_hidden_bwd_f32(_ptr(p), ps, _ptr(p2), p2s, _ptr(_dev(idx, torch.int32)), n, k, h,
                                                       _ptr(r), _ptr(gr), _ptr(dP1), _ptr(dc1), _stream()))
     return dP1, dc1
@@ -937,6 +1024,8 @@ def interp_bwd(dy, idx, w, n_table):
     dy, ldy = _rows(_dev(dy, name='dy'), 'dy')
     n, k = idx.shape
     d = dy.shape[1]
+    if DETERMINISTIC:
+        return segment_gather_sum(dy, _dev(idx, torch.int32).contiguous().view(-1), n_table, weights=w, div=k)
     dtable = torch.zeros((n_table, d), dtype=torch.float32, device=dy.device)
     _lib.check(_lib.lib().occ4d_interp_bwd_f32(_ptr(dy), ldy, _ptr(_dev(idx, torch.int32)), _ptr(_cont(w)), n, k, d,
                                                _ptr(dtable), d, _stream()))

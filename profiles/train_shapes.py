@@ -1,0 +1,25 @@
+import sys, os, json
+sys.path.insert(0, '/root/repo')
+sys.argv = ['bench_train.py', '--steps', '1', '--warmup', '1']
+import bench_train as bt
+import torch
+class ShapeCounter(bt.StepCounter):
+    def want(self, name, **shape):
+        self._shape = tuple(sorted(shape.items()))
+        return True
+    def launch(self, name, flops, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); rc = fn(); e1.record()
+        self.events.append((name + ' ' + str(dict(self._shape)), e0, e1, float(flops)))
+        return rc
+bt.StepCounter = ShapeCounter
+import io, contextlib
+buf = io.StringIO()
+with contextlib.redirect_stdout(buf):
+    bt.main()
+d = json.loads(buf.getvalue().strip().split('\n')[-1])
+ks = d['roofline']['kernels']
+tot = sum(v['total_ms'] for v in ks.values())
+print('step %.1f ms; timed launches %.1f ms' % (d['ms_per_step'], tot))
+for k, v in list(ks.items())[:40]:
+    print('%-70s x%3d  %7.2f ms  %6.1f TF' % (k[:70], v['launches'], v['total_ms'], v['tflops']))

@@ -272,6 +272,9 @@ def test_config5_train_step_full_size():
         g = dict(mod.named_parameters())[name].grad.detach().cpu().double()
         r = ref_sd[name].grad.double()
         rel = float((g - r).norm() / max(1e-12, float(r.norm())))
+        # full-size sanity probe, NOT the parity test: a 28672-point encode has ~10^7 ReLU units, hundreds of them with
+        # an input within fp32 rounding of zero, each free to land on either side in two correct implementations (the
+        # strict 1e-4 whole-network parity tests, with those units audited, are tests/test_gpu_training.py)
         assert rel <= 2e-3, (name, rel)
 
     loss = step(pcl.cuda(), q.cuda(), target.cuda())

@@ -1,7 +1,9 @@
 """GPU: backward pass.  Gradients of the HIP training path against torch
 autograd over the CPU oracle (oracle/path.py is plain differentiable torch code) on the same seeded
 inputs and weights: every parameter gradient and the gradients flowing back into the encoder, within
-1e-4 relative to the largest entry of each gradient tensor."""
+1e-4 relative to the largest entry of each gradient tensor -- at op, layer AND whole-network level (the
+network-level checks enumerate the handful of ReLU units whose input sits within rounding of zero, see
+strict_with_kinks)."""
 import numpy as np
 import pytest
 import torch
@@ -22,31 +24,80 @@ def rel_err(a, b):
     return float((a - b).abs().max() / max(1e-12, float(b.abs().max())))
 
 
-def check_grads(module, ref_sd, tol=REL, floor=2e-6, kinks=False):
-    """Per parameter: max|grad - ref| <= tol * max|ref| + floor.  The absolute floor covers parameters
-    whose true gradient is zero (attn_mlp.2.bias: a per-channel constant cancels in the softmax over the
-    neighbours), where both sides are rounding noise.
-
-    kinks=True (whole-network checks): a ReLU input within ~1e-6 of zero can land on different sides in
-    the two implementations (measured: 1-2 of 1.1 M hidden activations in the decoder case; swapping
-    every HIP op for its torch-GPU equivalent leaves the mismatch unchanged, and fp32-CPU vs fp64-CPU
-    can differ the same way).  One flipped mask moves a bias-gradient entry by one summand, so the
-    criterion there is the relative L2 error (<= 1e-3) with a loose cap on the single worst entry; the
-    op- and layer-level tests below stay at the strict max-norm tolerance."""
+def grad_excess(module, ref_sd, tol=REL, floor=2e-6):
+    """Worst (name, max|grad - ref| / (tol * max|ref| + floor)) over the parameters: <= 1 passes.  The absolute floor
+    covers parameters whose true gradient is zero (attn_mlp.2.bias: a per-channel constant cancels in the softmax over
+    the neighbours), where both sides are rounding noise."""
     worst = ('', 0.0)
     for name, p in module.named_parameters():
         assert p.grad is not None, 'no gradient for ' + name
         ref = ref_sd[name].grad
         assert ref is not None, 'oracle has no gradient for ' + name
         d = p.grad.detach().cpu().double() - ref.double()
-        if kinks:
-            e = max(float(d.norm()) / (1e-3 * float(ref.double().norm()) + floor),
-                    float(d.abs().max()) / (5e-2 * float(ref.abs().max()) + floor))
-        else:
-            e = float(d.abs().max()) / (tol * float(ref.abs().max()) + floor)
+        e = float(d.abs().max()) / (tol * float(ref.abs().max()) + floor)
         if e > worst[1]:
             worst = (name, e)
+    return worst
+
+
+def check_grads(module, ref_sd, tol=REL, floor=2e-6):
+    """Per parameter: max|grad - ref| <= tol * max|ref| + floor (1e-4 relative)."""
+    worst = grad_excess(module, ref_sd, tol, floor)
     assert worst[1] <= 1.0, 'worst gradient mismatch %s: %.3g x tolerance' % worst
+
+
+KINK_TAU = 5e-6      # |ReLU input| below this: two fp32 implementations may decide differently (their rounding: ~1e-6)
+
+
+def grad_score(module, ref_sd):
+    """Smooth mismatch measure that guides the search below: sum over the parameters of |grad - ref|^2 / |ref|^2."""
+    tot = 0.0
+    for name, p in module.named_parameters():
+        ref = ref_sd[name].grad.double()
+        tot += float((p.grad.detach().cpu().double() - ref).norm() ** 2) / (float(ref.norm() ** 2) + 1e-20)
+    return tot
+
+
+def strict_with_kinks(oracle_run, compare, max_units=64):
+    """Whole-network gradient checks at the STRICT tolerance.  A ReLU input within rounding of zero can land on
+    different sides in two correct fp32 implementations; one flipped mask moves gradients by one summand of a sum over
+    ~100 rows, far above 1e-4.  Instead of loosening the tolerance: the oracle pass is audited (oracle.path.relu_kinks)
+    for units with |input| < KINK_TAU -- a few dozen out of ~10^6 -- and replayed with chosen units deciding the other
+    way; a greedy search (one unit at a time, kept when it lowers the smooth mismatch score) has to arrive at an
+    assignment for which the product's gradients agree to the strict tolerance.  Units outside the KINK_TAU band
+    are never touched.  oracle_run() -> whatever compare needs (fresh leaves, gradients populated);
+    compare(ref) -> (worst excess: <= 1 passes, smooth score).
+    Returns (number of ambiguous units, number of units that had to decide against the oracle's sign)."""
+    with op.relu_kinks(KINK_TAU) as log:
+        ref = oracle_run()
+    val = {}
+    for (c, i, v) in log:
+        val[(c, i)] = v
+    units = sorted(val, key=lambda u: abs(val[u]))
+    assert len(units) <= max_units, '%d ReLU inputs within %.0e of zero: search too large' % (len(units), KINK_TAU)
+    excess, score = compare(ref)
+    forced = {}
+    sweeps = 0
+    while excess > 1.0 and sweeps < 3:
+        sweeps += 1
+        changed = False
+        for u in units:
+            trial = dict(forced)
+            if u in trial:
+                del trial[u]                                  # back to the oracle's own sign
+            else:
+                trial[u] = not (val[u] > 0)                   # decide against it
+            with op.relu_kinks(KINK_TAU, forced=trial):
+                e, sc = compare(oracle_run())
+            if sc < score:
+                excess, score, forced, changed = e, sc, trial, True
+                if excess <= 1.0:
+                    break
+        if not changed:
+            break
+    assert excess <= 1.0, ('no assignment of the %d ambiguous ReLU units brings the gradients within the strict '
+                           'tolerance: best %.3g x (flipped %d)' % (len(units), excess, len(forced)))
+    return len(units), len(forced)
 
 
 def leaf_sd(sd):
@@ -187,15 +238,76 @@ def test_checkpointed_attention_with_frozen_parameters():
         agg = layer(xg[None], T(pos).cuda()[None], x2g[None], T(pos2).cuda()[None])[0]
         (agg * go).sum().backward()
         return layer, xg.grad, x2g.grad
+    # default mode: the scatter reductions accumulate with fp32 atomics, two backward passes agree to rounding only
     full, gx, gx2 = run(())
     part, hx, hx2 = run(('to_v', 'attn_mlp.0', 'pos_mlp.2.bias'))
-    # (two backward passes agree to rounding only: the scatter reductions accumulate with atomics)
     assert rel_err(hx, gx) < 1e-5 and rel_err(hx2, gx2) < 1e-5
     for (name, p), (_, q) in zip(part.named_parameters(), full.named_parameters()):
         if name.startswith(('to_v', 'attn_mlp.0', 'pos_mlp.2.bias')):
             assert p.grad is None
         else:
             assert rel_err(p.grad, q.grad) < 1e-5, name
+    # deterministic mode (fixed-order reductions): the original 1e-6 bound holds, and a repeated run is bit-identical
+    with pk.ops.deterministic():
+        full, gx, gx2 = run(())
+        again, ax, ax2 = run(())
+        part, hx, hx2 = run(('to_v', 'attn_mlp.0', 'pos_mlp.2.bias'))
+    assert torch.equal(ax, gx) and torch.equal(ax2, gx2)
+    assert all(torch.equal(p.grad, q.grad) for p, q in zip(again.parameters(), full.parameters()))
+    assert rel_err(hx, gx) < 1e-6 and rel_err(hx2, gx2) < 1e-6
+    for (name, p), (_, q) in zip(part.named_parameters(), full.named_parameters()):
+        if not name.startswith(('to_v', 'attn_mlp.0', 'pos_mlp.2.bias')):
+            assert rel_err(p.grad, q.grad) < 1e-6, name
+
+
+def test_deterministic_reductions_match_the_atomic_ones_and_repeat_bit_for_bit():
+    """ops.deterministic(): every backward reduction in a fixed order (stable sort by target row + in-order segment sums;
+    two-stage sums for the small vector gradients).  Same values as the atomic kernels to rounding, identical bits on
+    a second run; the end-to-end step's gradients repeat bit for bit."""
+    rng = np.random.default_rng(77)
+    n, k, m, d, h = 700, 14, 60, 416, 32
+    Tc = lambda a, dt=np.float32: torch.from_numpy(np.asarray(a, dtype=dt)).cuda()   # noqa: E731
+    idx = Tc(rng.integers(0, m, size=(n, k)), np.int32)
+    src = Tc(rng.normal(size=(n * k, 96)))
+    logits, pe = Tc(rng.normal(size=(n * k, d))), Tc(rng.normal(size=(n * k, d)))
+    v, dagg = Tc(rng.normal(size=(m, d))), Tc(rng.normal(size=(n, d)))
+    pos, pos2 = Tc(rng.normal(size=(n, 3))), Tc(rng.normal(size=(m, 3)))
+    r, gr = Tc(np.abs(rng.normal(size=(n * k, h))) * (rng.uniform(size=(n * k, h)) > 0.3)), Tc(rng.normal(size=(n * k, h)))
+    w8, i8, dy = Tc(rng.uniform(size=(n, 8))), Tc(rng.integers(0, m, size=(n, 8)), np.int32), Tc(rng.normal(size=(n, 288)))
+    y, pidx, dz = Tc(rng.normal(size=(n, 72))), Tc(rng.integers(0, n, size=(233, 12)), np.int32), Tc(rng.normal(size=(233, 72)))
+    xl, gl, gam = Tc(rng.normal(size=(n, 72))), Tc(rng.normal(size=(n, 72))), Tc(rng.normal(size=(72,)))
+
+    def every():
+        return [pk.ops.scatter_add_rows(src, idx, m, scale=-1.0), *pk.ops.pt_softmax_agg_bwd(logits, v, pe, idx, dagg),
+                *pk.ops.pt_pos_hidden_bwd(pos, pos2, idx, r, gr), pk.ops.interp_bwd(dy, i8, w8, m),
+                pk.ops.maxpool_gather_bwd(y, pidx, dz), *pk.ops.layernorm_bwd(xl, gam, gl, 1e-5)]
+    atomic = every()
+    with pk.ops.deterministic():
+        det1, det2 = every(), every()
+    for a, b, c in zip(atomic, det1, det2):
+        assert torch.equal(b, c)
+        assert rel_err(b, a) < 2e-5
+    # whole step: gradients of two identical eager steps are bit-identical in deterministic mode
+    kind, npts = 'carla', 512
+    pa, ia, inf = pk.configs.model_args(kind, npts)
+    pcl = pk.configs.synthetic_pcl(kind, npts, 4, 31).cuda()
+    esd, dsd = pk.configs.synthetic_weights(pa, ia, 32)
+    q = Tc(np.concatenate([rng.uniform(-3, 3, size=(2, 200, 3)), np.zeros((2, 200, 1))], -1))
+    tgt = Tc(np.concatenate([rng.integers(0, 2, size=(2, 200, 1)), rng.uniform(size=(2, 200, 3)), np.zeros((2, 200, 1)),
+                             rng.integers(-1, 13, size=(2, 200, 1))], -1))
+
+    def grads():
+        enc = pk.model.PointCompletionNetV3(**pa).cuda().train()
+        dec = pk.implicit.LocalPclResnetFC(**ia).cuda().train()
+        enc.load_state_dict(esd)
+        dec.load_state_dict(dsd)
+        step = pk.training.TrainStep(enc, dec, loss_kwargs=dict(density_lw=1.0, segmentation_lw=0.6))
+        loss = step.forward_loss(pcl, q, tgt)
+        loss.backward()
+        return [p.grad.clone() for p in step.params]
+    with pk.ops.deterministic():
+        g1, g2 = grads(), grads()
+    assert all(torch.equal(a, b) for a, b in zip(g1, g2))
 
 
 def test_chained_blocks_gradients_strict():
@@ -227,24 +339,31 @@ def test_decoder_gradients(case):
     rng = np.random.default_rng(5)
     go = torch.from_numpy(rng.normal(size=(q.shape[0], ia['d_out'])).astype(np.float32))
     gp = torch.from_numpy(rng.normal(size=(q.shape[0], ia['d_hidden'])).astype(np.float32)) * 0.1
-    # oracle
-    rsd = leaf_sd(sd)
-    ab_r = T(abstract).clone().requires_grad_(True)
-    fg_r = T(fglob).clone().requires_grad_(True)
-    with op.stable_ties():
-        out_r, pen_r = op.decoder_forward(rsd, ia, T(q), ab_r, fg_r)
-    ((out_r * go).sum() + (pen_r * gp).sum()).backward()
     # HIP
     net = pk.implicit.LocalPclResnetFC(**ia).cuda().train()
     net.load_state_dict(sd)
     ab = T(abstract).cuda().requires_grad_(True)
     fg = T(fglob).cuda().requires_grad_(True)
     out, pen = net(T(q).cuda(), ab, fg, None)
-    assert rel_err(out, out_r) < 2e-5 and rel_err(pen, pen_r) < 2e-5
     ((out * go.cuda()).sum() + (pen * gp.cuda()).sum()).backward()
-    check_grads(net, rsd, kinks=True)
-    assert rel_err(ab.grad[:, 3:], ab_r.grad[:, 3:]) <= 5e-2
-    assert rel_err(fg.grad, fg_r.grad) <= 5e-2
+
+    def oracle_run():
+        rsd = leaf_sd(sd)
+        ab_r = T(abstract).clone().requires_grad_(True)
+        fg_r = T(fglob).clone().requires_grad_(True)
+        with op.stable_ties():
+            out_r, pen_r = op.decoder_forward(rsd, ia, T(q), ab_r, fg_r)
+        ((out_r * go).sum() + (pen_r * gp).sum()).backward()
+        return rsd, ab_r, fg_r, out_r, pen_r
+
+    def compare(ref):
+        rsd, ab_r, fg_r, out_r, pen_r = ref
+        assert rel_err(out, out_r) < 2e-5 and rel_err(pen, pen_r) < 2e-5
+        return (max(grad_excess(net, rsd)[1], rel_err(ab.grad[:, 3:], ab_r.grad[:, 3:]) / REL, rel_err(fg.grad, fg_r.grad) / REL),
+                grad_score(net, rsd))
+    n_units, n_flipped = strict_with_kinks(oracle_run, compare)
+    print('decoder gradients (%s): %d ReLU inputs within %.0e of zero, %d decided the other way in the product'
+          % (case['name'], n_units, KINK_TAU, n_flipped))
 
 
 @pytest.mark.parametrize('kind', ['greater', 'carla'])
@@ -254,17 +373,28 @@ def test_encoder_gradients(kind):
     pcl = pk.configs.synthetic_pcl(kind, n, 4, 21)
     sd = pk.configs.fill_state_dict(pk.configs.encoder_param_shapes(pa), 22)
     rng = np.random.default_rng(23)
-    rsd = leaf_sd(sd)
-    out_r, xg_r = op.encoder_forward(rsd, pa, pcl)
-    g1 = torch.from_numpy(rng.normal(size=tuple(out_r.shape)).astype(np.float32))
-    g2 = torch.from_numpy(rng.normal(size=tuple(xg_r.shape)).astype(np.float32))
-    ((out_r * g1).sum() + (xg_r * g2).sum()).backward()
+    with torch.no_grad():
+        shp = [tuple(t.shape) for t in op.encoder_forward(sd, pa, pcl)]
+    g1 = torch.from_numpy(rng.normal(size=shp[0]).astype(np.float32))
+    g2 = torch.from_numpy(rng.normal(size=shp[1]).astype(np.float32))
     net = pk.model.PointCompletionNetV3(**pa).cuda().train()
     net.load_state_dict(sd)
     out, xg, _ = net(pcl.cuda(), False)
-    assert rel_err(out, out_r) < 2e-5 and rel_err(xg, xg_r) < 2e-5
     ((out * g1.cuda()).sum() + (xg * g2.cuda()).sum()).backward()
-    check_grads(net, rsd, kinks=True)
+
+    def oracle_run():
+        rsd = leaf_sd(sd)
+        out_r, xg_r = op.encoder_forward(rsd, pa, pcl)
+        ((out_r * g1).sum() + (xg_r * g2).sum()).backward()
+        return rsd, out_r, xg_r
+
+    def compare(ref):
+        rsd, out_r, xg_r = ref
+        assert rel_err(out, out_r) < 2e-5 and rel_err(xg, xg_r) < 2e-5
+        return grad_excess(net, rsd)[1], grad_score(net, rsd)
+    n_units, n_flipped = strict_with_kinks(oracle_run, compare)
+    print('encoder gradients (%s): %d ReLU inputs within %.0e of zero, %d decided the other way in the product'
+          % (kind, n_units, KINK_TAU, n_flipped))
 
 
 def test_end_to_end_training_step_gradients():
@@ -278,12 +408,6 @@ def test_end_to_end_training_step_gradients():
     q = T(op.sample_query_points(64, inf['min_z'], inf['cube_bounds'], 1, kind, 4, 'random'))
     target = torch.from_numpy(np.concatenate([rng.integers(0, 2, size=(64, 1)), rng.uniform(size=(64, 3)),
                                               np.zeros((64, 1)), rng.integers(-1, 13, size=(64, 1))], 1).astype(np.float32))
-    res, red = leaf_sd(esd), leaf_sd(dsd)
-    with op.stable_ties():
-        ab_r, fg_r = op.encoder_forward(res, pa, pcl)
-        out_r, _ = op.decoder_forward(red, ia, q, ab_r[0], fg_r[0])
-    loss_r = pk.training.implicit_loss(out_r[None], target[None], density_lw=1.0, segmentation_lw=0.6)
-    loss_r.backward()
     enc = pk.model.PointCompletionNetV3(**pa).cuda().train()
     dec = pk.implicit.LocalPclResnetFC(**ia).cuda().train()
     enc.load_state_dict(esd)
@@ -291,10 +415,24 @@ def test_end_to_end_training_step_gradients():
     ab, fg, _ = enc(pcl.cuda(), False)
     out, _ = dec(q.cuda(), ab[0], fg[0], None)
     loss = pk.training.implicit_loss(out[None], target.cuda()[None], density_lw=1.0, segmentation_lw=0.6)
-    assert abs(float(loss) - float(loss_r)) < 1e-5
     loss.backward()
-    check_grads(dec, red, kinks=True)
-    check_grads(enc, res, kinks=True)
+
+    def oracle_run():
+        res, red = leaf_sd(esd), leaf_sd(dsd)
+        with op.stable_ties():
+            ab_r, fg_r = op.encoder_forward(res, pa, pcl)
+            out_r, _ = op.decoder_forward(red, ia, q, ab_r[0], fg_r[0])
+        loss_r = pk.training.implicit_loss(out_r[None], target[None], density_lw=1.0, segmentation_lw=0.6)
+        loss_r.backward()
+        return res, red, loss_r
+
+    def compare(ref):
+        res, red, loss_r = ref
+        assert abs(float(loss.detach()) - float(loss_r.detach())) < 1e-5
+        return max(grad_excess(dec, red)[1], grad_excess(enc, res)[1]), grad_score(dec, red) + grad_score(enc, res)
+    n_units, n_flipped = strict_with_kinks(oracle_run, compare)
+    print('end-to-end step gradients: %d ReLU inputs within %.0e of zero, %d decided the other way in the product'
+          % (n_units, KINK_TAU, n_flipped))
 
 
 def test_train_step_reduces_loss():
