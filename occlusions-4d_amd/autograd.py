@@ -11,6 +11,46 @@ from torch.autograd import Function
 
 from . import ops
 
+# Training-path Linear layers with a 416-wide operand (the decoder trunk, the 416 -> 832 / 832 <- 416 layers of the
+# attention MLP and their data gradients) run on the row-resident kernel of the inference trunk (occ4d_rowlin_f32:
+# 0.72-0.79 of the fp32 MFMA peak against 0.46-0.65 for the generic kernel at these shapes, profiles/train_shapes.py).
+# The stage-packed copy of a weight (and of its transpose, for the data gradient) is rebuilt when the weight changes.
+ROWLIN_IN_TRAINING = True
+_PACKS = {}
+
+
+def _packed(w, transposed):
+    from . import point_transformer_layer as ptl
+    key = (w.data_ptr(), w._version, tuple(w.shape), bool(transposed), ptl.weights_epoch())
+    hit = _PACKS.get(key)
+    if hit is not None and hit[0] is w:
+        return hit[1]
+    src = w.detach().t().contiguous() if transposed else w.detach()
+    packed = ops.pack_trunk_rows(src)
+    if len(_PACKS) > 128:
+        _PACKS.clear()
+    _PACKS[key] = (w, packed)          # (w kept alive: its address cannot be recycled under this key)
+    return packed
+
+
+def _zeros(n, device):
+    key = ('zeros', n, str(device))
+    z = _PACKS.get(key)
+    if z is None:
+        z = _PACKS[key] = torch.zeros((n,), dtype=torch.float32, device=device)
+    return z
+
+
+def _linear_fwd(x, w, b, relu_in=False, relu_out=False, residual=None, transposed=False):
+    """[relu]([relu](x) W'^T + b) + residual with W' = w (or w^T when `transposed`: the data gradient)."""
+    n_out, k = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
+    if (ROWLIN_IN_TRAINING and k == ops.TRUNK_WIDTH and n_out % 32 == 0 and not relu_out and x.shape[0] >= 1024
+            and x.is_contiguous() and (residual is None or residual.is_contiguous())):
+        bias = b if b is not None else _zeros(n_out, x.device)
+        return ops.rowlin(x, _packed(w, transposed), bias, n_out, relu_in=relu_in, residual=residual)
+    return ops.linear(x, w.t().contiguous() if transposed else w, b, relu_in=relu_in, relu_out=relu_out,
+                      residual=residual)
+
 
 class LinearFn(Function):
     """y = [relu]( [relu](x) W^T + b ) + residual   (never relu_out together with residual)."""
@@ -18,7 +58,7 @@ class LinearFn(Function):
     @staticmethod
     def forward(ctx, x, w, b, relu_in, relu_out, residual):
         assert not (relu_out and residual is not None)
-        y = ops.linear(x, w, b, relu_in=relu_in, relu_out=relu_out, residual=residual)
+        y = _linear_fwd(x, w, b, relu_in=relu_in, relu_out=relu_out, residual=residual)
         ctx.flags = (relu_in, relu_out, b is not None, residual is not None)
         ctx.save_for_backward(x, w, y if relu_out else None)
         return y
@@ -31,7 +71,7 @@ class LinearFn(Function):
         g = ops.relu_mask(dy, y) if relu_out else dy
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
-            dx = ops.linear(g, w.t().contiguous())
+            dx = _linear_fwd(g, w, None, transposed=True)
             if relu_in:
                 dx = ops.relu_mask(dx, x)
         want_db = has_b and ctx.needs_input_grad[2]
