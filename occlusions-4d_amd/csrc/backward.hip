@@ -420,6 +420,12 @@ extern "C" {
 
 int occ4d_linear_wgrad_workspace(int M, int N, int K, int* splits_out, int64_t* floats_out) {
   OCC4D_REQUIRE(M >= 0 && N >= 1 && K >= 1 && splits_out && floats_out, "occ4d_linear_wgrad_workspace: bad arguments");
+  int s16 = 0, mps16 = 0;
+  if (occ4d::wgrad16_plan(M, N, K, &s16, &mps16)) {        // the wide decoder layers: csrc/wgrad16.hip
+    *splits_out = s16;
+    *floats_out = (int64_t)(s16 + 1) * N * K + (int64_t)(s16 + 1) * N;      // (+ 1: the partial of the rows behind the
+    return OCC4D_OK;                                                            // last full 16-row tile)
+  }
   // enough m-chunks to give every CU a workgroup, each at least 256 rows deep
   const int tiles = occ4d::cdiv(N, 128) * occ4d::cdiv(K, 416);
   int splits = occ4d::cdiv(512, tiles);
@@ -448,6 +454,14 @@ int occ4d_linear_wgrad_bias_f32(const float* g, int64_t ldg, const float* x, int
   const int mps = occ4d::cdiv(occ4d::cdiv(M, splits), WG_BM) * WG_BM;
   const int64_t nk = (int64_t)N * K;
   float* part_b = db ? workspace + (int64_t)splits * nk : nullptr;
+  int s16 = 0, mps16 = 0;
+  if (occ4d::wgrad16_plan(M, N, K, &s16, &mps16) && s16 == splits) {
+    float* pb16 = db ? workspace + (int64_t)(splits + 1) * nk : nullptr;
+    if (int rc = occ4d::wgrad16_launch(g, ldg, x, ldx, M, N, K, splits, mps16, workspace, pb16, relu_x, st)) return rc;
+    wgrad_reduce_kernel<<<grid1d(nk), TPB, 0, st>>>(workspace, splits + 1, nk, dw, accumulate);
+    if (db) wgrad_reduce_kernel<<<grid1d(N), TPB, 0, st>>>(pb16, splits + 1, N, db, accumulate);
+    return occ4d::check_launch("occ4d_linear_wgrad_f32(reduce)");
+  }
 #define OCC4D_WGRAD(NT) launch_wgrad<NT>(g, ldg, x, ldx, M, N, K, splits, mps, workspace, part_b, relu_x, st)
   if (K <= 32) OCC4D_WGRAD(1);
   else if (K <= 64) OCC4D_WGRAD(2);

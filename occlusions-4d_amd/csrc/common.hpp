@@ -36,4 +36,11 @@ constexpr int FPS_BUCKET_MIN_POINTS = 9600;
 int fps_bucket_launch(const float* xyz, int64_t stride, int n, int m, int start, int32_t* out_sorted,
                       int32_t* out_order, hipStream_t stream);
 
+
+// wgrad16.hip: weight gradient for N a multiple of 416, K a multiple of 32 (>= 64), M >= 4096 (the wide decoder
+// layers); false = the shape is not taken (backward.hip's wgrad_kernel then runs).
+bool wgrad16_plan(int M, int N, int K, int* splits, int* m_per_split);
+int wgrad16_launch(const float* g, int64_t ldg, const float* x, int64_t ldx, int M, int N, int K, int splits,
+                   int m_per_split, float* part, float* part_b, int relu_x, hipStream_t stream);
+
 }  // namespace occ4d
