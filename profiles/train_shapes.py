@@ -3,7 +3,11 @@ sys.path.insert(0, '/root/repo')
 sys.argv = ['bench_train.py', '--steps', '1', '--warmup', '1']
 import bench_train as bt
 import torch
+LAST = [None]
 class ShapeCounter(bt.StepCounter):
+    def __init__(self):
+        super().__init__()
+        LAST[0] = self
     def want(self, name, **shape):
         self._shape = tuple(sorted(shape.items()))
         return True
@@ -18,6 +22,12 @@ buf = io.StringIO()
 with contextlib.redirect_stdout(buf):
     bt.main()
 d = json.loads(buf.getvalue().strip().split('\n')[-1])
+import collections
+per = collections.defaultdict(list)
+for (name, a, b, f) in LAST[0].events:
+    per[name].append(round(a.elapsed_time(b), 3))
+for k, v in per.items():
+    if 'rowlin' in k and '458752' in k: print(k, v)
 ks = d['roofline']['kernels']
 tot = sum(v['total_ms'] for v in ks.values())
 print('step %.1f ms; timed launches %.1f ms' % (d['ms_per_step'], tot))
