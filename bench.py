@@ -25,7 +25,7 @@ grid on one GPU) and `strong_config2` on the N > 1 lines (the 534 528-query grid
 where the serial 7.6 ms encode is the Amdahl term).
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel = cross_attn16_kernel (fused vector attention, 14
+  roofline      the dominant kernel = cross_attn16p_kernel (fused vector attention, 14
                 neighbours, D = 416), timed with HIP events on its launch stream.  achieved / frac
                 = the FLOP the kernel EXECUTES (after the exact-in-R refactoring of DESIGN.md 4,
                 counted once: 2 * 14 * (32*832 + 832*416 + 32*416) per query) / time, against the
@@ -393,9 +393,11 @@ def main():
             'scaling': 'strong' if world > 1 else 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s inference (BASELINE configs[%d]): n_points=%d video_len=%d num_sample=%d (-> %d grid '
-                                   'queries%s) implicit_batch_size=%d, seeded random-init weights'
+                                   'queries%s) implicit_batch_size=%d (decoded in mini-batches of %d = 3584 workgroups of 9 '
+                                   'queries; every query is decoded, results do not depend on the split), seeded '
+                                   'random-init weights'
                                    % (args.kind.upper(), 1 if world == 1 else 3, N_POINTS, VIDEO_LEN, num_sample, n_total,
-                                      ', %d per GPU' % (hi - lo) if world > 1 else '', BATCH),
+                                      ', %d per GPU' % (hi - lo) if world > 1 else '', BATCH, chunk),
                        'abstract_points': m_abs, 'outputs_per_query': ia['d_out'],
                        'parallelism': 'query-sharded x%d, rank 0 encodes, abstract cloud broadcast (RCCL)' % world
                                       if world > 1 else 'single GPU',
@@ -411,8 +413,10 @@ def main():
                 'achieved_as_written': as_written / 1e12, 'frac_as_written': as_written / FP32_MFMA_PEAK,
                 'traffic': traffic, 'traffic_source': traffic_source,
                 'traffic_over_algorithmic': (traffic / (chunk * (2 * H + H + 14) * 4.0)) if traffic else None,
-                'kernel': 'cross_attn16_kernel (csrc/crossattn16.hip: fused vector attention = pos-MLP + attn-MLP + softmax '
-                          '+ aggregate, 14 neighbours, D=416, v_mfma_f32_16x16x4_f32)',
+                'kernel': ('cross_attn16p_kernel (csrc/crossattn16p.hip: fused vector attention = pos-MLP + attn-MLP + softmax '
+                           '+ aggregate, 14 neighbours, D=416, v_mfma_f32_16x16x4_f32, two 4-wave workgroups per CU)'
+                           if pk.point_transformer_layer.USE_ATTN16P else
+                           'cross_attn16_kernel (csrc/crossattn16.hip: fused vector attention, one 8-wave workgroup per CU)'),
                 'launches': psum['launches'], 'avg_launch_ms': psum['total_ms'] / max(1, psum['launches']),
                 'flop_per_launch_executed': psum['total_flops'] / max(1, psum['launches']),
                 'flop_per_launch_as_written': psum['total_flops'] / max(1, psum['launches'])
