@@ -272,6 +272,12 @@ int occ4d_rowlin_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const f
                      int n_out, int relu_in, const float* res, int64_t ldr, const float* zconst, const float* ztab,
                      int64_t ldz, const int32_t* zidx, const float* zw, int kz, int n, void* stream);
 
+/* occ4d_rowlin_f32 with an output mask: y = mask > 0 ? ([res +] W [relu](x) + b) : 0 -- the data gradient of a
+ * relu_in Linear, dx = (x > 0) . (g W), with the ReLU mask applied in the epilogue (training, train.py:101-118). */
+int occ4d_rowlin_masked_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed, const float* b,
+                            int n_out, int relu_in, const float* res, int64_t ldr, const float* mask, int64_t ldm, int n,
+                            void* stream);
+
 /* Half-CU re-cut of the two kernels above (csrc/trunk4.hip): the same contracts, arithmetic and register layout, with
  * 4-wave workgroups of 64 rows and 26 KB stages of 16 channels, so that two workgroups -- of these kernels, of
  * occ4d_pt_cross_attn16p_f32, or of whatever the other decode stream runs -- share a CU and one's memory phases sit

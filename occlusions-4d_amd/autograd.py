@@ -41,15 +41,19 @@ def _zeros(n, device):
     return z
 
 
-def _linear_fwd(x, w, b, relu_in=False, relu_out=False, residual=None, transposed=False):
-    """[relu]([relu](x) W'^T + b) + residual with W' = w (or w^T when `transposed`: the data gradient)."""
+def _linear_fwd(x, w, b, relu_in=False, relu_out=False, residual=None, transposed=False, mask=None):
+    """[relu]([relu](x) W'^T + b) + residual with W' = w (or w^T when `transposed`: the data gradient); `mask`: the
+    result is zeroed where mask <= 0 (the ReLU of a relu_in layer applied to its data gradient)."""
     n_out, k = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
     if (ROWLIN_IN_TRAINING and k == ops.TRUNK_WIDTH and n_out % 32 == 0 and not relu_out and x.shape[0] >= 1024
             and x.is_contiguous() and (residual is None or residual.is_contiguous())):
         bias = b if b is not None else _zeros(n_out, x.device)
-        return ops.rowlin(x, _packed(w, transposed), bias, n_out, relu_in=relu_in, residual=residual)
-    return ops.linear(x, w.t().contiguous() if transposed else w, b, relu_in=relu_in, relu_out=relu_out,
-                      residual=residual)
+        if mask is not None and not mask.is_contiguous():
+            mask = mask.contiguous()
+        return ops.rowlin(x, _packed(w, transposed), bias, n_out, relu_in=relu_in, residual=residual, mask=mask)
+    y = ops.linear(x, w.t().contiguous() if transposed else w, b, relu_in=relu_in, relu_out=relu_out,
+                   residual=residual)
+    return y if mask is None else ops.relu_mask(y, mask)
 
 
 class LinearFn(Function):
@@ -71,9 +75,7 @@ class LinearFn(Function):
         g = ops.relu_mask(dy, y) if relu_out else dy
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
-            dx = _linear_fwd(g, w, None, transposed=True)
-            if relu_in:
-                dx = ops.relu_mask(dx, x)
+            dx = _linear_fwd(g, w, None, transposed=True, mask=x if relu_in else None)
         want_db = has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             # one kernel: dW = g^T [relu](x) on the MFMA, db = column sums of the g tiles it stages
@@ -122,6 +124,31 @@ class AttnInFn(Function):
         da = da.contiguous()
         k = idx.shape[1]
         return ops.segment_sum(da, k), ops.scatter_add_rows(da, idx, ctx.m, scale=-1.0), da, None
+
+
+class AttnInLinearFn(Function):
+    """a[p] = q[i] - kf[idx[p]] + r[p] Wp^T  (p = i k + j): AttnInFn fused with the K = 32 Linear that feeds it -- the
+    (N k, 2D) product Wp r is never written on its own and the gather / subtract pass over it disappears (the generic
+    Linear kernel adds the gathered rows in its epilogue)."""
+
+    @staticmethod
+    def forward(ctx, q, kf, r, wp, idx):
+        k = idx.shape[1]
+        a = ops.linear(r, wp, add_rows=q, add_div=k, sub_rows=kf, sub_idx=idx.reshape(-1))
+        ctx.save_for_backward(r, wp, idx)
+        ctx.m = kf.shape[0]
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        r, wp, idx = ctx.saved_tensors
+        da = da.contiguous()
+        k = idx.shape[1]
+        dq = ops.segment_sum(da, k) if ctx.needs_input_grad[0] else None
+        dkf = ops.scatter_add_rows(da, idx, ctx.m, scale=-1.0) if ctx.needs_input_grad[1] else None
+        dr = _linear_fwd(da, wp, None, transposed=True) if ctx.needs_input_grad[2] else None
+        dwp = ops.linear_wgrad(da, r) if ctx.needs_input_grad[3] else None
+        return dq, dkf, dr, dwp, None
 
 
 class SoftmaxAggFn(Function):

@@ -48,6 +48,7 @@ struct TrunkArgs {
   int n;                                     // rows
   int n_stages;                              // rowlin: output channels / 32
   int relu_in;                               // rowlin: relu on the operand
+  const float* mask; int64_t ldm;            // rowlin: output rows zeroed where mask <= 0 (ReLU mask of a data gradient), or null
 };
 
 // LDS byte address of a __shared__ object (wave-uniform, for M0)
@@ -316,6 +317,12 @@ __device__ __forceinline__ void rowlin_stage(const TrunkArgs& a, int s, const fl
       o1.x = fmaf(w, zb.x, o1.x); o1.y = fmaf(w, zb.y, o1.y); o1.z = fmaf(w, zb.z, o1.z); o1.w = fmaf(w, zb.w, o1.w);
     }
   }
+  if (a.mask) {      // dx = (x > 0) ? dx : 0: the ReLU of a relu_in layer, applied to its data gradient in the epilogue
+    const f32x4 m0 = *reinterpret_cast<const f32x4*>(a.mask + (int64_t)rowc * a.ldm + c0);
+    const f32x4 m1 = *reinterpret_cast<const f32x4*>(a.mask + (int64_t)rowc * a.ldm + c0 + 16);
+    o0.x = m0.x > 0.f ? o0.x : 0.f; o0.y = m0.y > 0.f ? o0.y : 0.f; o0.z = m0.z > 0.f ? o0.z : 0.f; o0.w = m0.w > 0.f ? o0.w : 0.f;
+    o1.x = m1.x > 0.f ? o1.x : 0.f; o1.y = m1.y > 0.f ? o1.y : 0.f; o1.z = m1.z > 0.f ? o1.z : 0.f; o1.w = m1.w > 0.f ? o1.w : 0.f;
+  }
   if (row < a.n) {
     float* yp = a.y + (int64_t)row * a.ldy + c0;
     *reinterpret_cast<f32x4*>(yp) = o0;
@@ -378,7 +385,7 @@ extern "C" int occ4d_resblock_f32(const float* x, int64_t ldx, float* y, int64_t
                                   const float* b0, const float* w1_packed, const float* b1, const float* zconst,
                                   const float* ztab, int64_t ldz, const int32_t* zidx, const float* zw, int kz, int n,
                                   void* stream) {
-  TrunkArgs a{x, ldx, y, ldy, w0_packed, b0, w1_packed, b1, nullptr, 0, zconst, ztab, ldz, zidx, zw, kz, n, TNS, 1};
+  TrunkArgs a{x, ldx, y, ldy, w0_packed, b0, w1_packed, b1, nullptr, 0, zconst, ztab, ldz, zidx, zw, kz, n, TNS, 1, nullptr, 0};
   if (n == 0) return OCC4D_OK;               // (an empty batch has no storage: nothing to check)
   if (int rc = check_common(a, "occ4d_resblock_f32")) return rc;
   OCC4D_REQUIRE(w1_packed && b1 && ((uintptr_t)w1_packed % 16) == 0 && ((uintptr_t)b1 % 16) == 0 && ldy >= TH,
@@ -388,12 +395,16 @@ extern "C" int occ4d_resblock_f32(const float* x, int64_t ldx, float* y, int64_t
   return occ4d::check_launch("occ4d_resblock_f32");
 }
 
+extern "C" int occ4d_rowlin_masked_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed,
+                                       const float* b, int n_out, int relu_in, const float* res, int64_t ldr,
+                                       const float* mask, int64_t ldm, int n, void* stream);
+
 extern "C" int occ4d_rowlin_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed,
                                 const float* b, int n_out, int relu_in, const float* res, int64_t ldr,
                                 const float* zconst, const float* ztab, int64_t ldz, const int32_t* zidx,
                                 const float* zw, int kz, int n, void* stream) {
   TrunkArgs a{x, ldx, y, ldy, w_packed, b, nullptr, nullptr, res, ldr, zconst, ztab, ldz, zidx, zw, kz, n,
-              n_out / 32, relu_in};
+              n_out / 32, relu_in, nullptr, 0};
   if (n == 0) return OCC4D_OK;
   if (int rc = check_common(a, "occ4d_rowlin_f32")) return rc;
   OCC4D_REQUIRE(n_out >= 32 && n_out % 32 == 0 && ldy >= n_out, "occ4d_rowlin_f32: n_out = %d must be a multiple of 32 <= ldy",
@@ -403,4 +414,23 @@ extern "C" int occ4d_rowlin_f32(const float* x, int64_t ldx, float* y, int64_t l
   if (n == 0) return OCC4D_OK;
   rowlin_kernel<<<occ4d::cdiv(n, TROWS), 512, 0, (hipStream_t)stream>>>(a);
   return occ4d::check_launch("occ4d_rowlin_f32");
+}
+
+// y = mask > 0 ? ([res +] W [relu](x) + b) : 0 -- occ4d_rowlin_f32 with the ReLU mask of a data gradient applied in
+// the epilogue (training: dx of a relu_in layer = (x > 0) . (g W); the separate masking pass read and wrote dx again)
+extern "C" int occ4d_rowlin_masked_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed,
+                                       const float* b, int n_out, int relu_in, const float* res, int64_t ldr,
+                                       const float* mask, int64_t ldm, int n, void* stream) {
+  TrunkArgs a{x, ldx, y, ldy, w_packed, b, nullptr, nullptr, res, ldr, nullptr, nullptr, 0, nullptr, nullptr, 0, n,
+              n_out / 32, relu_in, mask, ldm};
+  if (n == 0) return OCC4D_OK;
+  if (int rc = check_common(a, "occ4d_rowlin_masked_f32")) return rc;
+  OCC4D_REQUIRE(n_out >= 32 && n_out % 32 == 0 && ldy >= n_out, "occ4d_rowlin_masked_f32: n_out = %d must be a multiple of 32 <= ldy",
+                n_out);
+  OCC4D_REQUIRE(!res || (ldr % 4 == 0 && ((uintptr_t)res % 16) == 0 && ldr >= n_out),
+                "occ4d_rowlin_masked_f32: residual rows must be 16-byte aligned with ldr %% 4 == 0");
+  OCC4D_REQUIRE(mask && ldm % 4 == 0 && ((uintptr_t)mask % 16) == 0 && ldm >= n_out,
+                "occ4d_rowlin_masked_f32: mask rows must be 16-byte aligned with ldm %% 4 == 0 and ldm >= n_out");
+  rowlin_kernel<<<occ4d::cdiv(n, TROWS), 512, 0, (hipStream_t)stream>>>(a);
+  return occ4d::check_launch("occ4d_rowlin_masked_f32");
 }

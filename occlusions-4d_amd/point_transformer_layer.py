@@ -155,7 +155,7 @@ class _CheckpointedAttention(torch.autograd.Function):
                 ic = idx[lo:hi].contiguous()
                 aq = L(xc, wq_l, bq_l, False, False, None)                                      # (c, 2D)
                 r = autograd.PosHiddenFn.apply(pos[lo:hi].contiguous(), pos2, ic, P1, c1)      # (c*K, 32)
-                a = autograd.AttnInFn.apply(aq, kt_l, L(r, wp_l, None, False, False, None), ic) # aq_i - kt_j + Wp r
+                a = autograd.AttnInLinearFn.apply(aq, kt_l, r, wp_l, ic)                         # aq_i - kt_j + Wp r
                 logits = L(a, W2, b2, True, False, None)                                        # W2 relu(.) + b2
                 pe = L(r, P2l, c2l, False, False, None)
                 out = autograd.SoftmaxAggFn.apply(logits, vt_l, pe, ic)
@@ -342,7 +342,7 @@ class PointTransformerLayer(nn.Module):
         vt = L(x2, self.to_v.weight, None, False, False, None)         # (M, D)
         aq = L(x, wq, bq, False, False, None)                          # (N, 2D)
         r = autograd.PosHiddenFn.apply(pos, pos2, idx, P1, c1)         # (N*K, 32)
-        a = autograd.AttnInFn.apply(aq, kt, L(r, wp, None, False, False, None), idx)    # aq_i - kt_j + Wp r
+        a = autograd.AttnInLinearFn.apply(aq, kt, r, wp, idx)                           # aq_i - kt_j + Wp r
         logits = L(a, W2, b2, True, False, None)                       # W2 relu(.) + b2
         pe = L(r, P2, c2, False, False, None)
         return autograd.SoftmaxAggFn.apply(logits, vt, pe, idx)
