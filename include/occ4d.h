@@ -203,6 +203,12 @@ int occ4d_interp_weights_f32(const float* dist, int n, int k, float* w, void* st
 int occ4d_interp_add_f32(float* x, int64_t ldx, const float* cvec, const float* table, int64_t ldt,
                          const int32_t* idx, const float* w, int n, int k, int d, void* stream);
 
+/* c (m, n) = a b in fp64 with element strides for both operands (a[i sam + l sak], b[l sbk + j sbn]; c contiguous):
+ * the merged weights of the exact-in-R refactoring (W1 Wq etc., formed in fp64 and rounded once; their gradients in
+ * training) -- model/point_transformer_layer.py:170-176 as rearranged in DESIGN.md 4 (i). */
+int occ4d_matmul_f64(const double* a, int64_t sam, int64_t sak, const double* b, int64_t sbk, int64_t sbn, double* c,
+                     int m, int n, int k, void* stream);
+
 /* Second-generation fused vector attention for d = 416, K <= 14 (csrc/crossattn16.hip): the same contract as
  * occ4d_pt_cross_attn_f32 (model/point_transformer_layer.py:168-179 with the merged first attn_mlp layer), on
  * v_mfma_f32_16x16x4_f32 with one wave per 16 pair rows and all 416 channels (no duplicated GEMM1, no spills), weights

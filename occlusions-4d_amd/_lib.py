@@ -70,6 +70,7 @@ SIGNATURES = {
     'occ4d_pt_cross_attn_bf16x3_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, C.c_int64, _i, _f, C.c_int64, _f,
                                                  C.c_int64, _f, _f, _f, _f, _f, _f, _f, _f, C.c_int64, C.c_int,
                                                  C.c_int, C.c_int, C.c_int, C.c_float, _s]),
+    'occ4d_matmul_f64': (C.c_int, [_f, C.c_int64, C.c_int64, _f, C.c_int64, C.c_int64, _f, C.c_int, C.c_int, C.c_int, _s]),
     'occ4d_pt_cross_attn16_stream_floats': (C.c_int64, []),
     'occ4d_pt_cross_attn16_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, C.c_int64, _i, _f, C.c_int64, _f,
                                             C.c_int64, _f, _f, _f, _f, C.c_int64, C.c_int, C.c_int, C.c_int,

@@ -56,6 +56,38 @@ def _linear_fwd(x, w, b, relu_in=False, relu_out=False, residual=None, transpose
     return y if mask is None else ops.relu_mask(y, mask)
 
 
+class MatmulF64Fn(Function):
+    """c = a @ b in fp64 on the library (the merged weights of DESIGN.md 4 (i) and, in training, their gradients back
+    to the original parameters); b may be a vector."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.vec = b.dim() == 1
+        b2 = b[:, None] if ctx.vec else b
+        ctx.save_for_backward(a, b2)
+        c = ops.matmul_f64(a, b2)
+        return c[:, 0] if ctx.vec else c
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b2 = ctx.saved_tensors
+        dc2 = dc[:, None] if ctx.vec else dc
+        da = ops.matmul_f64(dc2, b2.t()) if ctx.needs_input_grad[0] else None
+        db = ops.matmul_f64(a.t(), dc2) if ctx.needs_input_grad[1] else None
+        if db is not None and ctx.vec:
+            db = db[:, 0]
+        return da, db
+
+
+def matmul64(a, b):
+    """fp64 product of the merged-weight algebra.  CUDA tensors: the library kernel.  CPU tensors only occur when the
+    algebra itself is checked on the host (tests/test_host.py builds a module on the CPU and compares the merged
+    matrices with the as-written expression); such a module cannot run a forward pass -- every op rejects CPU tensors."""
+    if not a.is_cuda:
+        return a @ b
+    return MatmulF64Fn.apply(a, b)
+
+
 class LinearFn(Function):
     """y = [relu]( [relu](x) W^T + b ) + residual   (never relu_out together with residual)."""
 

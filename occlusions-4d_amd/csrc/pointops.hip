@@ -269,6 +269,30 @@ __global__ __launch_bounds__(TPB) void squash_kernel(float* __restrict__ out, in
   out[i * ld + c] = v;
 }
 
+
+// C[m][n] = sum_k A[m sam + k sak] * B[k sbk + n sbn] in fp64 (element strides: either operand may be a transposed
+// view).  The merged weights of refactoring (i) (W1 Wq, W1 Wk, W1 P2, W1 c2 + b1 -- a few hundred MFLOP
+// once per weight update) were torch fp64 matmuls, i.e. the one vendor-BLAS call on the path; 16 x 16 output tiles
+// through LDS, one thread per output.
+__global__ __launch_bounds__(256) void matmul_f64_kernel(const double* __restrict__ A, int64_t sam, int64_t sak,
+                                                         const double* __restrict__ B, int64_t sbk, int64_t sbn,
+                                                         double* __restrict__ Cm, int M, int N, int K) {
+  __shared__ double sa[16][17], sb[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m = blockIdx.y * 16 + ty, n = blockIdx.x * 16 + tx;
+  double acc = 0.0;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    const int ka = k0 + tx, kb = k0 + ty;
+    sa[ty][tx] = (m < M && ka < K) ? A[(int64_t)m * sam + (int64_t)ka * sak] : 0.0;
+    sb[ty][tx] = (kb < K && n < N) ? B[(int64_t)kb * sbk + (int64_t)n * sbn] : 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) acc = fma(sa[ty][kk], sb[kk][tx], acc);
+    __syncthreads();
+  }
+  if (m < M && n < N) Cm[(int64_t)m * N + n] = acc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -400,3 +424,12 @@ int occ4d_squash_f32(float* out, int64_t ld, int n, int g, const int32_t* ops_ho
 }
 
 }  // extern "C"
+
+extern "C" int occ4d_matmul_f64(const double* a, int64_t sam, int64_t sak, const double* b, int64_t sbk, int64_t sbn,
+                                double* c, int m, int n, int k, void* stream) {
+  OCC4D_REQUIRE(a && b && c && m >= 0 && n >= 0 && k >= 1, "occ4d_matmul_f64: bad arguments");
+  if (m == 0 || n == 0) return OCC4D_OK;
+  matmul_f64_kernel<<<dim3(occ4d::cdiv(n, 16), occ4d::cdiv(m, 16)), 256, 0, (hipStream_t)stream>>>(a, sam, sak, b, sbk,
+                                                                                                   sbn, c, m, n, k);
+  return occ4d::check_launch("occ4d_matmul_f64");
+}

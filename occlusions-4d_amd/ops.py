@@ -286,6 +286,18 @@ def pt_softmax_agg(logits, v, pe, idx, out=None):
     return out
 
 
+def matmul_f64(a, b):
+    """(m, k) @ (k, n) in fp64 on the library (occ4d_matmul_f64); either operand may be a strided (transposed) view."""
+    assert a.is_cuda and b.is_cuda and a.dtype == torch.float64 and b.dtype == torch.float64, 'matmul_f64: CUDA fp64 tensors'
+    assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[0]
+    m, k = a.shape
+    n = b.shape[1]
+    c = torch.empty((m, n), dtype=torch.float64, device=a.device)
+    _lib.check(_lib.lib().occ4d_matmul_f64(a.data_ptr(), a.stride(0), a.stride(1), b.data_ptr(), b.stride(0), b.stride(1),
+                                           c.data_ptr(), m, n, k, _stream()))
+    return c
+
+
 FUSED_ATTN_DIMS = (288, 416)
 FUSED_ATTN_MAX_K = 14
 

@@ -137,8 +137,9 @@ class _CheckpointedAttention(torch.autograd.Function):
         with torch.enable_grad():
             # merged matrices as differentiable functions of the parameters (fp64 products, rounded once)
             W1d = W1.to(f64)
-            merged = [(W1d @ Wq.to(f64)).float(), (W1d @ c2.to(f64) + b1.to(f64)).float(),
-                      (W1d @ Wk.to(f64)).float(), (W1d @ P2.to(f64)).float()]
+            mm = autograd.matmul64
+            merged = [mm(W1d, Wq.to(f64)).float(), (mm(W1d, c2.to(f64)) + b1.to(f64)).float(),
+                      mm(W1d, Wk.to(f64)).float(), mm(W1d, P2.to(f64)).float()]
             wq_l, bq_l, wk_l, wp_l = (m.detach().requires_grad_(True) for m in merged)
             x2d = x2.detach().requires_grad_(True)
             kt = L(x2d, wk_l, None, False, False, None)                    # (M, 2D), once per backward
@@ -244,15 +245,16 @@ class PointTransformerLayer(nn.Module):
         b1 = self.attn_mlp[0].bias.detach().to(f64)
         P2 = self.pos_mlp[2].weight.detach().to(f64)
         c2 = self.pos_mlp[2].bias.detach().to(f64)
-        wq = W1 @ self.to_q.weight.detach().to(f64)
-        bq = W1 @ c2 + b1
+        mm = autograd.matmul64               # fp64 products on the library (occ4d_matmul_f64)
+        wq = mm(W1, self.to_q.weight.detach().to(f64))
+        bq = mm(W1, c2) + b1
         if pre is not None:
-            bq = bq + wq @ pre.bias.detach().to(f64)
-            wq = wq @ pre.weight.detach().to(f64)
+            bq = bq + mm(wq, pre.bias.detach().to(f64))
+            wq = mm(wq, pre.weight.detach().to(f64))
         m = dict(
             wq=wq.float().contiguous(), bq=bq.float().contiguous(),
-            wk=(W1 @ self.to_k.weight.detach().to(f64)).float().contiguous(),
-            wp=(W1 @ P2).float().contiguous())
+            wk=mm(W1, self.to_k.weight.detach().to(f64)).float().contiguous(),
+            wp=mm(W1, P2).float().contiguous())
         m['wq_packed'] = trunk_pack(m['wq'])          # (2D, 416) query projection on the row-resident kernel
         if self.dim == 416 and self.pos_mlp[0].out_features == 32 and self.attn_mlp[2].weight.is_cuda:
             pack = ops.pack_attn16p_stream if USE_ATTN16P else ops.pack_attn16_stream
@@ -334,10 +336,11 @@ class PointTransformerLayer(nn.Module):
         W1, b1 = self.attn_mlp[0].weight, self.attn_mlp[0].bias
         W2, b2 = self.attn_mlp[2].weight, self.attn_mlp[2].bias
         W1d = W1.to(f64)
-        wq = (W1d @ self.to_q.weight.to(f64)).float()
-        bq = (W1d @ c2.to(f64) + b1.to(f64)).float()
-        wk = (W1d @ self.to_k.weight.to(f64)).float()
-        wp = (W1d @ P2.to(f64)).float()
+        mm = autograd.matmul64
+        wq = mm(W1d, self.to_q.weight.to(f64)).float()
+        bq = (mm(W1d, c2.to(f64)) + b1.to(f64)).float()
+        wk = mm(W1d, self.to_k.weight.to(f64)).float()
+        wp = mm(W1d, P2.to(f64)).float()
         kt = L(x2, wk, None, False, False, None)                       # (M, 2D)
         vt = L(x2, self.to_v.weight, None, False, False, None)         # (M, D)
         aq = L(x, wq, bq, False, False, None)                          # (N, 2D)

@@ -272,3 +272,27 @@ def test_attention_chain_gradients_random(pk):
         torch.nn.functional.layer_norm(xt, (d,), gt, bt, 1e-5).backward(torch.from_numpy(go).double())
         dx, dg, dbeta = pk.ops.layernorm_bwd(C(x), C(gam), C(go), 1e-5)
         assert _rel(dx, xt.grad) <= 2e-5 and _rel(dg, gt.grad) <= 2e-5 and _rel(dbeta, bt.grad) <= 2e-5
+
+
+def test_matmul_f64_and_its_gradients(pk):
+    """occ4d_matmul_f64 (the merged-weight products, fp64): contiguous, transposed-view and vector operands against
+    torch on the CPU, and the autograd Function's gradients."""
+    rng = np.random.default_rng(5)
+    for (m, k, n) in [(832, 416, 416), (33, 17, 5), (416, 32, 1), (1, 1, 1)]:
+        a = torch.from_numpy(rng.normal(size=(m, k))).cuda()
+        b = torch.from_numpy(rng.normal(size=(k, n))).cuda()
+        want = a.cpu() @ b.cpu()
+        assert float((pk.ops.matmul_f64(a, b).cpu() - want).abs().max()) < 1e-12 * k
+        at = torch.from_numpy(rng.normal(size=(k, m))).cuda()
+        assert float((pk.ops.matmul_f64(at.t(), b).cpu() - at.cpu().t() @ b.cpu()).abs().max()) < 1e-12 * k
+    a = torch.from_numpy(rng.normal(size=(40, 24))).cuda().requires_grad_(True)
+    v = torch.from_numpy(rng.normal(size=(24,))).cuda().requires_grad_(True)
+    b = torch.from_numpy(rng.normal(size=(24, 9))).cuda().requires_grad_(True)
+    go, gv = torch.from_numpy(rng.normal(size=(40, 9))).cuda(), torch.from_numpy(rng.normal(size=(40,))).cuda()
+    ((pk.autograd.matmul64(a, b) * go).sum() + (pk.autograd.matmul64(a, v) * gv).sum()).backward()
+    ar, vr, br = (t.detach().cpu().requires_grad_(True) for t in (a, v, b))
+    (((ar @ br) * go.cpu()).sum() + ((ar @ vr) * gv.cpu()).sum()).backward()
+    for got, ref in ((a.grad, ar.grad), (v.grad, vr.grad), (b.grad, br.grad)):
+        assert float((got.cpu() - ref).abs().max()) < 1e-11
+    with pytest.raises(AssertionError):
+        pk.ops.matmul_f64(torch.zeros((2, 2), dtype=torch.float64), torch.zeros((2, 2), dtype=torch.float64))   # CPU tensors
