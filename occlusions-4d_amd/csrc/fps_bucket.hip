@@ -16,6 +16,17 @@
 //   3. wave maximum = DPP reduction over the bm lanes; the buckets at that maximum are searched for the lowest
 //      ORIGINAL index at that distance (the sort permutes the points, the tie rule does not change).
 //   4. wave winners (key, xyz) go to LDS, one barrier, every wave picks the block winner.
+//
+// Several samples per round.  The serial chain of one round (wave maximum -> index search -> LDS -> barrier -> block
+// winner) costs about as much as the arithmetic, so a round accepts every following sample it can PROVE: beside its
+// winner a wave publishes a floor (an upper bound of the running mins of all its other points).  After the barrier
+// every wave holds the NW candidates c_w with their exact running mins and F = the largest floor.  The block winner A
+// is the next sample as before.  The candidates' running mins are then lowered by their distance to A (the same
+// ((dx*dx + dy*dy) + dz*dz) expression the point update uses, so bit-identical to what the update will store); if the
+// best of them is STRICTLY above F it is above every other point's running min (those only shrink), so it is exactly the
+// sample the next sequential step would pick (ties between candidates: lowest index, as always; a tie with F stops the
+// round because an unseen point of lower index could sit at that distance).  Repeat until the test fails, up to CMAX
+// samples.  The next round then applies all accepted samples: lane 8 c + u tests bucket u against sample c in one pass.
 #include "common.hpp"
 
 namespace {
@@ -91,7 +102,9 @@ __global__ __launch_bounds__(T) void fps_bucket_kernel(const float* __restrict__
                                                        int32_t* __restrict__ out_order) {
   static_assert(NB >= 1 && NB <= 8, "buckets per wave: at most 8 (32 slots per lane)");
   constexpr int NW = T / 64;
-  constexpr int REFRESH = 32;                    // steps between exact bucket bounds (power of two)
+  static_assert(NW == 8, "the candidate round below keeps candidate l % 8 in lane l");
+  constexpr int CMAX = 8;                        // samples per round: lane 8 c + u pairs sample c with bucket u
+  constexpr int REFRESH = 8;                     // rounds between exact bucket bounds (power of two)
   constexpr int SORT_MAX = 16384;
   constexpr int CELL_BITS = 4, CELLS = 1 << (3 * CELL_BITS);
   static_assert(CELLS == 8 * T, "the scan below gives every thread eight cells");
@@ -213,7 +226,7 @@ __global__ __launch_bounds__(T) void fps_bucket_kernel(const float* __restrict__
       bh[a] = wave_reduce_f32<true>(fmaxf(fmaxf(c[0][a], c[1][a]), fmaxf(c[2][a], c[3][a])));
     }
     const bool any_live = ((u * NW + wave) << 8) < n;
-    if (lane == u) {
+    if ((lane & 7) == u) {                           // lane 8 c + u: bucket u (against accepted sample c, step 1)
       bminx = bl[0]; bminy = bl[1]; bminz = bl[2];
       bmaxx = bh[0]; bmaxy = bh[1]; bmaxz = bh[2];
       bm = any_live ? __builtin_inff() : -1.f;
@@ -225,7 +238,8 @@ __global__ __launch_bounds__(T) void fps_bucket_kernel(const float* __restrict__
 #pragma unroll
   for (int g = 0; g < NB; ++g) gm[g] = max(max(md[4 * g], md[4 * g + 1]), max(md[4 * g + 2], md[4 * g + 3]));
   const float* first = xyz + (int64_t)start * stride;
-  float cx = first[0], cy = first[1], cz = first[2];
+  float ccx = first[0], ccy = first[1], ccz = first[2];   // lane l: accepted sample l / 8 of the last round
+  int nacc = 1;                                           // how many of them are live
   if (t == 0) {
     out_sorted[0] = start;                          // (out_sorted carries the picks in selection order until the end)
     if (out_order) out_order[0] = start;
@@ -233,45 +247,60 @@ __global__ __launch_bounds__(T) void fps_bucket_kernel(const float* __restrict__
 
 #ifdef OCC4D_FPSB_STAMP
   // per-wave cycle accounting (debug build): [0] box test, [1] bucket updates, [2] wave max, [3] index search +
-  // coordinates, [4] publish + barrier, [5] block winner
-  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+  // coordinates + floor, [4] publish + barrier, [5] candidates from LDS, [6] candidate round, [7] accepted samples
+  // from LDS; [8] rounds
+  unsigned long long tacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = __builtin_amdgcn_s_memtime();
 #define STAMP(i) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tacc[i] += tn - tprev; tprev = tn; }
 #else
 #define STAMP(i)
 #endif
-  int par = 0;
-  for (int it = 1; it < m; ++it) {
-    // (0) every REFRESH steps the bounds become exact again (in between they only go stale upwards: running mins
+  // 8-lane group reductions (candidate l % 8 in lane l): quad, quad, half-row mirror
+#define OCC4D_DPP8(op, v)                                                                          \
+  asm volatile("s_nop 1\n\t" op " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"   \
+               "s_nop 1\n\t" op " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"   \
+               "s_nop 1\n\t" op " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(v))
+  int par = 0, round = 0;
+  for (int it = 1; it < m;) {
+    // (0) every REFRESH rounds the bounds become exact again (in between they only go stale upwards: running mins
     // never grow, so a stale bound still is an upper bound and the skip test stays conservative)
-    if ((it & (REFRESH - 1)) == 0) {
+    if (round != 0 && (round & (REFRESH - 1)) == 0) {
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
         const int top = wave_reduce<1>(gm[u]);
-        bm = lane == u ? __int_as_float(top) : bm;
+        bm = (lane & 7) == u ? __int_as_float(top) : bm;
       }
     }
-    // (1) which of this wave's buckets can change: one bucket per lane
-    const float ex = fmaxf(fmaxf(bminx - cx, cx - bmaxx), 0.f);
-    const float ey = fmaxf(fmaxf(bminy - cy, cy - bmaxy), 0.f);
-    const float ez = fmaxf(fmaxf(bminz - cz, cz - bmaxz), 0.f);
+    ++round;
+    // (1) which of this wave's buckets can change: lane 8 c + u tests bucket u against accepted sample c
+    const float ex = fmaxf(fmaxf(bminx - ccx, ccx - bmaxx), 0.f);
+    const float ey = fmaxf(fmaxf(bminy - ccy, ccy - bmaxy), 0.f);
+    const float ez = fmaxf(fmaxf(bminz - ccz, ccz - bmaxz), 0.f);
     const float db = (ex * ex + ey * ey) + ez * ez;
-    const unsigned touch = (unsigned)__ballot(db < bm);       // lanes >= NB hold bm = -1: never set
+    const u64 touch = __ballot(db < bm && (lane >> 3) < nacc);   // lanes with l % 8 >= NB hold bm = -1: never set
     STAMP(0)
     // (2) update the touched buckets
-    const f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
-      if ((touch >> u) & 1u) {
+      u64 mu = (touch >> u) & 0x0101010101010101ull;
+      if (mu) {
+        do {
+          const int src = (int)__builtin_ctzll(mu) ;            // lane 8 c (+ 0): sample c
+          mu &= mu - 1;
+          const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ccx), src));
+          const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ccy), src));
+          const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ccz), src));
+          const f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
 #pragma unroll
-        for (int e = 4 * u; e < 4 * u + 4; e += 2) {
-          const f32x2 dx = f32x2{px[e], px[e + 1]} - c2x;
-          const f32x2 dy = f32x2{py[e], py[e + 1]} - c2y;
-          const f32x2 dz = f32x2{pz[e], pz[e + 1]} - c2z;
-          const f32x2 d = (dx * dx + dy * dy) + dz * dz;        // -ffp-contract=off: no FMA; d >= +0 for finite input
-          md[e] = min(__float_as_int(d[0]), md[e]);
-          md[e + 1] = min(__float_as_int(d[1]), md[e + 1]);
-        }
+          for (int e = 4 * u; e < 4 * u + 4; e += 2) {
+            const f32x2 dx = f32x2{px[e], px[e + 1]} - c2x;
+            const f32x2 dy = f32x2{py[e], py[e + 1]} - c2y;
+            const f32x2 dz = f32x2{pz[e], pz[e + 1]} - c2z;
+            const f32x2 d = (dx * dx + dy * dy) + dz * dz;      // -ffp-contract=off: no FMA; d >= +0 for finite input
+            md[e] = min(__float_as_int(d[0]), md[e]);
+            md[e + 1] = min(__float_as_int(d[1]), md[e + 1]);
+          }
+        } while (mu);
         gm[u] = max(max(md[4 * u], md[4 * u + 1]), max(md[4 * u + 2], md[4 * u + 3]));
       }
     }
@@ -286,28 +315,35 @@ __global__ __launch_bounds__(T) void fps_bucket_kernel(const float* __restrict__
     // a single hit (the usual case) is the answer, several hits (exact ties) take the exhaustive scan below.
     // (the hit COUNT is kept per lane on the vector side, off the scalar select chain: a dependent SALU op costs
     // 8 cycles, profiles/micro/chain_latency.hip)
-    int hgroup = 0, lane_hits = 0;
+    // Beside it, per lane, the largest running min that is NOT at the maximum (og over the buckets' lane maxima, sn
+    // over the hit bucket's slots): with a single hit that covers every point of the wave but the winner.
+    constexpr int NEG1 = (int)0xbf800000;           // -1.0f
+    int hgroup = 0, lane_hits = 0, og = NEG1, sn = NEG1;
 #pragma unroll
     for (int g = NB - 1; g >= 0; --g) {
       const bool e = gm[g] == wtop;
       hgroup = __ballot(e) ? g : hgroup;
       lane_hits += e ? 1 : 0;
+      og = max(og, e ? NEG1 : gm[g]);
     }
     unsigned long long hit = 0ull;
     int hslot = 0, slot_hits = 0;
 #pragma unroll
     for (int sl = 3; sl >= 0; --sl) {
       const int slot = hgroup * 4 + sl;
-      const bool e = md[slot] == wtop;                                    // (uniform register index)
+      const int v = md[slot];                                             // (uniform register index)
+      const bool e = v == wtop;
       const unsigned long long mk = __ballot(e);
       hit = mk ? mk : hit;
       hslot = mk ? slot : hslot;
       slot_hits += e ? 1 : 0;
+      sn = max(sn, e ? NEG1 : v);
     }
     // exactly one lane with exactly one bucket and one slot at the maximum?
     const bool single = __popcll(__ballot(lane_hits != 0)) == 1 && __ballot(lane_hits > 1 || slot_hits > 1) == 0ull;
     int hlane = (int)__builtin_ctzll(hit | (1ull << 63));
     unsigned widx;
+    int wfloor = wtop;                             // ties: another point of the wave sits at the maximum itself
     if (wtop >= 0 && !single) {
       // ties: the lowest index over every slot at the maximum (the sort permuted the points, so slot / lane order is
       // not index order)
@@ -326,51 +362,102 @@ __global__ __launch_bounds__(T) void fps_bucket_kernel(const float* __restrict__
     } else {
       const unsigned pair = (unsigned)__builtin_amdgcn_readlane(id[hslot >> 1], hlane);
       widx = (hslot & 1) ? (pair >> 16) : (pair & 0xffffu);
+      if (wtop >= 0) wfloor = wave_reduce<1>(max(og, sn));
     }
     const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px[hslot]), hlane));
     const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py[hslot]), hlane));
     const float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz[hslot]), hlane));
     STAMP(3)
     // (5) key: distance bits + 1 (0 = the wave holds padding only: loses against every real candidate, whatever its
-    // low word says), then the LOWER index, then the wave (indices are unique)
+    // low word says), then the LOWER index, then the wave (indices are unique); the floor rides in the fourth float
     if (lane == 0) {
       s_key[par][wave] = ((u64)(unsigned)max(wtop + 1, 0) << 32) |
                          (u64)(((IDX_MASK << 8) | (unsigned)wave) - ((widx & IDX_MASK) << 8));
-      s_c[par][wave] = float4{wx, wy, wz, 0.f};
+      s_c[par][wave] = float4{wx, wy, wz, __int_as_float(wfloor)};
     }
     __syncthreads();
     STAMP(4)
-    u64 k[NW];
-#pragma unroll
-    for (int w = 0; w < NW; ++w) k[w] = s_key[par][w];
-    const float4 mine = s_c[par][t & (NW - 1)];              // lane l holds wave l % NW's candidate
-#pragma unroll
-    for (int span = NW / 2; span > 0; span >>= 1)
-#pragma unroll
-      for (int w = 0; w < span; ++w) k[w] = k[w] > k[w + span] ? k[w] : k[w + span];
-    const unsigned low = __builtin_amdgcn_readfirstlane((unsigned)(k[0] & 0xffffffffu));
-    const unsigned gi = IDX_MASK - (low >> 8);
-    const int ww = (int)(low & 0xffu);
-    cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.x), ww));
-    cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.y), ww));
-    cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.z), ww));
-    STAMP(5)
-    if (t == 0) {
-      // The pick goes to global memory only (fire-and-forget stores): an LDS flag update here put a full LDS round
-      // trip in front of wave 0's next step (the loop header waits for lgkmcnt(0)), and wave 0 is the wave the
-      // others then wait for at the barrier.  The selection mask is rebuilt from out_sorted after the loop.
-      const unsigned g = min(gi, (unsigned)(n - 1));
-      out_sorted[it] = (int)g;
-      if (out_order) out_order[it] = (int)g;
+    // (6) the candidate round.  Lane l = 8 k + i holds candidate i (cmd: its running min) and D = its distance to
+    // candidate k (the point update's expression), so that an accepted sample a lowers every candidate with one short
+    // lane reduction: cmd_i = min(cmd_i, min over k of (k == a ? D : inf)).
+    const int ci = lane & (NW - 1), ck = lane >> 3;
+    const u64 key = s_key[par][ci];
+    const float4 mine = s_c[par][ci], oth = s_c[par][ck];
+    constexpr int TAKEN = (int)0x80000000, FAR = 0x7fffffff;
+    const int khi = (int)(unsigned)(key >> 32);
+    int cmd = khi ? khi - 1 : TAKEN;                               // (key 0: padding only, never a sample)
+    const int cidx = (int)(IDX_MASK - (((unsigned)key >> 8) & IDX_MASK));
+    int fl = __float_as_int(mine.w);
+    OCC4D_DPP8("v_max_i32_dpp", fl);
+    const int F = __builtin_amdgcn_readfirstlane(fl);
+    int D;
+    {
+      const float dx = mine.x - oth.x, dy = mine.y - oth.y, dz = mine.z - oth.z;
+      D = __float_as_int((dx * dx + dy * dy) + dz * dz);
     }
+    STAMP(5)
+    const int room = min(CMAX, m - it);
+    unsigned alist = 0u;                                          // accepted candidates, four bits each
+    int nnew = 0;
+    // (fully unrolled, one forward exit per sample: the rolled loop's exits cost five taken branches per sample)
+#pragma unroll
+    for (int j = 0; j < CMAX; ++j) {
+      int best = cmd;
+      OCC4D_DPP8("v_max_i32_dpp", best);
+      bool eq = cmd == best;
+      unsigned m8 = (unsigned)__ballot(eq) & 0xffu;
+      if (j == 0) {
+        // the block winner, as always: lowest index among equals
+        int low = eq ? cidx : FAR;
+        OCC4D_DPP8("v_min_i32_dpp", low);
+        eq = eq && cidx == low;
+        m8 = (unsigned)__ballot(eq) & 0xffu;
+      } else if (j >= room || !(__builtin_amdgcn_readfirstlane(best) > F) || (m8 & (m8 - 1u)) != 0u) {
+        break;        // not provably the next sample (or two candidates tie: the next round resolves it by index)
+      }
+      const int a = __builtin_ctz(m8);
+      alist |= (unsigned)a << (4 * j);
+      nnew = j + 1;
+      if (j == CMAX - 1) break;
+      int red = ck == a ? D : FAR;
+      asm volatile("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(red));
+      {
+        const auto r16 = __builtin_amdgcn_permlane16_swap((unsigned)red, (unsigned)red, false, false);
+        red = min((int)r16[0], (int)r16[1]);
+        const auto r32 = __builtin_amdgcn_permlane32_swap((unsigned)red, (unsigned)red, false, false);
+        red = min((int)r32[0], (int)r32[1]);                          // over k, for this lane's i
+      }
+      cmd = eq ? TAKEN : min(cmd, red);
+    }
+    STAMP(6)
+    // the accepted samples for the next round's updates: lane 8 c + u takes sample c
+    {
+      const int asel = (int)((alist >> (4 * ck)) & 7u);
+      const float4 acc = s_c[par][asel];
+      ccx = acc.x; ccy = acc.y; ccz = acc.z;
+      if (wave == 0 && ci == 0 && ck < nnew) {
+        // The picks go to global memory only (fire-and-forget stores): an LDS flag update here put a full LDS round
+        // trip in front of wave 0's next step (the loop header waits for lgkmcnt(0)), and wave 0 is the wave the
+        // others then wait for at the barrier.  The selection mask is rebuilt from out_sorted after the loop.
+        const unsigned gi = IDX_MASK - (((unsigned)s_key[par][asel] >> 8) & IDX_MASK);
+        const unsigned g = min(gi, (unsigned)(n - 1));
+        out_sorted[it + ck] = (int)g;
+        if (out_order) out_order[it + ck] = (int)g;
+      }
+    }
+    nacc = nnew;
+    it += nnew;
+    STAMP(7)
     par ^= 1;
   }
+#undef OCC4D_DPP8
   __syncthreads();
 #ifdef OCC4D_FPSB_STAMP
-  if (lane == 0 && out_order) {   // debug build: out_order has 8 * NW * 2 spare ints behind the (even-rounded) m entries
-    unsigned long long* o = (unsigned long long*)(out_order + ((m + 1) & ~1)) + wave * 8;
+  if (lane == 0 && out_order) {   // debug build: out_order has 16 * NW * 2 spare ints behind the (even-rounded) m entries
+    unsigned long long* o = (unsigned long long*)(out_order + ((m + 1) & ~1)) + wave * 16;
+    tacc[8] = (unsigned long long)round;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) o[i] = tacc[i];
+    for (int i = 0; i < 9; ++i) o[i] = tacc[i];
   }
 #endif
 

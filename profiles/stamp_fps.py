@@ -28,8 +28,9 @@ def main():
     fn = lib.occ4d_fps_f32
     fn.restype = C.c_int
     fn.argtypes = pk._lib.SIGNATURES['occ4d_fps_f32'][1]
-    names = ['box test', 'bucket updates', 'wave max', 'index + coordinates', 'publish+barrier', 'block winner']
-    exhaustive_names = ['distance update', 'wave max + index + coordinates', 'publish+barrier', 'block winner', '-', '-']
+    names = ['box test', 'bucket updates', 'wave max', 'index + coordinates + floor', 'publish+barrier', 'candidates from LDS',
+             'candidate round', 'accepted from LDS']
+    exhaustive_names = ['distance update', 'wave max + index + coordinates', 'publish+barrier', 'block winner', '-', '-', '-', '-']
     pruned_names = names
     for n, m in sizes:
         names = exhaustive_names if (os.environ.get('OCC4D_FPS_PRUNE') == '0' or n < 9600) else pruned_names
@@ -45,15 +46,20 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         s0 = (m + 1) & ~1
-        st = order[s0:s0 + 128].cpu().numpy().view(np.int64).reshape(-1, 8)[:8, :6].astype(np.float64) / (m - 1)
+        if names is pruned_names:
+            raw = order[s0:s0 + 256].cpu().numpy().view(np.int64).reshape(-1, 16)[:8]
+            print('rounds %d: %.2f samples per round' % (raw[0, 8], (m - 1) / max(raw[0, 8], 1)))
+        else:
+            raw = order[s0:s0 + 128].cpu().numpy().view(np.int64).reshape(-1, 8)[:8]
+        st = raw[:, :8].astype(np.float64) / (m - 1)
         print('n=%d m=%d: %.3f ms, %.3f us/step; cycles per step (mean over steps), per wave:' %
               (n, m, e0.elapsed_time(e1), 1e3 * e0.elapsed_time(e1) / m))
         nw = 4 if (n <= 7168 and (os.environ.get('OCC4D_FPS_PRUNE') == '0' or n < 9600)) else 8
         st = st[:nw]
         for w in range(nw):
-            print('  wave %d: ' % w + '  '.join('%s %.0f' % (names[i], st[w, i]) for i in range(6)) +
+            print('  wave %d: ' % w + '  '.join('%s %.0f' % (names[i], st[w, i]) for i in range(8)) +
                   '  total %.0f' % st[w].sum())
-        print('  mean  : ' + '  '.join('%s %.0f' % (names[i], st[:, i].mean()) for i in range(6)) +
+        print('  mean  : ' + '  '.join('%s %.0f' % (names[i], st[:, i].mean()) for i in range(8)) +
               '  total %.0f' % st.sum(1).mean())
 
 
