@@ -60,7 +60,7 @@ int occ4d_knn_f32(const float* query, int64_t q_stride, int n_query,
  * random_start=False, model/modules.py:133-135): start at index 0, then
  * repeatedly the first argmax of the running min of ((dx*dx+dy*dy)+dz*dz).
  * One workgroup, register-resident points.  n <= 32768, 1 <= m <= n.
- * 9600 <= n <= 16384 runs the spatially pruned kernel (csrc/fps_bucket.hip): same picks, ties included.
+ * 1536 <= n <= 16384 runs the spatially pruned kernel (csrc/fps_bucket.hip, several samples per round): same picks, ties included.
  * out_sorted: (m) int32 selected indices in ASCENDING order (the reference sorts
  * them, :135);  out_order: (m) int32 in selection order, or NULL.
  * When the cloud holds fewer than m distinct points the greedy rule re-picks (distance 0, lowest index):

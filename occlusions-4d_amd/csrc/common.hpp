@@ -30,9 +30,11 @@ inline int check_launch(const char* what) {
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // fps_bucket.hip: the pruned single-workgroup FPS (FPS_BUCKET_MIN_POINTS <= n <= 16384); -1 = n outside that range.
-// Below ~9600 points the exhaustive kernel wins: the step is then bound by its serial argmax chain, not by the distance
-// updates the pruning saves (profiles/time_fps.py: 9558 points 3.61 vs 3.68 ms, 4779 points 1.80 vs 1.22 ms).
-constexpr int FPS_BUCKET_MIN_POINTS = 9600;
+// Since a round of the pruned kernel accepts several samples (round 3) it also wins on the small encoder levels, whose
+// step is bound by the serial argmax chain (profiles/time_fps.py, pruned vs exhaustive: 9558 points 1.84 vs 3.54 ms,
+// 4779 points 0.91 vs 1.15 ms, 1593 points 0.27 vs 0.31 ms; 2049 uniform points in a half-empty second bucket row
+// 0.42 vs 0.40 ms).  OCC4D_FPS_BUCKET_MIN overrides the threshold (ablation).
+constexpr int FPS_BUCKET_MIN_POINTS = 1536;
 int fps_bucket_launch(const float* xyz, int64_t stride, int n, int m, int start, int32_t* out_sorted,
                       int32_t* out_order, hipStream_t stream);
 

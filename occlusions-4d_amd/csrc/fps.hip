@@ -272,7 +272,7 @@ extern "C" int occ4d_fps_start_f32(const float* xyz, int64_t stride, int n, int 
   // measured (profiles/time_fps.py): 4779 pts 256 / 512 threads = 0.76 / 0.90 us per step, 9558 pts 1.38 / 1.16,
   // 14336 pts 1.39 / 1.34 / 1.78 (1024); above 56 points per thread only 1024 threads fit
   static const int forced_threads = [] { const char* e = getenv("OCC4D_FPS_THREADS"); return e ? atoi(e) : 0; }();   // read once
-  // 9600 .. 16384 points: the spatially pruned kernel (fps_bucket.hip), same indices.  OCC4D_FPS_PRUNE=0 keeps the
+  // 1536 .. 16384 points: the spatially pruned kernel (fps_bucket.hip), same indices.  OCC4D_FPS_PRUNE=0 keeps the
   // exhaustive kernel below (experiments: profiles/time_fps.py, profiles/stamp_fps.py).
   static const int prune = [] { const char* e = getenv("OCC4D_FPS_PRUNE"); return e ? atoi(e) : 1; }();
   if (prune && forced_threads <= 0 && occ4d::fps_bucket_launch(xyz, stride, n, m, start, out_sorted, out_order, st) == 0)

@@ -1,4 +1,4 @@
-// Farthest point sampling with spatial pruning (K5b): ONE workgroup, 9600 .. 16384 points.
+// Farthest point sampling with spatial pruning (K5b): ONE workgroup, 1536 .. 16384 points.
 //
 // Same greedy selection as fps.hip (argmax of the running min-distance, lowest index on ties; distances
 // ((dx*dx + dy*dy) + dz*dz) without FMA: oracle/cluster.py), but a step only touches the points that the new
@@ -28,6 +28,8 @@
 // round because an unseen point of lower index could sit at that distance).  Repeat until the test fails, up to CMAX
 // samples.  The next round then applies all accepted samples: lane 8 c + u tests bucket u against sample c in one pass.
 #include "common.hpp"
+
+#include <cstdlib>
 
 namespace {
 
@@ -504,11 +506,16 @@ namespace occ4d {
 // FPS_BUCKET_MIN_POINTS <= n <= 16384.  Returns -1 when n is outside that range.
 int fps_bucket_launch(const float* xyz, int64_t stride, int n, int m, int start, int32_t* os, int32_t* oo,
                       hipStream_t st) {
-  if (n < FPS_BUCKET_MIN_POINTS || n > 16384) return -1;
+  static const int min_points = [] { const char* e = getenv("OCC4D_FPS_BUCKET_MIN"); return e ? atoi(e) : FPS_BUCKET_MIN_POINTS; }();
+  if (n < min_points || n > 16384) return -1;
   constexpr int T = 512;
   const int nb = cdiv(n, 256 * (T / 64));
 #define OCC4D_FPSB(B) fps_bucket_kernel<B, T><<<1, T, 0, st>>>(xyz, stride, n, m, start, os, oo)
-  if (nb <= 5) OCC4D_FPSB(5);
+  if (nb <= 1) OCC4D_FPSB(1);
+  else if (nb <= 2) OCC4D_FPSB(2);
+  else if (nb <= 3) OCC4D_FPSB(3);
+  else if (nb <= 4) OCC4D_FPSB(4);
+  else if (nb <= 5) OCC4D_FPSB(5);
   else if (nb <= 6) OCC4D_FPSB(6);
   else if (nb <= 7) OCC4D_FPSB(7);
   else OCC4D_FPSB(8);

@@ -33,7 +33,7 @@ def main():
     exhaustive_names = ['distance update', 'wave max + index + coordinates', 'publish+barrier', 'block winner', '-', '-', '-', '-']
     pruned_names = names
     for n, m in sizes:
-        names = exhaustive_names if (os.environ.get('OCC4D_FPS_PRUNE') == '0' or n < 9600) else pruned_names
+        names = exhaustive_names if (os.environ.get('OCC4D_FPS_PRUNE') == '0' or n < 1536) else pruned_names
         level = pk.configs.synthetic_pcl('greater', n, 12)[0].cuda()[:, :3].contiguous()
         sel = torch.empty(m, dtype=torch.int32, device='cuda')
         order = torch.zeros(m + 2 + 8 * 16 * 2, dtype=torch.int32, device='cuda')
@@ -54,7 +54,7 @@ def main():
         st = raw[:, :8].astype(np.float64) / (m - 1)
         print('n=%d m=%d: %.3f ms, %.3f us/step; cycles per step (mean over steps), per wave:' %
               (n, m, e0.elapsed_time(e1), 1e3 * e0.elapsed_time(e1) / m))
-        nw = 4 if (n <= 7168 and (os.environ.get('OCC4D_FPS_PRUNE') == '0' or n < 9600)) else 8
+        nw = 4 if (n <= 7168 and (os.environ.get('OCC4D_FPS_PRUNE') == '0' or n < 1536)) else 8
         st = st[:nw]
         for w in range(nw):
             print('  wave %d: ' % w + '  '.join('%s %.0f' % (names[i], st[w, i]) for i in range(8)) +

@@ -1,4 +1,4 @@
-"""The spatially pruned single-workgroup FPS (csrc/fps_bucket.hip, 9600 .. 16384 points) selects exactly what the
+"""The spatially pruned single-workgroup FPS (csrc/fps_bucket.hip, 1536 .. 16384 points) selects exactly what the
 reference's greedy scan selects: same order, lowest index on ties (oracle/cluster.py restates torch_cluster.fps,
 which the reference's DownTransition calls: model/point_transformer/modules.py:67-80).  The pruning reorders the points
 along a Morton curve and skips whole buckets, so the cases here stress what that could break: exact ties (lattice
@@ -64,9 +64,13 @@ def _cloud(kind, n, rng):
     ('uniform', 14337, 1200), ('uniform', 16384, 2000), ('uniform', 15361, 900),
     ('lattice', 9700, 2500), ('lattice', 14336, 3000), ('half_lattice', 10000, 2400), ('planar', 11000, 1700),
     ('line', 9601, 1400), ('clusters', 12000, 2000), ('all_equal', 9800, 50),
-    # below the pruned kernel's range: the exhaustive kernel, 256 and 512 threads
+    # the smaller encoder levels: one to five buckets per wave, part of them padding
     ('uniform', 2049, 683), ('uniform', 3000, 3000), ('uniform', 7168, 1000), ('uniform', 7169, 1000),
-    ('uniform', 9558, 3186), ('lattice', 2500, 2500), ('half_lattice', 7000, 2400), ('all_equal', 2100, 50)])
+    ('uniform', 9558, 3186), ('lattice', 2500, 2500), ('half_lattice', 7000, 2400), ('all_equal', 2100, 50),
+    ('uniform', 1536, 512), ('uniform', 1593, 531), ('lattice', 1600, 1600), ('all_equal', 1700, 40),
+    ('clusters', 4779, 1593), ('planar', 2048, 2048), ('line', 4097, 700),
+    # below the pruned kernel's range: the exhaustive kernel
+    ('uniform', 1535, 500), ('lattice', 1200, 1200), ('all_equal', 900, 30)])
 def test_pruned_fps_matches_the_greedy_scan(pk, kind, n, m):
     rng = np.random.default_rng(n * 7 + m)
     p = _cloud(kind, n, rng).astype(np.float32)
