@@ -247,6 +247,20 @@ int occ4d_pt_cross_attn16p_f32(const float* aq, int64_t ld_aq, const float* qpos
                                float* agg, int64_t ld_agg, int n, int m, int k, int d, float divisor, int skew,
                                void* stream);
 
+/* Training companion of occ4d_pt_cross_attn16p_f32 (same file, same weight stream and MFMA chain, no softmax): the
+ * pair tensors of the layer in its merged form, which backward needs (the ops are
+ * model/point_transformer_layer.py:168-176 up to the softmax), for p = i k + j < n k:
+ *   a_out[p]  = aq[i] - kt[idx[p]] + Wp r[p]            (n k, 832)   BEFORE the ReLU of attn_mlp
+ *   logits[p] = W2 relu(a_out[p])                       (n k, 416)   attn_mlp[2].bias NOT added (it is constant over
+ *                                                                    the neighbour axis of the softmax that follows)
+ *   pe[p]     = P2 r[p] + c2                            (n k, 416)
+ * r (n k, 32) = relu(P1 (pos_i - pos2_j) + c1) from occ4d_pt_pos_hidden_f32; idx (n, k); all three outputs contiguous.
+ * One launch replaces three generic GEMM launches (K = 32 -> 832 with gathered rows, 832 -> 416, 32 -> 416).
+ * 32-bit row offsets: n k 3328 B, n ld_aq 4 B and m ld_kt 4 B must stay below 4 GiB (chunk the queries). */
+int occ4d_pt_pair_mlp_f32(const float* aq, int64_t ld_aq, const float* kt, int64_t ld_kt, const float* r,
+                          const int32_t* idx, const float* c2, const float* wstream, float* a_out, float* logits,
+                          float* pe, int n, int m, int k, int d, int skew, void* stream);
+
 /* ------------------------------------------------------------------------
  * Row-resident fused trunk layers (csrc/trunk.hip), width 416 = d_hidden of every published configuration
  * (train.py:255-256).  A row tile's activations stay in registers across the layers of a block; weights are

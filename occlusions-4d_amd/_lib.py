@@ -79,6 +79,8 @@ SIGNATURES = {
     'occ4d_pt_cross_attn16p_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, C.c_int64, _i, _f, C.c_int64, _f,
                                              C.c_int64, _f, _f, _f, _f, C.c_int64, C.c_int, C.c_int, C.c_int,
                                              C.c_int, C.c_float, C.c_int, _s]),
+    'occ4d_pt_pair_mlp_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, _i, _f, _f, _f, _f, _f, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, _s]),
     'occ4d_layernorm_f32': (C.c_int, [_f, C.c_int64, _f, _f, C.c_float, C.c_int, _f, C.c_int64, C.c_int, C.c_int,
                                       _s]),
     'occ4d_maxpool_gather_f32': (C.c_int, [_f, C.c_int64, _i, C.c_int, C.c_int, C.c_int, _f, C.c_int64, _s]),

@@ -6,6 +6,8 @@ supplies the tape, tensor glue (cat / slicing) and the optimiser only.  The trai
 uses the as-written op order of model/*.py (no weight merging), built from the unfused kernels;
 kNN / FPS carry no gradient (they depend on coordinates only).
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -181,6 +183,63 @@ class AttnInLinearFn(Function):
         dr = _linear_fwd(da, wp, None, transposed=True) if ctx.needs_input_grad[2] else None
         dwp = ops.linear_wgrad(da, r) if ctx.needs_input_grad[3] else None
         return dq, dkf, dr, dwp, None
+
+
+PAIR_MLP_FUSED = os.environ.get('OCC4D_PAIR_MLP', '1') == '1'
+
+
+def pair_mlp_fused_ok(aq, r, idx):
+    """The fused pair-tensor kernel is built for d = 416 and 32 positional hidden units, with 32-bit row offsets."""
+    d = ops.TRUNK_WIDTH
+    return (PAIR_MLP_FUSED and aq.shape[1] == 2 * d and r.shape[1] == 32
+            and idx.numel() * 2 * d * 4 < 2 ** 32 and aq.shape[0] * aq.stride(0) * 4 < 2 ** 32)
+
+
+class PairMlpFn(Function):
+    """(logits, pe) of the merged-form layer from ONE kernel (ops.pt_pair_mlp), for the chain
+        a = aq_i - kt_j + Wp r;  logits = W2 relu(a) [+ b2];  pe = P2 r + c2
+    (AttnInLinearFn -> LinearFn(relu_in) -> LinearFn in separate launches otherwise).  b2 is not added: the logits only
+    feed the softmax over the neighbour axis, where a per-channel constant cancels; its gradient (the column sums of
+    dlogits, zero up to rounding) is still returned.  backward = the backward passes of those three Functions."""
+
+    @staticmethod
+    def forward(ctx, aq, kt, r, wp, W2, b2, P2, c2, idx):
+        stream = ops.pack_attn16p_stream(W2, b2, wp, P2, c2)
+        a, logits, pe = ops.pt_pair_mlp(aq, kt, r, idx, c2, stream)
+        ctx.save_for_backward(a, r, wp, W2, P2, idx)
+        ctx.m = kt.shape[0]
+        return logits, pe
+
+    @staticmethod
+    def backward(ctx, dlogits, dpe):
+        a, r, wp, W2, P2, idx = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        k = idx.shape[1]
+        dlogits, dpe = dlogits.contiguous(), dpe.contiguous()
+        dW2 = db2 = dP2 = dc2 = dwp = daq = dkt = dr = None
+        if need[4] or need[5]:
+            if need[4]:
+                res = ops.linear_wgrad(dlogits, a, bias=bool(need[5]), relu_x=True)
+                (dW2, db2) = res if need[5] else (res, None)
+            else:
+                db2 = ops.colsum(dlogits)
+        da = _linear_fwd(dlogits, W2, None, transposed=True, mask=a)          # (x > 0) . (g W2)
+        if need[0]:
+            daq = ops.segment_sum(da, k)
+        if need[1]:
+            dkt = ops.scatter_add_rows(da, idx, ctx.m, scale=-1.0)
+        if need[3]:
+            dwp = ops.linear_wgrad(da, r)
+        if need[6] or need[7]:
+            if need[6]:
+                res = ops.linear_wgrad(dpe, r, bias=bool(need[7]))
+                (dP2, dc2) = res if need[7] else (res, None)
+            else:
+                dc2 = ops.colsum(dpe)
+        if need[2]:
+            dr = _linear_fwd(da, wp, None, transposed=True)
+            dr += _linear_fwd(dpe, P2, None, transposed=True)
+        return daq, dkt, dr, dwp, dW2, db2, dP2, dc2, None
 
 
 class SoftmaxAggFn(Function):

@@ -97,6 +97,18 @@ __device__ __forceinline__ void mm_ab_p(const f32x4 a, const f32x4 b0, const f32
   c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, c0, 0, 0, 0);
   c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, c1, 0, 0, 0);
 }
+// the same with the operands swapped: the fragments are the A operand, so that the result is TRANSPOSED -- lane (g, c)
+// holds channels 4 g .. 4 g + 3 of pair row c (one float4 per row: the training kernel's stores)
+__device__ __forceinline__ void mm_ba_p(const f32x4 b, const f32x4 a0, const f32x4 a1, f32x4& c0, f32x4& c1) {
+  c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.x, c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.y, c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b.z, c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b.w, c1, 0, 0, 0);
+}
 // GEMM1 of a stage: K = 32 on ONE accumulator (a second accumulator would cost four VALU adds per stage; the dependent
 // chain's 8 cycles per MFMA are the co-resident wave's)
 __device__ __forceinline__ void mm_g1_p(const f32x4 a0, const f32x4 a1, const f32x4 b0, const f32x4 b1, f32x4& c) {
@@ -475,6 +487,148 @@ __global__ __launch_bounds__(256, 2) void cross_attn16p_kernel(const Attn16pArgs
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Training: the pair tensors of the same layer in its merged form, for backward (the ops are
+// model/point_transformer_layer.py:168-176 before the softmax).  One kernel instead of three generic GEMM launches:
+//   a[p]      = aq[p / K] - kt[idx[p]] + Wp r[p]        (P, 832)   written stage by stage, BEFORE the ReLU
+//   logits[p] = W2 relu(a[p])                           (P, 416)   (attn_mlp[2].bias is left out: constant over the
+//                                                                   neighbour axis the softmax normalises over)
+//   pe[p]     = P2 r[p] + c2                            (P, 416)
+// Same weight stream, stage protocol and MFMA chain as the inference kernel above; a workgroup owns 128 consecutive
+// pair rows (two passes of 64), every MFMA row is live, and there is no softmax: the epilogue is stores.  Rows past
+// P are clamped to row P - 1 (they recompute and rewrite that row's values: no predicates in the loop).
+struct PairMlpArgs {
+  const float* aq; int64_t ld_aq;
+  const float* kt; int64_t ld_kt;
+  const float* r;                         // (P, 32) contiguous
+  const int32_t* idx;                     // (P) = (N, K) flat
+  const float* c2;
+  const float* wstream;
+  float* a_out;                           // (P, 832) contiguous
+  float* logits;                          // (P, 416) contiguous
+  float* pe;                              // (P, 416) contiguous
+  int P, K;
+  int first_round, skew;
+};
+
+__global__ __launch_bounds__(256, 2) void pair_mlp_kernel(const PairMlpArgs a) {
+  __shared__ __attribute__((aligned(16))) float buf0[PSTAGE];
+  __shared__ __attribute__((aligned(16))) float buf1[PSTAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const unsigned lane16 = lane * 16;
+  dma_stage_p(a.wstream, buf0, wave, lane16);
+  if (a.skew > 0 && (int)blockIdx.x < a.first_round) {      // phase skew of the two workgroups of a CU, as above
+    const unsigned hw = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+    if (hw & 1)
+      for (int i = 0; i < a.skew; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  f32x4 acc[PTD];
+  auto slice = [](const float* base, unsigned off) {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + off);
+  };
+  auto put = [](float* base, unsigned off, const f32x4 v) {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(base) + off) = v;
+  };
+
+#pragma clang loop unroll(disable)
+  for (int ps = 0; ps < 2; ++ps) {
+    const int p = min((int)blockIdx.x * 128 + 64 * ps + 16 * wave + c, a.P - 1);
+    const int q = p / a.K;
+    const int j = a.idx[p];
+    float rr[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) rr[s] = a.r[(int64_t)p * 32 + 4 * s + g];    // MFMA step s consumes k = 4 s + g
+    const f32x4 r_lo = {rr[0], rr[1], rr[2], rr[3]}, r_hi = {rr[4], rr[5], rr[6], rr[7]};
+    const unsigned aq_off = (unsigned)(q * (int)a.ld_aq + 4 * g) * 4u;
+    const unsigned kt_off = (unsigned)(j * (int)a.ld_kt + 4 * g) * 4u;
+    const unsigned a_off = ((unsigned)p * (2u * PD) + 4u * g) * 4u;
+    const unsigned l_off = ((unsigned)p * (unsigned)PD + 4u * g) * 4u;
+    f32x4 ia = slice(a.aq, aq_off);
+    f32x4 ik = slice(a.kt, kt_off);
+    dma_wait_p();
+    __syncthreads();
+
+    auto stage = [&](auto firstc, const int s, const float* __restrict__ cur, const float* nxt) {
+      constexpr bool FIRST = decltype(firstc)::value;
+      f32x4 h = f32x4{ia.x - ik.x, ia.y - ik.y, ia.z - ik.z, ia.w - ik.w};
+      const float* f = cur + lane * 4;
+      f32x4 wa = *reinterpret_cast<const f32x4*>(f + 26 * PFRAG);
+      f32x4 wb = *reinterpret_cast<const f32x4*>(f + 27 * PFRAG);
+      __builtin_amdgcn_sched_barrier(0);
+      const int sn = s + 1 < PHS ? s + 1 : s;
+      const float* nsrc = a.wstream + (int64_t)(s + 1) * PSTAGE;
+#pragma unroll
+      for (int gq = 0; gq < 14; ++gq) {
+        const f32x4 ca = wa, cb = wb;
+        if (gq + 1 < 14) {
+          wa = *reinterpret_cast<const f32x4*>(f + (2 * gq) * PFRAG);
+          wb = *reinterpret_cast<const f32x4*>(f + (2 * gq + 1) * PFRAG);
+        }
+        if (gq == 0) ia = slice(a.aq + 16 * sn, aq_off);
+        if (gq == 1) ik = slice(a.kt + 16 * sn, kt_off);
+        if (gq >= 2 && gq <= 8)
+          dma_frag_p(nsrc + (wave + 4 * (gq - 2)) * PFRAG, lds_addr_p(nxt) + (unsigned)(wave + 4 * (gq - 2)) * (PFRAG * 4), lane16);
+        __builtin_amdgcn_sched_barrier(0);
+        if (gq == 0) {
+          mm_g1_p(ca, cb, r_lo, r_hi, h);
+        } else {
+          if (FIRST) acc[2 * (gq - 1)] = acc[2 * (gq - 1) + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+          mm_ba_p(h, ca, cb, acc[2 * (gq - 1)], acc[2 * (gq - 1) + 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (gq == 0) {
+          put(a.a_out + 16 * s, a_off, h);                 // units 16 s + 4 g .. + 3 of this lane's pair row
+          __builtin_amdgcn_sched_barrier(0);
+          h.x = fmaxf(h.x, 0.f); h.y = fmaxf(h.y, 0.f); h.z = fmaxf(h.z, 0.f); h.w = fmaxf(h.w, 0.f);
+        }
+      }
+    };
+    stage(std::true_type{}, 0, buf0, buf1);
+    dma_wait_p();
+    __syncthreads();
+    stage(std::false_type{}, 1, buf1, buf0);
+    dma_wait_p();
+    __syncthreads();
+#pragma clang loop unroll(disable)
+    for (int s = 2; s < PHS; s += 2) {
+      stage(std::false_type{}, s, buf0, buf1);
+      dma_wait_p();
+      __syncthreads();
+      stage(std::false_type{}, s + 1, buf1, buf0);
+      dma_wait_p();
+      __syncthreads();
+    }
+    // ---- epilogue: the logits, then pe = P2 r + c2 on the two P2 stages (buf0 holds the first, the second lands in
+    // buf1 under it).  GEMM2 / GEMM3 ran with the fragments as the A operand (mm_ba_p): lane (g, c) holds channels
+    // 16 t + 4 g .. + 3 of pair row c in every accumulator tile
+    dma_stage_p(a.wstream + (int64_t)(PHS + 1) * PSTAGE, buf1, wave, lane16);
+#pragma unroll
+    for (int t = 0; t < PTD; ++t) put(a.logits + 16 * t, l_off, acc[t]);
+    auto pe_tiles = [&](auto T0c, auto NPc, const float* __restrict__ pbuf) {
+      constexpr int T0 = decltype(T0c)::value, NP = decltype(NPc)::value;
+      const float* fp = pbuf + lane * 4;
+#pragma unroll
+      for (int pr = 0; pr < NP; ++pr) {
+        const int t = T0 + 2 * pr;
+        f32x4 e0 = *reinterpret_cast<const f32x4*>(a.c2 + 16 * t + 4 * g);
+        f32x4 e1 = *reinterpret_cast<const f32x4*>(a.c2 + 16 * (t + 1) + 4 * g);
+        mm_ba_p(r_lo, *reinterpret_cast<const f32x4*>(fp + (4 * pr) * PFRAG),
+                *reinterpret_cast<const f32x4*>(fp + (4 * pr + 2) * PFRAG), e0, e1);
+        mm_ba_p(r_hi, *reinterpret_cast<const f32x4*>(fp + (4 * pr + 1) * PFRAG),
+                *reinterpret_cast<const f32x4*>(fp + (4 * pr + 3) * PFRAG), e0, e1);
+        put(a.pe + 16 * t, l_off, e0);
+        put(a.pe + 16 * (t + 1), l_off, e1);
+      }
+    };
+    pe_tiles(std::integral_constant<int, 0>{}, std::integral_constant<int, PTA / 2>{}, buf0);
+    dma_wait_p();
+    __syncthreads();
+    if (ps == 0) dma_stage_p(a.wstream, buf0, wave, lane16);   // pass B's first hidden stage
+    pe_tiles(std::integral_constant<int, PTA>{}, std::integral_constant<int, PTB / 2>{}, buf1);
+  }
+}
+
 int cu_count() {
   static int n = 0;
   if (n == 0) {
@@ -517,4 +671,27 @@ extern "C" int occ4d_pt_cross_attn16p_f32(const float* aq, int64_t ld_aq, const 
   if (k == PKMAX) cross_attn16p_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(a);
   else cross_attn16p_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(a);
   return occ4d::check_launch("occ4d_pt_cross_attn16p");
+}
+
+extern "C" int occ4d_pt_pair_mlp_f32(const float* aq, int64_t ld_aq, const float* kt, int64_t ld_kt, const float* r,
+                                     const int32_t* idx, const float* c2, const float* wstream, float* a_out,
+                                     float* logits, float* pe, int n, int m, int k, int d, int skew, void* stream) {
+  OCC4D_REQUIRE(d == PD, "occ4d_pt_pair_mlp: built for d = %d, got %d", PD, d);
+  OCC4D_REQUIRE(k >= 1 && m >= 1 && n >= 0, "occ4d_pt_pair_mlp: bad n/m/k");
+  if (n == 0) return OCC4D_OK;
+  OCC4D_REQUIRE(aq && kt && r && idx && c2 && wstream && a_out && logits && pe, "occ4d_pt_pair_mlp: null pointer");
+  OCC4D_REQUIRE(ld_aq >= 2 * d && ld_kt >= 2 * d && ld_aq % 4 == 0 && ld_kt % 4 == 0,
+                "occ4d_pt_pair_mlp: aq / kt leading dimensions must be >= 832 and multiples of 4");
+  auto al16 = [](const void* p) { return ((uintptr_t)p % 16) == 0; };
+  OCC4D_REQUIRE(al16(aq) && al16(kt) && al16(c2) && al16(wstream) && al16(a_out) && al16(logits) && al16(pe),
+                "occ4d_pt_pair_mlp: aq, kt, c2, wstream and the outputs must be 16-byte aligned");
+  const int64_t pairs = (int64_t)n * k;
+  OCC4D_REQUIRE(pairs * 2 * d * 4 < ((int64_t)1 << 32) && (int64_t)n * ld_aq * 4 < ((int64_t)1 << 32) &&
+                    (int64_t)m * ld_kt * 4 < ((int64_t)1 << 32),
+                "occ4d_pt_pair_mlp: 32-bit row offsets: n * k * 3328 B, n * ld_aq * 4 B and m * ld_kt * 4 B must stay "
+                "below 4 GiB (split the queries into chunks)");
+  OCC4D_REQUIRE(skew >= 0 && skew <= 64, "occ4d_pt_pair_mlp: skew=%d outside [0,64]", skew);
+  PairMlpArgs a{aq, ld_aq, kt, ld_kt, r, idx, c2, wstream, a_out, logits, pe, (int)pairs, k, 2 * cu_count(), skew};
+  pair_mlp_kernel<<<occ4d::cdiv(pairs, 128), 256, 0, (hipStream_t)stream>>>(a);
+  return occ4d::check_launch("occ4d_pt_pair_mlp");
 }

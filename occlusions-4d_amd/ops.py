@@ -452,6 +452,30 @@ def pt_cross_attn16p(aq, qpos, apos, idx, kt, vt, P1, c1, wstream, out=None, ske
     return out
 
 
+def pt_pair_mlp(aq, kt, r, idx, c2, wstream, skew=None):
+    """Training: the pair tensors of the merged-form layer in one kernel (occ4d_pt_pair_mlp_f32):
+    a (n k, 832) = aq_i - kt_j + Wp r before the ReLU, logits (n k, 416) = W2 relu(a) (attn_mlp[2].bias left out: it
+    cancels in the softmax), pe (n k, 416) = P2 r + c2.  wstream = pack_attn16p_stream(W2, ., Wp, P2, .)."""
+    aq, ld_aq = _aligned_rows(_dev(aq, name='aq'), 'aq')
+    kt, ld_kt = _aligned_rows(_dev(kt, name='kt'), 'kt')
+    idx = _dev(idx, torch.int32, 'idx')
+    n, k = idx.shape
+    d = TRUNK_WIDTH
+    r = _dev(r, name='r')
+    c2 = _dev(c2).contiguous()
+    assert idx.is_contiguous() and r.is_contiguous() and r.shape == (n * k, 32) and aq.shape == (n, 2 * d)
+    assert kt.shape[1] == 2 * d and c2.shape == (d,) and wstream.is_contiguous()
+    a = torch.empty((n * k, 2 * d), dtype=torch.float32, device=aq.device)
+    logits = torch.empty((n * k, d), dtype=torch.float32, device=aq.device)
+    pe = torch.empty((n * k, d), dtype=torch.float32, device=aq.device)
+    flops = 2.0 * n * k * (32 * 2 * d + 2 * d * d + 32 * d)
+    sk = ATTN16P_SKEW if skew is None else int(skew)
+    _lib.check(_launch('pair_mlp', dict(n=n, k=k, d=d), flops, lambda: _lib.lib().occ4d_pt_pair_mlp_f32(
+        _ptr(aq), ld_aq, _ptr(kt), ld_kt, _ptr(r), _ptr(idx), _ptr(c2), _ptr(wstream), _ptr(a), _ptr(logits),
+        _ptr(pe), n, kt.shape[0], k, d, sk, _stream())))
+    return a, logits, pe
+
+
 def layernorm(x, gamma, beta, eps=1e-5, relu=False, out=None):
     x, ldx = _rows(_dev(x, name='x'), 'x')
     n, d = x.shape

@@ -156,9 +156,13 @@ class _CheckpointedAttention(torch.autograd.Function):
                 ic = idx[lo:hi].contiguous()
                 aq = L(xc, wq_l, bq_l, False, False, None)                                      # (c, 2D)
                 r = autograd.PosHiddenFn.apply(pos[lo:hi].contiguous(), pos2, ic, P1, c1)      # (c*K, 32)
-                a = autograd.AttnInLinearFn.apply(aq, kt_l, r, wp_l, ic)                         # aq_i - kt_j + Wp r
-                logits = L(a, W2, b2, True, False, None)                                        # W2 relu(.) + b2
-                pe = L(r, P2l, c2l, False, False, None)
+                if autograd.pair_mlp_fused_ok(aq, r, ic):
+                    # a = aq_i - kt_j + Wp r, logits = W2 relu(a), pe = P2 r + c2 from one kernel
+                    logits, pe = autograd.PairMlpFn.apply(aq, kt_l, r, wp_l, W2, b2, P2l, c2l, ic)
+                else:
+                    a = autograd.AttnInLinearFn.apply(aq, kt_l, r, wp_l, ic)                     # aq_i - kt_j + Wp r
+                    logits = L(a, W2, b2, True, False, None)                                    # W2 relu(.) + b2
+                    pe = L(r, P2l, c2l, False, False, None)
                 out = autograd.SoftmaxAggFn.apply(logits, vt_l, pe, ic)
                 grads = torch.autograd.grad(out, [xc] + leaves, g[lo:hi])
                 gx[lo:hi] = grads[0]
@@ -345,9 +349,12 @@ class PointTransformerLayer(nn.Module):
         vt = L(x2, self.to_v.weight, None, False, False, None)         # (M, D)
         aq = L(x, wq, bq, False, False, None)                          # (N, 2D)
         r = autograd.PosHiddenFn.apply(pos, pos2, idx, P1, c1)         # (N*K, 32)
-        a = autograd.AttnInLinearFn.apply(aq, kt, r, wp, idx)                           # aq_i - kt_j + Wp r
-        logits = L(a, W2, b2, True, False, None)                       # W2 relu(.) + b2
-        pe = L(r, P2, c2, False, False, None)
+        if autograd.pair_mlp_fused_ok(aq, r, idx):
+            logits, pe = autograd.PairMlpFn.apply(aq, kt, r, wp, W2, b2, P2, c2, idx)
+        else:
+            a = autograd.AttnInLinearFn.apply(aq, kt, r, wp, idx)                       # aq_i - kt_j + Wp r
+            logits = L(a, W2, b2, True, False, None)                   # W2 relu(.) + b2
+            pe = L(r, P2, c2, False, False, None)
         return autograd.SoftmaxAggFn.apply(logits, vt, pe, idx)
 
     def forward_train(self, x, pos, x2=None, pos2=None, idx=None):

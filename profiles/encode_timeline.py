@@ -10,7 +10,7 @@ def main():
     n_enc = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     # one encode = everything from one fps_kernel<28 (level 0) launch's neighbourhood to the next; split on level-0 FPS
-    starts = [i for i, r in enumerate(rows) if 'fps_kernel<28' in r['Kernel_Name']]
+    starts = [i for i, r in enumerate(rows) if 'fps_bucket_kernel<7' in r['Kernel_Name'] or 'fps_kernel<28' in r['Kernel_Name']]
     assert len(starts) >= 2, 'need at least two encodes in the trace'
     # an encode begins a few kernels before its level-0 FPS: take the first kernel after the previous encode's last one
     a = starts[-1]

@@ -222,6 +222,68 @@ def test_stored_attention_gradients_strict(form):
     check_grads(layer, rsd)
 
 
+@pytest.mark.parametrize('n,m,k', [(200, 90, 14), (37, 50, 5), (1, 3, 1), (129, 300, 16)])
+def test_fused_pair_tensors_match_the_unfused_chain(n, m, k):
+    """occ4d_pt_pair_mlp_f32 (one kernel) against AttnInLinearFn -> LinearFn(relu_in) -> LinearFn: the three pair
+    tensors and every gradient of the chain, ragged row counts (the kernel owns 128 pair rows per workgroup)."""
+    ag = pk.autograd
+    d = 416
+    g = torch.Generator().manual_seed(1000 * n + k)
+    rnd = lambda *sh, s=1.0: (torch.randn(*sh, generator=g) * s).cuda()     # noqa: E731
+    aq0, kt0 = rnd(n, 2 * d), rnd(m, 2 * d)
+    r0 = torch.relu(rnd(n * k, 32))
+    wp0, W20, b20 = rnd(2 * d, 32, s=0.2), rnd(d, 2 * d, s=0.05), rnd(d, s=0.1)
+    P20, c20 = rnd(d, 32, s=0.2), rnd(d, s=0.1)
+    idx = torch.randint(0, m, (n, k), generator=g).int().cuda()
+    gl, gp = rnd(n * k, d), rnd(n * k, d)
+    L = ag.LinearFn.apply
+    results = []
+    for fused in (True, False):
+        leaves = [t.clone().requires_grad_(True) for t in (aq0, kt0, r0, wp0, W20, b20, P20, c20)]
+        aq, kt, r, wp, W2, b2, P2, c2 = leaves
+        if fused:
+            assert ag.pair_mlp_fused_ok(aq, r, idx)
+            logits, pe = ag.PairMlpFn.apply(aq, kt, r, wp, W2, b2, P2, c2, idx)
+            logits = logits + b2.detach()            # (the kernel leaves the bias out: it cancels in the softmax)
+        else:
+            a = ag.AttnInLinearFn.apply(aq, kt, r, wp, idx)
+            logits = L(a, W2, b2, True, False, None)
+            pe = L(r, P2, c2, False, False, None)
+        ((logits * gl).sum() + (pe * gp).sum()).backward()
+        results.append((logits.detach(), pe.detach(), [t.grad for t in leaves]))
+    (lf, pf, gf), (lu, pu, gu) = results
+    assert rel_err(lf, lu) < 2e-6 and rel_err(pf, pu) < 2e-6
+    names = ['aq', 'kt', 'r', 'wp', 'W2', 'b2', 'P2', 'c2']
+    for name, a_, b_ in zip(names, gf, gu):
+        assert a_ is not None and b_ is not None, name
+        assert rel_err(a_, b_) <= 2e-5, (name, rel_err(a_, b_))
+    # the stored pre-activation itself
+    stream = pk.ops.pack_attn16p_stream(W20, b20, wp0, P20, c20)
+    a_f, _, _ = pk.ops.pt_pair_mlp(aq0, kt0, r0, idx, c20, stream)
+    a_u = pk.ops.linear(r0, wp0, add_rows=aq0, add_div=k, sub_rows=kt0, sub_idx=idx.reshape(-1))
+    assert rel_err(a_f, a_u) < 2e-6
+
+
+def test_pair_tensor_paths_are_both_exercised(monkeypatch):
+    """The strict layer-level tests above run the fused pair-tensor kernel (d = 416); with it switched off the unfused
+    chain must satisfy the same criterion."""
+    ag = pk.autograd
+    calls = {'n': 0}
+    real = ag.PairMlpFn.forward
+
+    def counted(ctx, *a):
+        calls['n'] += 1
+        return real(ctx, *a)
+    monkeypatch.setattr(ag.PairMlpFn, 'forward', staticmethod(counted))
+    test_checkpointed_attention_gradients_strict(4096)
+    test_stored_attention_gradients_strict('merged')
+    assert calls['n'] == 2
+    monkeypatch.setattr(ag, 'PAIR_MLP_FUSED', False)
+    test_checkpointed_attention_gradients_strict(17)
+    test_stored_attention_gradients_strict('merged')
+    assert calls['n'] == 2
+
+
 def test_checkpointed_attention_with_frozen_parameters():
     """Frozen parameters (requires_grad False) get no gradient and do not disturb the others."""
     case = gc.PTL_CASES[2]
@@ -537,11 +599,16 @@ def test_batched_frames_equal_the_per_frame_loop():
     esd, dsd = pk.configs.synthetic_weights(dict(pa), ia, 72)
     rng = np.random.default_rng(73)
     np.random.seed(1333)          # (the oracle sampler draws from numpy's global generator)
-    q = torch.stack([T(op.sample_query_points(96, inf['min_z'], inf['cube_bounds'], t, kind, 4, 'random'))
+    # 99 = 11 x 9 queries per frame: a query keeps its slot in the fused attention kernel's 9-query workgroups in both
+    # modes, so the forward pass is bit-identical and both modes decide every ReLU the same way (with 96 the softmax
+    # partials of a query are summed in another order, the next block's pre-activations move by an ulp, and a unit at
+    # 1e-7 can land on the other side of zero: a rank-one gradient difference of 1e-3 that says nothing about batching)
+    nq = 99
+    q = torch.stack([T(op.sample_query_points(nq, inf['min_z'], inf['cube_bounds'], t, kind, 4, 'random'))
                      for t in range(3)]).cuda()
     target = torch.from_numpy(np.concatenate(
-        [rng.integers(0, 2, size=(3, 96, 1)), rng.uniform(size=(3, 96, 3)), np.zeros((3, 96, 1)),
-         rng.integers(-1, 13, size=(3, 96, 1))], -1).astype(np.float32)).cuda()
+        [rng.integers(0, 2, size=(3, nq, 1)), rng.uniform(size=(3, nq, 3)), np.zeros((3, nq, 1)),
+         rng.integers(-1, 13, size=(3, nq, 1))], -1).astype(np.float32)).cuda()
     res = []
     for batched in (False, True):
         e = pk.model.PointCompletionNetV3(**pa).cuda().train()
