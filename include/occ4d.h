@@ -315,6 +315,11 @@ int occ4d_resblock4_f32(const float* x, int64_t ldx, float* y, int64_t ldy, cons
 int occ4d_rowlin4_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed, const float* b,
                       int n_out, int relu_in, const float* res, int64_t ldr, const float* zconst, const float* ztab,
                       int64_t ldz, const int32_t* zidx, const float* zw, int kz, int n, void* stream);
+/* occ4d_rowlin4_f32 with the output mask of occ4d_rowlin_masked_f32 (training data gradients: at row counts that are
+ * not a whole number of 256-workgroup rounds the half-CU kernel is the faster one, profiles/time_rowlin_tail.py). */
+int occ4d_rowlin4_masked_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed, const float* b,
+                             int n_out, int relu_in, const float* res, int64_t ldr, const float* mask, int64_t ldm,
+                             int n, void* stream);
 
 /* Trunk chain (csrc/trunk4.hip): a short program of row-tile operations run with the (n, 416) activation RESIDENT IN
  * REGISTERS between them -- the decoder trunk between two cross-attention layers (model/implicit.py:411-425: per block

@@ -18,17 +18,22 @@ from . import ops
 # 0.72-0.79 of the fp32 MFMA peak against 0.46-0.65 for the generic kernel at these shapes, profiles/train_shapes.py).
 # The stage-packed copy of a weight (and of its transpose, for the data gradient) is rebuilt when the weight changes.
 ROWLIN_IN_TRAINING = True
+# ... in its half-CU re-cut (csrc/trunk4.hip: 64-row workgroups, two per CU).  The training row counts are not whole
+# dispatch rounds of the 8-wave kernel (68812 query rows = 2.1 rounds of 256 x 128 rows: the third round runs 26
+# workgroups); a half-CU workgroup that has its CU to itself in the last round runs faster, and at whole rounds the two
+# are level: 232 vs 301 us at 68812 rows, 276 vs 302 us at 98304 (profiles/time_rowlin_tail.py).
+ROWLIN_HALF_CU = os.environ.get('OCC4D_TRAIN_ROWLIN_HALF_CU', '1') == '1'
 _PACKS = {}
 
 
 def _packed(w, transposed):
     from . import point_transformer_layer as ptl
-    key = (w.data_ptr(), w._version, tuple(w.shape), bool(transposed), ptl.weights_epoch())
+    key = (w.data_ptr(), w._version, tuple(w.shape), bool(transposed), ptl.weights_epoch(), ROWLIN_HALF_CU)
     hit = _PACKS.get(key)
     if hit is not None and hit[0] is w:
         return hit[1]
     src = w.detach().t().contiguous() if transposed else w.detach()
-    packed = ops.pack_trunk_rows(src)
+    packed = ops.pack_trunk4_rows(src) if ROWLIN_HALF_CU else ops.pack_trunk_rows(src)
     if len(_PACKS) > 128:
         _PACKS.clear()
     _PACKS[key] = (w, packed)          # (w kept alive: its address cannot be recycled under this key)

@@ -38,6 +38,7 @@ struct Trunk4Args {
   int n;
   int n_stages;                              // rowlin: output channels / 16
   int relu_in;
+  const float* mask; int64_t ldm;            // rowlin: output zeroed where mask <= 0 (ReLU mask of a data gradient), or null
 };
 
 __device__ __forceinline__ unsigned lds_addr_q(const float* p) {
@@ -238,6 +239,8 @@ __device__ __forceinline__ void rowlin4_stage(const Trunk4Args& a, int s, const 
   const f32x4 bz = *reinterpret_cast<const f32x4*>(a.b0 + c0);
   f32x4 rs = {0.f, 0.f, 0.f, 0.f};
   if (a.res) rs = *reinterpret_cast<const f32x4*>(a.res + (int64_t)rowc * a.ldr + c0);
+  f32x4 mk = {1.f, 1.f, 1.f, 1.f};
+  if (a.mask) mk = *reinterpret_cast<const f32x4*>(a.mask + (int64_t)rowc * a.ldm + c0);
   f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
   {
     f32x4 wa = *reinterpret_cast<const f32x4*>(frag);
@@ -264,6 +267,10 @@ __device__ __forceinline__ void rowlin4_stage(const Trunk4Args& a, int s, const 
       const f32x4 za = *reinterpret_cast<const f32x4*>(a.ztab + (int64_t)a.zidx[(int64_t)rowc * a.kz + j] * a.ldz + c0);
       o0.x = fmaf(w, za.x, o0.x); o0.y = fmaf(w, za.y, o0.y); o0.z = fmaf(w, za.z, o0.z); o0.w = fmaf(w, za.w, o0.w);
     }
+  }
+  if (a.mask) {
+    o0.x = mk.x > 0.f ? o0.x : 0.f; o0.y = mk.y > 0.f ? o0.y : 0.f;
+    o0.z = mk.z > 0.f ? o0.z : 0.f; o0.w = mk.w > 0.f ? o0.w : 0.f;
   }
   if (row < a.n) *reinterpret_cast<f32x4*>(a.y + (int64_t)row * a.ldy + c0) = o0;
 }
@@ -529,7 +536,7 @@ extern "C" int occ4d_rowlin4_f32(const float* x, int64_t ldx, float* y, int64_t 
                                  const float* zconst, const float* ztab, int64_t ldz, const int32_t* zidx,
                                  const float* zw, int kz, int n, void* stream) {
   Trunk4Args a{x, ldx, y, ldy, w_packed, b, nullptr, nullptr, res, ldr, zconst, ztab, ldz, zidx, zw, kz, n,
-               n_out / 16, relu_in};
+               n_out / 16, relu_in, nullptr, 0};
   if (n == 0) return OCC4D_OK;
   if (int rc = check_common4(a, "occ4d_rowlin4_f32")) return rc;
   OCC4D_REQUIRE(n_out >= 16 && n_out % 16 == 0 && ldy >= n_out, "occ4d_rowlin4_f32: n_out = %d must be a multiple of 16 <= ldy",
@@ -538,6 +545,24 @@ extern "C" int occ4d_rowlin4_f32(const float* x, int64_t ldx, float* y, int64_t 
                 "occ4d_rowlin4_f32: residual rows must be 16-byte aligned with ldr %% 4 == 0");
   rowlin4_kernel<<<occ4d::cdiv(n, QROWS), 256, 0, (hipStream_t)stream>>>(a);
   return occ4d::check_launch("occ4d_rowlin4_f32");
+}
+
+// occ4d_rowlin4_f32 with an output mask (the contract of occ4d_rowlin_masked_f32)
+extern "C" int occ4d_rowlin4_masked_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed,
+                                        const float* b, int n_out, int relu_in, const float* res, int64_t ldr,
+                                        const float* mask, int64_t ldm, int n, void* stream) {
+  Trunk4Args a{x, ldx, y, ldy, w_packed, b, nullptr, nullptr, res, ldr, nullptr, nullptr, 0, nullptr, nullptr, 0, n,
+               n_out / 16, relu_in, mask, ldm};
+  if (n == 0) return OCC4D_OK;
+  if (int rc = check_common4(a, "occ4d_rowlin4_masked_f32")) return rc;
+  OCC4D_REQUIRE(n_out >= 16 && n_out % 16 == 0 && ldy >= n_out,
+                "occ4d_rowlin4_masked_f32: n_out = %d must be a multiple of 16 <= ldy", n_out);
+  OCC4D_REQUIRE(!res || (ldr % 4 == 0 && ((uintptr_t)res % 16) == 0 && ldr >= n_out),
+                "occ4d_rowlin4_masked_f32: residual rows must be 16-byte aligned with ldr %% 4 == 0");
+  OCC4D_REQUIRE(mask && ldm % 4 == 0 && ((uintptr_t)mask % 16) == 0 && ldm >= n_out,
+                "occ4d_rowlin4_masked_f32: mask rows must be 16-byte aligned with ldm %% 4 == 0 and ldm >= n_out");
+  rowlin4_kernel<<<occ4d::cdiv(n, QROWS), 256, 0, (hipStream_t)stream>>>(a);
+  return occ4d::check_launch("occ4d_rowlin4_masked_f32");
 }
 
 extern "C" int occ4d_trunk_chain_f32(const occ4d_chain_args* p, void* stream) {

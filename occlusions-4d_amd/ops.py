@@ -654,9 +654,10 @@ def rowlin(x, w_packed, b, n_out, relu_in=False, residual=None, out=None, interp
     assert bc.numel() == n_out
     if mask is not None:
         mm, ldm = _rows(_dev(mask, name='mask'), 'mask')
-        assert mm.shape == (n, n_out) and interp is None and not half_cu
+        assert mm.shape == (n, n_out) and interp is None
+        mfn = _lib.lib().occ4d_rowlin4_masked_f32 if half_cu else _lib.lib().occ4d_rowlin_masked_f32
         _lib.check(_launch('rowlin', dict(n=n, n_out=n_out), 2.0 * n * d * n_out,
-                           lambda: _lib.lib().occ4d_rowlin_masked_f32(_ptr(xx), ldx, _ptr(o), ldo, _ptr(w_packed), _ptr(bc),
+                           lambda: mfn(_ptr(xx), ldx, _ptr(o), ldo, _ptr(w_packed), _ptr(bc),
                                                                       n_out, int(relu_in), _ptr(rr), ldr, _ptr(mm), ldm, n,
                                                                       _stream())))
         return out

@@ -225,16 +225,17 @@ def test_trunk_chain_rejects_bad_programs():
     assert pk._lib.lib().occ4d_trunk_chain_f32(ctypes.byref(args), None) == pk._lib.EINVAL
 
 
-@pytest.mark.parametrize('n,n_out', [(1, 416), (130, 832), (3000, 416)])
-def test_rowlin_output_mask(n, n_out):
-    """occ4d_rowlin_masked_f32: the data gradient of a relu_in Linear, dx = (x > 0) . (g W), with the mask in the
-    epilogue -- equal to the unmasked kernel followed by the masking pass, bit for bit."""
+@pytest.mark.parametrize('half_cu', [False, True])
+@pytest.mark.parametrize('n,n_out', [(1, 416), (130, 832), (3000, 416), (777, 32)])
+def test_rowlin_output_mask(n, n_out, half_cu):
+    """occ4d_rowlin_masked_f32 / occ4d_rowlin4_masked_f32: the data gradient of a relu_in Linear, dx = (x > 0) . (g W),
+    with the mask in the epilogue -- equal to the unmasked kernel followed by the masking pass, bit for bit."""
     rng = np.random.default_rng(n + n_out)
     g = torch.from_numpy(rng.normal(size=(n, H)).astype(np.float32)).cuda()
     w, b = _weights(rng, n_out)
     mask = torch.from_numpy(rng.normal(size=(n, n_out)).astype(np.float32)).cuda()
     mask[0, :5] = 0.0                                           # (zero counts as "not positive")
-    p = pk.ops.pack_trunk_rows(w)
+    p = pk.ops.pack_trunk4_rows(w) if half_cu else pk.ops.pack_trunk_rows(w)
     plain = pk.ops.rowlin(g, p, b, n_out)
     got = pk.ops.rowlin(g, p, b, n_out, mask=mask)
     assert torch.equal(got, torch.where(mask > 0, plain, torch.zeros_like(plain)))
