@@ -262,6 +262,19 @@ class SoftmaxAggFn(Function):
         return dlogits, dv, dpe, None
 
 
+class SoftmaxAggGradOnlyFn(Function):
+    """SoftmaxAggFn for a caller that only differentiates: the recompute-in-backward path rebuilds the pair tensors to
+    back-propagate a GIVEN output gradient and never looks at the output value (the forward pass already produced it
+    with the fused kernel), so forward returns an uninitialised tensor of the right shape and launches nothing."""
+
+    @staticmethod
+    def forward(ctx, logits, v, pe, idx):
+        ctx.save_for_backward(logits, v, pe, idx)
+        return logits.new_empty((idx.shape[0], v.shape[1]))
+
+    backward = SoftmaxAggFn.backward
+
+
 class MaxPoolGatherFn(Function):
     @staticmethod
     def forward(ctx, y, idx):

@@ -358,18 +358,51 @@ __global__ __launch_bounds__(TPB) void pos_hidden_bwd_kernel(const float* __rest
                                                              int h, const float* __restrict__ r,
                                                              const float* __restrict__ gr, float* __restrict__ dP1,
                                                              float* __restrict__ dc1) {
-  // thread = hidden unit m (h <= 64 threads active per pair-slice); blockDim = 256 = 4 pair lanes x 64
-  const int m = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  // A 64-lane slice covers pp = 64 / h pairs at a time (lane = pair-in-slice * h + hidden unit: every lane busy for
+  // h = 32, consecutive lanes read consecutive floats of r / gr); four slices per block, eight independent pairs in
+  // flight per lane (the loop is a chain of dependent loads: idx -> pos2 row).  The block's partial sums meet in LDS and
+  // ONE thread per (unit, component) adds them to the result: atomics on the same 4 h addresses serialise in L2
+  // (~90 ns each -- with one atomic per lane they, not the memory traffic, were the kernel's time).
+  __shared__ float s_acc[4 * 64];
+  const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int pp = 64 / h;
+  const int m = lane % h, sub = lane / h;
   float ax = 0.f, ay = 0.f, az = 0.f, ac = 0.f;
-  if (m < h) {
-    for (int64_t p = (int64_t)blockIdx.x * 4 + sl; p < npairs; p += (int64_t)gridDim.x * 4) {
+  for (int i = threadIdx.x; i < 4 * 64; i += TPB) s_acc[i] = 0.f;
+  __syncthreads();
+  if (sub < pp) {
+    const int64_t stride = (int64_t)gridDim.x * 4 * pp;
+    int64_t p = ((int64_t)blockIdx.x * 4 + sl) * pp + sub;
+    constexpr int U = 8;
+    for (; p + (U - 1) * stride < npairs; p += U * stride) {
+      float gv[U], dx[U], dy[U], dz[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t q = p + u * stride;
+        const float rv = r[q * h + m], gg = gr[q * h + m];
+        const float* a = pos + (q / k) * ps;
+        const float* b = pos2 + (int64_t)idx[q] * p2s;
+        gv[u] = rv > 0.f ? gg : 0.f;
+        dx[u] = a[0] - b[0]; dy[u] = a[1] - b[1]; dz[u] = a[2] - b[2];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) { ax += gv[u] * dx[u]; ay += gv[u] * dy[u]; az += gv[u] * dz[u]; ac += gv[u]; }
+    }
+    for (; p < npairs; p += stride) {
       const float gv = r[p * h + m] > 0.f ? gr[p * h + m] : 0.f;
       const float* a = pos + (p / k) * ps;
       const float* b = pos2 + (int64_t)idx[p] * p2s;
       ax += gv * (a[0] - b[0]); ay += gv * (a[1] - b[1]); az += gv * (a[2] - b[2]); ac += gv;
     }
-    atomicAdd(dP1 + 3 * m + 0, ax); atomicAdd(dP1 + 3 * m + 1, ay); atomicAdd(dP1 + 3 * m + 2, az);
-    atomicAdd(dc1 + m, ac);
+    atomicAdd(&s_acc[4 * m + 0], ax); atomicAdd(&s_acc[4 * m + 1], ay); atomicAdd(&s_acc[4 * m + 2], az);
+    atomicAdd(&s_acc[4 * m + 3], ac);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < 4 * h) {
+    const int mm = threadIdx.x >> 2, comp = threadIdx.x & 3;
+    const float v = s_acc[threadIdx.x];
+    if (comp < 3) atomicAdd(dP1 + 3 * mm + comp, v);
+    else atomicAdd(dc1 + mm, v);
   }
 }
 
@@ -551,8 +584,8 @@ int occ4d_pt_pos_hidden_bwd_f32(const float* pos, int64_t ps, const float* pos2,
   OCC4D_REQUIRE(n >= 0 && k >= 1 && h >= 1 && h <= 64, "occ4d_pt_pos_hidden_bwd_f32: need h <= 64");
   const int64_t npairs = (int64_t)n * k;
   if (!npairs) return OCC4D_OK;
-  const int64_t want = (npairs + 3) / 4;
-  const int blocks = (int)(want < 1024 ? want : 1024);
+  const int64_t want = (npairs + 4 * (64 / h) - 1) / (4 * (64 / h));
+  const int blocks = (int)(want < 512 ? want : 512);
   pos_hidden_bwd_kernel<<<blocks, TPB, 0, (hipStream_t)stream>>>(pos, ps, pos2, p2s, idx, npairs, k, h, r, gr, dP1, dc1);
   return occ4d::check_launch("occ4d_pt_pos_hidden_bwd_f32");
 }

@@ -163,7 +163,7 @@ class _CheckpointedAttention(torch.autograd.Function):
                     a = autograd.AttnInLinearFn.apply(aq, kt_l, r, wp_l, ic)                     # aq_i - kt_j + Wp r
                     logits = L(a, W2, b2, True, False, None)                                    # W2 relu(.) + b2
                     pe = L(r, P2l, c2l, False, False, None)
-                out = autograd.SoftmaxAggFn.apply(logits, vt_l, pe, ic)
+                out = autograd.SoftmaxAggGradOnlyFn.apply(logits, vt_l, pe, ic)      # (value unused: no launch)
                 grads = torch.autograd.grad(out, [xc] + leaves, g[lo:hi])
                 gx[lo:hi] = grads[0]
                 for acc, gr in zip(sums, grads[1:]):
