@@ -143,6 +143,28 @@ __global__ __launch_bounds__(TPB) void wgrad_reduce_kernel(const float* __restri
   dw[e] = s;
 }
 
+// the same sum (same order per element: z ascending) four elements per thread with eight partial planes in flight:
+// the scalar loop above ran the 40 .. 73 planes of the large weight gradients at 0.5 TB/s
+__global__ __launch_bounds__(TPB) void wgrad_reduce4_kernel(const float* __restrict__ part, int splits, int64_t nk4,
+                                                            float* __restrict__ dw, int accumulate) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (e >= nk4) return;
+  const f4* p = reinterpret_cast<const f4*>(part) + e;
+  f4* out = reinterpret_cast<f4*>(dw) + e;
+  f4 s = accumulate ? *out : f4{0.f, 0.f, 0.f, 0.f};
+  int z = 0;
+  for (; z + 8 <= splits; z += 8) {
+    f4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(z + u) * nk4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; z < splits; ++z) s += p[(int64_t)z * nk4];
+  *out = s;
+}
+
 // column sums: out[c] (+)= sum_i x[i][c]; stage 1 per (row chunk, 64-column strip), stage 2 reduce
 // (deterministic).  Block = 64 columns x 4 row lanes: 256-byte coalesced row segments, 4 rows in flight.
 __global__ __launch_bounds__(TPB) void colsum_partial_kernel(const float* __restrict__ x, int64_t ldx, int n, int d,
@@ -272,36 +294,66 @@ __global__ __launch_bounds__(TPB) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ g, int64_t ldg, float eps, int n,
                                                             int d, float* __restrict__ dx, int64_t lddx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int row = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+  // A wave walks rows with a grid stride and keeps its dgamma / dbeta contributions in registers (lane owns channels
+  // lane + 64 i, i < LNC): one atomic per channel and wave at the end.  (One atomic per channel and ROW put n
+  // serialised L2 atomics on each of the 2 d addresses: they were the kernel's time.)  d > 64 LNC: per-row atomics.
+  constexpr int LNC = 8;
+  const int wave0 = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (TPB / 64);
   const int lane = threadIdx.x & 63;
-  if (row >= n) return;
-  const float* xr = x + (int64_t)row * ldx;
-  const float* gr = g + (int64_t)row * ldg;
-  float s = 0.f;
-  for (int c = lane; c < d; c += 64) s += xr[c];
+  const bool in_regs = d <= 64 * LNC;
+  float ag[LNC], ab[LNC];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  const float mean = s / (float)d;
-  float q = 0.f;
-  for (int c = lane; c < d; c += 64) { const float t = xr[c] - mean; q += t * t; }
+  for (int i = 0; i < LNC; ++i) ag[i] = ab[i] = 0.f;
+  for (int row = wave0; row < n; row += nwaves) {
+    const float* xr = x + (int64_t)row * ldx;
+    const float* gr = g + (int64_t)row * ldg;
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) s += xr[c];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-  const float rstd = 1.0f / sqrtf(q / (float)d + eps);
-  float a = 0.f, b = 0.f;
-  for (int c = lane; c < d; c += 64) {
-    const float gh = gr[c] * (gamma ? gamma[c] : 1.f);
-    const float xh = (xr[c] - mean) * rstd;
-    a += gh; b += gh * xh;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)d;
+    float q = 0.f;
+    for (int c = lane; c < d; c += 64) { const float t = xr[c] - mean; q += t * t; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)d + eps);
+    float a = 0.f, b = 0.f;
+    for (int c = lane; c < d; c += 64) {
+      const float gh = gr[c] * (gamma ? gamma[c] : 1.f);
+      const float xh = (xr[c] - mean) * rstd;
+      a += gh; b += gh * xh;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    a /= (float)d; b /= (float)d;
+    float* dr = dx + (int64_t)row * lddx;
+    if (in_regs) {
+#pragma unroll
+      for (int i = 0; i < LNC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < d) {
+          const float xh = (xr[c] - mean) * rstd;
+          const float gh = gr[c] * (gamma ? gamma[c] : 1.f);
+          dr[c] = rstd * (gh - a - xh * b);
+          ag[i] += gr[c] * xh;
+          ab[i] += gr[c];
+        }
+      }
+    } else {
+      for (int c = lane; c < d; c += 64) {
+        const float xh = (xr[c] - mean) * rstd;
+        const float gh = gr[c] * (gamma ? gamma[c] : 1.f);
+        dr[c] = rstd * (gh - a - xh * b);
+        if (dgamma) { atomicAdd(dgamma + c, gr[c] * xh); atomicAdd(dbeta + c, gr[c]); }
+      }
+    }
   }
+  if (in_regs && dgamma) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-  a /= (float)d; b /= (float)d;
-  float* dr = dx + (int64_t)row * lddx;
-  for (int c = lane; c < d; c += 64) {
-    const float xh = (xr[c] - mean) * rstd;
-    const float gh = gr[c] * (gamma ? gamma[c] : 1.f);
-    dr[c] = rstd * (gh - a - xh * b);
-    if (dgamma) { atomicAdd(dgamma + c, gr[c] * xh); atomicAdd(dbeta + c, gr[c]); }
+    for (int i = 0; i < LNC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < d) { atomicAdd(dgamma + c, ag[i]); atomicAdd(dbeta + c, ab[i]); }
+    }
   }
 }
 
@@ -491,7 +543,10 @@ int occ4d_linear_wgrad_bias_f32(const float* g, int64_t ldg, const float* x, int
   if (occ4d::wgrad16_plan(M, N, K, &s16, &mps16) && s16 == splits) {
     float* pb16 = db ? workspace + (int64_t)(splits + 1) * nk : nullptr;
     if (int rc = occ4d::wgrad16_launch(g, ldg, x, ldx, M, N, K, splits, mps16, workspace, pb16, relu_x, st)) return rc;
-    wgrad_reduce_kernel<<<grid1d(nk), TPB, 0, st>>>(workspace, splits + 1, nk, dw, accumulate);
+    if (nk % 4 == 0 && ((uintptr_t)workspace % 16) == 0 && ((uintptr_t)dw % 16) == 0)
+      wgrad_reduce4_kernel<<<grid1d(nk / 4), TPB, 0, st>>>(workspace, splits + 1, nk / 4, dw, accumulate);
+    else
+      wgrad_reduce_kernel<<<grid1d(nk), TPB, 0, st>>>(workspace, splits + 1, nk, dw, accumulate);
     if (db) wgrad_reduce_kernel<<<grid1d(N), TPB, 0, st>>>(pb16, splits + 1, N, db, accumulate);
     return occ4d::check_launch("occ4d_linear_wgrad_f32(reduce)");
   }
@@ -505,7 +560,10 @@ int occ4d_linear_wgrad_bias_f32(const float* g, int64_t ldg, const float* x, int
 #undef OCC4D_WGRAD
   int rc = occ4d::check_launch("occ4d_linear_wgrad_f32");
   if (rc) return rc;
-  wgrad_reduce_kernel<<<grid1d(nk), TPB, 0, st>>>(workspace, splits, nk, dw, accumulate);
+  if (nk % 4 == 0 && ((uintptr_t)workspace % 16) == 0 && ((uintptr_t)dw % 16) == 0)
+    wgrad_reduce4_kernel<<<grid1d(nk / 4), TPB, 0, st>>>(workspace, splits, nk / 4, dw, accumulate);
+  else
+    wgrad_reduce_kernel<<<grid1d(nk), TPB, 0, st>>>(workspace, splits, nk, dw, accumulate);
   if (db) wgrad_reduce_kernel<<<grid1d(N), TPB, 0, st>>>(part_b, splits, N, db, accumulate);
   return occ4d::check_launch("occ4d_linear_wgrad_f32(reduce)");
 }
@@ -560,7 +618,8 @@ int occ4d_layernorm_bwd_f32(const float* x, int64_t ldx, const float* gamma, con
   OCC4D_REQUIRE(x && g && dx && n >= 0 && d >= 1, "occ4d_layernorm_bwd_f32: bad arguments");
   OCC4D_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "occ4d_layernorm_bwd_f32: dgamma/dbeta both or neither");
   if (!n) return OCC4D_OK;
-  layernorm_bwd_kernel<<<occ4d::cdiv(n, TPB / 64), TPB, 0, (hipStream_t)stream>>>(x, ldx, gamma, g, ldg, eps, n, d, dx,
+  const int ln_blocks = occ4d::cdiv(n, TPB / 64) < 2048 ? occ4d::cdiv(n, TPB / 64) : 2048;   // 8 K waves, rows by grid stride
+  layernorm_bwd_kernel<<<ln_blocks, TPB, 0, (hipStream_t)stream>>>(x, ldx, gamma, g, ldg, eps, n, d, dx,
                                                                                     lddx, dgamma, dbeta);
   return occ4d::check_launch("occ4d_layernorm_bwd_f32");
 }
