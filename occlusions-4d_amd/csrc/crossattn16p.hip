@@ -533,6 +533,7 @@ __global__ __launch_bounds__(256, 2) void pair_mlp_kernel(const PairMlpArgs a) {
 
 #pragma clang loop unroll(disable)
   for (int ps = 0; ps < 2; ++ps) {
+    asm volatile("; OCC4D_MARK pass_prologue");
     const int p = min((int)blockIdx.x * 128 + 64 * ps + 16 * wave + c, a.P - 1);
     const int q = p / a.K;
     const int j = a.idx[p];
@@ -578,12 +579,15 @@ __global__ __launch_bounds__(256, 2) void pair_mlp_kernel(const PairMlpArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
         if (gq == 0) {
+#ifndef OCC4D_PM_ABL_NOA
           put(a.a_out + 16 * s, a_off, h);                 // units 16 s + 4 g .. + 3 of this lane's pair row
+#endif
           __builtin_amdgcn_sched_barrier(0);
           h.x = fmaxf(h.x, 0.f); h.y = fmaxf(h.y, 0.f); h.z = fmaxf(h.z, 0.f); h.w = fmaxf(h.w, 0.f);
         }
       }
     };
+    asm volatile("; OCC4D_MARK loop");
     stage(std::true_type{}, 0, buf0, buf1);
     dma_wait_p();
     __syncthreads();
@@ -599,12 +603,18 @@ __global__ __launch_bounds__(256, 2) void pair_mlp_kernel(const PairMlpArgs a) {
       dma_wait_p();
       __syncthreads();
     }
+    asm volatile("; OCC4D_MARK epilogue");
     // ---- epilogue: the logits, then pe = P2 r + c2 on the two P2 stages (buf0 holds the first, the second lands in
     // buf1 under it).  GEMM2 / GEMM3 ran with the fragments as the A operand (mm_ba_p): lane (g, c) holds channels
     // 16 t + 4 g .. + 3 of pair row c in every accumulator tile
     dma_stage_p(a.wstream + (int64_t)(PHS + 1) * PSTAGE, buf1, wave, lane16);
 #pragma unroll
-    for (int t = 0; t < PTD; ++t) put(a.logits + 16 * t, l_off, acc[t]);
+    for (int t = 0; t < PTD; ++t) {
+#ifdef OCC4D_PM_ABL_NOLOGITS
+      if (acc[t].x == 123.456f)                      // (ablation: keep the accumulators live, store nothing)
+#endif
+      put(a.logits + 16 * t, l_off, acc[t]);
+    }
     auto pe_tiles = [&](auto T0c, auto NPc, const float* __restrict__ pbuf) {
       constexpr int T0 = decltype(T0c)::value, NP = decltype(NPc)::value;
       const float* fp = pbuf + lane * 4;
@@ -617,8 +627,13 @@ __global__ __launch_bounds__(256, 2) void pair_mlp_kernel(const PairMlpArgs a) {
                 *reinterpret_cast<const f32x4*>(fp + (4 * pr + 2) * PFRAG), e0, e1);
         mm_ba_p(r_hi, *reinterpret_cast<const f32x4*>(fp + (4 * pr + 1) * PFRAG),
                 *reinterpret_cast<const f32x4*>(fp + (4 * pr + 3) * PFRAG), e0, e1);
-        put(a.pe + 16 * t, l_off, e0);
-        put(a.pe + 16 * (t + 1), l_off, e1);
+#ifdef OCC4D_PM_ABL_NOPE
+        if (e0.x == 123.456f)
+#endif
+        {
+          put(a.pe + 16 * t, l_off, e0);
+          put(a.pe + 16 * (t + 1), l_off, e1);
+        }
       }
     };
     pe_tiles(std::integral_constant<int, 0>{}, std::integral_constant<int, PTA / 2>{}, buf0);
