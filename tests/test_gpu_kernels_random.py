@@ -274,6 +274,38 @@ def test_attention_chain_gradients_random(pk):
         assert _rel(dx, xt.grad) <= 2e-5 and _rel(dg, gt.grad) <= 2e-5 and _rel(dbeta, bt.grad) <= 2e-5
 
 
+@pytest.mark.parametrize('n,k,m,h', [(5, 3, 9, 32), (3000, 14, 700, 32), (9000, 16, 300, 24), (700, 7, 50, 64), (2000, 14, 90, 48),
+                                     (40000, 14, 1062, 32)])
+def test_pos_hidden_backward_sizes_and_widths(pk, n, k, m, h):
+    """occ4d_pt_pos_hidden_bwd_f32 (64 / h pairs per wave slice, eight pairs in flight per lane, block-level LDS reduction):
+    hidden widths that do and do not divide 64, pair counts below one block, beyond the grid and with ragged tails."""
+    rng = np.random.default_rng(n + h)
+    pos, pos2 = rng.uniform(-5, 5, size=(n, 3)).astype(np.float32), rng.uniform(-5, 5, size=(m, 3)).astype(np.float32)
+    idx = rng.integers(0, m, size=(n, k)).astype(np.int32)
+    P1, c1 = rng.normal(size=(h, 3)).astype(np.float32), rng.normal(size=(h,)).astype(np.float32)
+    gr = rng.normal(size=(n * k, h)).astype(np.float32)
+    r_dev = pk.ops.pt_pos_hidden(C(pos), C(pos2), C(idx), C(P1), C(c1))
+    dP1, dc1 = pk.ops.pt_pos_hidden_bwd(C(pos), C(pos2), C(idx), r_dev, C(gr))
+    rel = (torch.from_numpy(pos).double()[:, None, :] - torch.from_numpy(pos2).double()[torch.from_numpy(idx).long()]).view(n * k, 3)
+    gm = torch.from_numpy(gr).double() * (r_dev.cpu().double() > 0)
+    assert _rel(dP1, gm.t() @ rel) <= 2e-5 and _rel(dc1, gm.sum(0)) <= 2e-5
+
+
+@pytest.mark.parametrize('n,d', [(3, 36), (20000, 416), (9000, 72), (300, 600), (70000, 144)])
+def test_layernorm_backward_sizes(pk, n, d):
+    """occ4d_layernorm_bwd_f32: rows beyond the grid (grid-stride loop with dgamma / dbeta in registers) and a width above
+    the register path (per-row atomics)."""
+    rng = np.random.default_rng(n + d)
+    x = rng.normal(size=(n, d)).astype(np.float32)
+    gam = rng.normal(size=d).astype(np.float32)
+    go = rng.normal(size=(n, d)).astype(np.float32)
+    xt, gt = torch.from_numpy(x).double().requires_grad_(True), torch.from_numpy(gam).double().requires_grad_(True)
+    bt = torch.zeros(d, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.layer_norm(xt, (d,), gt, bt, 1e-5).backward(torch.from_numpy(go).double())
+    dx, dg, dbeta = pk.ops.layernorm_bwd(C(x), C(gam), C(go), 1e-5)
+    assert _rel(dx, xt.grad) <= 2e-5 and _rel(dg, gt.grad) <= 3e-5 and _rel(dbeta, bt.grad) <= 3e-5
+
+
 def test_matmul_f64_and_its_gradients(pk):
     """occ4d_matmul_f64 (the merged-weight products, fp64): contiguous, transposed-view and vector operands against
     torch on the CPU, and the autograd Function's gradients."""
