@@ -107,6 +107,39 @@ def test_perform_inference_split_matches_reference_rows(pk):
         assert np.abs(res['output_air'][:64, :4] - g['air_head'][:, :4]).max() <= 1e-4
 
 
+def test_perform_inference_results_own_their_buffers(pk, monkeypatch):
+    """The result arrays come through page-locked buffers with non-blocking copies (inference._HostCopies): a later call
+    must not overwrite an earlier call's arrays, the pinned path must return exactly what the blocking pageable path
+    returns, and the arrays must be ordinary writable float32 / float64 numpy arrays."""
+    case = gc.INFER_CASES[0]
+    pcl, pa, ia, inf, esd, dsd = gc.infer_inputs(case)
+    enc = pk.model.PointCompletionNetV3(**pa).cuda()
+    enc.load_state_dict(esd)
+    dec = pk.implicit.LocalPclResnetFC(**ia).cuda()
+    dec.load_state_dict(dsd)
+
+    def call(time_idx):
+        return pk.inference.perform_inference(
+            pcl.clone(), None, None, [enc.eval(), dec.eval()], torch.device('cuda'), 'if', inf['min_z'], inf['cube_bounds'],
+            inf['color_mode'], time_idx, None, sample_implicit=True, num_sample=case['num_sample'],
+            point_sample_mode='grid', batch_size=case['batch_size'], predict_segmentation=inf['predict_segmentation'],
+            track_mode='none', semantic_classes=13, density_threshold=0.5, data_kind=inf['data_kind'], cube_mode=4,
+            compress_air=True)
+    keys = ['output_solid', 'output_air', 'pcl_abstract', 'features_global', 'implicit_output', 'points_query']
+    first = call(case['time_idx'])
+    frozen = {k: first[k].copy() for k in keys}
+    for _ in range(3):                                   # later calls (another frame) recycle pinned blocks
+        other = call(case['time_idx'] + 1)
+    for k in keys:
+        assert np.array_equal(first[k], frozen[k]), k
+        assert first[k].flags.writeable and first[k].dtype == (np.float64 if k == 'output_air' else np.float32), k
+    assert not np.array_equal(other['points_query'], first['points_query'])
+    monkeypatch.setattr(pk.inference, 'PINNED_HOST_IO', False)
+    plain = call(case['time_idx'])
+    for k in keys:
+        assert np.array_equal(plain[k], frozen[k]) and plain[k].dtype == frozen[k].dtype, k
+
+
 def test_clip_pipeline_matches_sequential_calls(pk):
     """Throughput mode: the encode of clip i + 1 issued while clip i decodes gives bit-identical outputs to
     sequential encode + decode calls, for a stream of DIFFERENT clips."""
