@@ -371,6 +371,19 @@ int occ4d_grid_points_f32(int nx, int ny, int nz, float x0, float sx, float y0, 
                           float t, float* out, void* stream);
 int occ4d_split_count_f32(const float* implicit_output, int64_t ld, int n, float threshold, int* block_counts,
                           int* total_solid, void* stream);
+/* Radius test on a uniform grid (csrc/gridrad.hip): far[i] = 1.0f when NO target point lies within `radius` of query i,
+ * else 0.0f -- the decision of the sampler's air / solid gap filter (utils/geometry.py:1164-1196: 1-NN distance of every
+ * candidate to the whole target cloud > radius) without the 1-NN search: only the targets in the 27 cells around a
+ * query are visited, every visited distance is the streaming kNN kernel's metric-1 expression, so the decisions are
+ * those of occ4d_knn_f32(k = 1, metric = 1) followed by `dist > radius`, bit for bit.
+ * occ4d_radius_grid_build_f32 sorts the targets into cells of edge >= radius_max / 0.95 (bounding box and cell size on
+ * the device; at most 64^3 cells) inside `workspace` (occ4d_radius_grid_workspace_bytes(n) bytes, 16-byte aligned);
+ * occ4d_radius_far_f32 answers queries for any radius <= radius_max.  Points outside the box need no special case. */
+int64_t occ4d_radius_grid_workspace_bytes(int n);
+int occ4d_radius_grid_build_f32(const float* xyz, int64_t stride, int n, float radius_max, void* workspace, void* stream);
+int occ4d_radius_far_f32(const float* query, int64_t q_stride, int n_query, const void* workspace, float radius,
+                         float* far, void* stream);
+
 /* Generic order-preserving row compaction (training-time sampler, filter_air_solid_gap utils/geometry.py:1190-1194):
  * keep row i when key[i] >= threshold (key[i] > threshold when strict).  compact_count fills block_counts
  * (ceil(n/256) ints -> exclusive prefix) and *total_kept (device int); compact_rows writes the kept rows

@@ -6,6 +6,7 @@ dataloader's ``subsample_pad_pcl_torch`` (:294-376).
 Everything else in that file (camera / lidar transforms, guided samplers, cuboid
 filters) is data preparation or training-only and out of scope.
 """
+import os
 import numpy as np
 import torch
 
@@ -213,6 +214,24 @@ def filter_air_solid_gap(to_filter, target_coords, target_slice_size, point_occu
     return (kept, kept_dist, ratio)
 
 
+# The sampler itself only uses the ROWS the gap filter keeps (utils/geometry.py:692, :956-1010 discard the distances), i.e.
+# the decision "no target point within the radius": a uniform-grid radius test (ops.RadiusGrid, csrc/gridrad.hip) makes
+# the same decisions as the 1-NN search bit for bit and visits a few hundred targets per candidate instead of all 57 K.
+# '0': the 1-NN search (filter_air_solid_gap above, which also returns the distances).
+GRID_GAP_FILTER = os.environ.get('OCC4D_GRID_GAP_FILTER', '1') == '1'
+
+
+def _gap_rows(to_filter, target_coords, radius, grid=None):
+    """filter_air_solid_gap(...)[0]: the rows of to_filter with no target point within `radius`.  `grid`: a RadiusGrid
+    of target_coords built for a radius >= `radius` (reused across the calls of one frame)."""
+    if not GRID_GAP_FILTER:
+        return filter_air_solid_gap(to_filter, target_coords, 0, radius)[0]
+    if grid is None:
+        grid = ops.RadiusGrid(target_coords, radius)
+    far = grid.far(to_filter, radius)
+    return ops.compact_rows(to_filter, far, 0.5, strict=True)[0]
+
+
 def _take(rows, cpu_inds):
     """rows[cpu_inds] for a CPU LongTensor of indices, on the gather kernel."""
     return ops.gather_rows(rows, cpu_inds.to(torch.int32).to(rows.device))
@@ -275,8 +294,8 @@ class GuidedImplicitPointSampler(torch.nn.Module):
                     raise RuntimeError(f'Invalid due to cur_other_pcl_count: {oth_count}')
                 tgt_sub, oth_sub = tgt[:used], oth[:used]
                 r2 = self.point_occupancy_radius * 2.0
-                tgt_unique = filter_air_solid_gap(tgt_sub, oth_sub[..., :3], used, r2)[0]
-                other_unique = filter_air_solid_gap(oth_sub, tgt_sub[..., :3], used, r2)[0]
+                tgt_unique = _gap_rows(tgt_sub, oth_sub[..., :3], r2)
+                other_unique = _gap_rows(oth_sub, tgt_sub[..., :3], r2)
             (sq, st, ss) = self.construct_solid_input_target(tgt, tgt_unique, ids, time_idx)
             (aq, at, as_) = self.construct_air_input_target(tgt, other_unique, sq, ids, time_idx)
             for lst, v in zip(outs, (sq, aq, st, at, ss, as_)):
@@ -368,7 +387,6 @@ class GuidedImplicitPointSampler(torch.nn.Module):
         tgt = cur_tgt_pcl
         r = self.point_occupancy_radius
         tgt_xyz = tgt[..., :3]
-        slice_size = tgt.shape[0] // int(np.ceil(tgt.shape[0] / int((2 ** 27) // self.num_air))) + 1
         shares = torch.tensor([0.5, 0.0, 0.3, 0.2])           # regular, moving, hard_solid_query, hard_target
         if 'moving' in self.point_sample_bias:
             if cur_other_unique.shape[0] >= 256:
@@ -376,12 +394,13 @@ class GuidedImplicitPointSampler(torch.nn.Module):
             elif cur_other_unique.shape[0] >= 16:
                 shares[1] += cur_other_unique.shape[0] * 0.4 / 256.0
         shares /= shares.sum()
-        points, dists = [], []
+        points = []
+        grid = ops.RadiusGrid(tgt_xyz, r) if GRID_GAP_FILTER else None      # one grid of the target frame, four filters
 
         def keep(cand, count, warn=True):
-            (kept, d, _) = filter_air_solid_gap(cand, tgt_xyz, slice_size, r)
+            # (the reference also carries the kept candidates' 1-NN distances along and never uses them: :1003-1010)
+            kept = _gap_rows(cand, tgt_xyz, r, grid)
             points.append(self.select_safely(kept, count, warn_insufficient=warn))
-            dists.append(self.select_safely(d, count, warn_insufficient=warn))
 
         n_moving = int(shares[1] * self.num_air)
         if n_moving > 0:

@@ -802,6 +802,29 @@ def split_solid_air(points_query, implicit_output, threshold, compress_air=False
     return solid, air
 
 
+class RadiusGrid:
+    """Target cloud sorted into grid cells for radius tests (occ4d_radius_grid_build_f32): `far(query, r)` -> float32
+    flags, 1.0 where no target lies within r (r <= radius_max).  The decisions are those of knn(k=1, metric=1) followed by
+    dist > r."""
+
+    def __init__(self, xyz, radius_max):
+        p, ps = _rows(_dev(xyz, name='xyz'), 'xyz')
+        assert p.shape[0] >= 1 and p.shape[1] >= 3 and radius_max > 0
+        self.radius_max = float(radius_max)
+        self.n = p.shape[0]
+        nbytes = int(_lib.lib().occ4d_radius_grid_workspace_bytes(self.n))
+        self.ws = torch.empty(((nbytes + 3) // 4,), dtype=torch.float32, device=p.device)
+        _lib.check(_lib.lib().occ4d_radius_grid_build_f32(_ptr(p), ps, self.n, self.radius_max, _ptr(self.ws), _stream()))
+
+    def far(self, query, radius):
+        q, qs = _rows(_dev(query, name='query'), 'query')
+        assert q.shape[1] >= 3 and 0 <= radius <= self.radius_max
+        out = torch.empty((q.shape[0],), dtype=torch.float32, device=q.device)
+        _lib.check(_lib.lib().occ4d_radius_far_f32(_ptr(q), qs, q.shape[0], _ptr(self.ws), float(radius), _ptr(out),
+                                                   _stream()))
+        return out
+
+
 def compact_rows(rows, key, threshold, strict=True):
     """Order-preserving selection rows[key > threshold] (>= when not strict) -> (rows kept (n', d), keys kept (n'));
     one 4-byte device->host read (the kept count) sizes the outputs."""

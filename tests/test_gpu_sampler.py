@@ -61,6 +61,68 @@ def test_filter_air_solid_gap_matches_oracle(pk):
     assert np.array_equal(k1.cpu().numpy(), rows)
 
 
+@pytest.mark.parametrize('kind,n,nq,r', [('uniform', 5000, 4000, 0.35), ('uniform', 57344, 20000, 0.2), ('lattice', 4096, 3000, 0.5),
+                                          ('single', 1, 500, 0.3), ('wide', 3000, 2000, 0.05), ('dups', 2000, 1500, 0.25),
+                                          ('flat', 4000, 3000, 0.3)])
+def test_radius_grid_decisions_equal_the_1nn_search(pk, kind, n, nq, r):
+    """ops.RadiusGrid.far (uniform grid, 27 cells per query) == (1-NN distance > r) of the streaming kNN kernel, bit for
+    bit: lattice targets put many queries EXACTLY at the radius, queries reach far outside the targets' box, a cloud
+    wider than 64 cells of the radius gets coarser cells, a flat cloud has one cell along an axis."""
+    rng = np.random.default_rng(n + nq)
+    if kind == 'lattice':
+        g = np.arange(16, dtype=np.float32) * 0.5
+        tgt = np.stack(np.meshgrid(g, g, g, indexing='ij'), -1).reshape(-1, 3)
+        q = tgt[rng.integers(0, len(tgt), nq)] + rng.choice([0.0, 0.5, -0.5, 0.25], size=(nq, 3)).astype(np.float32)
+    elif kind == 'single':
+        tgt = np.array([[0.1, -0.2, 0.3]], dtype=np.float32)
+        q = rng.normal(scale=0.3, size=(nq, 3)).astype(np.float32) + tgt
+    elif kind == 'wide':
+        tgt = rng.uniform(-40, 40, size=(n, 3)).astype(np.float32)
+        q = tgt[rng.integers(0, n, nq)] + rng.normal(scale=0.04, size=(nq, 3)).astype(np.float32)
+    elif kind == 'dups':
+        tgt = np.repeat(rng.uniform(-2, 2, size=(n // 4, 3)).astype(np.float32), 4, axis=0)
+        q = rng.uniform(-3, 3, size=(nq, 3)).astype(np.float32)
+    elif kind == 'flat':
+        tgt = rng.uniform(-4, 4, size=(n, 3)).astype(np.float32)
+        tgt[:, 2] = 1.25
+        q = rng.uniform(-5, 5, size=(nq, 3)).astype(np.float32)
+        q[:, 2] = rng.choice([1.25, 1.0, 1.6, 9.0], size=nq)
+    else:
+        tgt = rng.uniform(-5, 5, size=(n, 3)).astype(np.float32)
+        q = rng.uniform(-8, 8, size=(nq, 3)).astype(np.float32)
+    tg, qg = torch.from_numpy(tgt).cuda(), torch.from_numpy(q.astype(np.float32)).cuda()
+    _, dist = pk.ops.knn(qg, tg, 1, metric=1, return_dist=True)
+    want = (dist[:, 0] > r)
+    grid = pk.ops.RadiusGrid(tg, r)
+    far = grid.far(qg, r)
+    assert torch.equal(far > 0.5, want), int(((far > 0.5) != want).sum())
+    half = grid.far(qg, 0.5 * r)                       # any radius up to the one the grid was built for
+    assert torch.equal(half > 0.5, dist[:, 0] > 0.5 * r)
+    if kind == 'lattice':
+        assert int((dist[:, 0] == r).sum()) > 100       # the boundary case is exercised: exactly at the radius = not far
+    rows = torch.cat([qg, torch.arange(nq, device='cuda', dtype=torch.float32)[:, None]], dim=1)
+    kept = pk.geometry._gap_rows(rows, tg, r)
+    assert torch.equal(kept, pk.geometry.filter_air_solid_gap(rows, tg, 0, r)[0])
+
+
+def test_sampler_grid_filter_switch_changes_nothing(pk, monkeypatch):
+    """The sampler's outputs with the grid radius test equal those with the 1-NN search (same RNG stream)."""
+    case = dict(name='sw', kind='carla', bias='low_moving_vehped_sembal', frames=3, m=20000, num_solid=2048,
+                num_air=3000, time_idx=1, segm=True, seed=78)
+    frames, sizes, valo, num_valo = gc.sampler_inputs(case)
+    cfg = gc.sampler_config(case)
+    outs = []
+    for on in (True, False):
+        monkeypatch.setattr(pk.geometry, 'GRID_GAP_FILTER', on)
+        sampler = pk.geometry.GuidedImplicitPointSampler(_Log(), **cfg)
+        np.random.seed(5)
+        torch.manual_seed(5)
+        outs.append(sampler([torch.from_numpy(f).cuda() for f in frames], [torch.from_numpy(z).cuda() for z in sizes],
+                            torch.from_numpy(valo).cuda(), torch.from_numpy(num_valo).cuda(), case['time_idx']))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_sampler_invariants_at_training_size(pk):
     """BASELINE config 5 sizes (num_solid 7168, num_air 10035, ~57 K target points, CARLA cuboid): every solid
     query lies within radius/2 of a target point and carries that point's colour / tag; every air query is farther
