@@ -112,8 +112,11 @@ def main():
     ap.add_argument('--no-prefetch', action='store_true', help='do not prefetch the next step\'s FPS chain / kNNs under this step\'s backward')
     ap.add_argument('--graph', action='store_true', help='replay the step as one captured hipGraph (GraphedTrainStep)')
     ap.add_argument('--sampler', action='store_true',
-                    help='draw the supervision points inside the step with GuidedImplicitPointSampler '
-                         '(57344-point target frames, bias low_moving_vehped_sembal) instead of fixed synthetic queries')
+                    help='draw the supervision points of every step with GuidedImplicitPointSampler (57344-point target '
+                         'frames, bias low_moving_vehped_sembal) instead of fixed synthetic queries: the NEXT step\'s points '
+                         'are drawn on a side stream while this step runs (they depend on the data and the random '
+                         'generators only, like a dataloader); --sampler-serial draws them in front of the step')
+    ap.add_argument('--sampler-serial', action='store_true', help='with --sampler: sample, synchronise, then step')
     args = ap.parse_args()
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         return self_launch(args.gpus)
@@ -167,7 +170,7 @@ def main():
     target = torch.from_numpy(target.astype(np.float32)).to(device)
     lkw = dict(density_lw=1.0, segmentation_lw=0.6)
     if args.graph:
-        assert not args.sampler, 'the guided sampler draws on the host: it cannot be part of a captured step'
+        # (the guided sampler draws on the host: it is not part of the captured step -- it runs beside the replay)
         step = pk.training.GraphedTrainStep(enc, dec, lr=1e-3, grad_clip=0.2, loss_kwargs=lkw,
                                             external_geometry=not args.no_prefetch)
         step.batch_frames = not args.per_frame
@@ -200,16 +203,41 @@ def main():
         torch.manual_seed(SEED + rank)
         sampler_time = [0.0]
 
-        def run_step():
+        samp_stream = torch.cuda.Stream()
+        samp_stream.wait_stream(torch.cuda.current_stream())     # (once: the target frames were uploaded on the main stream)
+
+        def draw():
+            """One step's supervision points on the sampling stream -> (queries, targets, completion event)."""
             ts = time.perf_counter()
-            qs, ts_ = [], []
-            for t in range(FRAMES):
-                (si, ai, st, at, _, _) = sampler(frames, sizes, valo, num_valo, t)
-                qs.append(torch.cat([si, ai], dim=1)[0])
-                ts_.append(torch.cat([st, at], dim=1)[0])
-            torch.cuda.synchronize()
+            main = torch.cuda.current_stream()
+            with torch.cuda.stream(samp_stream):     # (never waits for the main stream: the step queued there runs beside it)
+                qs, ts_ = [], []
+                for t in range(FRAMES):
+                    (si, ai, st, at, _, _) = sampler(frames, sizes, valo, num_valo, t)
+                    qs.append(torch.cat([si, ai], dim=1)[0])
+                    ts_.append(torch.cat([st, at], dim=1)[0])
+                qq, tt = torch.stack(qs), torch.stack(ts_)
+                done = torch.cuda.Event()
+                done.record()
+            qq.record_stream(main)
+            tt.record_stream(main)
             sampler_time[0] += time.perf_counter() - ts
-            return step(pcl, torch.stack(qs), torch.stack(ts_), **nxt)
+            return qq, tt, done
+
+        pending = [None]
+
+        def run_step():
+            if args.sampler_serial:
+                qq, tt, done = draw()
+                torch.cuda.synchronize()
+                return step(pcl, qq, tt, **nxt)
+            if pending[0] is None:
+                pending[0] = draw()
+            qq, tt, done = pending[0]
+            torch.cuda.current_stream().wait_event(done)
+            loss = step(pcl, qq, tt, **nxt)        # queued (eager launches or one graph replay), not waited for
+            pending[0] = draw()                    # the next step's points, beside it
+            return loss
     else:
         def run_step():
             return step(pcl, q, target, **nxt)
@@ -273,7 +301,7 @@ def main():
             'metric': 'training step (BASELINE config 5: CARLA-4D, batch 1/GPU, n_points=28672, 4 x 17203 queries)',
             'value': world * args.steps / elapsed, 'unit': 'examples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'dtype': 'f32', 'data': 'synthetic', 'losses': losses, 'sampler_ms_per_step': sampler_ms, 'graph': bool(args.graph), 'geometry_prefetch': bool(nxt), 'frames_batched': bool(step.batch_frames), 'attention_backward': ('stored pair tensors (%s form)' % pk.point_transformer_layer.STORED_ATTENTION_FORM) if args.no_checkpoint else 'recompute in backward (chunks of %d queries)' % pk.point_transformer_layer._CHECKPOINT_CHUNK,
+            'scaling': 'weak', 'dtype': 'f32', 'data': 'synthetic', 'losses': losses, 'sampler_ms_per_step': sampler_ms, 'sampler': (None if not args.sampler else 'in front of the step (serial)' if args.sampler_serial else "next step's points drawn on a side stream beside this step (host time per step in sampler_ms_per_step)"), 'graph': bool(args.graph), 'geometry_prefetch': bool(nxt), 'frames_batched': bool(step.batch_frames), 'attention_backward': ('stored pair tensors (%s form)' % pk.point_transformer_layer.STORED_ATTENTION_FORM) if args.no_checkpoint else 'recompute in backward (chunks of %d queries)' % pk.point_transformer_layer._CHECKPOINT_CHUNK,
             'peak_mem_gb': torch.cuda.max_memory_allocated() / 2 ** 30,
             'roofline': roof,
             'config': {'workload': 'CARLA-4D training step (BASELINE configs[4]): batch 1 per GPU, n_points=%d, %d x %d '
