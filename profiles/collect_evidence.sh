@@ -21,6 +21,12 @@ for flags in "" "--graph" "--no-checkpoint" "--graph --no-checkpoint"; do
   python bench_train.py --steps 5 --warmup 2 $flags 2>/dev/null | tail -1 >> "$OUT/bench_train.jsonl"
 done
 OCC4D_PAIR_MLP=0 OCC4D_TRAIN_ROWLIN_HALF_CU=0 python bench_train.py --steps 5 --warmup 2 --graph 2>/dev/null | tail -1 >> "$OUT/bench_train.jsonl"
+: > "$OUT/bench_train_sampler.jsonl"
+for flags in "--graph" "--sampler --graph" "--sampler" "--sampler --sampler-serial"; do
+  python bench_train.py --steps 5 --warmup 2 $flags 2>/dev/null | tail -1 >> "$OUT/bench_train_sampler.jsonl"
+done
+python profiles/time_pair_mlp.py > "$OUT/time_pair_mlp.txt" 2>/dev/null
+python profiles/profile_sampler.py 2>/dev/null | head -3 > "$OUT/profile_sampler.txt"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof3" -- python bench_train.py --steps 4 --warmup 2 > /dev/null 2>&1
 cp "$(find "$OUT/prof3" -name '*kernel_stats.csv' | head -1)" "$OUT/train_kernel_stats.csv"
 python profiles/train_shapes.py > "$OUT/train_shapes.txt" 2>/dev/null
