@@ -203,40 +203,27 @@ def main():
         torch.manual_seed(SEED + rank)
         sampler_time = [0.0]
 
-        samp_stream = torch.cuda.Stream()
-        samp_stream.wait_stream(torch.cuda.current_stream())     # (once: the target frames were uploaded on the main stream)
+        side = pk.training.SideStreamSampler(sampler, FRAMES)
 
         def draw():
-            """One step's supervision points on the sampling stream -> (queries, targets, completion event)."""
             ts = time.perf_counter()
-            main = torch.cuda.current_stream()
-            with torch.cuda.stream(samp_stream):     # (never waits for the main stream: the step queued there runs beside it)
-                qs, ts_ = [], []
-                for t in range(FRAMES):
-                    (si, ai, st, at, _, _) = sampler(frames, sizes, valo, num_valo, t)
-                    qs.append(torch.cat([si, ai], dim=1)[0])
-                    ts_.append(torch.cat([st, at], dim=1)[0])
-                qq, tt = torch.stack(qs), torch.stack(ts_)
-                done = torch.cuda.Event()
-                done.record()
-            qq.record_stream(main)
-            tt.record_stream(main)
+            side.draw(frames, sizes, valo, num_valo)
             sampler_time[0] += time.perf_counter() - ts
-            return qq, tt, done
 
-        pending = [None]
+        primed = [False]
 
         def run_step():
             if args.sampler_serial:
-                qq, tt, done = draw()
+                draw()
+                qq, tt = side.take()
                 torch.cuda.synchronize()
                 return step(pcl, qq, tt, **nxt)
-            if pending[0] is None:
-                pending[0] = draw()
-            qq, tt, done = pending[0]
-            torch.cuda.current_stream().wait_event(done)
+            if not primed[0]:
+                draw()
+                primed[0] = True
+            qq, tt = side.take()
             loss = step(pcl, qq, tt, **nxt)        # queued (eager launches or one graph replay), not waited for
-            pending[0] = draw()                    # the next step's points, beside it
+            draw()                                 # the next step's points, beside it
             return loss
     else:
         def run_step():

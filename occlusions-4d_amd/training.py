@@ -152,6 +152,46 @@ def allreduce_gradients(params, world=None):
         off += n
 
 
+class SideStreamSampler:
+    """Draws the supervision points of the NEXT training step on a side stream while the current step runs.
+
+    The reference samples inside the step on the training stream (pipeline.py:118-161 calls
+    GuidedImplicitPointSampler per target frame before the forward pass); the points depend on the target frames and on
+    the random generators only, so they can be drawn one step ahead like any dataloader work.  The sampling stream
+    never waits for the main stream (the step queued there runs beside it); `take()` makes the main stream wait for the
+    draw's completion event and hands the tensors over (record_stream: the allocator must not recycle them under the
+    consumer).  The random stream is the one a serial loop would consume: same points, same losses."""
+
+    def __init__(self, sampler, n_frames):
+        self.sampler, self.n_frames = sampler, n_frames
+        self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())     # (inputs uploaded so far on the main stream)
+        self._pending = None
+
+    def draw(self, frames, sizes, valo_ids, num_valo_ids):
+        """Queues one step's draw: (queries (T, N, 4), targets (T, N, 6)) of batch element 0, as the bench consumes them."""
+        with torch.cuda.stream(self.stream):
+            qs, ts = [], []
+            for t in range(self.n_frames):
+                (si, ai, st, at, _, _) = self.sampler(frames, sizes, valo_ids, num_valo_ids, t)
+                qs.append(torch.cat([si, ai], dim=1)[0])
+                ts.append(torch.cat([st, at], dim=1)[0])
+            q, tgt = torch.stack(qs), torch.stack(ts)
+            done = torch.cuda.Event()
+            done.record()
+        self._pending = (q, tgt, done)
+
+    def take(self):
+        """The pending draw, ordered before everything queued on the current stream from here on."""
+        assert self._pending is not None, 'draw() first'
+        (q, tgt, done), self._pending = self._pending, None
+        cur = torch.cuda.current_stream()
+        cur.wait_event(done)
+        q.record_stream(cur)
+        tgt.record_stream(cur)
+        return q, tgt
+
+
 class TrainStep:
     """One optimisation step: forward (encoder + decoder per target frame), losses, backward,
     gradient all-reduce, clip (train.py:107-109, max norm 0.2), optimiser step."""

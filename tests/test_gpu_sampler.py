@@ -123,6 +123,39 @@ def test_sampler_grid_filter_switch_changes_nothing(pk, monkeypatch):
         assert torch.equal(a, b)
 
 
+def test_side_stream_sampler_draws_the_same_points(pk):
+    """training.SideStreamSampler (the next step's points drawn on a side stream) consumes the random stream exactly as
+    direct calls do: two consecutive draws equal two consecutive rounds of direct sampler calls."""
+    case = dict(name='ss', kind='carla', bias='low_moving_vehped_sembal', frames=3, m=20000, num_solid=1024,
+                num_air=1500, time_idx=1, segm=True, seed=79)
+    frames, sizes, valo, num_valo = gc.sampler_inputs(case)
+    cfg = gc.sampler_config(case)
+    dev = ([torch.from_numpy(f).cuda() for f in frames], [torch.from_numpy(z).cuda() for z in sizes],
+           torch.from_numpy(valo).cuda(), torch.from_numpy(num_valo).cuda())
+    sampler = pk.geometry.GuidedImplicitPointSampler(_Log(), **cfg)
+    np.random.seed(9)
+    torch.manual_seed(9)
+    direct = []
+    for _ in range(2):
+        qs, ts = [], []
+        for t in range(3):
+            (si, ai, st, at, _, _) = sampler(*dev, t)
+            qs.append(torch.cat([si, ai], dim=1)[0])
+            ts.append(torch.cat([st, at], dim=1)[0])
+        direct.append((torch.stack(qs), torch.stack(ts)))
+    np.random.seed(9)
+    torch.manual_seed(9)
+    side = pk.training.SideStreamSampler(sampler, 3)
+    busy = torch.zeros((4096, 4096), device='cuda')
+    for i in range(2):
+        side.draw(*dev)
+        for _ in range(3):
+            busy = busy * 1.0001 + 1.0           # main-stream work the draw must not wait for
+        q, tgt = side.take()
+        assert torch.equal(q, direct[i][0]) and torch.equal(tgt, direct[i][1])
+    assert q.shape == (3, 2524, 4) and tgt.shape == (3, 2524, 6)
+
+
 def test_sampler_invariants_at_training_size(pk):
     """BASELINE config 5 sizes (num_solid 7168, num_air 10035, ~57 K target points, CARLA cuboid): every solid
     query lies within radius/2 of a target point and carries that point's colour / tag; every air query is farther
