@@ -94,8 +94,9 @@ class _HostCopies:
     base reference); the allocator reuses a block only after the caller has dropped the array."""
 
     def __init__(self, device):
-        self.on = PINNED_HOST_IO and torch.device(device).type == 'cuda'
-        self.stream = torch.cuda.Stream() if self.on else None
+        self.device = torch.device(device)
+        self.on = PINNED_HOST_IO and self.device.type == 'cuda'
+        self.stream = torch.cuda.Stream(device=self.device) if self.on else None
         self.pending = []
 
     def fetch(self, t, dtype=None):
@@ -109,7 +110,7 @@ class _HostCopies:
             return t.cpu().numpy()
         t = t.contiguous()
         host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-        self.stream.wait_stream(torch.cuda.current_stream())
+        self.stream.wait_stream(torch.cuda.current_stream(t.device))
         with torch.cuda.stream(self.stream):
             host.copy_(t, non_blocking=True)
         t.record_stream(self.stream)
