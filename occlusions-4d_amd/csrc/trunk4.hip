@@ -39,6 +39,9 @@ struct Trunk4Args {
   int n_stages;                              // rowlin: output channels / 16
   int relu_in;
   const float* mask; int64_t ldm;            // rowlin: output zeroed where mask <= 0 (ReLU mask of a data gradient), or null
+  // rowlin: the row tiles behind the last FULL dispatch round (full_tiles = a multiple of 2 x CUs) are each split over
+  // `tail_parts` workgroups by output stage range, so that a nearly empty last round is a fraction of a round long
+  int full_tiles, tail_parts;
 };
 
 __device__ __forceinline__ unsigned lds_addr_q(const float* p) {
@@ -281,9 +284,18 @@ __global__ __launch_bounds__(256, 2) void rowlin4_kernel(const Trunk4Args a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
   const unsigned lane16 = lane * 16;
-  const int row = blockIdx.x * QROWS + wave * 16 + r;
+  int tile = blockIdx.x, s0 = 0, s1 = a.n_stages;
+  if (a.tail_parts > 1 && (int)blockIdx.x >= a.full_tiles) {          // (workgroup-uniform)
+    const int t = (int)blockIdx.x - a.full_tiles;
+    const int per = (a.n_stages + a.tail_parts - 1) / a.tail_parts;
+    tile = a.full_tiles + t / a.tail_parts;
+    s0 = (t % a.tail_parts) * per;
+    s1 = min(a.n_stages, s0 + per);
+    if (s0 >= s1) return;
+  }
+  const int row = tile * QROWS + wave * 16 + r;
   const int rowc = min(row, a.n - 1);
-  dma_stage_q(a.w0p, bufA, wave, lane16);
+  dma_stage_q(a.w0p + (int64_t)s0 * QSTAGE, bufA, wave, lane16);
   f32x4 xr[QKG];
   {
     const float* xp = a.x + (int64_t)rowc * a.ldx + 4 * g;
@@ -297,11 +309,11 @@ __global__ __launch_bounds__(256, 2) void rowlin4_kernel(const Trunk4Args a) {
   __syncthreads();
   // the packed stream carries n_stages + 1 stages (the last repeats stage 0): prefetching is branch-free
 #pragma clang loop unroll(disable)
-  for (int s = 0; s < a.n_stages; s += 2) {
+  for (int s = s0; s < s1; s += 2) {
     rowlin4_stage(a, s, bufA + lane * 4, xr, row, rowc, g, a.w0p + (int64_t)(s + 1) * QSTAGE, bufB, wave, lane16);
     dma_wait_q();
     __syncthreads();
-    if (s + 1 < a.n_stages)
+    if (s + 1 < s1)
       rowlin4_stage(a, s + 1, bufB + lane * 4, xr, row, rowc, g, a.w0p + (int64_t)(s + 2) * QSTAGE, bufA, wave, lane16);
     dma_wait_q();
     __syncthreads();
@@ -531,6 +543,21 @@ extern "C" int occ4d_resblock4_f32(const float* x, int64_t ldx, float* y, int64_
   return occ4d::check_launch("occ4d_resblock4_f32");
 }
 
+// Launch geometry of rowlin4_kernel: whole rounds of 2 workgroups per CU as they are; when what remains is at most a
+// quarter round, every remaining row tile is split over four workgroups by output stage range (measured at 68812 rows,
+// 2.1 rounds: the 52 tail workgroups took half a round alone on their CUs; split, a sixth).
+static int rowlin4_grid(Trunk4Args& a) {
+  const int tiles = occ4d::cdiv(a.n, QROWS);
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    cus = 256;
+  const int round = 2 * cus;
+  a.full_tiles = tiles / round * round;
+  const int tail = tiles - a.full_tiles;
+  a.tail_parts = (a.full_tiles > 0 && tail > 0 && 4 * tail <= round && a.n_stages >= 8) ? 4 : 1;
+  return a.full_tiles + tail * a.tail_parts;
+}
+
 extern "C" int occ4d_rowlin4_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed,
                                  const float* b, int n_out, int relu_in, const float* res, int64_t ldr,
                                  const float* zconst, const float* ztab, int64_t ldz, const int32_t* zidx,
@@ -543,7 +570,8 @@ extern "C" int occ4d_rowlin4_f32(const float* x, int64_t ldx, float* y, int64_t 
                 n_out);
   OCC4D_REQUIRE(!res || (ldr % 4 == 0 && ((uintptr_t)res % 16) == 0 && ldr >= n_out),
                 "occ4d_rowlin4_f32: residual rows must be 16-byte aligned with ldr %% 4 == 0");
-  rowlin4_kernel<<<occ4d::cdiv(n, QROWS), 256, 0, (hipStream_t)stream>>>(a);
+  const int grid = rowlin4_grid(a);
+  rowlin4_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
   return occ4d::check_launch("occ4d_rowlin4_f32");
 }
 
@@ -561,7 +589,8 @@ extern "C" int occ4d_rowlin4_masked_f32(const float* x, int64_t ldx, float* y, i
                 "occ4d_rowlin4_masked_f32: residual rows must be 16-byte aligned with ldr %% 4 == 0");
   OCC4D_REQUIRE(mask && ldm % 4 == 0 && ((uintptr_t)mask % 16) == 0 && ldm >= n_out,
                 "occ4d_rowlin4_masked_f32: mask rows must be 16-byte aligned with ldm %% 4 == 0 and ldm >= n_out");
-  rowlin4_kernel<<<occ4d::cdiv(n, QROWS), 256, 0, (hipStream_t)stream>>>(a);
+  const int grid = rowlin4_grid(a);
+  rowlin4_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
   return occ4d::check_launch("occ4d_rowlin4_masked_f32");
 }
 

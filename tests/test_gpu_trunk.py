@@ -240,3 +240,29 @@ def test_rowlin_output_mask(n, n_out, half_cu):
     got = pk.ops.rowlin(g, p, b, n_out, mask=mask)
     assert torch.equal(got, torch.where(mask > 0, plain, torch.zeros_like(plain)))
     assert torch.equal(got, pk.ops.relu_mask(plain, mask))
+
+
+@pytest.mark.parametrize('n,n_out,masked', [(512 * 64 + 37 * 64 + 5, 416, False), (2 * 512 * 64 + 64, 832, True),
+                                            (512 * 64 + 128 * 64, 416, True), (512 * 64 + 129 * 64, 32, False),
+                                            (512 * 64 + 3, 112, False)])
+def test_half_cu_rowlin_tail_split(n, n_out, masked):
+    """occ4d_rowlin4_f32 / _masked with row tiles behind the last full dispatch round (512 workgroups on a 256-CU part):
+    up to a quarter round of them is split over four workgroups by output stage range -- same results as the 8-wave
+    kernel row for row (both sum k in the same order), also at the split threshold, one tile past it, and with fewer
+    than eight stages (no split)."""
+    rng = np.random.default_rng(n_out)
+    x = torch.from_numpy(rng.normal(size=(n, H)).astype(np.float32)).cuda()
+    w, b = _weights(rng, n_out)
+    res = torch.from_numpy(rng.normal(size=(n, n_out)).astype(np.float32)).cuda()
+    mask = torch.from_numpy(rng.normal(size=(n, n_out)).astype(np.float32)).cuda() if masked else None
+    got = pk.ops.rowlin(x, pk.ops.pack_trunk4_rows(w), b, n_out, relu_in=True, residual=res, mask=mask)
+    if n_out % 32 == 0:
+        ref = pk.ops.rowlin(x, pk.ops.pack_trunk_rows(w), b, n_out, relu_in=True, residual=res, mask=mask)
+        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    rows = torch.from_numpy(rng.integers(0, n, size=4000)).cuda()
+    rows[:64] = torch.arange(n - 64, n)                    # the very last rows
+    want = torch.relu(x[rows]).double() @ w.double().t() + b.double() + res[rows].double()
+    if masked:
+        want = torch.where(mask[rows] > 0, want, torch.zeros_like(want))
+    assert float((got[rows].double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
