@@ -82,6 +82,24 @@ def test_pruned_fps_matches_the_greedy_scan(pk, kind, n, m):
     assert np.array_equal(sel.cpu().numpy()[:expect_sorted.size], expect_sorted.astype(np.int32))
 
 
+def test_pruned_fps_tie_storms(pk):
+    """Clouds on a coarse integer grid (few distinct coordinates: running mins tie in large groups, floors tie with
+    candidates, several waves publish the same distance): the multi-sample rounds must still make the sequential scan's
+    picks, lowest index first."""
+    rng = np.random.default_rng(20260928)
+    for trial in range(10):
+        n = int(rng.integers(1536, 5000))
+        k = int(rng.integers(2, 7))
+        p = rng.integers(0, k, size=(n, 3)).astype(np.float32) * np.float32(0.5)
+        if trial % 2:
+            p += rng.integers(0, 2, size=(n, 3)).astype(np.float32) * np.float32(1e-3)   # near-duplicates
+        m = int(rng.integers(n // 8, n // 2))
+        sel, order = pk.ops.fps(torch.from_numpy(p).cuda(), m, return_order=True)
+        ref = _oracle_order(p, m)
+        got = order.cpu().numpy()
+        assert np.array_equal(got, ref), (trial, n, m, k, int(np.argmax(got != ref)))
+
+
 def test_pruned_fps_against_the_cooperative_kernel_random(pk):
     rng = np.random.default_rng(2718)
     kinds = ['uniform', 'lattice', 'half_lattice', 'planar', 'clusters']
