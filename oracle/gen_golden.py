@@ -233,6 +233,84 @@ def main():
              terms=np.array([float(l_rgb), float(l_dens), float(l_segm), float(l_track)], dtype=np.float64),
              squashed=torch.stack(outs).detach().numpy()[:, :, ::16], grad=raw.grad.numpy())
 
+    regimes(ref)
+
+
+def _f64(sd):
+    return {k: v.double() for k, v in sd.items()}
+
+
+@torch.no_grad()
+def regimes(ref):
+    """Round 4 ("What's weak" 1): the same reference code outside the init-scale / tie-free regime.
+    For the scaled-weight cases the reference runs in fp32 AND in fp64 (same modules, .double()): the fp64 result of
+    the reference's op order is the yardstick for a principled bound, max(1e-4, 2 max|ref32 - ref64|)."""
+    ptl, mods, mdl, imp, geo, inf = (ref.point_transformer_layer, ref.modules, ref.model,
+                                     ref.implicit, ref.geometry, ref.inference)
+
+    # G2r: PointTransformerLayer with scaled weights / equal logits / one dominant neighbour
+    for case in gc.PTL_REGIME_CASES:
+        x, pos, x2, pos2, sd = gc.ptl_inputs(case)
+        res = {}
+        for tag, conv in (('', lambda a: t(a)), ('64', lambda a: t(a).double())):
+            layer = ptl.PointTransformerLayer(case['dim'], num_neighbors=case['k'], dim2=case.get('dim2'))
+            layer.load_state_dict(sd)
+            if tag:
+                layer = layer.double()
+            args = (conv(x)[None], conv(pos)[None]) + ((conv(x2)[None], conv(pos2)[None]) if x2 is not None else ())
+            res['agg' + tag] = layer(*args)[0].numpy()
+            a2 = args if x2 is not None else args + args
+            res['idx' + tag] = ptl.kNN_torch(a2[1], a2[3], case['k'])[0].numpy()
+        # the fp64 run must see the same neighbour lists as a SET (tie-free clouds), else it is no yardstick
+        assert np.array_equal(np.sort(res['idx'], 1), np.sort(res['idx64'], 1)), case['name']
+        save('g2r_ptl_' + case['name'], agg=res['agg'], agg64=res['agg64'])
+
+    # G5p: encoder on zero-padded clouds; the input IS what the reference's pad function returns
+    for case in gc.ENC_PAD_CASES:
+        pcl, pa, sd = gc.enc_inputs(case)
+        real = pk.configs.synthetic_pcl(case['kind'], case['n_real'], case['video_len'], case['seed'])
+        assert torch.equal(geo.subsample_pad_pcl_torch(real, case['n']), pcl)
+        net = mdl.PointCompletionNetV3(**pa)
+        net.load_state_dict(sd)
+        net.eval()
+        out, xg, _ = net(pcl, False)
+        save('g5_enc_' + case['name'], pcl_out=out[0].numpy(), x_global=xg[0].numpy())
+
+    # G8r: decoder with scaled cross-attention weights / features, and with queries far outside the cuboid
+    for case in gc.DEC_REGIME_CASES:
+        q, abstract, fglob, ia, sd = gc.dec_inputs(case)
+        res = {}
+        for tag, conv in (('', lambda a: t(a)), ('64', lambda a: t(a).double())):
+            net = imp.LocalPclResnetFC(**ia)
+            net.load_state_dict(sd)
+            if tag:
+                net = net.double()
+            net.eval()
+            out, pen = net(conv(q), conv(abstract), conv(fglob), None)
+            res['output' + tag], res['penult' + tag] = out.numpy(), pen.numpy()[:, ::8]
+        save('g8r_dec_' + case['name'], **res)
+
+    # G10p: perform_inference end to end on zero-padded clouds
+    for case in gc.INFER_PAD_CASES:
+        pcl, pa, ia, ia_inf, esd, dsd = gc.infer_inputs(case)
+        enc = mdl.PointCompletionNetV3(**pa)
+        enc.load_state_dict(esd)
+        dec = imp.LocalPclResnetFC(**ia)
+        dec.load_state_dict(dsd)
+        enc.eval()
+        dec.eval()
+        res = inf.perform_inference(
+            pcl.clone(), None, None, [enc, dec], torch.device('cpu'), 'if', ia_inf['min_z'],
+            ia_inf['cube_bounds'], ia_inf['color_mode'], case['time_idx'], None,
+            sample_implicit=True, num_sample=case['num_sample'], point_sample_mode='grid',
+            batch_size=case['batch_size'], predict_segmentation=ia_inf['predict_segmentation'],
+            track_mode='none', semantic_classes=13, density_threshold=0.5,
+            data_kind=ia_inf['data_kind'], cube_mode=4, compress_air=True)
+        save('g10_infer_' + case['name'], implicit_output=res['implicit_output'],
+             pcl_abstract=res['pcl_abstract'], features_global=res['features_global'],
+             n_solid=np.array([res['output_solid'].shape[0]]), n_air=np.array([res['output_air'].shape[0]]),
+             air_head=res['output_air'][:64], solid_head=res['output_solid'][:64])
+
 
 if __name__ == '__main__':
     main()

@@ -34,6 +34,22 @@ def test_g2_pt_layer(case):
     close(agg, load_golden('g2_ptl_' + case['name'])['agg'])
 
 
+@pytest.mark.parametrize('case', gc.PTL_REGIME_CASES, ids=lambda c: c['name'])
+def test_g2r_pt_layer_regimes(case):
+    """Scaled weights (saturated per-channel softmax), all-equal logits, one dominant neighbour: the restatement
+    against the reference's fp32 run at the oracle tolerance scaled to the outputs' size, and against the reference's
+    fp64 run at the principled bound."""
+    x, pos, x2, pos2, sd = gc.ptl_inputs(case)
+    kw = {} if x2 is None else dict(x2=T(x2)[None], pos2=T(pos2)[None])
+    agg = op.pt_layer(sd, T(x)[None], T(pos)[None], num_neighbors=case['k'], **kw)[0].numpy()
+    g = load_golden('g2r_ptl_' + case['name'])
+    close(agg, g['agg'], TOL * max(1.0, float(np.abs(g['agg']).max())))
+    close(agg.astype(np.float64), g['agg64'], gc.regime_bound(g, 'agg'))
+    if 'equal_logits' in case['name']:
+        # uniform softmax weights: the layer is the plain mean of v + pe over the K neighbours
+        assert gc.regime_bound(g, 'agg') == 1e-4
+
+
 @pytest.mark.parametrize('case', gc.PTB_CASES, ids=lambda c: c['name'])
 def test_g3_pt_block(case):
     x, pos, x2, pos2, sd = gc.ptb_inputs(case)
@@ -51,7 +67,7 @@ def test_g4_down(case):
     close(z[0], g['z'])
 
 
-@pytest.mark.parametrize('case', gc.ENC_CASES, ids=lambda c: c['name'])
+@pytest.mark.parametrize('case', gc.ENC_CASES + gc.ENC_PAD_CASES, ids=lambda c: c['name'])
 def test_g5_encoder(case):
     pcl, pa, sd = gc.enc_inputs(case)
     out, xg = op.encoder_forward(sd, pa, pcl)
@@ -86,6 +102,24 @@ def test_g8_decoder(case):
     close(pen[:, ::8], g['penult'])
 
 
+@pytest.mark.parametrize('case', gc.DEC_REGIME_CASES, ids=lambda c: c['name'])
+def test_g8r_decoder_regimes(case):
+    q, abstract, fglob, ia, sd = gc.dec_inputs(case)
+    out, pen = op.decoder_forward(sd, ia, T(q), T(abstract), T(fglob))
+    g = load_golden('g8r_dec_' + case['name'])
+    close(out, g['output'], TOL * max(1.0, float(np.abs(g['output']).max())))
+    close(pen[:, ::8], g['penult'], TOL * max(1.0, float(np.abs(g['penult']).max())))
+    close(out.double(), g['output64'], gc.regime_bound(g, 'output'))
+    close(pen[:, ::8].double(), g['penult64'], gc.regime_bound(g, 'penult'))
+    if 'far' in case['name']:
+        lo, hi = np.array([[a for a, _ in cfg_cuboid(case)], [b for _, b in cfg_cuboid(case)]])
+        assert ((q[:, :3] < lo) | (q[:, :3] > hi)).any(axis=1).mean() > 0.9       # the queries ARE outside
+
+
+def cfg_cuboid(case):
+    return gc.cfg.input_cuboid(case['kind'])
+
+
 def test_g9_grid():
     g = load_golden('g9_grid')
     for case in gc.GRID_CASES:
@@ -107,7 +141,13 @@ def test_g9_grid_sizes_match_survey():
     assert sizes['greater_2097152'] == 2125568
 
 
-@pytest.mark.parametrize('case', gc.INFER_CASES, ids=lambda c: c['name'])
+def test_padded_cases_really_contain_coincident_points():
+    for case in gc.ENC_PAD_CASES + gc.INFER_PAD_CASES:
+        pcl = gc.padded_pcl(case)
+        assert pcl.shape[1] == case['n'] and int((pcl[0].abs().sum(dim=1) == 0).sum()) == case['n'] - case['n_real']
+
+
+@pytest.mark.parametrize('case', gc.INFER_CASES + gc.INFER_PAD_CASES, ids=lambda c: c['name'])
 def test_g10_perform_inference(case):
     pcl, pa, ia, inf, esd, dsd = gc.infer_inputs(case)
     res = op.perform_inference(
@@ -128,7 +168,7 @@ def test_g10_perform_inference(case):
     assert res['output_air'].shape[1] == g['air_head'].shape[1]
 
 
-@pytest.mark.parametrize('case', gc.INFER_CASES, ids=lambda c: c['name'])
+@pytest.mark.parametrize('case', gc.INFER_CASES + gc.INFER_PAD_CASES, ids=lambda c: c['name'])
 def test_stable_tie_rule_agrees_with_reference_where_defined(case):
     """The product's tie rule (lowest index first) must reproduce the reference wherever the
     reference itself is well defined (no equidistant neighbours at a k boundary)."""
