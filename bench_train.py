@@ -204,10 +204,12 @@ def main():
         sampler_time = [0.0]
 
         side = pk.training.SideStreamSampler(sampler, FRAMES)
+        uploaded = torch.cuda.Event()
+        uploaded.record()        # the target frames are complete here; a real loop records one such event per upload
 
         def draw():
             ts = time.perf_counter()
-            side.draw(frames, sizes, valo, num_valo)
+            side.draw(frames, sizes, valo, num_valo, ready=uploaded)
             sampler_time[0] += time.perf_counter() - ts
 
         primed = [False]

@@ -23,28 +23,42 @@ ROWLIN_IN_TRAINING = True
 # workgroups); a half-CU workgroup that has its CU to itself in the last round runs faster, and at whole rounds the two
 # are level: 232 vs 301 us at 68812 rows, 276 vs 302 us at 98304 (profiles/time_rowlin_tail.py).
 ROWLIN_HALF_CU = os.environ.get('OCC4D_TRAIN_ROWLIN_HALF_CU', '1') == '1'
-_PACKS = {}
+_PACKS = {}           # stage-packed copies of nn.Parameters only (small LRU); transient leaves are packed uncached
+_PACKS_MAX = 64
+_ZEROS = {}           # zero bias vectors, kept apart from the packs and created eagerly (never inside a capture)
 
 
 def _packed(w, transposed):
     from . import point_transformer_layer as ptl
-    key = (w.data_ptr(), w._version, tuple(w.shape), bool(transposed), ptl.weights_epoch(), ROWLIN_HALF_CU)
-    hit = _PACKS.get(key)
-    if hit is not None and hit[0] is w:
-        return hit[1]
     src = w.detach().t().contiguous() if transposed else w.detach()
+    if not isinstance(w, torch.nn.Parameter):
+        # a transient leaf (the merged matrices rebuilt by every _CheckpointedAttention.backward): caching it would only
+        # pin the leaf and its packed copy (a few MB each) until the table is cleared -- it can never hit again
+        return ops.pack_trunk4_rows(src) if ROWLIN_HALF_CU else ops.pack_trunk_rows(src)
+    key = (id(w), bool(transposed))
+    tag = (w.data_ptr(), w._version, tuple(w.shape), ptl.weights_epoch(), ROWLIN_HALF_CU)
+    hit = _PACKS.get(key)
+    if hit is not None and hit[0] is w and hit[1] == tag:
+        _PACKS[key] = _PACKS.pop(key)              # most recently used last
+        return hit[2]
     packed = ops.pack_trunk4_rows(src) if ROWLIN_HALF_CU else ops.pack_trunk_rows(src)
-    if len(_PACKS) > 128:
-        _PACKS.clear()
-    _PACKS[key] = (w, packed)          # (w kept alive: its address cannot be recycled under this key)
+    _PACKS.pop(key, None)
+    while len(_PACKS) >= _PACKS_MAX:
+        _PACKS.pop(next(iter(_PACKS)))             # least recently used first
+    _PACKS[key] = (w, tag, packed)                 # (w kept alive: its id cannot be recycled under this key)
     return packed
 
 
 def _zeros(n, device):
-    key = ('zeros', n, str(device))
-    z = _PACKS.get(key)
+    key = (n, str(device))
+    z = _ZEROS.get(key)
     if z is None:
-        z = _PACKS[key] = torch.zeros((n,), dtype=torch.float32, device=device)
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            # a buffer first created inside a capture would be a captured memset that has not run yet: an eager use
+            # before the first replay would read garbage as the bias.  Capture warm-up steps create every size eagerly.
+            raise RuntimeError('zero-bias buffer of %d floats requested for the first time inside a stream capture; '
+                               'run one eager step before capturing' % n)
+        z = _ZEROS[key] = torch.zeros((n,), dtype=torch.float32, device=device)
     return z
 
 

@@ -958,14 +958,17 @@ class deterministic:
         DETERMINISTIC = self._old
 
 
-_SEGMENTS = []       # a few recent (key, idx tensor, order, offsets): one neighbour list serves several scatters
+_SEGMENTS = []       # a few recent (key, base tensor, order, offsets): one neighbour list serves several scatters
 
 
 def _segments(idx_flat, n_out):
-    """Pair indices sorted stably by target row (int32) and the (n_out + 1) segment bounds."""
-    key = (idx_flat.data_ptr(), idx_flat._version, idx_flat.numel(), n_out)
+    """Pair indices sorted stably by target row (int32) and the (n_out + 1) segment bounds.  Cached on the STORAGE the
+    indices live in (+ offset, version, length) -- callers hand in a fresh `.view(-1)` object every time, so the tensor
+    object's identity says nothing; the storage's owner is kept alive so that its address cannot be recycled."""
+    key = (idx_flat.untyped_storage().data_ptr(), idx_flat.storage_offset(), idx_flat._version, idx_flat.numel(),
+           idx_flat.stride(0) if idx_flat.numel() > 1 else 1, n_out)
     for k, keep, order, off in _SEGMENTS:
-        if k == key and keep is idx_flat:
+        if k == key:
             return order, off
     order = torch.argsort(idx_flat.long(), stable=True).to(torch.int32)
     counts = torch.bincount(idx_flat.long(), minlength=n_out)

@@ -106,12 +106,22 @@ def implicit_loss(implicit_output, implicit_target, density_lw=1.0, color_lw=0.0
     return total
 
 
-_PARTICIPATION = {}      # parameter list (ids) -> which of them some rank produced a gradient for, last eager step
+class Participation:
+    """Which parameters some rank produced a gradient for, as agreed in the last eager step of ONE training-step object
+    (the mask lives on the TrainStep, not in a module-level table keyed by id(): ids are recycled after a model is
+    freed).  `used` is None until an eager agreement exists."""
+
+    def __init__(self):
+        self.used = None
+
+    def clear(self):
+        self.used = None
 
 
-def allreduce_gradients(params, world=None):
+def allreduce_gradients(params, world=None, participation=None):
     """Average gradients over ranks with ONE flat all-reduce (28.8 MB for the 7.21 M parameters:
-    latency/bandwidth of a single bucket; xGMI is point to point, so few large messages)."""
+    latency/bandwidth of a single bucket; xGMI is point to point, so few large messages).  `participation`: the
+    caller's Participation record; a captured step REQUIRES one that an eager step has filled."""
     if not (dist.is_available() and dist.is_initialized()):
         return
     world = world or dist.get_world_size()
@@ -126,14 +136,17 @@ def allreduce_gradients(params, world=None):
     # The agreement needs one host read, which a stream capture forbids: a captured step (GraphedTrainStep) reuses the
     # agreement of the eager warm-up steps that precede every capture -- all ranks are capturing (or not) at the same
     # point of the program, so they take the same branch.
-    key = tuple(id(p) for p in params)
     if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
-        used = _PARTICIPATION.get(key) or [True] * len(params)
+        assert participation is not None and participation.used is not None and \
+            len(participation.used) == len(params), \
+            'a captured step needs the participation mask of a preceding eager step (GraphedTrainStep.capture warmup >= 1)'
+        used = participation.used
     else:
         has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], device=params[0].device)
         dist.all_reduce(has, op=dist.ReduceOp.MAX)
         used = [bool(v) for v in has.tolist()]
-        _PARTICIPATION[key] = used
+        if participation is not None:
+            participation.used = used
     grads = []
     for p, u in zip(params, used):
         if u:
@@ -168,8 +181,20 @@ class SideStreamSampler:
         self.stream.wait_stream(torch.cuda.current_stream())     # (inputs uploaded so far on the main stream)
         self._pending = None
 
-    def draw(self, frames, sizes, valo_ids, num_valo_ids):
-        """Queues one step's draw: (queries (T, N, 4), targets (T, N, 6)) of batch element 0, as the bench consumes them."""
+    def draw(self, frames, sizes, valo_ids, num_valo_ids, ready=None):
+        """Queues one step's draw: (queries (T, N, 4), targets (T, N, 6)) of batch element 0, as the bench consumes them.
+        The inputs must be COMPLETE on the device before the side stream reads them: either they were uploaded before
+        this object was built, or the caller passes `ready` -- an event recorded on the producing stream right after the
+        upload (as PointCompletionNetV3.prefetch_geometry takes it): the side stream waits for that event only, not for
+        the step queued behind it.  Without `ready` the side stream waits for everything queued on the current stream
+        so far (safe, but it then also waits for a step already queued there)."""
+        if ready is not None:
+            self.stream.wait_event(ready)
+        else:
+            self.stream.wait_stream(torch.cuda.current_stream())
+        for t_ in list(frames) + list(sizes) + [valo_ids, num_valo_ids]:
+            if torch.is_tensor(t_) and t_.is_cuda:
+                t_.record_stream(self.stream)      # the allocator must not recycle an input under the side stream
         with torch.cuda.stream(self.stream):
             qs, ts = [], []
             for t in range(self.n_frames):
@@ -202,6 +227,7 @@ class TrainStep:
         self.optimizer = torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay)
         self.grad_clip = grad_clip
         self.loss_kwargs = loss_kwargs or {}
+        self.participation = Participation()
 
     batch_frames = True
 
@@ -231,7 +257,7 @@ class TrainStep:
         if next_pcl_input is not None:
             self.pcl_net.prefetch_geometry(next_pcl_input)
         loss.backward()
-        allreduce_gradients(self.params)
+        allreduce_gradients(self.params, participation=self.participation)
         if self.grad_clip:
             torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
         self.optimizer.step()
@@ -283,7 +309,7 @@ class GraphedTrainStep(TrainStep):
     def _eager(self, pcl_input, points_query, implicit_target):
         loss = self.forward_loss(pcl_input, points_query, implicit_target)
         loss.backward()
-        allreduce_gradients(self.params)
+        allreduce_gradients(self.params, participation=self.participation)
         if self.grad_clip:
             torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
         self.optimizer.step()
@@ -292,6 +318,9 @@ class GraphedTrainStep(TrainStep):
     def capture(self, pcl_input, points_query, implicit_target, warmup=2):
         """Warm-up steps on a side stream (they DO update the parameters), then the capture."""
         self.static = (pcl_input.clone(), points_query.clone(), implicit_target.clone())
+        self.participation.clear()          # the mask the graph freezes comes from THIS capture's warm-up steps
+        if dist.is_available() and dist.is_initialized():
+            assert warmup >= 1, 'a distributed capture needs at least one eager warm-up step (gradient participation mask)'
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)

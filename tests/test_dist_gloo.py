@@ -142,7 +142,9 @@ def _grad_worker(rank, world, port, ret):
         params.append(torch.nn.Parameter(torch.zeros(3)))
         if rank == 1:
             params[2].grad = torch.full((2, 2), 4.0)
-        pk.training.allreduce_gradients(params)
+        part = pk.training.Participation()
+        pk.training.allreduce_gradients(params, participation=part)
+        assert part.used == [True, True, True, False]       # the mask a captured step would reuse lives on the caller
         ret[rank] = [None if p.grad is None else p.grad.clone() for p in params]
     finally:
         dist.destroy_process_group()

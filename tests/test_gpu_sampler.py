@@ -148,12 +148,26 @@ def test_side_stream_sampler_draws_the_same_points(pk):
     side = pk.training.SideStreamSampler(sampler, 3)
     busy = torch.zeros((4096, 4096), device='cuda')
     for i in range(2):
-        side.draw(*dev)
+        # a real training loop uploads new target frames on the MAIN stream every step: fresh device copies
+        # behind queued main-stream work, an event right after the upload, and the side stream waits for that event only
+        for _ in range(3):
+            busy = busy * 1.0001 + 1.0           # main-stream work queued in front of the upload
+        fresh = ([f.clone() for f in dev[0]], [z.clone() for z in dev[1]], dev[2].clone(), dev[3].clone())
+        ready = torch.cuda.Event()
+        ready.record()
         for _ in range(3):
             busy = busy * 1.0001 + 1.0           # main-stream work the draw must not wait for
+        side.draw(*fresh, ready=ready)
+        del fresh                                # (record_stream keeps the allocator from recycling them under the draw)
         q, tgt = side.take()
         assert torch.equal(q, direct[i][0]) and torch.equal(tgt, direct[i][1])
     assert q.shape == (3, 2524, 4) and tgt.shape == (3, 2524, 6)
+    # without an event the draw orders itself behind everything queued on the current stream so far: still the same points
+    np.random.seed(9)
+    torch.manual_seed(9)
+    side.draw(*dev)
+    q0, t0 = side.take()
+    assert torch.equal(q0, direct[0][0]) and torch.equal(t0, direct[0][1])
 
 
 def test_sampler_invariants_at_training_size(pk):

@@ -350,6 +350,22 @@ def test_deterministic_reductions_match_the_atomic_ones_and_repeat_bit_for_bit()
     for a, b, c in zip(atomic, det1, det2):
         assert torch.equal(b, c)
         assert rel_err(b, a) < 2e-5
+    # the sorted-segment cache: one neighbour list serves several scatters (callers pass a fresh .view(-1) every time, so
+    # the cache is keyed on the storage, not on the tensor object); an in-place edit of the indices invalidates it
+    with pk.ops.deterministic():
+        pk.ops._SEGMENTS.clear()
+        a = pk.ops.scatter_add_rows(src, idx, m)
+        entry = pk.ops._SEGMENTS[-1]
+        b = pk.ops.scatter_add_rows(src, idx.view(n, k), m)
+        assert len(pk.ops._SEGMENTS) == 1 and pk.ops._SEGMENTS[-1] is entry and torch.equal(a, b)
+        idx2 = idx.clone()
+        pk.ops.scatter_add_rows(src, idx2, m)
+        assert len(pk.ops._SEGMENTS) == 2
+        idx2[:, 0] = (idx2[:, 0] + 1) % m
+        c = pk.ops.scatter_add_rows(src, idx2, m)
+        assert len(pk.ops._SEGMENTS) == 3
+        ref = torch.zeros((m, src.shape[1]), device='cuda', dtype=torch.float64).index_add_(0, idx2.view(-1).long(), src.double())
+        assert rel_err(c, ref.float()) < 2e-5
     # whole step: gradients of two identical eager steps are bit-identical in deterministic mode
     kind, npts = 'carla', 512
     pa, ia, inf = pk.configs.model_args(kind, npts)
