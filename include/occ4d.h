@@ -32,7 +32,7 @@ extern "C" {
 #define OCC4D_EINVAL (-1)   /* bad argument (maps to AssertionError / ValueError) */
 #define OCC4D_ELAUNCH (-2)  /* HIP launch failure */
 
-#define OCC4D_ABI_VERSION 1
+#define OCC4D_ABI_VERSION 2
 
 int occ4d_abi_version(void);
 const char* occ4d_last_error(void);
@@ -402,8 +402,11 @@ int occ4d_split_write_f32(const float* points_query, const float* implicit_outpu
  * ATen ops above, train.py:101-118).  Scatter reductions use fp32 atomics.
  * ======================================================================== */
 
-/* dW (N,K) (+)= g^T x for y = x W^T: g (M,N) = dL/dy, x (M,K).  Split over M; `workspace` holds
- * splits*N*K floats (sizes from occ4d_linear_wgrad_workspace, which does not touch the GPU).
+/* dW (N,K) (+)= g^T x for y = x W^T: g (M,N) = dL/dy, x (M,K).  Split over M into partial products that a second
+ * kernel adds up.  `workspace`: its size in floats comes ONLY from occ4d_linear_wgrad_workspace(M, N, K, &splits,
+ * &floats) (host arithmetic, does not touch the GPU) -- do not derive it from `splits`: the wide-layer kernel
+ * (csrc/wgrad16.hip) lays out (splits + 1) partial planes of N*K floats followed by (splits + 1) bias partials of N
+ * floats, the generic kernel splits*N*K.  Pass the `splits` that call returned.
  * N, K, ldg, ldx multiples of 4; g, x 16-byte aligned. */
 int occ4d_linear_wgrad_workspace(int M, int N, int K, int* splits_out, int64_t* floats_out);
 int occ4d_linear_wgrad_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int M, int N, int K,
@@ -462,6 +465,133 @@ int occ4d_pt_pos_hidden_bwd_det_f32(const float* pos, int64_t ps, const float* p
 int occ4d_axpby_f32(const float* a, int64_t lda, float alpha, const float* b, int64_t ldb, float beta, int n, int d,
                     float* out, int64_t ldo, void* stream);
 int occ4d_broadcast_rows_f32(const float* vec, float scale, int n, int d, float* out, int64_t ldo, void* stream);
+
+/* ========================================================================
+ * Weight packers and PATH-LEVEL entry points (SURVEY.md 8(b) "minimum set": pt_layer_fwd, down_pool_fwd,
+ * decoder_prepare_scene, decoder_query_fwd).  They take the reference's parameters IN THE REFERENCE'S LAYOUT (torch
+ * Linear (out, in) row-major fp32, exactly the tensors of the checkpoint's state_dict) and run the whole launch sequence
+ * of one reference forward on `stream`: a binder that keeps the reference's Python and only loads this library needs
+ * nothing from the Python modules of occlusions-4d_amd -- the merged-weight algebra of DESIGN.md 4 and every stage packing above happen
+ * inside the library (device kernels, no host round trip).  tests/test_gpu_cabi_only.py drives them with ctypes + torch
+ * alone; the package's own nn.Modules call the same functions.
+ *
+ * Memory: three kinds of caller-provided device buffers, all sized by host-only query functions, 16-byte aligned:
+ *   prepared   per WEIGHT UPDATE: merged matrices + stage-packed weight streams (+ fp64 scratch for forming them)
+ *   scene      per ABSTRACT CLOUD: key / value / lin_z tables (the reference recomputes them per forward call, D7)
+ *   workspace  per CALL: activations; contents undefined afterwards, may be shared by calls on the SAME stream
+ * `flags` select kernel variants (A/B partners of the default, measured in DESIGN.md 6); prepare / scene / forward of
+ * one object must be given the same flags.
+ * ======================================================================== */
+#define OCC4D_PATH_DEFAULT 0
+#define OCC4D_PATH_UNFUSED 1        /* vector attention as the unfused kernel chain (pos_hidden .. softmax_agg) */
+#define OCC4D_PATH_FIRST_GEN 2      /* d = 416: csrc/crossattn.hip instead of crossattn16p.hip */
+#define OCC4D_PATH_BF16X3 4         /* opt-in: attention-logit GEMMs on split-bf16 MFMAs (implies FIRST_GEN) */
+#define OCC4D_PATH_GENERIC_LINEAR 8 /* generic Linear kernel instead of the row-resident trunk kernels */
+#define OCC4D_PATH_TRUNK4 16        /* half-CU trunk kernels (csrc/trunk4.hip) */
+
+/* Stage packers as device kernels (layouts: occ4d_resblock_f32 / occ4d_resblock4_f32 / occ4d_pt_cross_attn16p_f32 /
+ * occ4d_pt_cross_attn_bf16x3_f32 above).  w: (n_out, 416) row-major with row stride ldw. */
+int occ4d_pack_trunk_rows_f32(const float* w, int64_t ldw, int n_out, float* packed, void* stream);
+int occ4d_pack_trunk_cols_f32(const float* w, int64_t ldw, float* packed, void* stream);
+int occ4d_pack_trunk4_rows_f32(const float* w, int64_t ldw, int n_out, float* packed, void* stream);
+int occ4d_pack_trunk4_cols_f32(const float* w, int64_t ldw, float* packed, void* stream);
+/* w2 (416, 832) = attn_mlp[2].weight, wp (832, 32) = W1 P2 (merged), p2 (416, 32) = pos_mlp[2].weight */
+int occ4d_pack_attn16p_stream_f32(const float* w2, const float* wp, const float* p2, float* wstream, void* stream);
+/* w (rows, cols) contiguous, cols % 32 == 0 -> same shape: per row and 32-column block [32 hi | 32 lo] bf16 (hi =
+ * bf16(w), lo = bf16(w - hi), round to nearest even) in MFMA fragment order (position 16 t + 8 half + j holds column
+ * 16 t + 8 (j >> 2) + 4 half + (j & 3)) */
+int occ4d_pack_bf16x3_f32(const float* w, int rows, int cols, float* packed, void* stream);
+
+/* Optional profiling hook of the path-level forwards: the library records events[2 i] / events[2 i + 1] (hipEvent_t,
+ * created by the caller with timing enabled) on `stream` right before / after the i-th launch of the chosen kernel
+ * family inside the call, i < capacity; `used` (host, out) = launches bracketed.  No synchronisation. */
+#define OCC4D_PROFILE_CROSS_ATTN 1
+#define OCC4D_PROFILE_RESBLOCK 2
+#define OCC4D_PROFILE_ROWLIN 3
+typedef struct occ4d_launch_events {
+  void** events;
+  int32_t capacity, used, kernel, reserved;
+} occ4d_launch_events;
+
+/* E3 / E2: PointTransformerLayer.forward (model/point_transformer_layer.py:148-183), optionally wrapped as a
+ * PointTransformerBlock (model/modules.py:45-67: z = x + layer3(layer2(layer1(x), p, x2, p2))).
+ * Parameters in the reference layout: to_q (dim, dim), to_k / to_v (dim, dim2) (no bias); pos_mlp.0 (pos_hidden, 3) +
+ * bias, pos_mlp.2 (dim, pos_hidden) + bias; attn_mlp.0 (2 dim, dim) + bias, attn_mlp.2 (dim, 2 dim) + bias.
+ * pre_w (dim, d_in) / pre_b = layer1 or NULL; post_w (d_out, dim) / post_b = layer3 or NULL (then out = x + layer3(agg)
+ * and d_out must equal d_in).  cross != 0: keys / values come from a second cloud (x2, pos2) with dim2 features;
+ * cross == 0: self-attention (dim2 == dim, x2 / pos2 ignored). */
+typedef struct occ4d_pt_layer_weights {
+  int32_t dim, dim2, pos_hidden, cross, d_in, d_out, reserved0, reserved1;
+  const float *to_q, *to_k, *to_v;
+  const float *pos0_w, *pos0_b, *pos2_w, *pos2_b;
+  const float *attn0_w, *attn0_b, *attn2_w, *attn2_b;
+  const float *pre_w, *pre_b, *post_w, *post_b;
+} occ4d_pt_layer_weights;
+
+int64_t occ4d_pt_layer_prepared_floats(const occ4d_pt_layer_weights* w, int flags);
+int occ4d_pt_layer_prepare_f32(const occ4d_pt_layer_weights* w, float* prepared, int flags, void* stream);
+/* per-scene key / value tables of a cross layer: (W1 Wk) x2 (m, 2 dim), Wv x2 (m, dim), Wv x2 + c2 (m, dim) */
+int64_t occ4d_pt_layer_scene_floats(const occ4d_pt_layer_weights* w, int m);
+int occ4d_pt_layer_scene_f32(const occ4d_pt_layer_weights* w, const float* prepared, const float* x2, int64_t ldx2,
+                             int m, float* scene, int flags, void* stream);
+int64_t occ4d_pt_layer_workspace_floats(const occ4d_pt_layer_weights* w, int n, int m, int k, int flags);
+/* x (n, d_in), pos (n, >= 3); cross: x2 (m, dim2), pos2 (m, >= 3).  k = num_neighbors <= 16.  knn_idx: (n, k) int32 =
+ * kNN_torch(pos, pos2, k) when the caller already has it, or NULL (computed: occ4d_knn_f32 metric 0).  scene: the
+ * tables of occ4d_pt_layer_scene_f32 for (x2, these weights), or NULL (computed per call, as the reference does).
+ * out (n, d_out if post else dim); may alias x only when post != NULL. */
+int occ4d_pt_layer_fwd_f32(const occ4d_pt_layer_weights* w, const float* prepared, const float* x, int64_t ldx,
+                           const float* pos, int64_t pos_stride, int n, const float* x2, int64_t ldx2,
+                           const float* pos2, int64_t pos2_stride, int m, int k, const int32_t* knn_idx,
+                           const float* scene, float* out, int64_t ldo, float* workspace, int flags,
+                           occ4d_launch_events* ev, void* stream);
+
+/* E6 feature half: DownTransition.forward after its FPS / kNN (model/modules.py:152-158): y = ReLU(norm(Linear(x))) on
+ * ALL n points, z[i] = max_j y[nn_idx[i, j]].  norm 0 none, 1 LayerNorm(gamma, beta, eps), 2 BatchNorm1d in eval mode
+ * (running mean / var, gamma, beta, eps) -- model/modules.py:95-109.  w (d_out, d_in), b (d_out).
+ * workspace: n * d_out floats.  nn_idx (n_new, k) int32 from occ4d_knn_f32(p_sub, p, k, metric 0). */
+int occ4d_down_pool_fwd_f32(const float* x, int64_t ldx, int n, int d_in, const float* w, const float* b, int d_out,
+                            int norm, const float* gamma, const float* beta, const float* mean, const float* var,
+                            float eps, const int32_t* nn_idx, int n_new, int k, float* z, int64_t ldz,
+                            float* workspace, void* stream);
+
+/* D1-D7: LocalPclResnetFC (model/implicit.py:110-150,217-269 parameters; :271-445 forward), local_mode 'attention'
+ * (n_cross >= 1) or 'feature' (n_cross == 0), B == 1.  lin_in (d_hidden, lin_in_ld >= d_in (2 n_freq + 1)), lin_z[i]
+ * (d_hidden, d_latent) with the GLOBAL part in the first d_latent - d_latent_local columns (model/implicit.py:342),
+ * blocks[i].fc_0 / fc_1 (d_hidden, d_hidden), lin_out (d_out, d_hidden); cross[j] = pt_blocks[j] as an
+ * occ4d_pt_layer_weights with cross = 1, pre = layer1, post = layer3, applied after block cross_after[j]
+ * (model/implicit.py:265: int((j + 1) n_blocks / (n_cross + 1))).  activation 0 = relu, 1 = swish (:46-64). */
+#define OCC4D_MAX_BLOCKS 16
+#define OCC4D_MAX_CROSS 4
+typedef struct occ4d_decoder_weights {
+  int32_t d_in, n_freq, d_hidden, d_out, d_latent, d_latent_local, n_blocks, n_cross, k_local, k_cross, activation,
+      lin_in_ld;
+  float base_frequency, reserved;
+  const float *lin_in_w, *lin_in_b, *lin_out_w, *lin_out_b;
+  const float* lin_z_w[OCC4D_MAX_BLOCKS];
+  const float* lin_z_b[OCC4D_MAX_BLOCKS];
+  const float* fc0_w[OCC4D_MAX_BLOCKS];
+  const float* fc0_b[OCC4D_MAX_BLOCKS];
+  const float* fc1_w[OCC4D_MAX_BLOCKS];
+  const float* fc1_b[OCC4D_MAX_BLOCKS];
+  int32_t cross_after[OCC4D_MAX_CROSS];
+  occ4d_pt_layer_weights cross[OCC4D_MAX_CROSS];
+} occ4d_decoder_weights;
+
+int64_t occ4d_decoder_prepared_floats(const occ4d_decoder_weights* w, int flags);
+int occ4d_decoder_prepare_f32(const occ4d_decoder_weights* w, float* prepared, int flags, void* stream);
+/* Per abstract cloud (model/implicit.py:286-290 split of pcl_abstract; D7 hoisting; refactoring (ii) of DESIGN.md 4):
+ * xyz (m, >= 3) stride xyz_stride, feats (m, d_latent_local) ld_feats, fglobal (d_latent - d_latent_local). */
+int64_t occ4d_decoder_scene_floats(const occ4d_decoder_weights* w, int m);
+int occ4d_decoder_prepare_scene_f32(const occ4d_decoder_weights* w, const float* prepared, const float* xyz,
+                                    int64_t xyz_stride, const float* feats, int64_t ld_feats, const float* fglobal,
+                                    int m, float* scene, int flags, void* stream);
+/* One mini-batch of queries (any n; processed in chunks of 32768 rows): queries (n, d_in) rows (x, y, z, t) ->
+ * out (n, d_out) raw network outputs, penult (n, d_hidden) or NULL. */
+int64_t occ4d_decoder_query_workspace_floats(const occ4d_decoder_weights* w, int n, int m, int flags);
+int occ4d_decoder_query_fwd_f32(const occ4d_decoder_weights* w, const float* prepared, const float* scene, int m,
+                                const float* queries, int64_t q_stride, int n, float* out, int64_t ld_out,
+                                float* penult, int64_t ld_pen, float* workspace, int flags, occ4d_launch_events* ev,
+                                void* stream);
 
 #ifdef __cplusplus
 }

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libocc4d.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK, EINVAL, ELAUNCH = 0, -1, -2
 
@@ -47,6 +47,37 @@ class ChainArgs(C.Structure):
                 ('zw', C.c_void_p), ('kz', C.c_int32), ('n', C.c_int32), ('n_ops', C.c_int32), ('skew', C.c_int32),
                 ('ops', ChainOp * CHAIN_MAX_OPS)]
 
+
+# path-level entry points (include/occ4d.h, last section)
+PATH_DEFAULT, PATH_UNFUSED, PATH_FIRST_GEN, PATH_BF16X3, PATH_GENERIC_LINEAR, PATH_TRUNK4 = 0, 1, 2, 4, 8, 16
+PROFILE_CROSS_ATTN, PROFILE_RESBLOCK, PROFILE_ROWLIN = 1, 2, 3
+MAX_BLOCKS, MAX_CROSS = 16, 4
+
+
+class PtLayerWeights(C.Structure):
+    """occ4d_pt_layer_weights (include/occ4d.h)."""
+    _fields_ = [(n, C.c_int32) for n in ('dim', 'dim2', 'pos_hidden', 'cross', 'd_in', 'd_out', 'reserved0', 'reserved1')] + \
+               [(n, C.c_void_p) for n in ('to_q', 'to_k', 'to_v', 'pos0_w', 'pos0_b', 'pos2_w', 'pos2_b', 'attn0_w',
+                                          'attn0_b', 'attn2_w', 'attn2_b', 'pre_w', 'pre_b', 'post_w', 'post_b')]
+
+
+class LaunchEvents(C.Structure):
+    """occ4d_launch_events (include/occ4d.h)."""
+    _fields_ = [('events', C.POINTER(C.c_void_p)), ('capacity', C.c_int32), ('used', C.c_int32), ('kernel', C.c_int32),
+                ('reserved', C.c_int32)]
+
+
+class DecoderWeights(C.Structure):
+    """occ4d_decoder_weights (include/occ4d.h)."""
+    _fields_ = [(n, C.c_int32) for n in ('d_in', 'n_freq', 'd_hidden', 'd_out', 'd_latent', 'd_latent_local', 'n_blocks',
+                                         'n_cross', 'k_local', 'k_cross', 'activation', 'lin_in_ld')] + \
+               [('base_frequency', C.c_float), ('reserved', C.c_float)] + \
+               [(n, C.c_void_p) for n in ('lin_in_w', 'lin_in_b', 'lin_out_w', 'lin_out_b')] + \
+               [(n, C.c_void_p * MAX_BLOCKS) for n in ('lin_z_w', 'lin_z_b', 'fc0_w', 'fc0_b', 'fc1_w', 'fc1_b')] + \
+               [('cross_after', C.c_int32 * MAX_CROSS), ('cross', PtLayerWeights * MAX_CROSS)]
+
+
+_LW, _DW, _EV = C.POINTER(PtLayerWeights), C.POINTER(DecoderWeights), C.POINTER(LaunchEvents)
 
 # name -> (restype, argtypes): every symbol include/occ4d.h declares
 SIGNATURES = {
@@ -144,6 +175,29 @@ SIGNATURES = {
     'occ4d_axpby_f32': (C.c_int, [_f, C.c_int64, C.c_float, _f, C.c_int64, C.c_float, C.c_int, C.c_int, _f,
                                   C.c_int64, _s]),
     'occ4d_broadcast_rows_f32': (C.c_int, [_f, C.c_float, C.c_int, C.c_int, _f, C.c_int64, _s]),
+    # packers + path-level entry points
+    'occ4d_pack_trunk_rows_f32': (C.c_int, [_f, C.c_int64, C.c_int, _f, _s]),
+    'occ4d_pack_trunk_cols_f32': (C.c_int, [_f, C.c_int64, _f, _s]),
+    'occ4d_pack_trunk4_rows_f32': (C.c_int, [_f, C.c_int64, C.c_int, _f, _s]),
+    'occ4d_pack_trunk4_cols_f32': (C.c_int, [_f, C.c_int64, _f, _s]),
+    'occ4d_pack_attn16p_stream_f32': (C.c_int, [_f, _f, _f, _f, _s]),
+    'occ4d_pack_bf16x3_f32': (C.c_int, [_f, C.c_int, C.c_int, _f, _s]),
+    'occ4d_pt_layer_prepared_floats': (C.c_int64, [_LW, C.c_int]),
+    'occ4d_pt_layer_prepare_f32': (C.c_int, [_LW, _f, C.c_int, _s]),
+    'occ4d_pt_layer_scene_floats': (C.c_int64, [_LW, C.c_int]),
+    'occ4d_pt_layer_scene_f32': (C.c_int, [_LW, _f, _f, C.c_int64, C.c_int, _f, C.c_int, _s]),
+    'occ4d_pt_layer_workspace_floats': (C.c_int64, [_LW, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'occ4d_pt_layer_fwd_f32': (C.c_int, [_LW, _f, _f, C.c_int64, _f, C.c_int64, C.c_int, _f, C.c_int64, _f, C.c_int64,
+                                         C.c_int, C.c_int, _i, _f, _f, C.c_int64, _f, C.c_int, _EV, _s]),
+    'occ4d_down_pool_fwd_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, _f, _f, C.c_int, C.c_int, _f, _f, _f, _f,
+                                          C.c_float, _i, C.c_int, C.c_int, _f, C.c_int64, _f, _s]),
+    'occ4d_decoder_prepared_floats': (C.c_int64, [_DW, C.c_int]),
+    'occ4d_decoder_prepare_f32': (C.c_int, [_DW, _f, C.c_int, _s]),
+    'occ4d_decoder_scene_floats': (C.c_int64, [_DW, C.c_int]),
+    'occ4d_decoder_prepare_scene_f32': (C.c_int, [_DW, _f, _f, C.c_int64, _f, C.c_int64, _f, C.c_int, _f, C.c_int, _s]),
+    'occ4d_decoder_query_workspace_floats': (C.c_int64, [_DW, C.c_int, C.c_int, C.c_int]),
+    'occ4d_decoder_query_fwd_f32': (C.c_int, [_DW, _f, _f, C.c_int, _f, C.c_int64, C.c_int, _f, C.c_int64, _f, C.c_int64,
+                                              _f, C.c_int, _EV, _s]),
 }
 
 _lib = None

@@ -45,4 +45,7 @@ bool wgrad16_plan(int M, int N, int K, int* splits, int* m_per_split);
 int wgrad16_launch(const float* g, int64_t ldg, const float* x, int64_t ldx, int M, int N, int K, int splits,
                    int m_per_split, float* part, float* part_b, int relu_x, hipStream_t stream);
 
+// path.hip: phase offset of the paired attention workgroups (units of s_sleep(127); OCC4D_CA16P_SKEW, default 6)
+int attn16p_skew();
+
 }  // namespace occ4d
