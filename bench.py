@@ -414,9 +414,9 @@ def main():
                 'traffic': traffic, 'traffic_source': traffic_source,
                 'traffic_over_algorithmic': (traffic / (chunk * (2 * H + H + 14) * 4.0)) if traffic else None,
                 'kernel': ('cross_attn16p_kernel (csrc/crossattn16p.hip: fused vector attention = pos-MLP + attn-MLP + softmax '
-                           '+ aggregate, 14 neighbours, D=416, v_mfma_f32_16x16x4_f32, two 4-wave workgroups per CU)'
-                           if pk.point_transformer_layer.USE_ATTN16P else
-                           'cross_attn16_kernel (csrc/crossattn16.hip: fused vector attention, one 8-wave workgroup per CU)'),
+                           '+ aggregate, 14 neighbours, D=416, v_mfma_f32_16x16x4_f32, two 4-wave workgroups per CU); HIP '
+                           'events recorded by the library around each launch on its launch stream '
+                           '(occ4d_launch_events of occ4d_decoder_query_fwd_f32)'),
                 'launches': psum['launches'], 'avg_launch_ms': psum['total_ms'] / max(1, psum['launches']),
                 'flop_per_launch_executed': psum['total_flops'] / max(1, psum['launches']),
                 'flop_per_launch_as_written': psum['total_flops'] / max(1, psum['launches'])

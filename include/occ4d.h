@@ -88,7 +88,8 @@ int occ4d_fps_coop_f32(const float* xyz, int64_t stride, int n, int m, int start
 /* ------------------------------------------------------------------------
  * K3 / K11  torch.nn.Linear on row tiles with fused prologue/epilogue, exact
  * fp32 on v_mfma_f32_32x32x2_f32:
- *     t = (relu_in ? relu(x) : x) @ w^T + bias
+ *     t = act_in(x) @ w^T + bias          act_in by relu_in: 0 identity, 1 relu, 2 swish = x * sigmoid(x)
+ *                                         (the reference's activation options, model/implicit.py:46-64)
  *         + add_rows[row / add_div] - sub_rows[sub_idx[row]]      (each optional)
  *     t = relu_out ? relu(t) : t
  *     y = t + residual                                            (optional)
@@ -209,33 +210,20 @@ int occ4d_interp_add_f32(float* x, int64_t ldx, const float* cvec, const float* 
 int occ4d_matmul_f64(const double* a, int64_t sam, int64_t sak, const double* b, int64_t sbk, int64_t sbn, double* c,
                      int m, int n, int k, void* stream);
 
-/* Second-generation fused vector attention for d = 416, K <= 14 (csrc/crossattn16.hip): the same contract as
- * occ4d_pt_cross_attn_f32 (model/point_transformer_layer.py:168-179 with the merged first attn_mlp layer), on
- * v_mfma_f32_16x16x4_f32 with one wave per 16 pair rows and all 416 channels (no duplicated GEMM1, no spills), weights
- * DMA-streamed from a stage-packed copy `wstream` of occ4d_pt_cross_attn16_stream_floats() floats:
- *   27 stages of 56 fragments x 256 floats; stage hb < 26 = hidden units 32 hb .. 32 hb + 31:
- *     fragment 2 t + nt   (t < 26 channel tiles, nt < 2):  [(g*16 + c)*4 + e] = W2[16 t + c][32 hb + 16 nt + 4 g + e]
- *     fragment 52 + 2 nt + kh (kh < 2):                    [(g*16 + r)*4 + e] = Wp[32 hb + 16 nt + r][16 kh + 4 e + g]
- *   stage 26: fragment 2 t + kh:                           [(g*16 + c)*4 + e] = P2[16 t + c][16 kh + 4 e + g];
- *             floats 52*256 + ch = b2[ch] * log2(e) / sqrt(416), 54*256 + ch = c2[ch] (ch < 416), rest zero
- * (g < 4, c, r < 16, e < 4; W2, b2 = attn_mlp[2] (416, 832), Wp = W1 P2 (832, 32), P2, c2 = pos_mlp[2] (416, 32)). */
-int64_t occ4d_pt_cross_attn16_stream_floats(void);
-int occ4d_pt_cross_attn16_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t q_stride, const float* apos,
-                              int64_t a_stride, const int32_t* idx, const float* kt, int64_t ld_kt, const float* vt,
-                              int64_t ld_vt, const float* P1, const float* c1, const float* wstream, float* agg,
-                              int64_t ld_agg, int n, int m, int k, int d, float divisor, void* stream);
-
-/* Third-generation fused vector attention for d = 416, K <= 14 (csrc/crossattn16p.hip): the same contract and the same
- * MFMA chain as occ4d_pt_cross_attn16_f32, restructured so that TWO independent 4-wave workgroups share a CU out of
- * phase (one's softmax epilogue / prologue / barrier waits run under the other's MFMA stream): a workgroup handles its
- * 9 queries in two passes of 64 pair rows over stages of 16 hidden units.  `wstream` holds
+/* Fused vector attention for d = 416, K <= 14 on v_mfma_f32_16x16x4_f32 (csrc/crossattn16p.hip; the default): the same
+ * contract as occ4d_pt_cross_attn_f32 (model/point_transformer_layer.py:168-179 with the merged first attn_mlp layer).  A wave
+ * owns 16 pair rows and all 416 channels (no duplicated GEMM1, no spills); weights are DMA-streamed from a stage-packed
+ * copy; TWO independent 4-wave workgroups share a CU out of phase (one's softmax epilogue / prologue / barrier waits run
+ * under the other's MFMA stream): a workgroup handles its 9 queries in two passes of 64 pair rows over stages of 16
+ * hidden units.  `wstream` holds
  * occ4d_pt_cross_attn16p_stream_floats() floats: 54 stages of 28 fragments x 256 floats;
  *   stage s < 52 = hidden units 16 s .. 16 s + 15:
  *     fragment t (t < 26 channel tiles):   [(g*16 + c)*4 + e] = W2[16 t + c][16 s + 4 g + e]
  *     fragment 26 + kh (kh < 2):           [(g*16 + r)*4 + e] = Wp[16 s + r][16 kh + 4 e + g]
  *   stage 52: fragment 2 t + kh (t < 14):        [(g*16 + c)*4 + e] = P2[16 t + c][16 kh + 4 e + g]
  *   stage 53: fragment 2 (t - 14) + kh (14 <= t < 26): the same for the remaining tiles; the last 4 fragments zero
- * (g < 4, c, r < 16, e < 4; matrices as for occ4d_pt_cross_attn16_f32).  Two biases are not in the stream:
+ * (g < 4, c, r < 16, e < 4; W2 = attn_mlp[2].weight (416, 832), Wp = W1 P2 (832, 32), P2 = pos_mlp[2].weight (416, 32);
+ * occ4d_pack_attn16p_stream_f32 builds it).  Two biases are not in the stream:
  * attn_mlp[2].bias is constant over the neighbour axis the softmax normalises over and cancels exactly; pos_mlp[2].bias
  * c2 must come folded into the value table: vt[j] = Wv f_j + c2 (the kernel adds P2 r_ij to it).
  * skew: phase offset given once to the later-placed workgroup of every CU in the first dispatch round, in units of
@@ -320,39 +308,6 @@ int occ4d_rowlin4_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const 
 int occ4d_rowlin4_masked_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed, const float* b,
                              int n_out, int relu_in, const float* res, int64_t ldr, const float* mask, int64_t ldm,
                              int n, void* stream);
-
-/* Trunk chain (csrc/trunk4.hip): a short program of row-tile operations run with the (n, 416) activation RESIDENT IN
- * REGISTERS between them -- the decoder trunk between two cross-attention layers (model/implicit.py:411-425: per block
- * `x = x + lin_z[i](features_query)`, `x = blocks[i](x)`, then the query projection of the next PointTransformerBlock
- * or lin_out) as one kernel instead of one kernel per layer with an HBM round trip of the activation between them.
- *   v = x rows;  then for every op in order:
- *     OCC4D_CHAIN_INTERP    v += zconst[zoff ..] + sum_j zw[:, j] ztab[zidx[:, j], zoff ..]   (occ4d_interp_add_f32)
- *     OCC4D_CHAIN_RESBLOCK  v = v + W1 relu(W0 relu(v) + b0) + b1                              (occ4d_resblock4_f32)
- *     OCC4D_CHAIN_LINEAR    dst[:, 0 .. n_cols) = W [relu](v) + b0   (flags & 1 = relu; v unchanged)
- *     OCC4D_CHAIN_STORE     dst[:, 0 .. 416) = v
- * wstream: the weight stages of all operations in execution order, 6656 floats each, in the packings of
- * occ4d_resblock4_f32 / occ4d_rowlin4_f32: a RESBLOCK contributes 52 stages (W0 "rows" stage 0, W1 "cols" stage 0,
- * W0 stage 1, ...), a LINEAR n_stages "rows" stages (n_stages even: pad with a zero stage; b0 padded to 16 * n_stages
- * floats), plus ONE padding stage at the very end; n_stream_stages = that total.  skew as for
- * occ4d_pt_cross_attn16p_f32.  At most OCC4D_CHAIN_MAX_OPS operations. */
-enum { OCC4D_CHAIN_INTERP = 1, OCC4D_CHAIN_RESBLOCK = 2, OCC4D_CHAIN_LINEAR = 3, OCC4D_CHAIN_STORE = 4 };
-#define OCC4D_CHAIN_MAX_OPS 12
-typedef struct occ4d_chain_op {
-  int32_t kind, n_stages, flags, n_cols;
-  const float* b0;
-  const float* b1;
-  float* dst;
-  int64_t ld_dst;
-  int32_t zoff, reserved;
-} occ4d_chain_op;
-typedef struct occ4d_chain_args {
-  const float* x; int64_t ldx;
-  const float* wstream; int64_t n_stream_stages;
-  const float* zconst; const float* ztab; int64_t ldz; const int32_t* zidx; const float* zw; int32_t kz;
-  int32_t n, n_ops, skew;
-  occ4d_chain_op ops[OCC4D_CHAIN_MAX_OPS];
-} occ4d_chain_args;
-int occ4d_trunk_chain_f32(const occ4d_chain_args* args, void* stream);
 
 /* K13 post-ops (eval/inference.py:218-243): per channel op code in `ops` (G ints):
  * 0 = identity, 1 = sigmoid, 2 = clamp to [0,1].  In place. */

@@ -29,29 +29,11 @@ class LinearArgs(C.Structure):
     ]
 
 
-CHAIN_INTERP, CHAIN_RESBLOCK, CHAIN_LINEAR, CHAIN_STORE = 1, 2, 3, 4
-CHAIN_MAX_OPS = 12
-
-
-class ChainOp(C.Structure):
-    """occ4d_chain_op (include/occ4d.h)."""
-    _fields_ = [('kind', C.c_int32), ('n_stages', C.c_int32), ('flags', C.c_int32), ('n_cols', C.c_int32),
-                ('b0', C.c_void_p), ('b1', C.c_void_p), ('dst', C.c_void_p), ('ld_dst', C.c_int64),
-                ('zoff', C.c_int32), ('reserved', C.c_int32)]
-
-
-class ChainArgs(C.Structure):
-    """occ4d_chain_args (include/occ4d.h)."""
-    _fields_ = [('x', C.c_void_p), ('ldx', C.c_int64), ('wstream', C.c_void_p), ('n_stream_stages', C.c_int64),
-                ('zconst', C.c_void_p), ('ztab', C.c_void_p), ('ldz', C.c_int64), ('zidx', C.c_void_p),
-                ('zw', C.c_void_p), ('kz', C.c_int32), ('n', C.c_int32), ('n_ops', C.c_int32), ('skew', C.c_int32),
-                ('ops', ChainOp * CHAIN_MAX_OPS)]
-
-
 # path-level entry points (include/occ4d.h, last section)
 PATH_DEFAULT, PATH_UNFUSED, PATH_FIRST_GEN, PATH_BF16X3, PATH_GENERIC_LINEAR, PATH_TRUNK4 = 0, 1, 2, 4, 8, 16
 PROFILE_CROSS_ATTN, PROFILE_RESBLOCK, PROFILE_ROWLIN = 1, 2, 3
 MAX_BLOCKS, MAX_CROSS = 16, 4
+PROFILE_KINDS = {'cross_attn': PROFILE_CROSS_ATTN, 'resblock': PROFILE_RESBLOCK, 'rowlin': PROFILE_ROWLIN}
 
 
 class PtLayerWeights(C.Structure):
@@ -102,10 +84,6 @@ SIGNATURES = {
                                                  C.c_int64, _f, _f, _f, _f, _f, _f, _f, _f, C.c_int64, C.c_int,
                                                  C.c_int, C.c_int, C.c_int, C.c_float, _s]),
     'occ4d_matmul_f64': (C.c_int, [_f, C.c_int64, C.c_int64, _f, C.c_int64, C.c_int64, _f, C.c_int, C.c_int, C.c_int, _s]),
-    'occ4d_pt_cross_attn16_stream_floats': (C.c_int64, []),
-    'occ4d_pt_cross_attn16_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, C.c_int64, _i, _f, C.c_int64, _f,
-                                            C.c_int64, _f, _f, _f, _f, C.c_int64, C.c_int, C.c_int, C.c_int,
-                                            C.c_int, C.c_float, _s]),
     'occ4d_pt_cross_attn16p_stream_floats': (C.c_int64, []),
     'occ4d_pt_cross_attn16p_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, C.c_int64, _i, _f, C.c_int64, _f,
                                              C.c_int64, _f, _f, _f, _f, C.c_int64, C.c_int, C.c_int, C.c_int,
@@ -135,7 +113,6 @@ SIGNATURES = {
                                       C.c_int, _s]),
     'occ4d_rowlin4_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, _f, C.c_int, C.c_int, _f, C.c_int64, _f, _f,
                                     C.c_int64, _i, _f, C.c_int, C.c_int, _s]),
-    'occ4d_trunk_chain_f32': (C.c_int, [C.POINTER(ChainArgs), _s]),
     'occ4d_squash_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int32), _s]),
     'occ4d_grid_points_f32': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                         C.c_float, C.c_float, _f, _s]),

@@ -32,7 +32,11 @@ constexpr int LDT = BK + 4;           // padded LDS row (floats): stride 5 or 9 
 
 // EPI: 0 = scalar epilogue (unaligned / N % 4 != 0), 1 = float4 epilogue with bias / relu only,
 //      2 = float4 epilogue with residual and/or gathered row terms (their loads are batched).
-template <int NT, int EPI>
+// SWISH: the activation applied to x on load is x * sigmoid(x) (relu_in == 2: the reference's 'swish' option,
+//      model/implicit.py:46-64) instead of the branch-free relu / identity floor.
+__device__ inline float swish1(float v) { return v * (1.0f / (1.0f + __expf(-v))); }
+
+template <int NT, int EPI, bool SWISH = false>
 __global__ __launch_bounds__(256, 1) void linear_kernel(const occ4d_linear_args a) {
   constexpr int BN = 32 * NT;
   constexpr int F4K = BK / 4;                              // float4 per tile row
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(256, 1) void linear_kernel(const occ4d_linear_args 
       rw[i].x = ok ? v.x : 0.f; rw[i].y = ok ? v.y : 0.f; rw[i].z = ok ? v.z : 0.f; rw[i].w = ok ? v.w : 0.f;
     }
   };
-  const float relu_floor = a.relu_in ? 0.f : -__builtin_inff();     // branch-free relu-on-load
+  const float relu_floor = a.relu_in == 1 ? 0.f : -__builtin_inff();     // branch-free relu-on-load
   auto sstore = [&](int buf) {
     float* As = As0 + buf * BM * LDT;
     float* Ws = Ws0 + buf * BN * LDT;
@@ -78,7 +82,11 @@ __global__ __launch_bounds__(256, 1) void linear_kernel(const occ4d_linear_args 
     for (int i = 0; i < ALOADS; ++i) {
       const int f = tid + 256 * i;
       f32x4 v = ra[i];
-      v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
+      if (SWISH) {
+        v.x = swish1(v.x); v.y = swish1(v.y); v.z = swish1(v.z); v.w = swish1(v.w);
+      } else {
+        v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
+      }
       *reinterpret_cast<f32x4*>(As + (f / F4K) * LDT + 4 * (f % F4K)) = v;
     }
 #pragma unroll
@@ -284,7 +292,11 @@ int launch(const occ4d_linear_args& a, hipStream_t st) {
                    (!a.add_rows || (al16(a.add_rows) && a.ld_add % 4 == 0)) &&
                    (!a.sub_rows || (al16(a.sub_rows) && a.ld_sub % 4 == 0));
   const bool extras = a.residual || a.add_rows || a.sub_rows;
-  if (!vec) linear_kernel<NT, 0><<<grid, block, 0, st>>>(a);
+  if (a.relu_in == 2) {
+    if (!vec) linear_kernel<NT, 0, true><<<grid, block, 0, st>>>(a);
+    else if (!extras) linear_kernel<NT, 1, true><<<grid, block, 0, st>>>(a);
+    else linear_kernel<NT, 2, true><<<grid, block, 0, st>>>(a);
+  } else if (!vec) linear_kernel<NT, 0><<<grid, block, 0, st>>>(a);
   else if (!extras) linear_kernel<NT, 1><<<grid, block, 0, st>>>(a);
   else linear_kernel<NT, 2><<<grid, block, 0, st>>>(a);
   return occ4d::check_launch("occ4d_linear_f32");
@@ -304,6 +316,8 @@ extern "C" int occ4d_linear_f32(const occ4d_linear_args* args, void* stream) {
                 "occ4d_linear_f32: x and w must be 16-byte aligned");
   OCC4D_REQUIRE(a.ldx >= a.K && a.ldw >= a.K && a.ldy >= a.N, "occ4d_linear_f32: leading dimension too small");
   OCC4D_REQUIRE(!a.add_rows || a.add_div >= 1, "occ4d_linear_f32: add_div must be >= 1");
+  OCC4D_REQUIRE(a.relu_in >= 0 && a.relu_in <= 2 && (a.relu_out == 0 || a.relu_out == 1),
+                "occ4d_linear_f32: relu_in = %d (0 none, 1 relu, 2 swish), relu_out = %d (0 / 1)", a.relu_in, a.relu_out);
   OCC4D_REQUIRE(!a.sub_rows || a.sub_idx, "occ4d_linear_f32: sub_rows needs sub_idx");
   if (a.M == 0) return OCC4D_OK;
   hipStream_t st = (hipStream_t)stream;

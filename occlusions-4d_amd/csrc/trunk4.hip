@@ -320,198 +320,6 @@ __global__ __launch_bounds__(256, 2) void rowlin4_kernel(const Trunk4Args a) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Trunk CHAIN: a program of row-tile operations executed with the activation resident in registers (occ4d.h:
-// occ4d_trunk_chain_f32): load rows -> [interpolation term -> residual block] x k -> Linear to memory -> store rows.
-// The separate kernels read and wrote the (n, 416) activation once per block (54 MB each way per decode chunk, all
-// CUs in the same phase) and the interpolation term was its own pass over it; here the HBM round trip happens once per
-// chain, the gathers of the interpolation term run in the registers of the (dead) operand tile, and the weight stages
-// of ALL operations form one flat stream in execution order, so the double-buffered DMA never drains between
-// operations.  Every operation consumes an even number of 26 KB stages (the host pads), i.e. starts on bufA.
-struct ChainArgsK {
-  const float* x; int64_t ldx;
-  const float* wstream;
-  const float* zconst; const float* ztab; int64_t ldz; const int32_t* zidx; const float* zw; int kz;
-  int n, n_ops, first_round, skew;
-  occ4d_chain_op ops[OCC4D_CHAIN_MAX_OPS];
-};
-
-__global__ __launch_bounds__(256, 2) void trunk_chain_kernel(const ChainArgsK a) {
-  __shared__ __attribute__((aligned(16))) float bufA[QSTAGE];
-  __shared__ __attribute__((aligned(16))) float bufB[QSTAGE];
-  __shared__ __attribute__((aligned(16))) float s_b0[QH];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 15, g = lane >> 4;
-  const unsigned lane16 = lane * 16;
-  const int row = blockIdx.x * QROWS + wave * 16 + r;
-  const int rowc = min(row, a.n - 1);
-  const float* const fa = bufA + lane * 4;
-  const float* const fb = bufB + lane * 4;
-
-  dma_stage_q(a.wstream, bufA, wave, lane16);
-  f32x4 v[QKG], xr[QKG];
-  {
-    const float* xp = a.x + (int64_t)rowc * a.ldx + 4 * g;
-#pragma unroll
-    for (int t = 0; t < QKG; ++t) v[t] = *reinterpret_cast<const f32x4*>(xp + 16 * t);
-  }
-  // phase skew of the two workgroups of a CU (csrc/crossattn16p.hip): the one in the odd wave slot starts late, so
-  // that the gather phases between the blocks of one sit under the other's MFMA stream.  Performance only.
-  if (a.skew > 0 && (int)blockIdx.x < a.first_round) {
-    const unsigned hw = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID[3:0] = WAVE_ID
-    if (hw & 1)
-      for (int i = 0; i < a.skew; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-  dma_wait_q();
-  __syncthreads();
-  const float* wnext = a.wstream + QSTAGE;            // the stage after the one in flight / in use (wave-uniform)
-
-  // one 16-output Linear stage on the fragments in `frag`: o = W[16 s .. 16 s + 16, :] act (+ bias), 13 groups of 8
-  // MFMAs on two accumulators (even / odd K groups); the next stage's DMA goes to `ndst` meanwhile
-  auto lin_stage = [&](const float* __restrict__ frag, const float* ndst) {   // (operand tile: xr)
-    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 wa = *reinterpret_cast<const f32x4*>(frag);
-    f32x4 wb = *reinterpret_cast<const f32x4*>(frag + QFRAG);
-#pragma unroll
-    for (int q = 0; q < QKG / 2; ++q) {
-      if (q >= 1 && q <= 7) dma_part_q(wnext, ndst, wave, lane16, q - 1);
-      const f32x4 ca = wa, cb = wb;
-      if (q + 1 < QKG / 2) {
-        wa = *reinterpret_cast<const f32x4*>(frag + (2 * q + 2) * QFRAG);
-        wb = *reinterpret_cast<const f32x4*>(frag + (2 * q + 3) * QFRAG);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      mm_kk(ca, cb, xr[2 * q], xr[2 * q + 1], o0, o1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    return f32x4{o0.x + o1.x, o0.y + o1.y, o0.z + o1.z, o0.w + o1.w};
-  };
-  auto store_cols = [&](const occ4d_chain_op& op, int s, f32x4 o) {
-    const int c0 = 16 * s + 4 * g;
-    if (row >= a.n || c0 >= op.n_cols) return;
-    const f32x4 b = *reinterpret_cast<const f32x4*>(op.b0 + c0);      // (bias padded to a multiple of 16 by the host)
-    o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
-    float* yp = op.dst + (int64_t)row * op.ld_dst + c0;
-    if (c0 + 4 <= op.n_cols && (op.ld_dst & 3) == 0) {
-      *reinterpret_cast<f32x4*>(yp) = o;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (c0 + e < op.n_cols) yp[e] = o[e];
-    }
-  };
-
-  for (int oi = 0; oi < a.n_ops; ++oi) {
-    const occ4d_chain_op& op = a.ops[oi];
-    if (op.kind == OCC4D_CHAIN_INTERP) {
-      // v += zconst + sum_j zw[row, j] ztab[zidx[row, j], :]  (columns zoff .. zoff + 416 of the table)
-      const float* zc = a.zconst + op.zoff + 4 * g;
-#pragma unroll
-      for (int t = 0; t < QKG; ++t) {
-        const f32x4 c = *reinterpret_cast<const f32x4*>(zc + 16 * t);
-        v[t].x += c.x; v[t].y += c.y; v[t].z += c.z; v[t].w += c.w;
-      }
-      const float* wrow = a.zw + (int64_t)rowc * a.kz;
-      const int32_t* irow = a.zidx + (int64_t)rowc * a.kz;
-      for (int j = 0; j < a.kz; ++j) {
-        const float w0 = wrow[j];
-        const float* z0 = a.ztab + (int64_t)irow[j] * a.ldz + op.zoff + 4 * g;
-#pragma unroll
-        for (int t = 0; t < QKG; ++t) xr[t] = *reinterpret_cast<const f32x4*>(z0 + 16 * t);
-#pragma unroll
-        for (int t = 0; t < QKG; ++t) {
-          v[t].x = fmaf(w0, xr[t].x, v[t].x); v[t].y = fmaf(w0, xr[t].y, v[t].y);
-          v[t].z = fmaf(w0, xr[t].z, v[t].z); v[t].w = fmaf(w0, xr[t].w, v[t].w);
-        }
-      }
-    } else if (op.kind == OCC4D_CHAIN_RESBLOCK) {
-      // v = v + W1 relu(W0 relu(v) + b0) + b1; stages in the stream: W0 chunk 0, W1 chunk 0, W0 chunk 1, ...
-      for (int i = tid; i < QH; i += 256) s_b0[i] = op.b0[i];
-#pragma unroll
-      for (int t = 0; t < QKG; ++t) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(op.b1 + 16 * t + 4 * g);
-        xr[t] = relu4q(v[t]);
-        v[t].x += b.x; v[t].y += b.y; v[t].z += b.z; v[t].w += b.w;
-      }
-      __syncthreads();
-#pragma clang loop unroll(disable)
-      for (int j = 0; j < QNC; ++j) {
-        f32x4 h0 = *reinterpret_cast<const f32x4*>(s_b0 + 16 * j + 4 * g);
-        f32x4 h1 = {0.f, 0.f, 0.f, 0.f};
-        {
-          f32x4 wa = *reinterpret_cast<const f32x4*>(fa);
-          f32x4 wb = *reinterpret_cast<const f32x4*>(fa + QFRAG);
-#pragma unroll
-          for (int q = 0; q < QKG / 2; ++q) {
-            if (q >= 1 && q <= 7) dma_part_q(wnext, bufB, wave, lane16, q - 1);
-            const f32x4 ca = wa, cb = wb;
-            if (q + 1 < QKG / 2) {
-              wa = *reinterpret_cast<const f32x4*>(fa + (2 * q + 2) * QFRAG);
-              wb = *reinterpret_cast<const f32x4*>(fa + (2 * q + 3) * QFRAG);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mm_kk(ca, cb, xr[2 * q], xr[2 * q + 1], h0, h1);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-        f32x4 h;
-        h.x = fmaxf(h0.x + h1.x, 0.f); h.y = fmaxf(h0.y + h1.y, 0.f);
-        h.z = fmaxf(h0.z + h1.z, 0.f); h.w = fmaxf(h0.w + h1.w, 0.f);
-        wnext += QSTAGE;
-        dma_wait_q();
-        __syncthreads();
-        {
-          f32x4 wa = *reinterpret_cast<const f32x4*>(fb);
-          f32x4 wb = *reinterpret_cast<const f32x4*>(fb + QFRAG);
-#pragma unroll
-          for (int p = 0; p < QKG / 2; ++p) {
-            if (p >= 1 && p <= 7) dma_part_q(wnext, bufA, wave, lane16, p - 1);
-            const f32x4 ca = wa, cb = wb;
-            if (p + 1 < QKG / 2) {
-              wa = *reinterpret_cast<const f32x4*>(fb + (2 * p + 2) * QFRAG);
-              wb = *reinterpret_cast<const f32x4*>(fb + (2 * p + 3) * QFRAG);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mm_nn(ca, cb, h, v[2 * p], v[2 * p + 1]);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-        wnext += QSTAGE;
-        dma_wait_q();
-        __syncthreads();
-      }
-    } else if (op.kind == OCC4D_CHAIN_LINEAR) {
-      // dst[:, 0 .. n_cols) = W [relu](v) + b0: n_stages (even, host-padded) stages of 16 output channels
-      if (op.flags & 1) {
-#pragma unroll
-        for (int t = 0; t < QKG; ++t) xr[t] = relu4q(v[t]);
-      } else {
-#pragma unroll
-        for (int t = 0; t < QKG; ++t) xr[t] = v[t];
-      }
-#pragma clang loop unroll(disable)
-      for (int s = 0; s < op.n_stages; s += 2) {
-        f32x4 o = lin_stage(fa, bufB);
-        store_cols(op, s, o);
-        wnext += QSTAGE;
-        dma_wait_q();
-        __syncthreads();
-        o = lin_stage(fb, bufA);
-        store_cols(op, s + 1, o);
-        wnext += QSTAGE;
-        dma_wait_q();
-        __syncthreads();
-      }
-    } else if (op.kind == OCC4D_CHAIN_STORE) {
-      if (row < a.n) {
-        float* yp = op.dst + (int64_t)row * op.ld_dst + 4 * g;
-#pragma unroll
-        for (int t = 0; t < QKG; ++t) *reinterpret_cast<f32x4*>(yp + 16 * t) = v[t];
-      }
-    }
-  }
-}
-
 int check_common4(const Trunk4Args& a, const char* who) {
   OCC4D_REQUIRE(a.x && a.y && a.w0p && a.b0, "%s: null pointer", who);
   OCC4D_REQUIRE(a.n >= 0, "%s: n = %d", who, a.n);
@@ -592,57 +400,4 @@ extern "C" int occ4d_rowlin4_masked_f32(const float* x, int64_t ldx, float* y, i
   const int grid = rowlin4_grid(a);
   rowlin4_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
   return occ4d::check_launch("occ4d_rowlin4_masked_f32");
-}
-
-extern "C" int occ4d_trunk_chain_f32(const occ4d_chain_args* p, void* stream) {
-  OCC4D_REQUIRE(p, "occ4d_trunk_chain_f32: null argument block");
-  const occ4d_chain_args& c = *p;
-  OCC4D_REQUIRE(c.n >= 0 && c.n_ops >= 1 && c.n_ops <= OCC4D_CHAIN_MAX_OPS, "occ4d_trunk_chain_f32: n = %d, n_ops = %d", c.n,
-                c.n_ops);
-  if (c.n == 0) return OCC4D_OK;
-  OCC4D_REQUIRE(c.x && c.wstream && c.ldx >= QH && c.ldx % 4 == 0 && ((uintptr_t)c.x % 16) == 0 &&
-                    ((uintptr_t)c.wstream % 16) == 0,
-                "occ4d_trunk_chain_f32: x / wstream must be 16-byte aligned, ldx %% 4 == 0 and >= %d", QH);
-  OCC4D_REQUIRE(c.skew >= 0 && c.skew <= 64, "occ4d_trunk_chain_f32: skew=%d outside [0,64]", c.skew);
-  int64_t stages = 0;
-  for (int i = 0; i < c.n_ops; ++i) {
-    const occ4d_chain_op& op = c.ops[i];
-    switch (op.kind) {
-      case OCC4D_CHAIN_INTERP:
-        OCC4D_REQUIRE(c.zconst && c.ztab && c.zidx && c.zw && c.kz >= 1 && c.ldz % 4 == 0 && op.zoff >= 0 &&
-                          op.zoff % 4 == 0 && op.zoff + QH <= c.ldz && ((uintptr_t)c.ztab % 16) == 0 &&
-                          ((uintptr_t)c.zconst % 16) == 0,
-                      "occ4d_trunk_chain_f32: op %d: interpolation needs zconst / ztab / zidx / zw, kz >= 1, 16-byte aligned "
-                      "tables and 0 <= zoff <= ldz - %d with zoff %% 4 == 0", i, QH);
-        break;
-      case OCC4D_CHAIN_RESBLOCK:
-        OCC4D_REQUIRE(op.b0 && op.b1 && ((uintptr_t)op.b1 % 16) == 0, "occ4d_trunk_chain_f32: op %d: biases missing / misaligned", i);
-        stages += 2 * QNC;
-        break;
-      case OCC4D_CHAIN_LINEAR:
-        OCC4D_REQUIRE(op.b0 && ((uintptr_t)op.b0 % 16) == 0 && op.dst && op.n_cols >= 1 && op.n_stages >= 2 &&
-                          op.n_stages % 2 == 0 && 16 * op.n_stages >= op.n_cols && op.ld_dst >= op.n_cols &&
-                          ((op.ld_dst & 3) != 0 || ((uintptr_t)op.dst % 16) == 0),
-                      "occ4d_trunk_chain_f32: op %d: Linear needs a 16-byte aligned bias padded to 16 * n_stages, an even "
-                      "n_stages >= n_cols / 16 and ld_dst >= n_cols", i);
-        stages += op.n_stages;
-        break;
-      case OCC4D_CHAIN_STORE:
-        OCC4D_REQUIRE(op.dst && op.ld_dst >= QH && op.ld_dst % 4 == 0 && ((uintptr_t)op.dst % 16) == 0,
-                      "occ4d_trunk_chain_f32: op %d: store needs a 16-byte aligned destination with ld %% 4 == 0", i);
-        break;
-      default:
-        OCC4D_REQUIRE(false, "occ4d_trunk_chain_f32: op %d: unknown kind %d", i, op.kind);
-    }
-  }
-  OCC4D_REQUIRE(stages >= 2 && c.n_stream_stages == stages + 1,
-                "occ4d_trunk_chain_f32: the program consumes %lld stages, the stream was declared with %lld (must be + 1)",
-                (long long)stages, (long long)c.n_stream_stages);
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-    cus = 256;
-  ChainArgsK k{c.x, c.ldx, c.wstream, c.zconst, c.ztab, c.ldz, c.zidx, c.zw, c.kz, c.n, c.n_ops, 2 * cus, c.skew, {}};
-  for (int i = 0; i < c.n_ops; ++i) k.ops[i] = c.ops[i];
-  trunk_chain_kernel<<<occ4d::cdiv(c.n, QROWS), 256, 0, (hipStream_t)stream>>>(k);
-  return occ4d::check_launch("occ4d_trunk_chain_f32");
 }

@@ -21,7 +21,6 @@ from . import autograd
 from . import point_transformer_layer as ptl
 from .point_transformer_layer import needs_grad, weights_epoch
 
-_QUERY_CHUNK = 32768
 
 
 def positional_encode(points, base_frequency, num_powers):
@@ -32,13 +31,29 @@ def positional_encode(points, base_frequency, num_powers):
     return enc.reshape(*points.shape[:-1], enc.shape[-1])
 
 
+ACTIVATIONS = {'relu': 1, 'swish': 2}       # act_in codes of occ4d_linear_f32 (0 = none); swish = x * sigmoid(x) (:46-64)
+
+
 def _check_activation(name):
-    if name == 'relu':
-        return
-    if name == 'swish':
-        raise NotImplementedError("activation 'swish' is not used by any published configuration; "
-                                  "the fused kernels implement 'relu'")
-    raise ValueError('Unknown activation: ' + str(name))
+    if name not in ACTIVATIONS:
+        raise ValueError('Unknown activation: ' + str(name))
+
+
+def _trunk_pack(weight, kind):
+    """Stage-packed copy of a (416, 416) weight for the fused residual-block kernel (ops.pack_trunk_rows / _cols =
+    the library's packers), cached on the tensor object while (storage, version, weights epoch, variant) are unchanged."""
+    if tuple(weight.shape) != (ops.TRUNK_WIDTH, ops.TRUNK_WIDTH) or not weight.is_cuda:
+        return None
+    key = (weights_epoch(), weight.data_ptr(), weight._version, kind, ptl.USE_TRUNK4)
+    hit = getattr(weight, '_occ4d_trunk_pack', None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    if ptl.USE_TRUNK4:
+        packed = ops.pack_trunk4_rows(weight) if kind == 'rows' else ops.pack_trunk4_cols(weight)
+    else:
+        packed = ops.pack_trunk_rows(weight) if kind == 'rows' else ops.pack_trunk_cols(weight)
+    weight._occ4d_trunk_pack = (key, packed)
+    return packed
 
 
 class ResnetBlockFC(torch.nn.Module):
@@ -47,6 +62,7 @@ class ResnetBlockFC(torch.nn.Module):
     def __init__(self, d_in=64, d_hidden=256, d_out=64, activation='relu'):
         super().__init__()
         _check_activation(activation)
+        self.activation = activation
         self.d_in, self.d_hidden, self.d_out = d_in, d_hidden, d_out
         self.fc_0 = torch.nn.Linear(d_in, d_hidden, bias=True)
         self.fc_1 = torch.nn.Linear(d_hidden, d_out, bias=True)
@@ -59,22 +75,26 @@ class ResnetBlockFC(torch.nn.Module):
         return self._run(flat).reshape(*x.shape[:-1], self.d_out)
 
     def _run_train(self, x):
+        if self.activation != 'relu':
+            raise NotImplementedError("training is implemented for activation 'relu' (every published configuration)")
         h = autograd.linear(x, self.fc_0, relu_in=True)
         xs = x if self.shortcut is None else autograd.linear(x, self.shortcut)
         return autograd.linear(h, self.fc_1, relu_in=True, residual=xs)
 
     def _run(self, x, inplace=False):
-        if self.shortcut is None and ptl.USE_TRUNK_KERNELS and self.d_in == self.d_hidden == self.d_out:
+        act = ACTIVATIONS[self.activation]
+        if (self.shortcut is None and ptl.USE_TRUNK_KERNELS and self.d_in == self.d_hidden == self.d_out
+                and self.activation == 'relu'):
             # both layers in one kernel, the (n, d_hidden) intermediate never leaves the registers (csrc/trunk.hip)
-            w0p, w1p = ptl.trunk_pack(self.fc_0.weight), ptl.trunk_pack(self.fc_1.weight, 'cols')
+            w0p, w1p = _trunk_pack(self.fc_0.weight, 'rows'), _trunk_pack(self.fc_1.weight, 'cols')
             if w0p is not None and w1p is not None:
                 return ops.resblock(x, w0p, self.fc_0.bias, w1p, self.fc_1.bias, out=x if inplace else None)
-        h = ops.linear(x, self.fc_0.weight, self.fc_0.bias, relu_in=True)
+        h = ops.linear(x, self.fc_0.weight, self.fc_0.bias, relu_in=act)
         if self.shortcut is None:
-            return ops.linear(h, self.fc_1.weight, self.fc_1.bias, relu_in=True, residual=x,
+            return ops.linear(h, self.fc_1.weight, self.fc_1.bias, relu_in=act, residual=x,
                               out=x if inplace else None)
         xs = ops.linear(x, self.shortcut.weight)
-        return ops.linear(h, self.fc_1.weight, self.fc_1.bias, relu_in=True, residual=xs, out=xs)
+        return ops.linear(h, self.fc_1.weight, self.fc_1.bias, relu_in=act, residual=xs, out=xs)
 
 
 class ResnetFC(torch.nn.Module):
@@ -87,6 +107,7 @@ class ResnetFC(torch.nn.Module):
         if mixed_precision:
             raise NotImplementedError('fp32 only (the reference default, args.py:55)')
         self.mixed_precision = mixed_precision
+        self.activation = activation
         self.d_in, self.d_hidden, self.d_out, self.d_latent = d_in, d_hidden, d_out, d_latent
         self.n_blocks = n_blocks
         self.pos_encoding_freqs = pos_encoding_freqs
@@ -139,7 +160,7 @@ class ResnetFC(torch.nn.Module):
                         x = ops.linear(f, lz.weight, lz.bias, residual=x, out=x)
                 x = self.blocks[i]._run(x, inplace=True)
             pens.append(x)
-            outs.append(ops.linear(x, self.lin_out.weight, self.lin_out.bias, relu_in=True))
+            outs.append(ops.linear(x, self.lin_out.weight, self.lin_out.bias, relu_in=ACTIVATIONS[self.activation]))
         output, penult = ops.stack_batch(outs), ops.stack_batch(pens)
         if no_batch:
             output, penult = output[0], penult[0]
@@ -174,17 +195,70 @@ class LocalPclResnetFC(ResnetFC):
             self.use_pt_inds = {j: i for i, j in enumerate(use_at)}
         self._scene = None
 
-    # -- per-scene precompute ---------------------------------------------------------
-    def _weights_key(self):
-        return (weights_epoch(),) + tuple((p.data_ptr(), p._version) for p in self.lin_z.parameters())
+    # -- the library's view of this module ------------------------------------------------
+    def path_weights(self):
+        """occ4d_decoder_weights over this module's parameters in the reference's layout and the library's prepared
+        buffer for them (occ4d_decoder_prepare_f32: stage-packed residual blocks, merged + packed cross-attention
+        layers).  Cached while the parameters (storage, version, weights epoch) and the kernel flags are unchanged."""
+        flags = ptl.path_flags()
+        key = (flags, weights_epoch()) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        hit = getattr(self, '_path', None)
+        if hit is not None and hit[0] == key:
+            return hit[1], hit[2], flags
+        L = ops._lib
+        assert self.n_blocks <= L.MAX_BLOCKS and len(getattr(self, 'pt_blocks', [])) <= L.MAX_CROSS
+        keep = []
 
+        def dp(t):
+            t = t.detach()
+            if not t.is_contiguous():
+                t = t.contiguous()
+            ops._dev(t, name='parameter')                  # (RuntimeError for CPU tensors: there is no fallback path)
+            keep.append(t)
+            return t.data_ptr()
+        p_in = self.actual_d_in
+        w_in = self.lin_in.weight.detach()
+        if p_in % 4:                                   # rows zero-padded to a multiple of 4 floats (vector loads)
+            w_in = torch.nn.functional.pad(w_in, (0, 4 - p_in % 4))
+        w = L.DecoderWeights(d_in=self.d_in, n_freq=self.pos_encoding_freqs, d_hidden=self.d_hidden, d_out=self.d_out,
+                             d_latent=self.d_latent, d_latent_local=self.d_latent_local, n_blocks=self.n_blocks,
+                             n_cross=len(self.pt_blocks) if self.local_mode == 'attention' else 0,
+                             k_local=self.num_local_features, k_cross=self.cross_attn_neighbors,
+                             activation=ACTIVATIONS[self.activation] - 1, lin_in_ld=w_in.shape[1], base_frequency=0.1)
+        w.lin_in_w, w.lin_in_b = dp(w_in), dp(self.lin_in.bias)
+        w.lin_out_w, w.lin_out_b = dp(self.lin_out.weight), dp(self.lin_out.bias)
+        for i in range(self.n_blocks):
+            w.lin_z_w[i], w.lin_z_b[i] = dp(self.lin_z[i].weight), dp(self.lin_z[i].bias)
+            w.fc0_w[i], w.fc0_b[i] = dp(self.blocks[i].fc_0.weight), dp(self.blocks[i].fc_0.bias)
+            w.fc1_w[i], w.fc1_b[i] = dp(self.blocks[i].fc_1.weight), dp(self.blocks[i].fc_1.bias)
+        if self.local_mode == 'attention':
+            after = sorted(self.use_pt_inds)
+            for j, blk in enumerate(self.pt_blocks):
+                lw, _, _ = blk.layer2.path_weights(cross=True, pre=blk.layer1, post=blk.layer3)
+                w.cross[j] = lw
+                keep.append(lw)
+                w.cross_after[j] = after[j]
+                assert self.use_pt_inds[after[j]] == j
+        w._keep = keep
+        prepared = ops.decoder_prepare(w, flags, self.lin_out.weight.device)
+        self._path = (key, w, prepared)
+        return w, prepared, flags
+
+    def _library_path_ok(self):
+        return (self.num_local_features > 0 and self.local_mode in ('feature', 'attention') and self.d_latent > 0
+                and self.d_latent_local > 0 and all(b.shortcut is None and b.d_hidden == self.d_hidden for b in self.blocks)
+                and self.d_hidden % 4 == 0 and self.d_latent_local % 4 == 0 and (self.d_latent - self.d_latent_local) % 4 == 0)
+
+    # -- per-scene precompute ---------------------------------------------------------
     def prepare_scene(self, points_abstract, features_global, features_abstract=None):
-        """Per-scene tables: abstract xyz / features made contiguous, Z = F @ [Wz_0^loc; ..]^T (M, n_blocks*H),
-        c = [Wz_i^glob g + b_i] (n_blocks*H).  Cached on the identity (+version) of the tensors the
-        caller passes, which are kept alive here so their storage cannot be recycled."""
+        """Per-scene tables of the library (occ4d_decoder_prepare_scene_f32): abstract xyz packed, Z = F [Wz_0^loc; ..]^T
+        (M, n_blocks*H), c = [Wz_i^glob g + b_i] (n_blocks*H), and per cross layer (W1 Wk) F, Wv F, Wv F + c2 -- the
+        reference recomputes to_k / to_v per forward call.  Cached on the identity (+version) of the
+        tensors the caller passes, which are kept alive here so their storage cannot be recycled."""
+        w, prepared, flags = self.path_weights()
         key = (id(points_abstract), points_abstract._version, id(features_global), features_global._version,
                id(features_abstract), None if features_abstract is None else features_abstract._version,
-               self._weights_key())
+               id(prepared), flags)
         sc = self._scene
         if sc is not None and sc['key'] == key and sc['owners'][0] is points_abstract \
                 and sc['owners'][1] is features_global and sc['owners'][2] is features_abstract:
@@ -201,15 +275,9 @@ class LocalPclResnetFC(ResnetFC):
             fg = fg[0]
         assert pa.shape[0] == fa.shape[0]
         assert fa.shape[-1] == self.d_latent_local
-        dg = self.d_latent - self.d_latent_local
-        assert fg.shape[-1] == dg
-        pa = pa.contiguous()
-        fa = fa.contiguous()
-        wl = torch.cat([lz.weight[:, dg:] for lz in self.lin_z], dim=0).contiguous()
-        wg = torch.cat([lz.weight[:, :dg] for lz in self.lin_z], dim=0).contiguous()
-        bz = torch.cat([lz.bias for lz in self.lin_z], dim=0).contiguous()
-        sc = dict(key=key, owners=(points_abstract, features_global, features_abstract), xyz=pa, feats=fa,
-                  ztab=ops.linear(fa, wl), zconst=ops.linear(fg[None].contiguous(), wg, bz)[0])
+        assert fg.shape[-1] == self.d_latent - self.d_latent_local
+        sc = dict(key=key, owners=(points_abstract, features_global, features_abstract), m=pa.shape[0], prepared=prepared,
+                  scene=ops.decoder_prepare_scene(w, prepared, pa, fa, fg, flags))
         self._scene = sc
         return sc
 
@@ -217,7 +285,9 @@ class LocalPclResnetFC(ResnetFC):
     def forward(self, points_query, points_abstract, features_global, features_abstract):
         """points_query (B,N,4) or (N,4); points_abstract (B,M,3) (or (B,M,3+E) with
         features_abstract None); features_global (B,D); features_abstract (B,M,E).
-        B must be 1.  Returns (output (B,N,G), penult (B,N,H)) (no batch dim if none came in)."""
+        B must be 1.  Returns (output (B,N,G), penult (B,N,H)) (no batch dim if none came in).
+        Inference: ONE library call per mini-batch (occ4d_decoder_query_fwd_f32) on per-scene tables built once per
+        abstract cloud (occ4d_decoder_prepare_scene_f32)."""
         if needs_grad(self, points_abstract, features_global, features_abstract):
             return self._forward_train(points_query, points_abstract, features_global, features_abstract)
         if self.num_local_features <= 0:
@@ -232,143 +302,24 @@ class LocalPclResnetFC(ResnetFC):
             assert points_abstract.shape[0] == 1 and features_global.shape[0] == 1
         q = points_query if no_batch else points_query[0]
         assert q.shape[-1] == self.d_in
+        assert self._library_path_ok(), 'unsupported LocalPclResnetFC configuration for the HIP library'
         sc = self.prepare_scene(points_abstract, features_global, features_abstract)
-        if self.local_mode == 'feature':
-            output, penult = self._forward_feature(q, sc)
-        else:
-            output, penult = self._forward_attention(q, sc, sc['owners'])
+        w, prepared, flags = self.path_weights()
+        output, penult = ops.decoder_query_fwd(w, prepared, sc['scene'], sc['m'], q, flags)
         if not no_batch:
             output, penult = output[None], penult[None]
         return (output, penult)
 
-    # -- trunk chains (occ4d_trunk_chain_f32): the blocks between two cross-attention layers as one kernel -----------
-    def _chain_plan(self):
-        """Segments of the trunk for local_mode 'attention': consecutive residual blocks up to (and including the query
-        projection of) the next PointTransformerBlock, or up to lin_out; per segment the flat weight stream and the
-        stage counts.  Cached while the parameters (storage, version, weights epoch) are unchanged; None when the
-        row-resident kernels do not apply to this configuration."""
-        if not (ptl.USE_TRUNK_KERNELS and ptl.USE_TRUNK4 and ptl.USE_TRUNK_CHAIN and self.d_hidden == ops.TRUNK_WIDTH
-                and self.d_latent > 0 and all(b.shortcut is None and b.d_hidden == self.d_hidden for b in self.blocks)
-                and self.lin_out.weight.is_cuda):
-            return None
-        key = (weights_epoch(), ptl.USE_ATTN16P) + tuple((p.data_ptr(), p._version) for p in self.parameters())
-        hit = getattr(self, '_chain_cache', None)
-        if hit is not None and hit[0] == key:
-            return hit[1]
-        plan, first = [], 0
-        for i in range(self.n_blocks):
-            last = i == self.n_blocks - 1
-            if i not in self.use_pt_inds and not last:
-                continue
-            blocks = list(range(first, i + 1))
-            first = i + 1
-            if 2 * len(blocks) + 2 > 12:          # (OCC4D_CHAIN_MAX_OPS)
-                return None
-            parts = [('resblock', self.blocks[j].fc_0.weight, self.blocks[j].fc_1.weight) for j in blocks]
-            seg = dict(blocks=blocks, pt=self.use_pt_inds.get(i), tail=False)
-            if seg['pt'] is not None:
-                blk = self.pt_blocks[seg['pt']]
-                m = blk.layer2.merged_weights(blk.layer1)
-                if m['wq'].shape[1] != ops.TRUNK_WIDTH:
-                    return None
-                parts.append(('linear', m['wq']))
-                seg['n_aq'], seg['bias'] = m['wq'].shape[0], m['bq']
-                plan.append(seg)
-                if last:                            # a cross-attention layer after the last block: lin_out on its own
-                    plan.append(dict(blocks=[], pt=None, tail=True))
-                    parts_tail = [('linear', self.lin_out.weight)]
-                    plan[-1]['stream'], plan[-1]['counts'] = ops.pack_chain_stream(parts_tail)
-                    plan[-1]['bias'] = ops.pad_bias(self.lin_out.bias, plan[-1]['counts'][-1])
-            else:
-                parts.append(('linear', self.lin_out.weight))
-                seg['tail'], seg['bias'] = True, self.lin_out.bias
-                plan.append(seg)
-            seg['stream'], seg['counts'] = ops.pack_chain_stream(parts)
-            seg['bias'] = ops.pad_bias(seg['bias'], seg['counts'][-1])
-        self._chain_cache = (key, plan)
-        return plan
-
-    def _run_chain(self, seg, x, interp, out_rows, aq=None):
-        """One segment on the rows of x (in place): returns x (also the penultimate activation after the tail)."""
-        H = self.d_hidden
-        prog = []
-        for j in seg['blocks']:
-            prog += [('interp', j * H), ('resblock', self.blocks[j].fc_0.bias, self.blocks[j].fc_1.bias)]
-        ns = seg['counts'][-1]
-        if seg['tail']:
-            prog += [('store', x)] if seg['blocks'] else []
-            prog.append(('linear', seg['bias'], ns, self.d_out, True, out_rows))
-        else:
-            prog += [('linear', seg['bias'], ns, seg['n_aq'], False, aq), ('store', x)]
-        ops.trunk_chain(x, seg['stream'], prog, interp=interp if seg['blocks'] else None)
-        return x
-
-    def _interp(self, q, sc):
-        idx, dist = ops.knn(q, sc['xyz'], self.num_local_features, metric=1, return_dist=True)
-        return idx, ops.interp_weights(dist)
-
-    def _forward_attention(self, q_all, sc, owner):
-        n = q_all.shape[0]
-        H = self.d_hidden
-        out = torch.empty((n, self.d_out), dtype=torch.float32, device=q_all.device)
-        single = 0 < n <= _QUERY_CHUNK        # one chunk: the trunk activation IS penult (no 54 MB copy)
-        pen = None if single else torch.empty((n, H), dtype=torch.float32, device=q_all.device)
-        xyz, feats = sc['xyz'], sc['feats']
-        for lo in range(0, n, _QUERY_CHUNK):
-            q = q_all[lo:lo + _QUERY_CHUNK]
-            idx8, w8 = self._interp(q, sc)
-            # every cross-attention layer attends from the same query xyz to the same abstract xyz with the same K:
-            # one kNN_torch (model/point_transformer_layer.py:167) serves them all (SURVEY.md 7 (iii))
-            idx_att = ops.knn(q[:, :3], xyz, self.cross_attn_neighbors, metric=0)[None] if self.use_pt_inds else None
-            x = self._embed(q)
-            plan = self._chain_plan()
-            if plan is not None:
-                # the trunk between two cross-attention layers is one kernel: [x += lin_z term; block] ..., then the merged
-                # query projection of the next PointTransformerBlock (or lin_out) while the rows are still in registers
-                interp = (sc['zconst'], sc['ztab'], idx8, w8)
-                for seg in plan:
-                    aq = None
-                    if seg['pt'] is not None:
-                        aq = torch.empty((x.shape[0], seg['n_aq']), dtype=torch.float32, device=x.device)
-                    self._run_chain(seg, x, interp, out[lo:lo + _QUERY_CHUNK], aq)
-                    if seg['pt'] is not None:
-                        blk = self.pt_blocks[seg['pt']]
-                        x = blk(x[None], q[None, :, :3], x2=feats[None], p2=xyz[None], scene_owner=owner,
-                                knn_idx=idx_att, aq_pre=aq[None])[0][0]
-                if single:
-                    pen = x
-                else:
-                    pen[lo:lo + _QUERY_CHUNK] = x
-                continue
-            for i in range(self.n_blocks):
-                ops.interp_add(x, sc['zconst'][i * H:(i + 1) * H], sc['ztab'][:, i * H:(i + 1) * H], idx8, w8)
-                x = self.blocks[i]._run(x, inplace=True)
-                if i in self.use_pt_inds:
-                    blk = self.pt_blocks[self.use_pt_inds[i]]
-                    x = blk(x[None], q[None, :, :3], x2=feats[None], p2=xyz[None], scene_owner=owner,
-                            knn_idx=idx_att)[0][0]
-            if single:
-                pen = x
-            else:
-                pen[lo:lo + _QUERY_CHUNK] = x
-            ops.linear(x, self.lin_out.weight, self.lin_out.bias, relu_in=True, out=out[lo:lo + _QUERY_CHUNK])
-        return out, pen
-
-    def _forward_feature(self, q_all, sc):
-        n = q_all.shape[0]
-        H = self.d_hidden
-        out = torch.empty((n, self.d_out), dtype=torch.float32, device=q_all.device)
-        pen = torch.empty((n, H), dtype=torch.float32, device=q_all.device)
-        for lo in range(0, n, _QUERY_CHUNK):
-            q = q_all[lo:lo + _QUERY_CHUNK]
-            idx8, w8 = self._interp(q, sc)
-            x = self._embed(q)
-            for i in range(self.n_blocks):
-                ops.interp_add(x, sc['zconst'][i * H:(i + 1) * H], sc['ztab'][:, i * H:(i + 1) * H], idx8, w8)
-                x = self.blocks[i]._run(x, inplace=True)
-            pen[lo:lo + _QUERY_CHUNK] = x
-            ops.linear(x, self.lin_out.weight, self.lin_out.bias, relu_in=True, out=out[lo:lo + _QUERY_CHUNK])
-        return out, pen
+    def forward_output_only(self, points_query, points_abstract, features_global, features_abstract, out):
+        """Extension for the device-resident driver (inference.decode_batches): the raw outputs of one mini-batch
+        written straight into `out` (a row slice of the caller's result tensor); the penultimate activation, which
+        perform_inference discards (eval/inference.py:211), is not materialised for the caller."""
+        assert not needs_grad(self, points_abstract, features_global, features_abstract)
+        assert self.num_local_features > 0 and self._library_path_ok() and points_query.dim() == 2
+        sc = self.prepare_scene(points_abstract, features_global, features_abstract)
+        w, prepared, flags = self.path_weights()
+        ops.decoder_query_fwd(w, prepared, sc['scene'], sc['m'], points_query, flags, out=out, want_penult=False)
+        return out
 
     # -- training path (as-written op order, differentiable kernels) ------------------------
     def _forward_train(self, points_query, points_abstract, features_global, features_abstract):
@@ -376,6 +327,8 @@ class LocalPclResnetFC(ResnetFC):
         reach this module's parameters and, through features_abstract / features_global, the encoder."""
         assert self.local_mode == 'attention' and self.num_local_features > 0, \
             "training is implemented for the published configuration (local_mode='attention')"
+        if self.activation != 'relu':
+            raise NotImplementedError("training is implemented for activation 'relu' (every published configuration)")
         no_batch = points_query.dim() == 2
         q = points_query if no_batch else points_query[0]
         pa, fa, fg = points_abstract, features_abstract, features_global
@@ -405,7 +358,7 @@ class LocalPclResnetFC(ResnetFC):
                 y = autograd.linear(x, blk.layer1)
                 if idx_att is None:       # one kNN_torch for all cross-attention layers (same xyz on both sides, same K)
                     idx_att = ops.knn(qxyz, pa, self.cross_attn_neighbors, metric=0)
-                agg = blk.layer2._forward(y[None], qxyz[None], fa[None], pa[None], pre=None, scene_owner=None,
+                agg = blk.layer2._forward(y[None], qxyz[None], fa[None], pa[None], pre=None,
                                           knn_idx=idx_att[None])[0]
                 x = autograd.linear(agg, blk.layer3, residual=x)
         output = autograd.linear(x, self.lin_out, relu_in=True)

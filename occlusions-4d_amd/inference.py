@@ -282,6 +282,18 @@ def decode_chunk(batch_size):
     return batch_size
 
 
+def _decode_into(implicit_net, q, pcl_abstract, features_global, out_rows):
+    """One mini-batch: the network's raw outputs written into `out_rows`.  The library-backed decoder writes them in
+    place and skips the penultimate activation perform_inference discards (eval/inference.py:211); any other module
+    with the reference's forward signature is called as the reference calls it."""
+    direct = getattr(implicit_net, 'forward_output_only', None)
+    if direct is not None and getattr(implicit_net, 'num_local_features', 0) > 0 and q.dim() == 2 and q.shape[0] > 0:
+        direct(q, pcl_abstract, features_global, None, out_rows)
+        return
+    (o, _) = implicit_net(q, pcl_abstract, features_global, None)
+    out_rows.copy_(o)
+
+
 def decode_batches(implicit_net, points_query, lo, hi, batch_size, pcl_abstract, features_global, out, out_offset=0):
     """Runs implicit_net on points_query[lo:hi] in mini-batches of `batch_size` (the reference's
     loop, eval/inference.py:204-246) and writes rows into out[out_offset:].  Mini-batches are
@@ -297,16 +309,14 @@ def decode_batches(implicit_net, points_query, lo, hi, batch_size, pcl_abstract,
     for bi, b in enumerate(starts):
         e = min(hi, b + batch_size)
         if bi == 0 or not side:
-            (o, _) = implicit_net(points_query[b:e], pcl_abstract, features_global, None)
-            out[out_offset + b - lo:out_offset + e - lo] = o
+            _decode_into(implicit_net, points_query[b:e], pcl_abstract, features_global, out[out_offset + b - lo:out_offset + e - lo])
             if bi == 0:
                 for st in side:
                     st.wait_stream(main)
             continue
         st = side[bi % len(side)]
         with torch.cuda.stream(st):
-            (o, _) = implicit_net(points_query[b:e], pcl_abstract, features_global, None)
-            out[out_offset + b - lo:out_offset + e - lo] = o
+            _decode_into(implicit_net, points_query[b:e], pcl_abstract, features_global, out[out_offset + b - lo:out_offset + e - lo])
     for st in side:
         main.wait_stream(st)
     return out

@@ -28,29 +28,20 @@ class PointTransformerBlock(torch.nn.Module):
             dim2=d_hidden_abstract)
         self.layer3 = torch.nn.Linear(d_hidden, d_out)
 
-    def forward(self, x, p, x2=None, p2=None, scene_owner=None, knn_idx=None, aq_pre=None):
+    def forward(self, x, p, x2=None, p2=None, knn_idx=None):
         """x (B,N,d_in), p (B,N,3) [, x2 (B,M,E), p2 (B,M,3)] -> (z (B,N,d_out), p).
-        `scene_owner` (extension, optional): tensor object identifying the abstract cloud so
-        its key/value tables are computed once per scene instead of once per call.  `knn_idx` (extension, optional):
-        (B,N,num_neighbors) int32 result of kNN_torch(p, p2) when the caller already has it.  `aq_pre` (extension,
-        optional): (B,N,2 d_hidden) merged query projection of layer1 + layer2 when the caller already has it."""
+        `knn_idx` (extension, optional): (B,N,num_neighbors) int32 result of kNN_torch(p, p2) when the caller already
+        has it.  Inference: the whole block -- layer1, the vector attention, layer3 + residual -- is ONE call of the
+        library's path-level entry point per cloud (occ4d_pt_layer_fwd_f32)."""
         assert x.shape[:2] == p.shape[:2]
         if x2 is not None:
             assert x2.shape[:2] == p2.shape[:2]
-        # layer1 is folded into the query-side merged matrix (cross) or applied once (self)
-        agg = self.layer2._forward(x, p, x2, p2, pre=self.layer1, scene_owner=scene_owner, knn_idx=knn_idx,
-                                   aq_pre=aq_pre)
         if needs_grad(self, x, x2):
+            agg = self.layer2._forward(x, p, x2, p2, pre=self.layer1, knn_idx=knn_idx)
             z = ops.stack_batch([autograd.linear(agg[b], self.layer3, residual=x[b]) for b in range(x.shape[0])])
-        else:
-            w3p = point_transformer_layer.trunk_pack(self.layer3.weight) \
-                if point_transformer_layer.USE_TRUNK_KERNELS and self.d_out == self.d_in else None
-            if w3p is not None:
-                z = ops.stack_batch([ops.rowlin(agg[b], w3p, self.layer3.bias, self.d_out, residual=x[b])
-                                     for b in range(x.shape[0])])
-            else:
-                z = ops.stack_batch([ops.linear(agg[b], self.layer3.weight, self.layer3.bias, residual=x[b])
-                                     for b in range(x.shape[0])])
+            return (z, p)
+        assert self.d_out == self.d_in, 'PointTransformerBlock adds its input to layer3\'s output (model/modules.py:66)'
+        z = self.layer2._forward(x, p, x2, p2, pre=self.layer1, knn_idx=knn_idx, post=self.layer3)
         return (z, p)
 
 
@@ -68,7 +59,10 @@ class DownTransition(torch.nn.Module):
             self.mlp = torch.nn.Sequential(torch.nn.Linear(d_in, d_out), torch.nn.LayerNorm(d_out),
                                            torch.nn.ReLU())
         elif norm_type == 'batch':
-            raise NotImplementedError("norm_type 'batch' is unused by every published configuration")
+            # (model/modules.py:98-102: eps 1e-3, default momentum)  Inference uses the running statistics (eval mode);
+            # batch statistics (training mode) are not implemented -- no published configuration trains with it
+            self.mlp = torch.nn.Sequential(torch.nn.Linear(d_in, d_out), torch.nn.BatchNorm1d(d_out, eps=1e-3),
+                                           torch.nn.ReLU())
         else:
             raise ValueError()
 
@@ -102,6 +96,9 @@ class DownTransition(torch.nn.Module):
         zs, ps = [], []
         for b in range(B):
             (inds, p_sub, nn_idx) = geometry[b] if geometry is not None else self.geometry(p[b].detach())
+            if self.norm_type == 'batch' and (train or self.mlp[1].training):
+                raise NotImplementedError("DownTransition(norm_type='batch') runs in eval mode only (running statistics); "
+                                          "call .eval() -- batch statistics are not implemented")
             if train:
                 if self.norm_type == 'layer':
                     ln = self.mlp[1]
@@ -111,12 +108,15 @@ class DownTransition(torch.nn.Module):
                 zs.append(autograd.MaxPoolGatherFn.apply(y, nn_idx))
                 ps.append(p_sub)
                 continue
+            # Linear [+ LayerNorm | BatchNorm (eval)] + ReLU on ALL points, then the K-way max pool: one library call
+            nm = self.mlp[1]
             if self.norm_type == 'layer':
-                y = ops.linear(x[b], lin.weight, lin.bias)
-                ln = self.mlp[1]
-                ops.layernorm(y, ln.weight, ln.bias, eps=ln.eps, relu=True, out=y)
+                z = ops.down_pool_fwd(x[b], lin.weight, lin.bias, nn_idx, norm=1, gamma=nm.weight, beta=nm.bias, eps=nm.eps)
+            elif self.norm_type == 'batch':
+                z = ops.down_pool_fwd(x[b], lin.weight, lin.bias, nn_idx, norm=2, gamma=nm.weight, beta=nm.bias,
+                                      mean=nm.running_mean, var=nm.running_var, eps=nm.eps)
             else:
-                y = ops.linear(x[b], lin.weight, lin.bias, relu_out=True)
-            zs.append(ops.maxpool_gather(y, nn_idx))
+                z = ops.down_pool_fwd(x[b], lin.weight, lin.bias, nn_idx, norm=0)
+            zs.append(z)
             ps.append(p_sub)
         return (ops.stack_batch(zs), ops.stack_batch(ps))

@@ -28,6 +28,24 @@ class KernelTimer:
         self.events.append((name, e0, e1, float(flops)))
         return rc
 
+    def path_events(self, name, flops_per_launch):
+        """occ4d_launch_events for a path-level call that issues len(flops_per_launch) launches of kernel family
+        `name`: the library records the event pairs on its launch stream (include/occ4d.h).  Returns (struct, finish);
+        call finish() after the library call: it books the pairs the call really used."""
+        n = len(flops_per_launch)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(2 * n)]
+        for e in evs:
+            e.record()                       # (torch creates the hipEvent_t lazily, at the first record)
+        arr = (C.c_void_p * (2 * n))(*[e.cuda_event for e in evs])
+        st = _lib.LaunchEvents(events=C.cast(arr, C.POINTER(C.c_void_p)), capacity=n, used=0,
+                               kernel=_lib.PROFILE_KINDS[name], reserved=0)
+
+        def finish():
+            for i in range(st.used):
+                self.events.append((name, evs[2 * i], evs[2 * i + 1], float(flops_per_launch[i])))
+        st._keep = (arr, evs)
+        return st, finish
+
     def summary(self):
         torch.cuda.synchronize()
         out = {}
@@ -311,23 +329,14 @@ FUSED_ATTN_MAX_K = 14
 
 
 def pack_w2_bf16x3(w2):
-    """(d, 2d) fp32 attn_mlp[2] weight -> same-shaped fp32 container holding, per 32-wide hidden block
-    and channel, [32 hi | 32 lo] bf16 (hi = bf16(w), lo = bf16(w - hi)) in MFMA fragment order: position
-    16*(2t + half) + j holds hidden 16t + 8(j>>2) + 4half + (j&3)."""
+    """(d, 2d) fp32 attn_mlp[2] weight -> same-shaped fp32 container holding, per 32-wide hidden block and channel,
+    [32 hi | 32 lo] bf16 (hi = bf16(w), lo = bf16(w - hi)) in MFMA fragment order (occ4d_pack_bf16x3_f32)."""
+    w2 = _cont(w2.detach().float(), 'w2')
     d, h2 = w2.shape
     assert h2 % 32 == 0
-    w2 = w2.detach().float()
-    hi = w2.bfloat16()
-    lo = (w2 - hi.float()).bfloat16()
-    # position 16 t + 8 half + j  <-  hidden 16 t + 8 (j >> 2) + 4 half + (j & 3); built with device arithmetic (a
-    # host list copied to the device is not allowed while a stream is being captured)
-    i = torch.arange(32, device=w2.device)
-    t_, half, j = i // 16, (i // 8) % 2, i % 8
-    perm = 16 * t_ + 8 * (j // 4) + 4 * half + (j % 4)
-    hi = hi.view(d, h2 // 32, 32)[:, :, perm]
-    lo = lo.view(d, h2 // 32, 32)[:, :, perm]
-    packed = torch.cat([hi, lo], dim=2).contiguous()            # (d, blocks, 64) bf16 = 128 B per block
-    return packed.view(torch.float32).reshape(d, h2).contiguous()
+    out = torch.empty_like(w2)
+    _lib.check(_lib.lib().occ4d_pack_bf16x3_f32(_ptr(w2), d, h2, _ptr(out), _stream()))
+    return out
 
 
 def pt_cross_attn(aq, qpos, apos, idx, kt, vt, P1, c1, wp, w2, b2, p2, c2, out=None, w2_packed=None,
@@ -365,71 +374,19 @@ def pt_cross_attn(aq, qpos, apos, idx, kt, vt, P1, c1, wp, w2, b2, p2, c2, out=N
     return out
 
 
-def pack_attn16_stream(w2, b2, wp, p2, c2):
-    """Stage-packed weight stream of occ4d_pt_cross_attn16_f32 (layout in include/occ4d.h): w2 (416, 832), b2 (416)
-    = attn_mlp[2]; wp (832, 32) = W1 P2 (merged); p2 (416, 32), c2 (416) = pos_mlp[2] -> (27, 56 * 256) fp32."""
-    w2, b2, wp, p2, c2 = (_dev(t.detach(), name='w') for t in (w2, b2, wp, p2, c2))
-    d = p2.shape[0]
-    assert d == 416 and tuple(w2.shape) == (d, 2 * d) and tuple(wp.shape) == (2 * d, 32) and p2.shape[1] == 32
-    nt, nhb = d // 16, 2 * d // 32
-    a = w2.reshape(nt, 16, nhb, 2, 4, 4).permute(2, 0, 3, 4, 1, 5).reshape(nhb, 2 * nt * 256)   # [hb][t][nt][g][c][e]
-    b = wp.reshape(nhb, 2, 16, 2, 4, 4).permute(0, 1, 3, 5, 2, 4).reshape(nhb, 4 * 256)         # [hb][nt][kh][g][r][e]
-    c = p2.reshape(nt, 16, 2, 4, 4).permute(0, 2, 4, 1, 3).reshape(1, 2 * nt * 256)             # [t][kh][g][c][e]
-    tail = torch.zeros((1, 4 * 256), dtype=torch.float32, device=c.device)
-    # attn_mlp[2].bias pre-scaled into the kernel's log2-domain logits: (acc + b2) / sqrt(d) * log2(e)
-    scale = float(torch.tensor(math.log2(math.e), dtype=torch.float64) / math.sqrt(d))
-    tail[0, :d] = (b2.double() * scale).float()
-    tail[0, 512:512 + d] = c2
-    last = torch.cat([c, tail], dim=1)
-    out = torch.cat([torch.cat([a, b], dim=1), last], dim=0).contiguous()
-    assert out.numel() == _lib.lib().occ4d_pt_cross_attn16_stream_floats()
-    return out
-
-
-def pt_cross_attn16(aq, qpos, apos, idx, kt, vt, P1, c1, wstream, out=None):
-    """Fused vector attention, d = 416 (occ4d_pt_cross_attn16_f32): agg (n, 416)."""
-    aq, ld_aq = _aligned_rows(_dev(aq, name='aq'), 'aq')
-    kt, ld_kt = _aligned_rows(_dev(kt, name='kt'), 'kt')
-    vt, ld_vt = _rows(_dev(vt, name='vt'), 'vt')
-    qp, qs = _rows(_dev(qpos, name='qpos'), 'qpos')
-    ap, as_ = _rows(_dev(apos, name='apos'), 'apos')
-    idx = _dev(idx, torch.int32, 'idx')
-    n, k = idx.shape
-    d = vt.shape[1]
-    assert idx.is_contiguous() and aq.shape == (n, 2 * d) and kt.shape[1] == 2 * d and qp.shape[0] == n
-    ws = [_dev(t).contiguous() for t in (P1, c1)]
-    assert ws[0].shape == (32, 3) and wstream.is_contiguous()
-    if out is None:
-        out = torch.empty((n, d), dtype=torch.float32, device=aq.device)
-    o, ldo = _rows(out, 'out')
-    assert o is out and o.shape == (n, d)
-    divisor = float(torch.tensor(math.sqrt(d), dtype=torch.float32))
-    flops = 2.0 * n * k * (32 * 2 * d + 2 * d * d + 32 * d)      # executed, useful (same count as pt_cross_attn)
-    _lib.check(_launch('cross_attn', dict(n=n, k=k, d=d), flops, lambda: _lib.lib().occ4d_pt_cross_attn16_f32(
-        _ptr(aq), ld_aq, _ptr(qp), qs, _ptr(ap), as_, _ptr(idx), _ptr(kt), ld_kt, _ptr(vt), ld_vt,
-        _ptr(ws[0]), _ptr(ws[1]), _ptr(wstream), _ptr(o), ldo, n, kt.shape[0], k, d, divisor, _stream())))
-    return out
-
-
 ATTN16P_SKEW = int(os.environ.get('OCC4D_CA16P_SKEW', '6'))   # phase offset of the paired workgroups (units of s_sleep(127))
 
 
 def pack_attn16p_stream(w2, b2, wp, p2, c2):
-    """Stage-packed weight stream of occ4d_pt_cross_attn16p_f32 (layout in include/occ4d.h): w2 (416, 832), b2 (416)
-    = attn_mlp[2]; wp (832, 32) = W1 P2 (merged); p2 (416, 32), c2 (416) = pos_mlp[2] -> (54, 28 * 256) fp32."""
-    w2, b2, wp, p2, c2 = (_dev(t.detach(), name='w') for t in (w2, b2, wp, p2, c2))
-    d = p2.shape[0]
-    assert d == 416 and tuple(w2.shape) == (d, 2 * d) and tuple(wp.shape) == (2 * d, 32) and p2.shape[1] == 32
-    nt, ns = d // 16, 2 * d // 16
-    a = w2.reshape(nt, 16, ns, 4, 4).permute(2, 0, 3, 1, 4).reshape(ns, nt * 256)        # [s][t][g][c][e]
-    b = wp.reshape(ns, 16, 2, 4, 4).permute(0, 2, 4, 1, 3).reshape(ns, 2 * 256)          # [s][kh][g][r][e]
-    c = p2.reshape(nt, 16, 2, 4, 4).permute(0, 2, 4, 1, 3).reshape(nt, 2 * 256)          # [t][kh][g][c][e]
-    # b2 / c2 are not part of the stream: b2 cancels in the softmax over the neighbours, c2 comes folded into the
-    # value table the kernel is given (vt + c2, see pt_cross_attn16p)
-    tail = torch.zeros((1, 4 * 256), dtype=torch.float32, device=c.device)
-    out = torch.cat([torch.cat([a, b], dim=1), c[:14].reshape(1, -1),
-                     torch.cat([c[14:].reshape(1, -1), tail], dim=1)], dim=0).contiguous()
+    """Stage-packed weight stream of occ4d_pt_cross_attn16p_f32 (occ4d_pack_attn16p_stream_f32; layout in
+    include/occ4d.h): w2 (416, 832) = attn_mlp[2].weight; wp (832, 32) = W1 P2 (merged); p2 (416, 32) = pos_mlp[2].weight
+    -> (54, 28 * 256) fp32.  b2 / c2 are not part of the stream: b2 cancels in the softmax over the neighbours, c2 comes
+    folded into the value table the kernel is given (vt + c2, see pt_cross_attn16p)."""
+    w2, wp, p2 = (_cont(t.detach(), 'w') for t in (w2, wp, p2))
+    assert tuple(w2.shape) == (416, 832) and tuple(wp.shape) == (832, 32) and tuple(p2.shape) == (416, 32)
+    out = torch.empty((54, 28 * 256), dtype=torch.float32, device=w2.device)
     assert out.numel() == _lib.lib().occ4d_pt_cross_attn16p_stream_floats()
+    _lib.check(_lib.lib().occ4d_pack_attn16p_stream_f32(_ptr(w2), _ptr(wp), _ptr(p2), _ptr(out), _stream()))
     return out
 
 
@@ -565,44 +522,44 @@ def interp_add(x, cvec, table, idx, w):
 TRUNK_WIDTH = 416          # width the row-resident trunk kernels are built for (occ4d_trunk_width)
 
 
+def _pack(fn_name, w, n_stages_plus_1, stage_floats, n_out=None):
+    w, ldw = _rows(_dev(w.detach(), name='w'), 'w')
+    out = torch.empty((n_stages_plus_1, stage_floats), dtype=torch.float32, device=w.device)
+    fn = getattr(_lib.lib(), fn_name)
+    args = (_ptr(w), ldw) + ((n_out,) if n_out is not None else ()) + (_ptr(out), _stream())
+    _lib.check(fn(*args))
+    return out
+
+
 def pack_trunk_rows(w):
     """(n_out, 416) weight -> stage-packed stream for occ4d_rowlin_f32 / the first layer of occ4d_resblock_f32
-    (include/occ4d.h "rows" packing): per 32-output stage the LDS image of its 52 MFMA fragments; one extra
-    stage (a copy of stage 0) at the end."""
-    w = _dev(w.detach(), name='w')
+    (occ4d_pack_trunk_rows_f32; include/occ4d.h "rows" packing): per 32-output stage the LDS image of its 52 MFMA
+    fragments; one extra stage (a copy of stage 0) at the end."""
     n_out, k = w.shape
     assert k == TRUNK_WIDTH and n_out % 32 == 0, 'pack_trunk_rows: (%d, %d) is not (32 s, %d)' % (n_out, k, TRUNK_WIDTH)
-    s = n_out // 32
-    p = w.reshape(s, 2, 16, 26, 4, 4).permute(0, 1, 3, 4, 2, 5).reshape(s, -1)      # [s][nt][t][g][r][e]
-    return torch.cat([p, p[:1]], dim=0).contiguous()
+    return _pack('occ4d_pack_trunk_rows_f32', w, n_out // 32 + 1, 13312, n_out)
 
 
 def pack_trunk_cols(w):
-    """(416, 416) second-layer weight of a residual block -> stage-packed stream ("cols" packing): stage j holds
+    """(416, 416) second-layer weight of a residual block -> "cols" packing (occ4d_pack_trunk_cols_f32): stage j holds
     the 32 input columns 32 j .. 32 j + 31 of every output row."""
-    w = _dev(w.detach(), name='w')
     assert tuple(w.shape) == (TRUNK_WIDTH, TRUNK_WIDTH)
-    p = w.reshape(26, 16, 13, 2, 4, 4).permute(2, 0, 3, 4, 1, 5).reshape(13, -1)    # [j][nt][tt][g][r][e]
-    return torch.cat([p, p[:1]], dim=0).contiguous()
+    return _pack('occ4d_pack_trunk_cols_f32', w, 14, 13312)
 
 
 def pack_trunk4_rows(w):
-    """(n_out, 416) weight -> stage-packed stream of the half-CU trunk kernels (include/occ4d.h, csrc/trunk4.hip):
-    per 16-output stage the LDS image of its 26 MFMA fragments; one extra stage (a copy of stage 0) at the end."""
-    w = _dev(w.detach(), name='w')
+    """(n_out, 416) weight -> stage-packed stream of the half-CU trunk kernels (occ4d_pack_trunk4_rows_f32): per
+    16-output stage the LDS image of its 26 MFMA fragments; one extra stage (a copy of stage 0) at the end."""
     n_out, k = w.shape
     assert k == TRUNK_WIDTH and n_out % 16 == 0, 'pack_trunk4_rows: (%d, %d) is not (16 s, %d)' % (n_out, k, TRUNK_WIDTH)
-    p = w.reshape(n_out // 16, 16, 26, 4, 4).permute(0, 2, 3, 1, 4).reshape(n_out // 16, -1)      # [s][t][g][r][e]
-    return torch.cat([p, p[:1]], dim=0).contiguous()
+    return _pack('occ4d_pack_trunk4_rows_f32', w, n_out // 16 + 1, 6656, n_out)
 
 
 def pack_trunk4_cols(w):
-    """(416, 416) second-layer weight of a residual block -> "cols" packing of csrc/trunk4.hip: stage j holds the 16
-    input columns 16 j .. 16 j + 15 of every output row."""
-    w = _dev(w.detach(), name='w')
+    """(416, 416) second-layer weight of a residual block -> "cols" packing of csrc/trunk4.hip
+    (occ4d_pack_trunk4_cols_f32): stage j holds the 16 input columns 16 j .. 16 j + 15 of every output row."""
     assert tuple(w.shape) == (TRUNK_WIDTH, TRUNK_WIDTH)
-    p = w.reshape(26, 16, 26, 4, 4).permute(2, 0, 3, 1, 4).reshape(26, -1)                          # [j][nt][g][r][e]
-    return torch.cat([p, p[:1]], dim=0).contiguous()
+    return _pack('occ4d_pack_trunk4_cols_f32', w, 27, 6656)
 
 
 def _interp_args(interp, n):
@@ -676,92 +633,151 @@ def rowlin(x, w_packed, b, n_out, relu_in=False, residual=None, out=None, interp
     return out
 
 
-CHAIN_SKEW = int(os.environ.get('OCC4D_CHAIN_SKEW', '2'))   # phase offset of a CU's two workgroups (units of s_sleep(127))
+# --------------------------------------------------------------------------------------
+# Path-level entry points (include/occ4d.h, last section; csrc/path.hip): one call = the launch sequence of one
+# reference forward.  The nn.Module mirrors build the weight structs from their parameters (reference layout) and call
+# these; `prepared` / `scene` buffers are cached by the modules, the per-call workspace comes from torch's caching allocator.
+# --------------------------------------------------------------------------------------
+PATH_ROW_CHUNK = 32768          # rows per pass inside the library (csrc/path.hip ROW_CHUNK)
 
 
-def pack_chain_stream(parts):
-    """Flat weight stream of occ4d_trunk_chain_f32 (include/occ4d.h): the 26 KB stages of every operation in execution
-    order.  parts: ('resblock', W0 (416, 416), W1 (416, 416)) -> 52 stages, W0 "rows" / W1 "cols" stages interleaved;
-    ('linear', W (n_out, 416)) -> "rows" stages of W zero-padded to an even stage count.  Returns (stream
-    (S + 1, 6656), [stage count of each part])."""
-    chunks, counts = [], []
-    for part in parts:
-        if part[0] == 'resblock':
-            a = pack_trunk4_rows(part[1])[:-1]              # (26, 6656)
-            b = pack_trunk4_cols(part[2])[:-1]
-            chunks.append(torch.stack([a, b], dim=1).reshape(52, -1))
-            counts.append(52)
-        elif part[0] == 'linear':
-            w = _dev(part[1].detach(), name='w')
-            n_out = w.shape[0]
-            n_pad = 32 * ((n_out + 31) // 32)
-            if n_pad != n_out:
-                w = torch.cat([w, w.new_zeros((n_pad - n_out, w.shape[1]))], dim=0)
-            chunks.append(pack_trunk4_rows(w)[:-1])
-            counts.append(n_pad // 16)
-        else:
-            raise ValueError(part[0])
-    flat = torch.cat(chunks, dim=0)
-    return torch.cat([flat, flat[:1]], dim=0).contiguous(), counts
+def _attn_flops(c, k, d):
+    return 2.0 * c * k * (32 * 2 * d + 2 * d * d + 32 * d)
 
 
-def pad_bias(b, n_stages):
-    """Bias of a chain Linear padded with zeros to 16 * n_stages floats."""
-    b = _dev(b.detach(), name='bias').contiguous()
-    n = 16 * n_stages
-    return b if b.numel() == n else torch.cat([b, b.new_zeros((n - b.numel(),))])
+def _path_timing(name, chunks_flops):
+    """(launch-events struct or None, finish callback): bench.py's roofline leg through the library's profiling hook."""
+    t = _timer
+    if t is None or not chunks_flops or not hasattr(t, 'path_events'):
+        return None, (lambda: None)
+    return t.path_events(name, chunks_flops)
 
 
-def trunk_chain(x, stream, program, interp=None, skew=None):
-    """One launch of occ4d_trunk_chain_f32 on the rows of x (n, 416).  program: list of
-    ('interp', zoff) | ('resblock', b0, b1) | ('linear', b0_padded, n_stages, n_cols, relu, dst) | ('store', dst);
-    interp = (zconst (>= zoff + 416), ztab (M, >= zoff + 416) rows, idx (n, k) int32, w (n, k)) for the 'interp' ops;
-    stream / stage counts from pack_chain_stream in the same order."""
-    xx, ldx = _rows(_dev(x, name='x'), 'x')
-    n, d = xx.shape
-    assert d == TRUNK_WIDTH and 1 <= len(program) <= _lib.CHAIN_MAX_OPS and stream.is_contiguous()
-    args = _lib.ChainArgs()
-    args.x, args.ldx, args.wstream, args.n_stream_stages = _ptr(xx), ldx, _ptr(stream), stream.shape[0]
-    keep = [xx, stream]
-    if interp is not None:
-        zconst, ztab, idx, w = interp
-        zt, ldz = _rows(_dev(ztab, name='ztab'), 'ztab')
-        idx = _dev(idx, torch.int32, 'idx')
-        w = _dev(w, name='w')
-        zc = _dev(zconst).contiguous()
-        assert idx.is_contiguous() and w.is_contiguous() and idx.shape == w.shape and idx.shape[0] == n
-        args.zconst, args.ztab, args.ldz, args.zidx, args.zw, args.kz = _ptr(zc), _ptr(zt), ldz, _ptr(idx), _ptr(w), idx.shape[1]
-        keep += [zc, zt, idx, w]
-    flops = 0.0
-    for i, op in enumerate(program):
-        o = args.ops[i]
-        if op[0] == 'interp':
-            assert interp is not None
-            o.kind, o.zoff = _lib.CHAIN_INTERP, int(op[1])
-        elif op[0] == 'resblock':
-            b0, b1 = _dev(op[1]).contiguous(), _dev(op[2]).contiguous()
-            o.kind, o.b0, o.b1 = _lib.CHAIN_RESBLOCK, _ptr(b0), _ptr(b1)
-            keep += [b0, b1]
-            flops += 4.0 * n * d * d
-        elif op[0] == 'linear':
-            _, b0, n_stages, n_cols, relu, dst = op
-            dd, ldd = _rows(_dev(dst, name='dst'), 'dst')
-            assert dd is dst and dst.shape == (n, n_cols) and b0.numel() == 16 * n_stages
-            o.kind, o.b0, o.n_stages, o.n_cols, o.flags = _lib.CHAIN_LINEAR, _ptr(b0), int(n_stages), int(n_cols), int(bool(relu))
-            o.dst, o.ld_dst = _ptr(dd), ldd
-            keep += [b0, dd]
-            flops += 2.0 * n * d * n_cols
-        elif op[0] == 'store':
-            dd, ldd = _rows(_dev(op[1], name='dst'), 'dst')
-            assert dd is op[1] and dd.shape == (n, d)
-            o.kind, o.dst, o.ld_dst = _lib.CHAIN_STORE, _ptr(dd), ldd
-            keep.append(dd)
-        else:
-            raise ValueError(op[0])
-    args.n, args.n_ops, args.skew = n, len(program), CHAIN_SKEW if skew is None else int(skew)
-    _lib.check(_launch('trunk_chain', dict(n=n, ops=len(program)), flops,
-                       lambda: _lib.lib().occ4d_trunk_chain_f32(C.byref(args), _stream())))
-    return keep
+def pt_layer_prepare(w, flags, device):
+    """prepared buffer of occ4d_pt_layer_prepare_f32 for the weight struct `w` (merged matrices + packed streams)."""
+    n = int(_lib.lib().occ4d_pt_layer_prepared_floats(C.byref(w), flags))
+    if n < 0:
+        _lib.check(_lib.EINVAL)
+    prep = torch.empty((n,), dtype=torch.float32, device=device)
+    _lib.check(_lib.lib().occ4d_pt_layer_prepare_f32(C.byref(w), _ptr(prep), flags, _stream()))
+    return prep
+
+
+def pt_layer_fwd(w, prepared, x, pos, x2, pos2, k, flags=0, knn_idx=None, out=None):
+    """occ4d_pt_layer_fwd_f32: PointTransformerLayer / PointTransformerBlock forward of ONE cloud.  x (n, d_in), pos
+    (n, >= 3) [, x2 (m, dim2), pos2 (m, >= 3)] -> (n, d_out | dim)."""
+    x, ldx = _aligned_rows(_dev(x, name='x'), 'x')
+    p, ps = _rows(_dev(pos, name='pos'), 'pos')
+    n = x.shape[0]
+    d_out = w.d_out if w.post_w else w.dim
+    m, x2p, ldx2, p2, p2s = 0, None, 0, None, 0
+    if w.cross:
+        x2p, ldx2 = _aligned_rows(_dev(x2, name='x2'), 'x2')
+        p2, p2s = _rows(_dev(pos2, name='pos2'), 'pos2')
+        m = x2p.shape[0]
+        assert p2.shape[0] == m
+    assert p.shape[0] == n and p.shape[1] >= 3
+    if knn_idx is not None:
+        knn_idx = _dev(knn_idx, torch.int32, 'knn_idx')
+        assert knn_idx.is_contiguous() and tuple(knn_idx.shape) == (n, k)
+    if out is None:
+        out = torch.empty((n, d_out), dtype=torch.float32, device=x.device)
+    o, ldo = _rows(_dev(out, name='out'), 'out')
+    assert o is out and tuple(o.shape) == (n, d_out)
+    nws = int(_lib.lib().occ4d_pt_layer_workspace_floats(C.byref(w), n, m, k, flags))
+    if nws < 0:
+        _lib.check(_lib.EINVAL)
+    ws = torch.empty((nws,), dtype=torch.float32, device=x.device)
+    fused = w.dim in FUSED_ATTN_DIMS and k <= FUSED_ATTN_MAX_K and w.pos_hidden == 32 and not (flags & _lib.PATH_UNFUSED)
+    chunks = [min(PATH_ROW_CHUNK, n - lo) for lo in range(0, n, PATH_ROW_CHUNK)] if fused else []
+    t = _timer
+    ev, finish = (None, lambda: None)
+    if t is not None and chunks and t.want('cross_attn', n=chunks[0], k=k, d=w.dim):
+        ev, finish = _path_timing('cross_attn', [_attn_flops(c, k, w.dim) for c in chunks])
+    _lib.check(_lib.lib().occ4d_pt_layer_fwd_f32(
+        C.byref(w), _ptr(prepared), _ptr(x), ldx, _ptr(p), ps, n, _ptr(x2p), ldx2, _ptr(p2), p2s, m, k, _ptr(knn_idx), None,
+        _ptr(o), ldo, _ptr(ws), flags, C.byref(ev) if ev is not None else None, _stream()))
+    finish()
+    return out
+
+
+def down_pool_fwd(x, weight, bias, nn_idx, norm=0, gamma=None, beta=None, mean=None, var=None, eps=1e-5):
+    """occ4d_down_pool_fwd_f32: z[i] = max_j relu(norm(x W^T + b))[nn_idx[i, j]] (model/modules.py:152-158)."""
+    x, ldx = _aligned_rows(_dev(x, name='x'), 'x')
+    n, d_in = x.shape
+    w = _cont(weight.detach(), 'weight')
+    b = _cont(bias.detach(), 'bias')
+    d_out = w.shape[0]
+    nn_idx = _dev(nn_idx, torch.int32, 'nn_idx')
+    assert nn_idx.is_contiguous() and nn_idx.dim() == 2 and w.shape[1] == d_in
+    n_new, k = nn_idx.shape
+    z = torch.empty((n_new, d_out), dtype=torch.float32, device=x.device)
+    ws = torch.empty((n * d_out,), dtype=torch.float32, device=x.device)
+    opt = [None if t is None else _cont(t.detach(), 'norm parameter') for t in (gamma, beta, mean, var)]
+    _lib.check(_lib.lib().occ4d_down_pool_fwd_f32(_ptr(x), ldx, n, d_in, _ptr(w), _ptr(b), d_out, int(norm), _ptr(opt[0]),
+                                                  _ptr(opt[1]), _ptr(opt[2]), _ptr(opt[3]), float(eps), _ptr(nn_idx), n_new,
+                                                  k, _ptr(z), d_out, _ptr(ws), _stream()))
+    return z
+
+
+def decoder_prepare(w, flags, device):
+    n = int(_lib.lib().occ4d_decoder_prepared_floats(C.byref(w), flags))
+    if n < 0:
+        _lib.check(_lib.EINVAL)
+    prep = torch.empty((n,), dtype=torch.float32, device=device)
+    _lib.check(_lib.lib().occ4d_decoder_prepare_f32(C.byref(w), _ptr(prep), flags, _stream()))
+    return prep
+
+
+def decoder_prepare_scene(w, prepared, xyz, feats, fglobal, flags):
+    xyz, xs = _rows(_dev(xyz, name='points_abstract'), 'points_abstract')
+    feats, ldf = _aligned_rows(_dev(feats, name='features_abstract'), 'features_abstract')
+    m = xyz.shape[0]
+    assert feats.shape[0] == m
+    fg = _cont(fglobal, 'features_global') if fglobal is not None and fglobal.numel() else None
+    n = int(_lib.lib().occ4d_decoder_scene_floats(C.byref(w), m))
+    if n < 0:
+        _lib.check(_lib.EINVAL)
+    scene = torch.empty((n,), dtype=torch.float32, device=xyz.device)
+    _lib.check(_lib.lib().occ4d_decoder_prepare_scene_f32(C.byref(w), _ptr(prepared), _ptr(xyz), xs, _ptr(feats), ldf,
+                                                          _ptr(fg), m, _ptr(scene), flags, _stream()))
+    return scene
+
+
+def decoder_query_fwd(w, prepared, scene, m, queries, flags=0, out=None, penult=None, want_penult=True):
+    """occ4d_decoder_query_fwd_f32 on one mini-batch: queries (n, d_in) -> (out (n, G), penult (n, H) or None)."""
+    q, qs = _rows(_dev(queries, name='points_query'), 'points_query')
+    n = q.shape[0]
+    if out is None:
+        out = torch.empty((n, w.d_out), dtype=torch.float32, device=q.device)
+    o, ldo = _rows(_dev(out, name='out'), 'out')
+    assert o is out and tuple(o.shape) == (n, w.d_out)
+    if penult is None and want_penult:
+        penult = torch.empty((n, w.d_hidden), dtype=torch.float32, device=q.device)
+    ldp = 0
+    if penult is not None:
+        pp, ldp = _rows(_dev(penult, name='penult'), 'penult')
+        assert pp is penult and tuple(pp.shape) == (n, w.d_hidden)
+    nws = int(_lib.lib().occ4d_decoder_query_workspace_floats(C.byref(w), min(n, PATH_ROW_CHUNK), m, flags))
+    if nws < 0:
+        _lib.check(_lib.EINVAL)
+    ws = torch.empty((nws,), dtype=torch.float32, device=q.device)
+    d, k = w.d_hidden, w.k_cross
+    fused = (w.n_cross > 0 and d in FUSED_ATTN_DIMS and k <= FUSED_ATTN_MAX_K and w.cross[0].pos_hidden == 32
+             and not (flags & _lib.PATH_UNFUSED))
+    t = _timer
+    ev, finish = (None, lambda: None)
+    if t is not None and fused and n and t.want('cross_attn', n=min(n, PATH_ROW_CHUNK), k=k, d=d):
+        chunks = [min(PATH_ROW_CHUNK, n - lo) for lo in range(0, n, PATH_ROW_CHUNK)]
+        ev, finish = _path_timing('cross_attn', [_attn_flops(c, k, d) for c in chunks for _ in range(w.n_cross)])
+    elif t is not None and n and t.want('resblock', n=min(n, PATH_ROW_CHUNK)):
+        chunks = [min(PATH_ROW_CHUNK, n - lo) for lo in range(0, n, PATH_ROW_CHUNK)]
+        ev, finish = _path_timing('resblock', [4.0 * c * d * d for c in chunks for _ in range(w.n_blocks)])
+    _lib.check(_lib.lib().occ4d_decoder_query_fwd_f32(
+        C.byref(w), _ptr(prepared), _ptr(scene), m, _ptr(q), qs, n, _ptr(o), ldo, _ptr(penult), ldp, _ptr(ws), flags,
+        C.byref(ev) if ev is not None else None, _stream()))
+    finish()
+    return out, penult
 
 
 def squash(out, ops):

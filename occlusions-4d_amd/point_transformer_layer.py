@@ -23,23 +23,34 @@ from torch import nn
 from . import autograd
 from . import ops
 
-_PAIR_CHUNK = 32768      # query rows per pass (bounds the (rows*K, 2D) workspace)
-USE_FUSED_ATTENTION = True   # tests flip this to cover the unfused kernel chain as well
-USE_ATTN16 = True            # d = 416: second-generation fused attention kernel (csrc/crossattn16.hip); False = crossattn.hip
-# d = 416: third generation, two 4-wave workgroups per CU out of phase (csrc/crossattn16p.hip); off = crossattn16.hip
-USE_ATTN16P = os.environ.get('OCC4D_ATTN16P', '1') != '0'
+USE_FUSED_ATTENTION = True   # tests flip this to cover the unfused kernel chain as well (OCC4D_PATH_UNFUSED)
+USE_ATTN16 = True            # d = 416: paired-workgroup 16x16x4 kernel (csrc/crossattn16p.hip); False = crossattn.hip
 USE_TRUNK_KERNELS = True     # row-resident fused trunk kernels (csrc/trunk*.hip) where the shapes allow; False = generic Linear
-# Opt-in variants, both measured SLOWER end to end than the default (csrc/trunk.hip, one 8-wave workgroup per CU) and
-# kept as tested alternatives (bench.py, 20 steps, 2 decode streams: default 122.5-122.8 ms / step; OCC4D_TRUNK4=1
-# 123.7; OCC4D_TRUNK4=1 OCC4D_TRUNK_CHAIN=1 123.8-124.4):
-# half-CU re-cut of the trunk kernels (csrc/trunk4.hip: 4-wave workgroups, two per CU)
+# Opt-in variant, measured SLOWER end to end than the default (csrc/trunk.hip, one 8-wave workgroup per CU) and kept as a
+# tested alternative (bench.py, 20 steps, 2 decode streams: default 122.5-122.8 ms / step; OCC4D_TRUNK4=1 123.7; DESIGN.md
+# 6c): half-CU re-cut of the trunk kernels (csrc/trunk4.hip: 4-wave workgroups, two per CU)
 USE_TRUNK4 = os.environ.get('OCC4D_TRUNK4', '0') != '0'
-# decoder trunk between two cross-attention layers as ONE kernel with the activation resident in registers
-# (occ4d_trunk_chain_f32, csrc/trunk4.hip; needs USE_TRUNK4); off = one kernel per layer
-USE_TRUNK_CHAIN = os.environ.get('OCC4D_TRUNK_CHAIN', '0') != '0'
-# 'f32' (default): every GEMM exact fp32 on v_mfma_f32_32x32x2_f32.  'bf16x3': the attention-logit GEMM of the
-# fused kernel on split-bf16 MFMAs (occ4d_pt_cross_attn_bf16x3_f32); everything else unchanged.  Opt-in.
+# 'f32' (default): every GEMM exact fp32.  'bf16x3': the attention-logit GEMM of the fused kernel on split-bf16 MFMAs
+# (occ4d_pt_cross_attn_bf16x3_f32); everything else unchanged.  Opt-in.
 LOGIT_PRECISION = os.environ.get('OCC4D_LOGIT_PRECISION', 'f32')
+
+
+def path_flags():
+    """The OCC4D_PATH_* flags (include/occ4d.h) the switches above select for the library's path-level entry points."""
+    assert LOGIT_PRECISION in ('f32', 'bf16x3'), LOGIT_PRECISION
+    L = ops._lib
+    f = L.PATH_DEFAULT
+    if not USE_FUSED_ATTENTION:
+        f |= L.PATH_UNFUSED
+    if not USE_ATTN16:
+        f |= L.PATH_FIRST_GEN
+    if LOGIT_PRECISION == 'bf16x3':
+        f |= L.PATH_BF16X3
+    if not USE_TRUNK_KERNELS:
+        f |= L.PATH_GENERIC_LINEAR
+    if USE_TRUNK4:
+        f |= L.PATH_TRUNK4
+    return f
 
 
 # Derived-weight caches (merged matrices, per-scene tables, bf16 packs) are keyed on (data_ptr, _version) of the
@@ -56,26 +67,6 @@ def invalidate_weight_caches():
 
 def weights_epoch():
     return _WEIGHTS_EPOCH[0]
-
-
-def trunk_pack(weight, kind='rows'):
-    """Stage-packed copy of a 416-input weight for the row-resident trunk kernels (ops.pack_trunk_rows / _cols),
-    cached on the tensor object while (storage, version, weights epoch) are unchanged; None when the kernels do
-    not apply to this shape."""
-    if weight.shape[1] != ops.TRUNK_WIDTH or weight.shape[0] % 32 != 0 or not weight.is_cuda:
-        return None
-    if kind == 'cols' and weight.shape[0] != ops.TRUNK_WIDTH:
-        return None
-    key = (weights_epoch(), weight.data_ptr(), weight._version, kind, USE_TRUNK4)
-    hit = getattr(weight, '_occ4d_trunk_pack', None)
-    if hit is not None and hit[0] == key:
-        return hit[1]
-    if USE_TRUNK4:
-        packed = ops.pack_trunk4_rows(weight) if kind == 'rows' else ops.pack_trunk4_cols(weight)
-    else:
-        packed = ops.pack_trunk_rows(weight) if kind == 'rows' else ops.pack_trunk_cols(weight)
-    weight._occ4d_trunk_pack = (key, packed)
-    return packed
 
 
 CHECKPOINT_ATTENTION = True   # training: cross-attention layers recompute their pair tensors in backward (below)
@@ -229,74 +220,79 @@ class PointTransformerLayer(nn.Module):
                                      nn.Linear(pos_mlp_hidden_dim, dim))
         self.attn_mlp = nn.Sequential(nn.Linear(dim, dim * attn_mlp_hidden_mult), nn.ReLU(),
                                       nn.Linear(dim * attn_mlp_hidden_mult, dim))
-        self._merged = {}
-        self._scene = None
+        self._path = {}
 
     # -- derived weights ---------------------------------------------------------------
-    def _params_key(self, pre):
-        ps = list(self.parameters()) + ([pre.weight, pre.bias] if pre is not None else [])
-        return (weights_epoch(), LOGIT_PRECISION, USE_ATTN16P, USE_TRUNK4) + tuple((p.data_ptr(), p._version) for p in ps)
+    def _params_key(self, *extra):
+        ps = list(self.parameters()) + [p for m in extra if m is not None for p in (m.weight, m.bias)]
+        return (weights_epoch(),) + tuple((p.data_ptr(), p._version) for p in ps)
+
+    def path_weights(self, cross, pre=None, post=None):
+        """occ4d_pt_layer_weights over this layer's parameters in the reference's layout (+ `pre` = the block's layer1,
+        `post` = its layer3), and the library's prepared buffer for them (merged matrices of refactoring (i), formed in
+        fp64 and rounded once, and the stage-packed weight streams: occ4d_pt_layer_prepare_f32).  Cached while the
+        parameters (storage, version, weights epoch) and the kernel-selection flags are unchanged."""
+        flags = path_flags()
+        slot = (bool(cross), pre is not None, post is not None)
+        key = (flags,) + self._params_key(pre, post)
+        hit = self._path.get(slot)
+        if hit is not None and hit[0] == key:
+            return hit[1], hit[2], flags
+        L = ops._lib
+        keep = []
+
+        def dp(t):
+            t = t.detach()
+            if not t.is_contiguous():
+                t = t.contiguous()
+            ops._dev(t, name='parameter')                  # (RuntimeError for CPU tensors: there is no fallback path)
+            keep.append(t)
+            return t.data_ptr()
+        w = L.PtLayerWeights(dim=self.dim, dim2=self.dim2 if cross else self.dim, pos_hidden=self.pos_mlp[0].out_features,
+                             cross=int(bool(cross)), d_in=pre.in_features if pre is not None else self.dim,
+                             d_out=post.out_features if post is not None else self.dim)
+        w.to_q, w.to_k, w.to_v = dp(self.to_q.weight), dp(self.to_k.weight), dp(self.to_v.weight)
+        w.pos0_w, w.pos0_b = dp(self.pos_mlp[0].weight), dp(self.pos_mlp[0].bias)
+        w.pos2_w, w.pos2_b = dp(self.pos_mlp[2].weight), dp(self.pos_mlp[2].bias)
+        w.attn0_w, w.attn0_b = dp(self.attn_mlp[0].weight), dp(self.attn_mlp[0].bias)
+        w.attn2_w, w.attn2_b = dp(self.attn_mlp[2].weight), dp(self.attn_mlp[2].bias)
+        if pre is not None:
+            w.pre_w, w.pre_b = dp(pre.weight), dp(pre.bias)
+        if post is not None:
+            w.post_w, w.post_b = dp(post.weight), dp(post.bias)
+        w._keep = keep
+        prepared = ops.pt_layer_prepare(w, flags, self.to_q.weight.device)
+        self._path[slot] = (key, w, prepared)
+        return w, prepared, flags
 
     def merged_weights(self, pre=None):
-        """fp64-merged matrices of refactoring (i); `pre` is an optional nn.Linear applied to
-        the query features just before this layer (PointTransformerBlock.layer1), folded in."""
-        key = self._params_key(pre)
-        hit = self._merged.get(pre is not None)
-        if hit is not None and hit[0] == key:
-            return hit[1]
-        f64 = torch.float64
-        W1 = self.attn_mlp[0].weight.detach().to(f64)
-        b1 = self.attn_mlp[0].bias.detach().to(f64)
-        P2 = self.pos_mlp[2].weight.detach().to(f64)
-        c2 = self.pos_mlp[2].bias.detach().to(f64)
-        mm = autograd.matmul64               # fp64 products on the library (occ4d_matmul_f64)
-        wq = mm(W1, self.to_q.weight.detach().to(f64))
-        bq = mm(W1, c2) + b1
-        if pre is not None:
-            bq = bq + mm(wq, pre.bias.detach().to(f64))
-            wq = mm(wq, pre.weight.detach().to(f64))
-        m = dict(
-            wq=wq.float().contiguous(), bq=bq.float().contiguous(),
-            wk=mm(W1, self.to_k.weight.detach().to(f64)).float().contiguous(),
-            wp=mm(W1, P2).float().contiguous())
-        m['wq_packed'] = trunk_pack(m['wq'])          # (2D, 416) query projection on the row-resident kernel
-        if self.dim == 416 and self.pos_mlp[0].out_features == 32 and self.attn_mlp[2].weight.is_cuda:
-            pack = ops.pack_attn16p_stream if USE_ATTN16P else ops.pack_attn16_stream
-            m['attn16p' if USE_ATTN16P else 'attn16_stream'] = pack(
-                self.attn_mlp[2].weight, self.attn_mlp[2].bias, m['wp'], self.pos_mlp[2].weight, self.pos_mlp[2].bias)
-        m['w2_bf16x3'] = m['wp_bf16x3'] = None
-        if LOGIT_PRECISION == 'bf16x3' and self.attn_mlp[2].weight.shape[1] % 32 == 0:     # (opt-in mode only)
-            m['w2_bf16x3'] = ops.pack_w2_bf16x3(self.attn_mlp[2].weight)
-            m['wp_bf16x3'] = ops.pack_w2_bf16x3(m['wp']) if m['wp'].shape[1] == 32 else None
-        self._merged[pre is not None] = (key, m)
-        return m
-
-    def scene_tables(self, x2, owner=None):
-        """Per-scene tables (W1 Wk) x2 and Wv x2.  Cached while `owner` (the tensor object, or tuple of
-        tensor objects, the caller keeps alive for the scene), the feature tensor x2's storage / version and the
-        weights are unchanged -- the reference recomputes them on every forward call."""
-        owners = owner if isinstance(owner, tuple) else (owner,)
-        key = (tuple((id(o), None if o is None else o._version) for o in owners),
-               (x2.data_ptr(), x2._version, tuple(x2.shape)), self._params_key(None))
-        if owner is not None and self._scene is not None and self._scene[0] == key \
-                and all(a is b for a, b in zip(self._scene[1], owners)):
-            return self._scene[2]
-        m = self.merged_weights(None)
-        # third entry: the value table with pos_mlp[2].bias folded in (v_j + pe_ij = (Wv f_j + c2) + P2 r_ij), which
-        # is what the paired-workgroup kernel reads (its GEMM3 then starts from 0: no VALU instruction for the bias)
-        tabs = (ops.linear(x2, m['wk']), ops.linear(x2, self.to_v.weight),
-                ops.linear(x2, self.to_v.weight, self.pos_mlp[2].bias))
-        if owner is not None:
-            self._scene = (key, owners, tabs)   # holds the owners alive: their addresses cannot be recycled
-        return tabs
+        """The fp64-merged matrices of refactoring (i) as the LIBRARY forms them (views of the prepared buffer of
+        occ4d_pt_layer_prepare_f32, layout of csrc/path.hip): wq = (W1 Wq [L1]), bq = W1 c2 + b1 [+ (W1 Wq) l1_b],
+        wk = W1 Wk, wp = W1 P2.  For inspection and tests (tests/test_gpu_contracts.py compares them with the as-written
+        expression in fp64); the forward passes never read them from Python."""
+        w, prepared, _ = self.path_weights(cross=True, pre=pre)
+        D, D2, h = self.dim, self.dim2, self.pos_mlp[0].out_features
+        kq = pre.in_features if pre is not None else D
+        up = lambda n: (n + 63) // 64 * 64          # noqa: E731   (ALIGN of csrc/path.hip)
+        o, out = 0, {}
+        for name, shape in (('wq', (2 * D, kq)), ('bq', (2 * D,)), ('wk', (2 * D, D2)), ('wp', (2 * D, h))):
+            n = 1
+            for v in shape:
+                n *= v
+            out[name] = prepared[o:o + n].view(*shape)
+            o += up(n)
+        return out
 
     # -- forward -----------------------------------------------------------------------
     def forward(self, x, pos, x2=None, pos2=None):
         """x (B,N,D), pos (B,N,3) [, x2 (B,M,D2), pos2 (B,M,3)] -> agg (B,N,D)."""
-        return self._forward(x, pos, x2, pos2, pre=None, scene_owner=None)
+        return self._forward(x, pos, x2, pos2, pre=None)
 
-    def _forward(self, x, pos, x2, pos2, pre, scene_owner, knn_idx=None, aq_pre=None):
-        if needs_grad(self, x, x2) or (pre is not None and needs_grad(pre)):
+    def _forward(self, x, pos, x2, pos2, pre, knn_idx=None, post=None):
+        """`pre` / `post`: the Linear layers of the PointTransformerBlock around this layer (layer1, layer3 + residual).
+        Inference: ONE library call per cloud runs the whole block (occ4d_pt_layer_fwd_f32) and the block's output is
+        returned.  Training (autograd recording): the differentiable kernels; `post` is left to the caller."""
+        if needs_grad(self, x, x2) or (pre is not None and needs_grad(pre)) or (post is not None and needs_grad(post)):
             out = []
             for b in range(x.shape[0]):
                 y = x[b] if pre is None else autograd.linear(x[b], pre)
@@ -318,12 +314,16 @@ class PointTransformerLayer(nn.Module):
             return ops.stack_batch(out)
         out = []
         for b in range(x.shape[0]):
-            xb2 = None if x2 is None else x2[b]
-            pb2 = None if pos2 is None else pos2[b]
-            out.append(self._forward_one(x[b], pos[b], xb2, pb2, pre, scene_owner,
-                                         None if knn_idx is None else knn_idx[b],
-                                         None if aq_pre is None else aq_pre[b]))
+            out.append(self._forward_one(x[b], pos[b], None if x2 is None else x2[b], None if pos2 is None else pos2[b],
+                                         pre, post, None if knn_idx is None else knn_idx[b]))
         return ops.stack_batch(out)
+
+    def _forward_one(self, x, pos, x2, pos2, pre=None, post=None, knn_idx=None):
+        """Inference forward of one cloud through the library's path-level entry point."""
+        w, prepared, flags = self.path_weights(cross=x2 is not None, pre=pre, post=post)
+        if knn_idx is not None and knn_idx.dtype != torch.int32:
+            knn_idx = knn_idx.to(torch.int32)
+        return ops.pt_layer_fwd(w, prepared, x, pos, x2, pos2, self.num_neighbors, flags, knn_idx=knn_idx)
 
     def forward_train_merged(self, x, pos, x2, pos2, idx=None):
         """Differentiable cross-attention for one cloud in the MERGED form of DESIGN.md 4 (i): the query / key halves of
@@ -374,61 +374,3 @@ class PointTransformerLayer(nn.Module):
         h = autograd.linear(a, self.attn_mlp[0], relu_out=True)
         logits = autograd.linear(h, self.attn_mlp[2])
         return autograd.SoftmaxAggFn.apply(logits, vf, pe, idx)
-
-    def _forward_one(self, x, pos, x2, pos2, pre, scene_owner, knn_idx=None, aq_pre=None):
-        """`aq_pre` (n, 2D): the merged query projection (W1 Wq L1) x + bias when the caller already has it (the decoder's
-        trunk chain writes it while the activation is still in registers)."""
-        K = self.num_neighbors
-        if x2 is None:
-            # self-attention: queries, keys and values all come from the (post-`pre`) features
-            y = x if pre is None else ops.linear(x, pre.weight, pre.bias)
-            m = self.merged_weights(None)
-            kt, vt = ops.linear(y, m['wk']), ops.linear(y, self.to_v.weight)
-            vtc = ops.linear(y, self.to_v.weight, self.pos_mlp[2].bias) if m.get('attn16p') is not None else None
-            aq_all = ops.linear(y, m['wq'], m['bq'])
-            pos2 = pos
-        else:
-            m = self.merged_weights(pre)
-            kt, vt, vtc = self.scene_tables(x2, owner=scene_owner)
-            aq_all = None
-        n = x.shape[0]
-        agg = torch.empty((n, self.dim), dtype=torch.float32, device=x.device)
-        P1, c1 = self.pos_mlp[0].weight, self.pos_mlp[0].bias
-        P2, c2 = self.pos_mlp[2].weight, self.pos_mlp[2].bias
-        W2, b2 = self.attn_mlp[2].weight, self.attn_mlp[2].bias
-        for lo in range(0, n, _PAIR_CHUNK):
-            hi = min(n, lo + _PAIR_CHUNK)
-            if knn_idx is not None:      # the caller already has kNN_torch(pos, pos2, K) (shared by the decoder's layers)
-                idx = knn_idx[lo:hi]
-            else:
-                idx = ops.knn(pos[lo:hi], pos2, K, metric=0)                    # (c,K) int32
-            if aq_pre is not None:
-                aq = aq_pre[lo:hi]
-            elif aq_all is not None:
-                aq = aq_all[lo:hi]
-            elif m.get('wq_packed') is not None and USE_TRUNK_KERNELS:
-                aq = ops.rowlin(x[lo:hi], m['wq_packed'], m['bq'], m['wq'].shape[0])
-            else:
-                aq = ops.linear(x[lo:hi], m['wq'], m['bq'])
-            if (self.dim in ops.FUSED_ATTN_DIMS and K <= ops.FUSED_ATTN_MAX_K
-                    and self.pos_mlp[0].out_features == 32 and USE_FUSED_ATTENTION):
-                assert LOGIT_PRECISION in ('f32', 'bf16x3'), LOGIT_PRECISION
-                if LOGIT_PRECISION == 'f32' and USE_ATTN16 and USE_ATTN16P and m.get('attn16p') is not None:
-                    ops.pt_cross_attn16p(aq, pos[lo:hi], pos2, idx, kt, vtc, P1, c1, m['attn16p'], out=agg[lo:hi])
-                    continue
-                if LOGIT_PRECISION == 'f32' and USE_ATTN16 and m.get('attn16_stream') is not None:
-                    ops.pt_cross_attn16(aq, pos[lo:hi], pos2, idx, kt, vt, P1, c1, m['attn16_stream'], out=agg[lo:hi])
-                    continue
-                ops.pt_cross_attn(aq, pos[lo:hi], pos2, idx, kt, vt, P1, c1, m['wp'], W2, b2, P2, c2,
-                                  out=agg[lo:hi],
-                                  w2_packed=m['w2_bf16x3'] if LOGIT_PRECISION == 'bf16x3' else None,
-                                  wp_packed=m['wp_bf16x3'] if LOGIT_PRECISION == 'bf16x3' else None)
-                continue
-            r = ops.pt_pos_hidden(pos[lo:hi], pos2, idx, P1, c1)                # (c*K,32)
-            h = ops.linear(r, m['wp'], relu_out=True, add_rows=aq, add_div=K,
-                           sub_rows=kt, sub_idx=idx.view(-1))                   # (c*K,2D)
-            logits = ops.linear(h, W2, b2)                                      # (c*K,D)
-            del h
-            pe = ops.linear(r, P2, c2)                                          # (c*K,D)
-            ops.pt_softmax_agg(logits, vt, pe, idx, out=agg[lo:hi])
-        return agg

@@ -184,6 +184,13 @@ def main():
         save('g13_sampler_' + case['name'], **{k: v.numpy() for k, v in zip(
             ['solid_input', 'air_input', 'solid_target', 'air_target', 'solid_sbs', 'air_sbs'], res)})
 
+    g14(ref, gc.LOSS_CASES)
+
+    regimes(ref)
+
+
+@torch.no_grad()
+def g14(ref, cases):
     # G14: training losses.  The REAL pipeline.MyTrainPipeline.handle_frame (pre-loss squashing, pipeline.py:198-212)
     # and loss.MyLosses.per_example / entire_batch (loss.py:50-294) run on seeded raw decoder outputs: the point
     # sampler and the implicit network are replaced by stand-ins that hand back the seeded tensors (with the stale
@@ -195,7 +202,7 @@ def main():
 
         def warning(self, *a, **k):
             pass
-    for case in gc.LOSS_CASES:
+    for case in cases:
         raw_np, target_np = gc.loss_inputs(case)
         T, B = raw_np.shape[:2]
         with torch.enable_grad():
@@ -233,7 +240,6 @@ def main():
              terms=np.array([float(l_rgb), float(l_dens), float(l_segm), float(l_track)], dtype=np.float64),
              squashed=torch.stack(outs).detach().numpy()[:, :, ::16], grad=raw.grad.numpy())
 
-    regimes(ref)
 
 
 def _f64(sd):
@@ -289,6 +295,26 @@ def regimes(ref):
             out, pen = net(conv(q), conv(abstract), conv(fglob), None)
             res['output' + tag], res['penult' + tag] = out.numpy(), pen.numpy()[:, ::8]
         save('g8r_dec_' + case['name'], **res)
+
+    # G4b: DownTransition with BatchNorm in eval mode (running statistics);  G8s: decoder with the swish activation
+    for case in gc.DOWN_BATCHNORM_CASES:
+        x, pos, sd = gc.down_inputs(case)
+        dt = mods.DownTransition(case['d_in'], case['d_out'], factor=3, knn_k=case['k'], norm_type=case['norm'],
+                                 fps_random_start=False)
+        dt.load_state_dict(sd)
+        dt.eval()
+        z, p_sub = dt(t(x)[None], t(pos)[None])
+        save('g4_down_' + case['name'], z=z[0].numpy(), p_sub=p_sub[0].numpy())
+    for case in gc.DEC_SWISH_CASES:
+        q, abstract, fglob, ia, sd = gc.dec_inputs(case)
+        net = imp.LocalPclResnetFC(**ia)
+        net.load_state_dict(sd)
+        net.eval()
+        out, pen = net(t(q), t(abstract), t(fglob), None)
+        save('g8_dec_' + case['name'], output=out.numpy(), penult=pen.numpy()[:, ::8])
+
+    # G14c: colour losses of the 'hsv' / 'bins' colour modes (loss.py:85-149)
+    g14(ref, gc.LOSS_COLOR_CASES)
 
     # G10p: perform_inference end to end on zero-padded clouds
     for case in gc.INFER_PAD_CASES:

@@ -165,8 +165,11 @@ def down_transition(sd, x, p, factor, knn_k, norm_type='none', return_inds=False
     y = _lin(sd, 'mlp.0', x.reshape(B * N, d_in))               # :152
     if norm_type == 'layer':
         y = F.layer_norm(y, (y.shape[-1],), sd['mlp.1.weight'], sd['mlp.1.bias'], 1e-5)
+    elif norm_type == 'batch':                                  # :98-102, eval mode (running statistics), eps 1e-3
+        y = F.batch_norm(y, sd['mlp.1.running_mean'], sd['mlp.1.running_var'], sd['mlp.1.weight'], sd['mlp.1.bias'],
+                         False, 0.0, 1e-3)
     elif norm_type != 'none':
-        raise ValueError(norm_type)   # 'batch' is unused by every published config
+        raise ValueError(norm_type)
     y = _relu(y)
     z = y[nn[:, 0]]                                             # :156-158
     for i in range(1, knn_k):

@@ -123,15 +123,27 @@ DOWN_CASES = [
 ]
 
 
+# Round 4: the BatchNorm variant of DownTransition (model/modules.py:98-102; a constructor option no published
+# configuration uses), in eval mode: running statistics as a trained checkpoint would carry them.
+DOWN_BATCHNORM_CASES = [
+    dict(name='batch_n200_72to144_k12', n=200, d_in=72, d_out=144, k=12, norm='batch', seed=43),
+]
+
+
 def down_inputs(case):
     rng = _rng(case['seed'])
     x = rng.normal(size=(case['n'], case['d_in'])).astype(np.float32)
     pos = _cloud(rng, case['n'])
     s = {'mlp.0.weight': (case['d_out'], case['d_in']), 'mlp.0.bias': (case['d_out'],)}
-    if case['norm'] == 'layer':
+    if case['norm'] in ('layer', 'batch'):
         s['mlp.1.weight'] = (case['d_out'],)
         s['mlp.1.bias'] = (case['d_out'],)
-    return x, pos, cfg.fill_state_dict(s, case['seed'] + 1000)
+    sd = cfg.fill_state_dict(s, case['seed'] + 1000)
+    if case['norm'] == 'batch':
+        sd['mlp.1.running_mean'] = torch.from_numpy((0.3 * rng.normal(size=(case['d_out'],))).astype(np.float32))
+        sd['mlp.1.running_var'] = torch.from_numpy(rng.uniform(0.05, 2.0, size=(case['d_out'],)).astype(np.float32))
+        sd['mlp.1.num_batches_tracked'] = torch.tensor(1234, dtype=torch.int64)
+    return x, pos, sd
 
 
 # ---------------------------------------------------------------- G5
@@ -209,6 +221,12 @@ DEC_CASES = [
 # Round 4 regimes: `attn_wscale` multiplies every rank-2 weight of the cross-attention layers (pt_blocks.*.layer2.*),
 # `fscale` the abstract features and the global embedding, `qscale` pushes the queries that many times outside the
 # query cuboid (inverse-distance weights 1 / (d + 1e-4) with large d, far neighbours for the attention).
+# Round 4: the reference's other activation option (model/implicit.py:46-64: swish = x * sigmoid(x))
+DEC_SWISH_CASES = [
+    dict(name='greater_m531_q256_swish', kind='greater', m=531, nq=256, seed=90, activation='swish'),
+    dict(name='carla_m2124_q256_swish', kind='carla', m=2124, nq=256, seed=91, activation='swish'),
+]
+
 DEC_REGIME_CASES = [
     dict(name='greater_m531_q256_w4', kind='greater', m=531, nq=256, seed=85, attn_wscale=4.0, fscale=4.0),
     dict(name='greater_m531_q256_w8', kind='greater', m=531, nq=256, seed=86, attn_wscale=8.0, fscale=4.0),
@@ -223,6 +241,7 @@ def dec_inputs(case):
     N(0, 0.5) features (the scale the encoder emits), N(0, 0.3) global embedding."""
     rng = _rng(case['seed'])
     _, ia, inf = cfg.model_args(case['kind'])
+    ia = dict(ia, activation=case.get('activation', 'relu'))
     (x0, x1), (y0, y1), (z0, z1) = cfg.input_cuboid(case['kind'])
     lo, hi = np.array([x0, y0, z0]), np.array([x1, y1, z1])
     xyz = rng.uniform(lo, hi, size=(case['m'], 3)).astype(np.float32)
@@ -390,6 +409,23 @@ LOSS_CASES = [
     dict(name='carla_segm', color_mode='rgb', d_out=18, frames=4, batch=1, n=311, seed=143,
          density_lw=1.0, color_lw=0.0, segmentation_lw=0.6, tracking_lw=0.0),
     dict(name='carla_all_terms', color_mode='rgb_nosigmoid', d_out=18, frames=2, batch=2, n=200, seed=144,
+         density_lw=0.7, color_lw=0.9, segmentation_lw=0.6, tracking_lw=0.3),
+]
+
+
+# Round 4: the colour losses of the reference's other two colour modes (loss.py:85-149; utils.get_track_idx: the tracking
+# logit sits at channel 15 / 10).  'hsv': 12 hue bins (CE / 2, only where saturation and value >= 0.2 and only when at
+# least 16 such points exist) + L1 on saturation and value; 'bins': 6 saturated colours + black / gray / white (CE / 3).
+LOSS_COLOR_CASES = [
+    dict(name='greater_hsv', color_mode='hsv', d_out=16, frames=3, batch=2, n=257, seed=145,
+         density_lw=1.0, color_lw=1.0, segmentation_lw=0.0, tracking_lw=1.0),
+    dict(name='carla_hsv_segm', color_mode='hsv', d_out=29, frames=2, batch=1, n=300, seed=146,
+         density_lw=0.7, color_lw=0.9, segmentation_lw=0.6, tracking_lw=0.3),
+    dict(name='hsv_too_few_hues', color_mode='hsv', d_out=16, frames=2, batch=1, n=24, seed=147,
+         density_lw=1.0, color_lw=1.0, segmentation_lw=0.0, tracking_lw=0.0),
+    dict(name='greater_bins', color_mode='bins', d_out=11, frames=3, batch=2, n=257, seed=148,
+         density_lw=1.0, color_lw=1.0, segmentation_lw=0.0, tracking_lw=1.0),
+    dict(name='carla_bins_segm', color_mode='bins', d_out=24, frames=2, batch=1, n=300, seed=149,
          density_lw=0.7, color_lw=0.9, segmentation_lw=0.6, tracking_lw=0.3),
 ]
 

@@ -50,6 +50,34 @@ def _fresh_copy(ia, dec):
     return fresh
 
 
+def test_merged_weights_of_the_library_are_exact_in_fp64():
+    """Refactoring (i) as occ4d_pt_layer_prepare_f32 forms it (fp64 products on the device, rounded once):
+    W1 (q - k + pe) + b1 == (W1 Wq L1) x + (W1 Wq l1b + W1 c2 + b1) - (W1 Wk) f + (W1 P2) r, checked against the as-written
+    expression evaluated in fp64 on the host from the same fp32 parameters; every merged entry is the correctly rounded
+    fp64 product (<= 1 ulp from an independent fp64 evaluation)."""
+    torch.manual_seed(0)
+    blk = pk.modules.PointTransformerBlock(416, 416, 416, num_neighbors=4, d_hidden_abstract=288).cuda()
+    lyr = blk.layer2
+    ref = pk.modules.PointTransformerBlock(416, 416, 416, num_neighbors=4, d_hidden_abstract=288).double()
+    ref.load_state_dict({k: v.detach().cpu().double() for k, v in blk.state_dict().items()})
+    x, f, r = torch.randn(5, 416).double(), torch.randn(5, 288).double(), torch.relu(torch.randn(5, 32)).double()
+    rl = ref.layer2
+    want = rl.attn_mlp[0](rl.to_q(ref.layer1(x)) - rl.to_k(f) + rl.pos_mlp[2](r))
+    m = {k: v.cpu() for k, v in lyr.merged_weights(pre=blk.layer1).items()}
+    got = x @ m['wq'].double().T + m['bq'].double() - f @ m['wk'].double().T + r @ m['wp'].double().T
+    assert float((got - want).abs().max()) < 2e-5
+    W1 = rl.attn_mlp[0].weight
+    exact = dict(wq=W1 @ rl.to_q.weight @ ref.layer1.weight, wk=W1 @ rl.to_k.weight, wp=W1 @ rl.pos_mlp[2].weight,
+                 bq=W1 @ rl.pos_mlp[2].bias + rl.attn_mlp[0].bias + (W1 @ rl.to_q.weight) @ ref.layer1.bias)
+    for name, e in exact.items():
+        ulp = (torch.abs(e.float()) * 2.0 ** -23).double()
+        assert bool(((m[name].double() - e).abs() <= 1.01 * ulp + 1e-12).all()), name
+    # without layer1 folded in (self-attention uses this form)
+    m0 = {k: v.cpu() for k, v in lyr.merged_weights(pre=None).items()}
+    e0 = W1 @ rl.to_q.weight
+    assert bool(((m0['wq'].double() - e0).abs() <= 1.01 * (e0.float().abs() * 2.0 ** -23).double() + 1e-12).all())
+
+
 def test_merged_weight_caches_follow_untracked_parameter_updates():
     """`p.data.mul_()` does not move p._version: the caches keyed on it alone would serve stale merged
     matrices.  invalidate_weight_caches() (what TrainStep / GraphedTrainStep call) must rebuild them."""
@@ -158,7 +186,7 @@ def test_linear_on_aligned_strided_view_with_k_not_multiple_of_4():
 
 # ---------------------------------------------------------------- training losses (G14: produced by the reference's own code)
 @pytest.mark.parametrize('static_shapes', [False, True], ids=['eager', 'static'])
-@pytest.mark.parametrize('case', gc.LOSS_CASES, ids=lambda c: c['name'])
+@pytest.mark.parametrize('case', gc.LOSS_CASES + gc.LOSS_COLOR_CASES, ids=lambda c: c['name'])
 def test_g14_loss_on_device(case, static_shapes):
     g = load_golden('g14_loss_' + case['name'])
     raw_np, target_np = gc.loss_inputs(case)

@@ -143,11 +143,11 @@ def test_pt_block(pk, case):
     close(z[0], load_golden('g3_ptb_' + case['name'])['z'])
 
 
-@pytest.mark.parametrize('case', gc.DOWN_CASES, ids=lambda c: c['name'])
+@pytest.mark.parametrize('case', gc.DOWN_CASES + gc.DOWN_BATCHNORM_CASES, ids=lambda c: c['name'])
 def test_down_transition(pk, case):
     x, pos, sd = gc.down_inputs(case)
     dt = pk.modules.DownTransition(case['d_in'], case['d_out'], factor=3, knn_k=case['k'], norm_type=case['norm'],
-                                   fps_random_start=False).cuda()
+                                   fps_random_start=False).cuda().eval()
     dt.load_state_dict(sd)
     with torch.no_grad():
         z, p_sub = dt(dev(x)[None], dev(pos)[None])
@@ -180,7 +180,7 @@ def test_posenc(pk):
     assert np.array_equal(enc[:, :4].cpu().numpy(), g['points'])
 
 
-@pytest.mark.parametrize('case', gc.DEC_CASES, ids=lambda c: c['name'])
+@pytest.mark.parametrize('case', gc.DEC_CASES + gc.DEC_SWISH_CASES, ids=lambda c: c['name'])
 def test_decoder(pk, case):
     q, abstract, fglob, ia, sd = gc.dec_inputs(case)
     net = pk.implicit.LocalPclResnetFC(**ia).cuda().eval()
@@ -194,41 +194,39 @@ def test_decoder(pk, case):
     assert out_b.shape == (1,) + tuple(out.shape) and torch.equal(out_b[0], out)
 
 
-@pytest.mark.parametrize('variant', ['trunk4', 'trunk4+chain', 'attn16', 'generic_trunk'])
+@pytest.mark.parametrize('variant', ['trunk4', 'generic_trunk', 'first_gen', 'unfused'])
 @pytest.mark.parametrize('case', gc.DEC_CASES, ids=lambda c: c['name'])
 def test_decoder_kernel_variants(pk, case, variant):
-    """The opt-in / fallback kernel selections of the decoder against the same golden vectors (G8): half-CU trunk kernels
-    (csrc/trunk4.hip), the trunk chain kernel (occ4d_trunk_chain_f32), the second-generation attention kernel
-    (csrc/crossattn16.hip) and the generic Linear kernels in place of the row-resident ones."""
+    """The opt-in / fallback kernel selections of the decoder (OCC4D_PATH_* flags of the library's path-level entry
+    points) against the same golden vectors (G8): half-CU trunk kernels (csrc/trunk4.hip), the generic Linear kernels in
+    place of the row-resident ones, the first-generation attention kernel (csrc/crossattn.hip) and the unfused attention
+    chain.  The library's launch-event hook tells which kernels really ran."""
     ptl = pk.point_transformer_layer
-    old = (ptl.USE_TRUNK4, ptl.USE_TRUNK_CHAIN, ptl.USE_ATTN16P, ptl.USE_TRUNK_KERNELS)
-    ptl.USE_TRUNK4 = variant.startswith('trunk4')
-    ptl.USE_TRUNK_CHAIN = variant == 'trunk4+chain'
-    ptl.USE_ATTN16P = variant != 'attn16'
+    old = (ptl.USE_TRUNK4, ptl.USE_TRUNK_KERNELS, ptl.USE_ATTN16, ptl.USE_FUSED_ATTENTION)
+    ptl.USE_TRUNK4 = variant == 'trunk4'
     ptl.USE_TRUNK_KERNELS = variant != 'generic_trunk'
+    ptl.USE_ATTN16 = variant != 'first_gen'
+    ptl.USE_FUSED_ATTENTION = variant != 'unfused'
     try:
         q, abstract, fglob, ia, sd = gc.dec_inputs(case)
         net = pk.implicit.LocalPclResnetFC(**ia).cuda().eval()
         net.load_state_dict(sd)
-        launches = []
-
-        class Spy:                       # (the hook bench.py's roofline leg uses: ops.set_kernel_timer)
-            @staticmethod
-            def want(name, **shape):
-                launches.append(name)
-                return False
-        pk.ops.set_kernel_timer(Spy)
-        with torch.no_grad():
-            out, pen = net(dev(q), dev(abstract), dev(fglob), None)
+        counts = {}
+        for fam in ('resblock', 'cross_attn'):
+            timer = pk.ops.KernelTimer(lambda name, fam=fam, **shape: name == fam)
+            pk.ops.set_kernel_timer(timer)
+            with torch.no_grad():
+                out, pen = net(dev(q), dev(abstract), dev(fglob), None)
+            pk.ops.set_kernel_timer(None)
+            counts[fam] = timer.summary().get(fam, dict(launches=0))['launches']
     finally:
         pk.ops.set_kernel_timer(None)
-        (ptl.USE_TRUNK4, ptl.USE_TRUNK_CHAIN, ptl.USE_ATTN16P, ptl.USE_TRUNK_KERNELS) = old
+        (ptl.USE_TRUNK4, ptl.USE_TRUNK_KERNELS, ptl.USE_ATTN16, ptl.USE_FUSED_ATTENTION) = old
     g = load_golden('g8_dec_' + case['name'])
     close(out, g['output'])
     close(pen[:, ::8], g['penult'])
-    if ia.get('local_mode', 'attention') == 'attention' and ia.get('d_hidden') == 416:
-        assert ('trunk_chain' in launches) == (variant == 'trunk4+chain')
-        assert ('resblock' in launches) == (variant in ('trunk4', 'attn16'))
+    assert counts['resblock'] == (0 if variant == 'generic_trunk' else ia['n_blocks'])      # fused residual blocks
+    assert counts['cross_attn'] == (0 if variant == 'unfused' else ia['cross_attn_layers'])   # fused attention launches
 
 
 def test_decoder_batch_split_invariance(pk):
@@ -294,14 +292,13 @@ def test_perform_inference(pk, case):
                                           (1, 10, 416, 288), (14, 531, 288, 288), (5, 1, 416, 288),
                                           (14, 8, 416, 288), (14, 10, 416, 288), (14, 17, 416, 288), (14, 18, 416, 288),
                                           (14, 19, 416, 288), (11, 2, 416, 288), (2, 4000, 416, 288)])
-@pytest.mark.parametrize('generation', ['attn16p', 'attn16', 'first'])
+@pytest.mark.parametrize('generation', ['attn16p', 'first'])
 def test_fused_attention_matches_unfused_chain(pk, k, n, dim, dim2, generation):
     """The fused kernels (9 queries x 14 rows packed per workgroup, masked slots for k < 14, ragged
     tail for n % 9 != 0) against the unfused kernel chain on the same inputs: the paired-workgroup 16 x 16
-    MFMA kernel (crossattn16p.hip, d = 416), its one-workgroup-per-CU predecessor (crossattn16.hip) and the
-    first-generation 32 x 32 kernel (crossattn.hip, d = 288 / 416)."""
+    MFMA kernel (crossattn16p.hip, d = 416) and the first-generation 32 x 32 kernel (crossattn.hip, d = 288 / 416)."""
     if generation != 'first' and dim != 416:
-        pytest.skip('crossattn16*.hip are built for d = 416')
+        pytest.skip('crossattn16p.hip is built for d = 416')
     rng = np.random.default_rng(1000 * k + n)
     m = 76
     x = rng.normal(size=(n, dim)).astype(np.float32)
@@ -315,7 +312,6 @@ def test_fused_attention_matches_unfused_chain(pk, k, n, dim, dim2, generation):
     args = (dev(x)[None], dev(pos)[None], dev(x2)[None], dev(pos2)[None])
     with torch.no_grad():
         ptl.USE_ATTN16 = generation != 'first'
-        old_p, ptl.USE_ATTN16P = ptl.USE_ATTN16P, generation == 'attn16p'
         try:
             fused = layer(*args)[0]
             ptl.USE_FUSED_ATTENTION = False
@@ -323,7 +319,6 @@ def test_fused_attention_matches_unfused_chain(pk, k, n, dim, dim2, generation):
         finally:
             ptl.USE_FUSED_ATTENTION = True
             ptl.USE_ATTN16 = True
-            ptl.USE_ATTN16P = old_p
     assert torch.isfinite(fused).all()
     close(fused, chain, 2e-5)
 

@@ -51,23 +51,22 @@ def bf16x3_bound(fp32_bound, ref64):
     return max(fp32_bound, 2.0 ** -13 * float(np.abs(ref64).max()))
 
 
-ATTN_PATHS = ['attn16p', 'attn16', 'first', 'chain', 'bf16x3']
+ATTN_PATHS = ['attn16p', 'first', 'chain', 'bf16x3']
 
 
 @contextlib.contextmanager
 def attention_path(pk, which):
-    """Selects the kernel generation the inference layer takes: 'attn16p' (default, csrc/crossattn16p.hip), 'attn16'
-    (crossattn16.hip), 'first' (crossattn.hip), 'chain' (unfused kernels), 'bf16x3' (split-bf16 logits, crossattn.hip)."""
+    """Selects the kernel generation the inference layer takes: 'attn16p' (default, csrc/crossattn16p.hip), 'first'
+    (crossattn.hip), 'chain' (unfused kernels), 'bf16x3' (split-bf16 logits, crossattn.hip)."""
     ptl = pk.point_transformer_layer
-    old = (ptl.USE_ATTN16, ptl.USE_ATTN16P, ptl.USE_FUSED_ATTENTION, ptl.LOGIT_PRECISION)
-    ptl.USE_ATTN16 = which in ('attn16p', 'attn16')
-    ptl.USE_ATTN16P = which == 'attn16p'
+    old = (ptl.USE_ATTN16, ptl.USE_FUSED_ATTENTION, ptl.LOGIT_PRECISION)
+    ptl.USE_ATTN16 = which == 'attn16p'
     ptl.USE_FUSED_ATTENTION = which != 'chain'
     ptl.LOGIT_PRECISION = 'bf16x3' if which == 'bf16x3' else 'f32'
     try:
         yield
     finally:
-        (ptl.USE_ATTN16, ptl.USE_ATTN16P, ptl.USE_FUSED_ATTENTION, ptl.LOGIT_PRECISION) = old
+        (ptl.USE_ATTN16, ptl.USE_FUSED_ATTENTION, ptl.LOGIT_PRECISION) = old
 
 
 # ------------------------------------------------------------------ G2r: one attention layer
@@ -76,8 +75,8 @@ def attention_path(pk, which):
 def test_pt_layer_regimes(pk, case, path):
     if case['dim'] not in pk.ops.FUSED_ATTN_DIMS and path != 'chain':
         pytest.skip('encoder widths run the unfused chain only')
-    if case['dim'] != 416 and path in ('attn16p', 'attn16'):
-        pytest.skip('crossattn16*.hip are built for d = 416')
+    if case['dim'] != 416 and path == 'attn16p':
+        pytest.skip('crossattn16p.hip is built for d = 416')
     x, pos, x2, pos2, sd = gc.ptl_inputs(case)
     layer = pk.point_transformer_layer.PointTransformerLayer(case['dim'], num_neighbors=case['k'],
                                                              dim2=case.get('dim2')).cuda()
@@ -133,22 +132,21 @@ def test_geometry_of_zero_padded_clouds_is_the_restated_torch_cluster(pk, case):
 
 
 # ------------------------------------------------------------------ G8r: decoder
-DEC_VARIANTS = ['default', 'trunk4', 'trunk4+chain', 'attn16', 'generic_trunk', 'first', 'chain', 'bf16x3']
+DEC_VARIANTS = ['default', 'trunk4', 'generic_trunk', 'first', 'chain', 'bf16x3']
 
 
 @contextlib.contextmanager
 def decoder_variant(pk, variant):
     ptl = pk.point_transformer_layer
-    old = (ptl.USE_TRUNK4, ptl.USE_TRUNK_CHAIN, ptl.USE_TRUNK_KERNELS)
-    ptl.USE_TRUNK4 = variant.startswith('trunk4')
-    ptl.USE_TRUNK_CHAIN = variant == 'trunk4+chain'
+    old = (ptl.USE_TRUNK4, ptl.USE_TRUNK_KERNELS)
+    ptl.USE_TRUNK4 = variant == 'trunk4'
     ptl.USE_TRUNK_KERNELS = variant != 'generic_trunk'
-    path = variant if variant in ('attn16', 'first', 'chain', 'bf16x3') else 'attn16p'
+    path = variant if variant in ('first', 'chain', 'bf16x3') else 'attn16p'
     try:
         with attention_path(pk, path):
             yield
     finally:
-        (ptl.USE_TRUNK4, ptl.USE_TRUNK_CHAIN, ptl.USE_TRUNK_KERNELS) = old
+        (ptl.USE_TRUNK4, ptl.USE_TRUNK_KERNELS) = old
 
 
 @pytest.mark.parametrize('variant', DEC_VARIANTS)

@@ -565,24 +565,29 @@ def test_geometry_prefetch_is_used_and_changes_nothing():
     pk.ops.fps_auto, pk.ops.knn = counting('fps', real_fps), counting('knn', real_knn)
     try:
         with torch.no_grad():
-            ref, ref_g, _ = enc(pcl, False)
-            per_forward = dict(calls)
-            assert per_forward['fps'] >= 2 and per_forward['knn'] >= 4
-            enc.prefetch_geometry(pcl)
-            assert calls == {k: 2 * v for k, v in per_forward.items()}          # all of it ran in the prefetch ...
-            out, out_g, _ = enc(pcl, False)
-            assert calls == {k: 2 * v for k, v in per_forward.items()}          # ... and none of it in the forward
+            def delta(fn):
+                before = dict(calls)
+                res = fn()
+                return res, {k: calls[k] - before[k] for k in calls}
+            (ref, ref_g, _), per_forward = delta(lambda: enc(pcl, False))
+            # (a forward issues the FPS chain and the pooling kNNs from the host; the self-attention kNNs run inside the
+            # library's block call unless a prefetch hands them over)
+            assert per_forward['fps'] >= 2 and per_forward['knn'] >= 2
+            _, per_prefetch = delta(lambda: enc.prefetch_geometry(pcl))
+            assert per_prefetch['fps'] == per_forward['fps'] and per_prefetch['knn'] >= per_forward['knn'] + 3
+            (out, out_g, _), d = delta(lambda: enc(pcl, False))
+            assert d == {'fps': 0, 'knn': 0}                                     # all of it ran in the prefetch
             assert torch.equal(out, ref) and torch.equal(out_g, ref_g)
             assert enc._prefetched is None                                       # consumed
-            out, _, _ = enc(pcl, False)                                          # (next forward computes its own)
-            assert calls == {k: 3 * v for k, v in per_forward.items()} and torch.equal(out, ref)
+            (out, _, _), d = delta(lambda: enc(pcl, False))                      # (next forward computes its own)
+            assert d == per_forward and torch.equal(out, ref)
             enc.prefetch_geometry(pcl.clone())                                   # another tensor: ignored, dropped
-            out, _, _ = enc(pcl, False)
-            assert calls == {k: 5 * v for k, v in per_forward.items()} and torch.equal(out, ref)
+            (out, _, _), d = delta(lambda: enc(pcl, False))
+            assert d == per_forward and torch.equal(out, ref)
             enc.prefetch_geometry(pcl)
             pcl.add_(0.0)                                                        # a newer version of this tensor
-            out, _, _ = enc(pcl, False)
-            assert calls == {k: 7 * v for k, v in per_forward.items()} and torch.equal(out, ref)
+            (out, _, _), d = delta(lambda: enc(pcl, False))
+            assert d == per_forward and torch.equal(out, ref)
     finally:
         pk.ops.fps_auto, pk.ops.knn = real_fps, real_knn
 

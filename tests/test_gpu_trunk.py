@@ -154,77 +154,6 @@ def test_empty_batch():
     assert rc == pk._lib.EINVAL
 
 
-@pytest.mark.parametrize('n', [1, 63, 64, 65, 700, 4099])
-@pytest.mark.parametrize('g_out', [5, 18])
-def test_trunk_chain_matches_fp64(n, g_out):
-    """occ4d_trunk_chain_f32: [interp -> resblock] x 3 -> Linear 416 -> 832 to memory -> store, and
-    interp -> resblock -> store -> relu Linear 416 -> G (G not a multiple of 4: element-wise stores), against fp64 torch
-    and against the one-kernel-per-layer path on the same inputs."""
-    rng = np.random.default_rng(n + g_out)
-    x = torch.from_numpy(rng.normal(size=(n, H)).astype(np.float32)).cuda()
-    blocks = [(_weights(rng, H), _weights(rng, H)) for _ in range(4)]
-    wq, bq = _weights(rng, 2 * H)
-    wo, bo = _weights(rng, g_out)
-    ztab, zconst, idx, w = _interp(rng, n)
-    # --- fp64 reference
-    v = x.double()
-    for i in range(3):
-        v = v + _interp_ref(ztab, zconst, idx, w, i)
-        (w0, b0), (w1, b1) = blocks[i]
-        v = v + torch.relu(torch.relu(v) @ w0.double().T + b0.double()) @ w1.double().T + b1.double()
-    aq_want = v @ wq.double().T + bq.double()
-    x3_want = v
-    v = v + _interp_ref(ztab, zconst, idx, w, 3)
-    (w0, b0), (w1, b1) = blocks[3]
-    v = v + torch.relu(torch.relu(v) @ w0.double().T + b0.double()) @ w1.double().T + b1.double()
-    out_want = torch.relu(v) @ wo.double().T + bo.double()
-    # --- chain 1
-    stream, counts = pk.ops.pack_chain_stream([('resblock', blocks[i][0][0], blocks[i][1][0]) for i in range(3)] + [('linear', wq)])
-    assert counts == [52, 52, 52, 52] and stream.shape == (209, 6656)
-    aq = torch.empty((n, 2 * H), device='cuda')
-    xs = x.clone()
-    prog = []
-    for i in range(3):
-        prog += [('interp', i * H), ('resblock', blocks[i][0][1], blocks[i][1][1])]
-    prog += [('linear', pk.ops.pad_bias(bq, counts[3]), counts[3], 2 * H, False, aq), ('store', xs)]
-    pk.ops.trunk_chain(xs, stream, prog, interp=(zconst, ztab, idx, w))
-    assert float((xs.double() - x3_want).abs().max()) < 5e-5
-    assert float((aq.double() - aq_want).abs().max()) < 5e-5
-    # --- chain 2: the tail of the decoder (penult stored, then lin_out on relu(penult))
-    stream2, counts2 = pk.ops.pack_chain_stream([('resblock', blocks[3][0][0], blocks[3][1][0]), ('linear', wo)])
-    assert counts2 == [52, 2]
-    out = torch.empty((n, g_out), device='cuda')
-    pen = torch.empty_like(xs)
-    pk.ops.trunk_chain(xs, stream2, [('interp', 3 * H), ('resblock', blocks[3][0][1], blocks[3][1][1]), ('store', pen),
-                                     ('linear', pk.ops.pad_bias(bo, 2), 2, g_out, True, out)],
-                       interp=(zconst, ztab, idx, w))
-    assert float((pen.double() - v).abs().max()) < 5e-5
-    assert float((out.double() - out_want).abs().max()) < 5e-5
-    # --- the per-layer kernels on the same inputs agree to fp32 rounding
-    y = x.clone()
-    for i in range(3):
-        pk.ops.interp_add(y, zconst[i * H:(i + 1) * H], ztab[:, i * H:(i + 1) * H], idx, w)
-        (w0, b0), (w1, b1) = blocks[i]
-        y = pk.ops.resblock(y, pk.ops.pack_trunk4_rows(w0), b0, pk.ops.pack_trunk4_cols(w1), b1)
-    assert float((y - xs).abs().max()) < 2e-5
-    assert float((pk.ops.rowlin(y, pk.ops.pack_trunk4_rows(wq), bq, 2 * H) - aq).abs().max()) < 2e-5
-
-
-def test_trunk_chain_rejects_bad_programs():
-    x = torch.zeros((8, H), device='cuda')
-    w = torch.zeros((H, H), device='cuda')
-    b = torch.zeros((H,), device='cuda')
-    stream, _ = pk.ops.pack_chain_stream([('resblock', w, w)])
-    with pytest.raises(AssertionError):      # stream too short for the program
-        pk.ops.trunk_chain(x, stream, [('resblock', b, b), ('resblock', b, b), ('store', x)])
-    with pytest.raises(AssertionError):      # interpolation op without tables
-        pk.ops.trunk_chain(x, stream, [('interp', 0), ('resblock', b, b)])
-    args = pk._lib.ChainArgs()
-    args.n, args.n_ops = 8, 0
-    import ctypes
-    assert pk._lib.lib().occ4d_trunk_chain_f32(ctypes.byref(args), None) == pk._lib.EINVAL
-
-
 @pytest.mark.parametrize('half_cu', [False, True])
 @pytest.mark.parametrize('n,n_out', [(1, 416), (130, 832), (3000, 416), (777, 32)])
 def test_rowlin_output_mask(n, n_out, half_cu):

@@ -75,19 +75,11 @@ def test_cross_attention_placement_and_errors():
         pk.modules.DownTransition(8, 16, norm_type='group')
 
 
-def test_merged_weights_are_exact_in_fp64():
-    """Refactoring (i): W1 (q - k + pe) + b1 == (W1 Wq L1) x + (W1 Wq l1b + W1 c2 + b1) - (W1 Wk) f + (W1 P2) r."""
-    torch.manual_seed(0)
-    blk = pk.modules.PointTransformerBlock(32, 32, 32, num_neighbors=4, d_hidden_abstract=16).double()
-    lyr = blk.layer2
-    x, f, r = torch.randn(5, 32).double(), torch.randn(5, 16).double(), torch.relu(torch.randn(5, 32)).double()
-    q = lyr.to_q(blk.layer1(x))
-    k = lyr.to_k(f)
-    pe = lyr.pos_mlp[2](r)
-    want = lyr.attn_mlp[0](q - k + pe)
-    m = lyr.merged_weights(pre=blk.layer1)
-    got = x.float() @ m['wq'].T + m['bq'] - f.float() @ m['wk'].T + r.float() @ m['wp'].T
-    assert torch.allclose(got.double(), want, atol=2e-5)
+def test_inference_forward_has_no_cpu_fallback():
+    """A module left on the CPU cannot run: building the library's weight view rejects CPU parameters."""
+    blk = pk.modules.PointTransformerBlock(32, 32, 32, num_neighbors=4, d_hidden_abstract=16)
+    with pytest.raises(RuntimeError, match='no CPU fallback'), torch.no_grad():
+        blk(torch.zeros(1, 8, 32), torch.zeros(1, 8, 3), torch.zeros(1, 9, 16), torch.zeros(1, 9, 3))
 
 
 def test_training_forward_has_no_cpu_fallback_either():

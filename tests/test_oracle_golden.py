@@ -58,7 +58,7 @@ def test_g3_pt_block(case):
     close(z, load_golden('g3_ptb_' + case['name'])['z'])
 
 
-@pytest.mark.parametrize('case', gc.DOWN_CASES, ids=lambda c: c['name'])
+@pytest.mark.parametrize('case', gc.DOWN_CASES + gc.DOWN_BATCHNORM_CASES, ids=lambda c: c['name'])
 def test_g4_down(case):
     x, pos, sd = gc.down_inputs(case)
     z, p_sub = op.down_transition(sd, T(x)[None], T(pos)[None], 3, case['k'], case['norm'])
@@ -93,7 +93,7 @@ def test_g7_posenc():
     assert np.array_equal(enc, g['enc'])
 
 
-@pytest.mark.parametrize('case', gc.DEC_CASES, ids=lambda c: c['name'])
+@pytest.mark.parametrize('case', gc.DEC_CASES + gc.DEC_SWISH_CASES, ids=lambda c: c['name'])
 def test_g8_decoder(case):
     q, abstract, fglob, ia, sd = gc.dec_inputs(case)
     out, pen = op.decoder_forward(sd, ia, T(q), T(abstract), T(fglob))
@@ -244,7 +244,7 @@ def test_point_sampler_replays_reference_draws(case):
 
 
 # ---------------------------------------------------------------- G14: training losses (reference pipeline + loss code)
-@pytest.mark.parametrize('case', gc.LOSS_CASES, ids=lambda c: c['name'])
+@pytest.mark.parametrize('case', gc.LOSS_CASES + gc.LOSS_COLOR_CASES, ids=lambda c: c['name'])
 def test_g14_oracle_loss_matches_reference(case):
     from oracle import loss as ol
     g = load_golden('g14_loss_' + case['name'])
@@ -260,7 +260,7 @@ def test_g14_oracle_loss_matches_reference(case):
 
 
 @pytest.mark.parametrize('static_shapes', [False, True], ids=['eager', 'static'])
-@pytest.mark.parametrize('case', gc.LOSS_CASES, ids=lambda c: c['name'])
+@pytest.mark.parametrize('case', gc.LOSS_CASES + gc.LOSS_COLOR_CASES, ids=lambda c: c['name'])
 def test_g14_product_loss_matches_reference(case, static_shapes):
     """training.implicit_loss is torch glue (runs on any device); the same check runs on the GPU in
     tests/test_gpu_training.py.  Value within 1e-6, gradient w.r.t. the raw logits within 1e-7 of the
@@ -276,10 +276,9 @@ def test_g14_product_loss_matches_reference(case, static_shapes):
     assert np.abs(raw.grad.numpy() - g['grad']).max() < 1e-7
 
 
-def test_product_loss_rejects_unpublished_colour_modes():
+def test_product_loss_rejects_unknown_colour_modes():
     import occlusions4d_amd as pk
-    o, y = torch.zeros(1, 4, 16), torch.zeros(1, 4, 6)
-    with pytest.raises(NotImplementedError):
-        pk.training.implicit_loss(o, y, color_lw=1.0, color_mode='hsv')
+    o, y = torch.zeros(1, 4, 16), torch.full((1, 4, 6), 0.5)
+    assert torch.isfinite(pk.training.implicit_loss(o, y, color_lw=1.0, color_mode='hsv'))     # (built in round 4)
     with pytest.raises(ValueError):
         pk.training.implicit_loss(o, y, color_lw=1.0, color_mode='nope')
