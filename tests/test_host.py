@@ -98,18 +98,20 @@ def test_synthetic_inputs_are_deterministic_and_tie_free():
     assert all(torch.equal(w1[k], w2[k]) for k in w1) and w1['l.weight'].abs().max() <= 1 / np.sqrt(8)
 
 
-def test_tracking_loss_rejects_colour_modes_with_another_channel_layout():
-    """training.implicit_loss reads the tracking logit at channel 4, which is where utils.get_track_idx puts it for
-    the three-channel colour modes only: 'hsv' / 'bins' must not silently read a colour logit."""
+def test_tracking_loss_reads_the_channel_of_the_colour_mode():
+    """training.implicit_loss reads the tracking logit where utils.get_track_idx puts it (utils/utils.py:204-224): channel 4
+    for the three-channel colour modes, 15 for 'hsv', 10 for 'bins' (never silently a colour logit)."""
     import occlusions4d_amd as pk
-    out, tgt = torch.zeros((1, 8, 5)), torch.zeros((1, 8, 6))
+    tgt = torch.zeros((1, 8, 6))
     tgt[..., 0] = 1.0                  # (every point solid: the tracking term has supervised points)
-    for mode in ('hsv', 'bins'):
-        with pytest.raises(NotImplementedError):
-            pk.training.implicit_loss(out, tgt, density_lw=1.0, color_lw=0.0, tracking_lw=0.5, color_mode=mode)
+    tgt[..., 4] = 1.0
+    for mode, width, idx in (('rgb', 5, 4), ('hsv', 16, 15), ('bins', 11, 10)):
+        out = torch.zeros((1, 8, width), requires_grad=True)
+        pk.training.implicit_loss(out, tgt, density_lw=0.0, color_lw=0.0, tracking_lw=0.5, color_mode=mode).backward()
+        touched = out.grad.abs().sum(dim=(0, 1)).nonzero()[:, 0].tolist()
+        assert touched == [idx], (mode, touched)
     with pytest.raises(ValueError):
-        pk.training.implicit_loss(out, tgt, density_lw=1.0, tracking_lw=0.5, color_mode='nonsense')
-    assert torch.isfinite(pk.training.implicit_loss(out, tgt, density_lw=1.0, tracking_lw=0.5, color_mode='rgb'))
+        pk.training.implicit_loss(torch.zeros((1, 8, 5)), tgt, density_lw=1.0, tracking_lw=0.5, color_mode='nonsense')
 
 
 def test_evaluate_clip_shares_the_encode_only_when_it_is_deterministic(monkeypatch):
