@@ -146,7 +146,9 @@ def cpu_baseline(kind, budget_s=240.0):
         note = ('oracle/path.py on host CPU: %d-query decode %.2f s extrapolated linearly to %d queries; the encode '
                 'did not finish within the %.0f s budget and is NOT included (decode-only upper bound)'
                 % (sample, rec['t_dec'], n, budget_s))
-    return dict(value=n / total, unit='query-points/s', cores=rec['cores'], kind='port', sample=note)
+    return dict(value=n / total, unit='query-points/s', cores=rec['cores'], host_cores=os.cpu_count(), kind='port',
+                sample=note + ' (torch threads capped at %d of the host\'s %d logical cores: the oracle\'s small ops thrash '
+                'beyond that)' % (rec['cores'], os.cpu_count() or 0))
 
 
 def self_launch(n_gpus):
@@ -323,7 +325,7 @@ def main():
         # issued on a side stream while step i decodes (distributed.ClipPipeline).  Every step still encodes and
         # decodes in full; K steps contain K encode launches and K decodes.
         pipelined = None
-        if extra and world == 1:   # extra legs only on the single-GPU run: nothing optional may endanger an N > 1 line
+        if extra:                  # (N > 1: rank 0's encode + broadcast of clip i + 1 under every rank's decode of clip i)
             pipe = pk.distributed.ClipPipeline(enc, dec, BATCH, inf['color_mode'], inf['predict_segmentation'], 'none', 13)
             pipe.submit(pcl)
 
@@ -361,6 +363,19 @@ def main():
             t_host = (time.perf_counter() - th) / reps
             host_boundary = dict(ms_per_call=1e3 * t_host, value=res['points_query'].shape[0] / t_host,
                                  what='perform_inference with host numpy inputs and outputs (PCIe inclusive)')
+        # the exchange step, measured on one more (untimed) step: HIP events around the encoder (rank 0) and around
+        # the two broadcasts, per rank
+        timing = {}
+        pk.distributed.sharded_inference(pcl, queries, enc, dec, BATCH, inf['color_mode'], inf['predict_segmentation'],
+                                         'none', 13, timing=timing)
+        torch.cuda.synchronize()
+        ex = [timing['encode'][0].elapsed_time(timing['encode'][1]), timing['broadcast'][0].elapsed_time(timing['broadcast'][1])]
+        exchange = [ex]
+        if use_dist:
+            tt = torch.tensor(ex, dtype=torch.float64, device=device)
+            allt = [torch.empty_like(tt) for _ in range(world)]
+            dist.all_gather(allt, tt)
+            exchange = [[float(v) for v in x.tolist()] for x in allt]
         # encode share, measured separately (informational; rank 0 is the rank that encodes)
         t_encode = None
         if rank == 0:
@@ -390,7 +405,7 @@ def main():
             'metric': '4D query-points/sec (encode+decode) at n_points=14336',
             'value': value, 'unit': 'query-points/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
-            'scaling': 'strong' if world > 1 else 'weak',
+            'scaling': 'strong',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s inference (BASELINE configs[%d]): n_points=%d video_len=%d num_sample=%d (-> %d grid '
                                    'queries%s) implicit_batch_size=%d (decoded in mini-batches of %d = 3584 workgroups of 9 '
@@ -401,8 +416,12 @@ def main():
                        'abstract_points': m_abs, 'outputs_per_query': ia['d_out'],
                        'parallelism': 'query-sharded x%d, rank 0 encodes, abstract cloud broadcast (RCCL)' % world
                                       if world > 1 else 'single GPU',
-                       'scaling_note': 'N = 1 runs configs[1] (534 528 queries); N = 2, 4, 8 run configs[3] (2 125 568 '
-                                       'queries, fixed total -> strong).  The other grid is the secondary leg of each line.',
+                       'scaling_note': 'strong scaling: the total work is fixed as N grows.  N = 1 runs configs[1] (534 528 '
+                                       'queries, the configuration the metric is quoted on); N = 2, 4, 8 run configs[3] '
+                                       '(2 125 568 queries, the same total for every N).  Each line carries the other grid as a '
+                                       'secondary leg (config4_single_gpu / strong_config2), so both strong curves have their '
+                                       'N = 1 point.',
+                       'encode_ms_per_rank': [e[0] for e in exchange], 'broadcast_ms_per_rank': [e[1] for e in exchange],
                        'rccl_ranks': rccl_ranks, 'backend': ('rccl' if backend == 'nccl' else backend) if use_dist else None,
                        'ranks_share_one_gpu': share_gpu or None,
                        'per_rank_ms_per_step': [1e3 * t / args.steps for t in per_rank_s],

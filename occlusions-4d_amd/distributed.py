@@ -22,10 +22,20 @@ def shard_bounds(n, rank, world):
     return lo, min(n, lo + per)
 
 
-def encode_and_share(pcl_input, pcl_net, abstract_shape, global_dim, device, src=0):
-    """Rank `src` runs the encoder; everyone receives (pcl_abstract (M,3+E), features_global (D))."""
+def encode_and_share(pcl_input, pcl_net, abstract_shape, global_dim, device, src=0, timing=None):
+    """Rank `src` runs the encoder; everyone receives (pcl_abstract (M,3+E), features_global (D)).
+    `timing` (optional dict): filled with HIP events on the current stream -- 'encode' = (start, end) around the encoder
+    on rank `src`, 'broadcast' = (start, end) around the two broadcasts -- for the bench's encode_ms / broadcast_ms."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
+
+    def mark():
+        if timing is None or not torch.cuda.is_available():
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+    t0 = mark()
     if rank == src:
         (pcl_abstract, features_global, _) = pcl_net(pcl_input, False)
         pcl_abstract = pcl_abstract.squeeze(0).contiguous()
@@ -34,9 +44,13 @@ def encode_and_share(pcl_input, pcl_net, abstract_shape, global_dim, device, src
     else:
         pcl_abstract = torch.empty(abstract_shape, dtype=torch.float32, device=device)
         features_global = torch.empty((global_dim,), dtype=torch.float32, device=device)
+    t1 = mark()
     if dist.is_initialized():
         dist.broadcast(pcl_abstract, src=src)
         dist.broadcast(features_global, src=src)
+    t2 = mark()
+    if timing is not None:
+        timing['encode'], timing['broadcast'] = (t0, t1), (t1, t2)
     return pcl_abstract, features_global
 
 
@@ -52,7 +66,7 @@ def abstract_shape(pcl_net, n_points):
 
 def sharded_inference(pcl_input, points_query, pcl_net, implicit_net, batch_size, color_mode,
                       predict_segmentation=False, track_mode='none', semantic_classes=13, gather=False,
-                      squash=None, encoded=None):
+                      squash=None, encoded=None, timing=None):
     """pcl_input (1,N,8) and points_query (Nq,4) are CUDA tensors present on every rank (the query
     grid is deterministic, every rank builds it).  Returns (local_output (n_local,G), (lo, hi)) or the
     gathered (Nq,G) tensor when gather=True.  `squash(out, codes)` applies the per-channel post-ops in
@@ -62,7 +76,8 @@ def sharded_inference(pcl_input, points_query, pcl_net, implicit_net, batch_size
     device = points_query.device
     if encoded is None:
         shape = abstract_shape(pcl_net, pcl_input.shape[1])
-        pcl_abstract, features_global = encode_and_share(pcl_input, pcl_net, shape, pcl_net.global_dim, device)
+        pcl_abstract, features_global = encode_and_share(pcl_input, pcl_net, shape, pcl_net.global_dim, device,
+                                                         timing=timing)
     else:
         pcl_abstract, features_global = encoded
     lo, hi = shard_bounds(points_query.shape[0], rank, world)

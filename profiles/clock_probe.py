@@ -51,9 +51,9 @@ def main():
         P1, c1 = T(rng.normal(size=(32, 3))), T(rng.normal(size=(32,)))
         wp, w2 = T(0.1 * rng.normal(size=(2 * d, 32))), T(0.03 * rng.normal(size=(d, 2 * d)))
         b2, p2, c2 = T(rng.normal(size=(d,))), T(0.1 * rng.normal(size=(d, 32))), T(rng.normal(size=(d,)))
-        stream = pk.ops.pack_attn16_stream(w2, b2, wp, p2, c2)
+        stream = pk.ops.pack_attn16p_stream(w2, b2, wp, p2, c2)
         out = torch.empty((n, d), device='cuda')
-        fn = lambda: pk.ops.pt_cross_attn16(aq, qpos, apos, idx, kt, vt, P1, c1, stream, out=out)   # noqa: E731
+        fn = lambda: pk.ops.pt_cross_attn16p(aq, qpos, apos, idx, kt, vt + c2, P1, c1, stream, out=out)   # noqa: E731
         flop = 2.0 * n * k * (32 * 2 * d + 2 * d * d + 32 * d)
     elif what == 'micro':
         exe = '/tmp/mfma_issue'

@@ -31,8 +31,6 @@ def main():
     variants = {
         'attn16p': (pk.ops.pack_attn16p_stream(w2, b2, wp, p2, c2),
                     lambda st: pk.ops.pt_cross_attn16p(aq, qpos, apos, idx, kt, vt, P1, c1, st, out=out)),
-        'attn16 ': (pk.ops.pack_attn16_stream(w2, b2, wp, p2, c2),
-                    lambda st: pk.ops.pt_cross_attn16(aq, qpos, apos, idx, kt, vt, P1, c1, st, out=out)),
     }
     trunks = {
         'resblock4': (pk.ops.pack_trunk4_rows(ws[0]), pk.ops.pack_trunk4_cols(ws[1])),

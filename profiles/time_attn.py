@@ -22,7 +22,6 @@ def main():
     P1, c1 = T(rng.normal(size=(32, 3))), T(rng.normal(size=(32,)))
     wp, w2 = T(0.1 * rng.normal(size=(2 * d, 32))), T(0.03 * rng.normal(size=(d, 2 * d)))
     b2, p2, c2 = T(rng.normal(size=(d,))), T(0.1 * rng.normal(size=(d, 32))), T(rng.normal(size=(d,)))
-    stream = pk.ops.pack_attn16_stream(w2, b2, wp, p2, c2)
     out_a, out_b = torch.empty((n, d), device='cuda'), torch.empty((n, d), device='cuda')
 
     def timeit(fn, reps=10):
@@ -38,9 +37,9 @@ def main():
         return e0.elapsed_time(e1) / reps
     flop = 2.0 * n * k * (32 * 2 * d + 2 * d * d + 32 * d)
     t_old = timeit(lambda: pk.ops.pt_cross_attn(aq, qpos, apos, idx, kt, vt, P1, c1, wp, w2, b2, p2, c2, out=out_a))
-    t_new = timeit(lambda: pk.ops.pt_cross_attn16(aq, qpos, apos, idx, kt, vt, P1, c1, stream, out=out_b))
     print('n = %d queries, m = %d abstract points, k = %d' % (n, m, k))
-    rows = [('crossattn.hip   (32x32x2, 2 channel groups)', t_old), ('crossattn16.hip (16x16x4, row-owning waves)', t_new)]
+    # (crossattn16.hip, the round-2 one-workgroup-per-CU kernel of r02 / r03 runs of this script, was deleted in round 4)
+    rows = [('crossattn.hip   (32x32x2, 2 channel groups)', t_old)]
     stream_p = pk.ops.pack_attn16p_stream(w2, b2, wp, p2, c2)
     out_c = torch.empty((n, d), device='cuda')
     vtc = vt + c2          # the paired kernel reads the value table with pos_mlp[2].bias folded in
@@ -50,8 +49,7 @@ def main():
         rows.append(('crossattn16p.hip (paired workgroups), skew %2d' % sk, t))
     for name, ms in rows:
         print('%-46s %8.3f ms  %6.1f TFLOP/s executed  %.3f of fp32 MFMA peak' % (name, ms, flop / ms / 1e9, flop / ms / 1e9 / 157.3))
-    print('max |difference| crossattn vs crossattn16: %.3g' % float((out_a - out_b).abs().max()))
-    print('max |difference| crossattn16 vs crossattn16p: %.3g' % float((out_b - out_c).abs().max()))
+    print('max |difference| crossattn vs crossattn16p: %.3g' % float((out_a - out_c).abs().max()))
 
 
 if __name__ == '__main__':

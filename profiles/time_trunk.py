@@ -82,48 +82,5 @@ def main():
 if __name__ == '__main__' and not (len(sys.argv) > 1 and sys.argv[1] == 'chain'):
     main()
 
-
-def chain_main():
-    """The trunk chain kernel against the per-layer kernels it replaces: python profiles/time_trunk.py chain [rows]"""
-    n = int(sys.argv[2]) if len(sys.argv) > 2 else 32256
-    rng = np.random.default_rng(0)
-    T = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32)).cuda()   # noqa: E731
-    x = T(rng.normal(size=(n, H)))
-    blocks = [((T(0.05 * rng.normal(size=(H, H))), T(0.1 * rng.normal(size=(H,)))),
-               (T(0.05 * rng.normal(size=(H, H))), T(0.1 * rng.normal(size=(H,))))) for _ in range(3)]
-    wq, bq = T(0.05 * rng.normal(size=(2 * H, H))), T(0.1 * rng.normal(size=(2 * H,)))
-    ztab, zc = T(rng.normal(size=(531, 6 * H))), T(rng.normal(size=(6 * H,)))
-    idx = torch.from_numpy(rng.integers(0, 531, size=(n, 8)).astype(np.int32)).cuda()
-    w8 = T(rng.uniform(size=(n, 8)))
-    aq = torch.empty((n, 2 * H), device='cuda')
-    packs = [(pk.ops.pack_trunk4_rows(b[0][0]), pk.ops.pack_trunk4_cols(b[1][0])) for b in blocks]
-    pq = pk.ops.pack_trunk4_rows(wq)
-
-    def separate(nb, with_interp=True):
-        for i in range(nb):
-            if with_interp:
-                pk.ops.interp_add(x, zc[i * H:(i + 1) * H], ztab[:, i * H:(i + 1) * H], idx, w8)
-            pk.ops.resblock(x, packs[i][0], blocks[i][0][1], packs[i][1], blocks[i][1][1], out=x)
-        pk.ops.rowlin(x, pq, bq, 2 * H, out=aq)
-
-    print('rows = %d' % n)
-    for nb in (1, 2, 3):
-        stream, counts = pk.ops.pack_chain_stream([('resblock', blocks[i][0][0], blocks[i][1][0]) for i in range(nb)] + [('linear', wq)])
-        bqp = pk.ops.pad_bias(bq, counts[-1])
-        for with_interp in (True, False):
-            prog = []
-            for i in range(nb):
-                prog += ([('interp', i * H)] if with_interp else []) + [('resblock', blocks[i][0][1], blocks[i][1][1])]
-            prog += [('linear', bqp, counts[-1], 2 * H, False, aq), ('store', x)]
-            flop = (4.0 * nb + 4.0) * n * H * H
-            for skew in (0, 2, 4, 8):
-                us = timeit(lambda: pk.ops.trunk_chain(x, stream, prog, interp=(zc, ztab, idx, w8) if with_interp else None, skew=skew))
-                print('chain %d x [%sresblock] + linear 832, skew %d: %8.1f us  %.3f of fp32 MFMA peak' % (
-                    nb, 'interp + ' if with_interp else '', skew, us, flop / us / 1e6 / 157.3))
-            us = timeit(lambda: separate(nb, with_interp))
-            print('separate kernels (%d x [%sresblock4] + rowlin4 832):      %8.1f us  %.3f of fp32 MFMA peak' % (
-                nb, 'interp_add + ' if with_interp else '', us, flop / us / 1e6 / 157.3))
-
-
-if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'chain':
-    chain_main()
+# (the `chain` mode of this script timed occ4d_trunk_chain_f32, the register-resident trunk chain kernel of round 3: measured
+# slower end to end -- profiles/r03_time_trunk.txt, DESIGN.md 6c -- and deleted in round 4)

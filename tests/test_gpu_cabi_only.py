@@ -331,3 +331,26 @@ def test_packers_match_the_layouts_of_the_header(lib):
     perm = 16 * (i // 16) + 8 * ((i % 8) // 4) + 4 * ((i // 8) % 2) + (i % 4)
     want = torch.cat([hi.view(64, 4, 32)[:, :, perm], lo.view(64, 4, 32)[:, :, perm]], dim=2).contiguous()
     assert torch.equal(got.view(torch.bfloat16).view(64, 4, 64), want)
+
+
+def test_the_binding_printed_in_integration_md_runs_as_printed():
+    """INTEGRATION.md B shows the ctypes patch a maintainer of the reference would apply to model/implicit.py.  The code
+    block is executed verbatim (only the library path is substituted) on a parameter container with the reference's
+    attribute names, and must reproduce the reference's golden vector G8."""
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    sec = text[text.index('## B. Library-level binding'):]
+    code = sec[sec.index('```python') + len('```python'):]
+    code = code[:code.index('```')]
+    code = code.replace('/path/to/occlusions-4d_amd/libocc4d.so', os.path.join(ROOT, 'occlusions-4d_amd', 'libocc4d.so'))
+    ns = {}
+    exec(compile(code, 'INTEGRATION.md#B', 'exec'), ns)
+    import occlusions4d_amd as pk           # (parameter container with the reference's attribute names; no compute through it)
+    case = gc.DEC_CASES[1]
+    q, abstract, fglob, ia, sd = gc.dec_inputs(case)
+    net = pk.implicit.LocalPclResnetFC(**ia).cuda().eval()
+    net.load_state_dict(sd)
+    with torch.no_grad():
+        out, pen = ns['forward'](net, dev(q), dev(abstract), dev(fglob), None)
+    torch.cuda.synchronize()
+    g = load_golden('g8_dec_' + case['name'])
+    assert err(out, g['output']) <= 1e-4 and err(pen[:, ::8], g['penult']) <= 1e-4
