@@ -413,6 +413,13 @@ int occ4d_interp_bwd_f32(const float* dy, int64_t ldy, const int32_t* idx, const
 int occ4d_segment_gather_sum_f32(const float* src, int64_t lds, const int32_t* order, const int32_t* offsets,
                                  const float* weights, int div, int n_out, int d, float scale, float* out, int64_t ldo,
                                  void* stream);
+/* segment_sum_sorted: the same sorted-segment reduction tuned for speed instead of reproducibility (the default of large
+ * scatters onto few rows, e.g. the key-table gradient of the attention backward: 458752 pair rows of 832 floats onto 4248
+ * abstract points): out[r][:] = scale * sum of src[order[t]][:] over the row's segment, every segment cut into `parts`
+ * slices that are summed independently (float4 loads, four in flight) and combined with one atomic per element and slice
+ * into the output, which the call clears first.  d, lds, ldo multiples of 4; src, out 16-byte aligned. */
+int occ4d_segment_sum_sorted_f32(const float* src, int64_t lds, const int32_t* order, const int32_t* offsets, int n_out,
+                                 int d, int parts, float scale, float* out, int64_t ldo, void* stream);
 int occ4d_pt_pos_hidden_bwd_det_workspace(int n, int k, int h, int64_t* floats);
 int occ4d_pt_pos_hidden_bwd_det_f32(const float* pos, int64_t ps, const float* pos2, int64_t p2s, const int32_t* idx,
                                     int n, int k, int h, const float* r, const float* gr, float* dP1, float* dc1,

@@ -225,6 +225,47 @@ __global__ __launch_bounds__(TPB) void segment_gather_sum_kernel(const float* __
   out[r * ldo + c] = scale * s;
 }
 
+// The same reduction for SPEED (not bit-reproducible): every target row's segment is cut into `parts` contiguous slices,
+// one thread per (row, slice, channel quad) sums its slice with four independent float4 loads in flight and adds the
+// result to the zero-initialised output with ONE atomic per element and slice -- parts x n_out x d atomics instead of one
+// per (pair, channel), and slices instead of whole segments as the unit of work (segments are very uneven: an abstract
+// point near many supervision queries collects thousands of pairs, most collect tens).
+__global__ __launch_bounds__(TPB) void segment_sum_sorted_kernel(const float* __restrict__ src, int64_t lds,
+                                                                 const int32_t* __restrict__ order,
+                                                                 const int32_t* __restrict__ off, int64_t total, int d4,
+                                                                 int parts, float scale, float* __restrict__ out,
+                                                                 int64_t ldo) {
+  const int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (e >= total) return;
+  const int c4 = (int)(e % d4);
+  const int64_t rp = e / d4;
+  const int part = (int)(rp % parts);
+  const int64_t r = rp / parts;
+  const int lo = off[r], hi = off[r + 1];
+  const int chunk = (hi - lo + parts - 1) / parts;
+  const int a = lo + part * chunk, b = min(hi, a + chunk);
+  if (a >= b) return;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const float* base = src + 4 * c4;
+  f4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  int t = a;
+  for (; t + 4 <= b; t += 4) {
+    const int p0 = order[t], p1 = order[t + 1], p2 = order[t + 2], p3 = order[t + 3];
+    const f4 v0 = *reinterpret_cast<const f4*>(base + (int64_t)p0 * lds);
+    const f4 v1 = *reinterpret_cast<const f4*>(base + (int64_t)p1 * lds);
+    const f4 v2 = *reinterpret_cast<const f4*>(base + (int64_t)p2 * lds);
+    const f4 v3 = *reinterpret_cast<const f4*>(base + (int64_t)p3 * lds);
+    s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+  }
+  for (; t < b; ++t) s0 += *reinterpret_cast<const f4*>(base + (int64_t)order[t] * lds);
+  const f4 s = (s0 + s1) + (s2 + s3);
+  float* o = out + r * ldo + 4 * c4;
+  atomicAdd(o + 0, scale * s.x);
+  atomicAdd(o + 1, scale * s.y);
+  atomicAdd(o + 2, scale * s.z);
+  atomicAdd(o + 3, scale * s.w);
+}
+
 // pos_hidden_bwd with the block partials written out (blocks x 4 slices x h x 4 floats) instead of atomics ...
 __global__ __launch_bounds__(TPB) void pos_hidden_bwd_partials_kernel(const float* __restrict__ pos, int64_t ps,
                                                                       const float* __restrict__ pos2, int64_t p2s,
@@ -668,6 +709,22 @@ int occ4d_segment_gather_sum_f32(const float* src, int64_t lds, const int32_t* o
   segment_gather_sum_kernel<<<grid1d(total), TPB, 0, (hipStream_t)stream>>>(src, lds, order, offsets, weights, div, total,
                                                                             d, scale, out, ldo);
   return occ4d::check_launch("occ4d_segment_gather_sum_f32");
+}
+
+int occ4d_segment_sum_sorted_f32(const float* src, int64_t lds, const int32_t* order, const int32_t* offsets, int n_out,
+                                 int d, int parts, float scale, float* out, int64_t ldo, void* stream) {
+  OCC4D_REQUIRE(src && order && offsets && out && n_out >= 0 && d >= 4 && d % 4 == 0 && parts >= 1 && lds >= d && ldo >= d &&
+                    lds % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)out % 16) == 0,
+                "occ4d_segment_sum_sorted_f32: bad arguments (d, lds, ldo multiples of 4; src, out 16-byte aligned)");
+  if (!n_out) return OCC4D_OK;
+  if (hipMemset2DAsync(out, ldo * sizeof(float), 0, d * sizeof(float), n_out, (hipStream_t)stream) != hipSuccess) {
+    occ4d::set_error("occ4d_segment_sum_sorted_f32: clearing the output failed");
+    return OCC4D_ELAUNCH;
+  }
+  const int64_t total = (int64_t)n_out * parts * (d / 4);
+  segment_sum_sorted_kernel<<<grid1d(total), TPB, 0, (hipStream_t)stream>>>(src, lds, order, offsets, total, d / 4, parts,
+                                                                            scale, out, ldo);
+  return occ4d::check_launch("occ4d_segment_sum_sorted_f32");
 }
 
 int occ4d_pt_pos_hidden_bwd_det_workspace(int n, int k, int h, int64_t* floats) {

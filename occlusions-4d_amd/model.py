@@ -69,6 +69,7 @@ class PointCompletionNetV3(torch.nn.Module):
         out = {}
         with torch.cuda.stream(side):
             cur = [pos[b].contiguous() for b in range(pos.shape[0])]
+            nested = [modules.NestedFps() for _ in cur]      # (the levels' farthest-point subsets are prefixes of level 0's)
             for c in cur:
                 # allocated on the side stream, read by the pooling kNN on the main stream: without this the block
                 # could be recycled by a later side-stream allocation while that kNN is still queued
@@ -78,7 +79,7 @@ class PointCompletionNetV3(torch.nn.Module):
                     # only the FPS subsets chain on the side stream; the down-kNN of a level (which the next level's
                     # FPS does not need) is issued on the main stream when the level is consumed -- queued behind the
                     # FPS it used to delay the whole chain by 0.45 ms per encode
-                    g = [block.sample(c) for c in cur]
+                    g = [block.sample(c, nested=nf) for c, nf in zip(cur, nested)]
                     if full:
                         g = [(inds, p_sub, block.neighbours(p_sub, c)) for (inds, p_sub), c in zip(g, cur)]
                     for tup in g:               # produced on `side`, consumed on `main`

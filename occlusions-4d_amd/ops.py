@@ -28,24 +28,6 @@ class KernelTimer:
         self.events.append((name, e0, e1, float(flops)))
         return rc
 
-    def path_events(self, name, flops_per_launch):
-        """occ4d_launch_events for a path-level call that issues len(flops_per_launch) launches of kernel family
-        `name`: the library records the event pairs on its launch stream (include/occ4d.h).  Returns (struct, finish);
-        call finish() after the library call: it books the pairs the call really used."""
-        n = len(flops_per_launch)
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(2 * n)]
-        for e in evs:
-            e.record()                       # (torch creates the hipEvent_t lazily, at the first record)
-        arr = (C.c_void_p * (2 * n))(*[e.cuda_event for e in evs])
-        st = _lib.LaunchEvents(events=C.cast(arr, C.POINTER(C.c_void_p)), capacity=n, used=0,
-                               kernel=_lib.PROFILE_KINDS[name], reserved=0)
-
-        def finish():
-            for i in range(st.used):
-                self.events.append((name, evs[2 * i], evs[2 * i + 1], float(flops_per_launch[i])))
-        st._keep = (arr, evs)
-        return st, finish
-
     def summary(self):
         torch.cuda.synchronize()
         out = {}
@@ -213,14 +195,14 @@ FPS_COOP_MIN_POINTS = 28673     # measured (profiles/time_fps.py, r02_fps_time.t
                                 # chain is prefetched under another step's backward (model.prefetch_geometry)
 
 
-def fps_auto(xyz, m, start=0):
-    """Ascending FPS indices with the faster kernel for the cloud size: one workgroup with the cloud in registers
-    (fps) below FPS_COOP_MIN_POINTS points, the cooperative multi-workgroup kernel above (the dataloader's whole
-    clips)."""
+def fps_auto(xyz, m, start=0, return_order=False):
+    """Ascending FPS indices [, the selection order] with the faster kernel for the cloud size: one workgroup with the
+    cloud in registers (fps) below FPS_COOP_MIN_POINTS points, the cooperative multi-workgroup kernel above (the
+    dataloader's whole clips)."""
     n = xyz.shape[0]
     if n < FPS_COOP_MIN_POINTS:
-        return fps(xyz, m, start=start)
-    return fps_coop(xyz, m, start=start, n_workgroups=16, check=False)
+        return fps(xyz, m, start=start, return_order=return_order)
+    return fps_coop(xyz, m, start=start, n_workgroups=16, check=False, return_order=return_order)
 
 
 def linear(x, w, b=None, relu_in=False, relu_out=False, residual=None, out=None,
@@ -645,12 +627,27 @@ def _attn_flops(c, k, d):
     return 2.0 * c * k * (32 * 2 * d + 2 * d * d + 32 * d)
 
 
-def _path_timing(name, chunks_flops):
-    """(launch-events struct or None, finish callback): bench.py's roofline leg through the library's profiling hook."""
+def _path_timing(name, flops_per_launch):
+    """(occ4d_launch_events struct or None, finish callback) for a path-level call that issues len(flops_per_launch)
+    launches of kernel family `name`: the library records the event pairs on its launch stream (include/occ4d.h);
+    finish(), called after the library call, books the pairs the call really used into the active timer's `events`
+    list ((name, start, end, flops) tuples, the format of KernelTimer / bench_train.StepCounter)."""
     t = _timer
-    if t is None or not chunks_flops or not hasattr(t, 'path_events'):
+    if t is None or not flops_per_launch or not hasattr(t, 'events'):
         return None, (lambda: None)
-    return t.path_events(name, chunks_flops)
+    n = len(flops_per_launch)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(2 * n)]
+    for e in evs:
+        e.record()                       # (torch creates the hipEvent_t lazily, at the first record)
+    arr = (C.c_void_p * (2 * n))(*[e.cuda_event for e in evs])
+    st = _lib.LaunchEvents(events=C.cast(arr, C.POINTER(C.c_void_p)), capacity=n, used=0,
+                           kernel=_lib.PROFILE_KINDS[name], reserved=0)
+    st._keep = (arr, evs)
+
+    def finish():
+        for i in range(st.used):
+            t.events.append((name, evs[2 * i], evs[2 * i + 1], float(flops_per_launch[i])))
+    return st, finish
 
 
 def pt_layer_prepare(w, flags, device):
@@ -986,10 +983,10 @@ def _segments(idx_flat, n_out):
     for k, keep, order, off in _SEGMENTS:
         if k == key:
             return order, off
-    order = torch.argsort(idx_flat.long(), stable=True).to(torch.int32)
-    counts = torch.bincount(idx_flat.long(), minlength=n_out)
-    off = torch.zeros((n_out + 1,), dtype=torch.int32, device=idx_flat.device)
-    off[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    keys, order = torch.sort(idx_flat.long(), stable=True)
+    order = order.to(torch.int32)
+    # segment bounds by binary search in the sorted keys (no host read, no data-dependent shape: capturable)
+    off = torch.searchsorted(keys, torch.arange(n_out + 1, device=idx_flat.device)).to(torch.int32)
     _SEGMENTS.append((key, idx_flat, order, off))
     del _SEGMENTS[:-4]
     return order, off
@@ -1008,6 +1005,14 @@ def segment_gather_sum(src, idx_flat, n_out, scale=1.0, weights=None, div=1):
     return out
 
 
+# Large scatters onto few target rows (the key-table gradient of the attention backward: 458752 pair rows of 832 floats
+# onto 4248 abstract points) as a sorted-segment sum instead of fp32 atomics: the pair gradient is read once at HBM speed
+# and every output row is written once (the atomics run at 2.7 TB/s: 0.66 T float-atomics / s at the L2).  The sort of one
+# neighbour list serves both attention layers (segment cache).  OCC4D_SORTED_SCATTER=0: atomics everywhere.
+SORTED_SCATTER = os.environ.get('OCC4D_SORTED_SCATTER', '1') != '0'
+SORTED_SCATTER_PARTS = int(os.environ.get('OCC4D_SORTED_SCATTER_PARTS', '8'))
+
+
 def scatter_add_rows(src, idx, n_out, scale=1.0):
     src, lds = _rows(_dev(src, name='src'), 'src')
     idx = _dev(idx, torch.int32, 'idx').contiguous().view(-1)
@@ -1015,6 +1020,13 @@ def scatter_add_rows(src, idx, n_out, scale=1.0):
     assert idx.numel() == n
     if DETERMINISTIC:
         return segment_gather_sum(src, idx, n_out, scale=scale)
+    if SORTED_SCATTER and n >= 65536 and 16 * n_out <= n and d >= 64 and d % 4 == 0 and lds % 4 == 0 \
+            and src.data_ptr() % 16 == 0:
+        order, off = _segments(idx, n_out)
+        out = torch.empty((n_out, d), dtype=torch.float32, device=src.device)
+        _lib.check(_lib.lib().occ4d_segment_sum_sorted_f32(_ptr(src), lds, _ptr(order), _ptr(off), n_out, d, SORTED_SCATTER_PARTS,
+                                                          float(scale), _ptr(out), d, _stream()))
+        return out
     out = torch.zeros((n_out, d), dtype=torch.float32, device=src.device)
     _lib.check(_lib.lib().occ4d_scatter_add_rows_f32(_ptr(src), lds, _ptr(idx), n, d, float(scale), _ptr(out), d,
                                                      _stream()))
@@ -1080,6 +1092,8 @@ def pt_softmax_agg_bwd(logits, v, pe, idx, dagg):
     idx32 = _dev(idx, torch.int32)
     if DETERMINISTIC:
         # the per-pair value gradients (the kernel's dpe output) are kept and summed per abstract point in pair order
+        # (measured in round 4: routing this sum through occ4d_segment_sum_sorted_f32 in the default mode instead of the
+        # kernel's own atomics changes nothing, 103.95 vs 103.91 ms per step)
         dval = torch.empty_like(logits)
         _lib.check(_lib.lib().occ4d_pt_softmax_agg_bwd_f32(_ptr(logits), _ptr(v), ldv, _ptr(pe), _ptr(idx32), n, k, d,
                                                            divisor, _ptr(dagg), ldda, _ptr(dlogits), _ptr(dval), None, d,

@@ -151,3 +151,48 @@ def test_single_workgroup_fps_with_a_start_index(pk, n, m, start):
     assert np.array_equal(sel.cpu().numpy(), np.sort(np.array(ref, dtype=np.int32)))
     with pytest.raises(AssertionError):
         pk.ops.fps(torch.from_numpy(p).cuda(), m, start=n)
+
+
+@pytest.mark.parametrize('kind,n', [('uniform', 14336), ('uniform', 5000), ('lattice', 4096), ('padded', 2048),
+                                    ('duplicates', 3000), ('planar', 2500)])
+def test_nested_levels_are_prefixes_of_the_first_selection_order(kind, n):
+    """Exact-in-R refactoring (iv): with a deterministic start the farthest-point subsets of consecutive DownTransitions
+    are the first m_l picks of level 0's selection order.  Three levels computed that way (modules.NestedFps: ONE FPS
+    launch) against three explicit FPS launches on the successive sub-clouds: the same indices, bit for bit -- on
+    tie-free clouds, integer lattices (exact distance ties at every step), clouds with coincident points and the
+    zero-padded clouds of the reference's data path."""
+    import occlusions4d_amd as pk
+    rng = np.random.default_rng(1000 + n)
+    if kind == 'uniform':
+        p = rng.uniform(-5, 5, size=(n, 3))
+    elif kind == 'lattice':
+        p = rng.integers(0, 12, size=(n, 3)).astype(np.float64)          # many exact ties AND duplicates
+    elif kind == 'padded':
+        p = np.concatenate([rng.uniform(-5, 5, size=(n - n // 4, 3)), np.zeros((n // 4, 3))])
+    elif kind == 'duplicates':
+        base = rng.uniform(-5, 5, size=(n // 3, 3))
+        p = np.concatenate([base, base, base])[rng.permutation(3 * (n // 3))]
+    else:
+        p = np.concatenate([rng.uniform(-5, 5, size=(n, 2)), np.zeros((n, 1))], axis=1)
+    p = torch.from_numpy(p.astype(np.float32)).cuda()
+    down = [pk.modules.DownTransition(8, 16, factor=3, knn_k=4, fps_random_start=False) for _ in range(3)]
+    old = pk.modules.NESTED_FPS
+    try:
+        results = {}
+        for nested_on in (False, True):
+            pk.modules.NESTED_FPS = nested_on
+            chain, cur, got = pk.modules.NestedFps(), p, []
+            for d in down:
+                inds, cur = d.sample(cur, nested=chain)
+                got.append((inds.cpu(), cur.cpu()))
+            results[nested_on] = got
+    finally:
+        pk.modules.NESTED_FPS = old
+    for (ia, pa), (ib, pb) in zip(results[False], results[True]):
+        assert ia.dtype == ib.dtype == torch.int32 and torch.equal(ia, ib) and torch.equal(pa, pb)
+    # and a random start (the training default) never takes the prefix path
+    rnd = pk.modules.DownTransition(8, 16, factor=3, knn_k=4, fps_random_start=True)
+    chain = pk.modules.NestedFps()
+    torch.manual_seed(3)
+    rnd.sample(p, nested=chain)
+    assert chain.order is None

@@ -323,6 +323,32 @@ def test_checkpointed_attention_with_frozen_parameters():
             assert rel_err(p.grad, q.grad) < 1e-6, name
 
 
+@pytest.mark.parametrize('n,k,m,d', [(32768, 14, 4248, 832), (5000, 14, 531, 416), (70000, 1, 300, 64)])
+def test_sorted_segment_scatter_matches_the_atomic_scatter(n, k, m, d):
+    """Large scatters onto few rows (the key-table gradient of the attention backward) run as a sorted-segment sum
+    (occ4d_segment_sum_sorted_f32: slices of every row's segment summed independently, one atomic per element and slice)
+    instead of one fp32 atomic per (pair, channel): same values as the atomic kernel and as an fp64 index_add, for very
+    uneven segments (half of the pairs land on 1 % of the rows), empty rows and a strided source."""
+    rng = np.random.default_rng(n + d)
+    hot = rng.integers(0, max(1, m // 100), size=(n * k) // 2)
+    idx = np.concatenate([hot, rng.integers(0, m - 3, size=n * k - hot.size)]).astype(np.int32)   # (the last rows stay empty)
+    rng.shuffle(idx)
+    idx_t = torch.from_numpy(idx).cuda().view(n, k)
+    wide = torch.from_numpy(rng.normal(size=(n * k, d + 8)).astype(np.float32)).cuda()
+    src = wide[:, :d]                                              # row stride d + 8
+    ref = torch.zeros((m, d), dtype=torch.float64, device='cuda').index_add_(0, idx_t.view(-1).long(), src.double()) * -0.5
+    old = pk.ops.SORTED_SCATTER
+    try:
+        pk.ops.SORTED_SCATTER = True
+        got = pk.ops.scatter_add_rows(src, idx_t, m, scale=-0.5)
+        pk.ops.SORTED_SCATTER = False
+        atomic = pk.ops.scatter_add_rows(src, idx_t, m, scale=-0.5)
+    finally:
+        pk.ops.SORTED_SCATTER = old
+    assert rel_err(got, ref.float()) < 2e-5 and rel_err(atomic, ref.float()) < 2e-5
+    assert torch.all(got[m - 3:] == 0)
+
+
 def test_deterministic_reductions_match_the_atomic_ones_and_repeat_bit_for_bit():
     """ops.deterministic(): every backward reduction in a fixed order (stable sort by target row + in-order segment sums;
     two-stage sums for the small vector gradients).  Same values as the atomic kernels to rounding, identical bits on
@@ -572,7 +598,7 @@ def test_geometry_prefetch_is_used_and_changes_nothing():
             (ref, ref_g, _), per_forward = delta(lambda: enc(pcl, False))
             # (a forward issues the FPS chain and the pooling kNNs from the host; the self-attention kNNs run inside the
             # library's block call unless a prefetch hands them over)
-            assert per_forward['fps'] >= 2 and per_forward['knn'] >= 2
+            assert per_forward['fps'] >= 1 and per_forward['knn'] >= 2
             _, per_prefetch = delta(lambda: enc.prefetch_geometry(pcl))
             assert per_prefetch['fps'] == per_forward['fps'] and per_prefetch['knn'] >= per_forward['knn'] + 3
             (out, out_g, _), d = delta(lambda: enc(pcl, False))
