@@ -418,6 +418,13 @@ int occ4d_segment_gather_sum_f32(const float* src, int64_t lds, const int32_t* o
  * abstract points): out[r][:] = scale * sum of src[order[t]][:] over the row's segment, every segment cut into `parts`
  * slices that are summed independently (float4 loads, four in flight) and combined with one atomic per element and slice
  * into the output, which the call clears first.  d, lds, ldo multiples of 4; src, out 16-byte aligned. */
+/* The segments themselves (kernels only, capturable): order (n) int32 = the pair indices grouped by target row idx[p] in
+ * [0, n_out), offsets (n_out + 1) = the group bounds; inside a group the order is unspecified (a multi-block counting
+ * sort with LDS arrival ranks) -- for sums whose order does not matter.  n_out <= 16384; workspace:
+ * occ4d_segments_workspace_ints(n_out) int32. */
+int64_t occ4d_segments_workspace_ints(int n_out);
+int occ4d_segments_build_i32(const int32_t* idx, int64_t n, int n_out, int32_t* order, int32_t* offsets, int32_t* workspace,
+                             void* stream);
 int occ4d_segment_sum_sorted_f32(const float* src, int64_t lds, const int32_t* order, const int32_t* offsets, int n_out,
                                  int d, int parts, float scale, float* out, int64_t ldo, void* stream);
 int occ4d_pt_pos_hidden_bwd_det_workspace(int n, int k, int h, int64_t* floats);

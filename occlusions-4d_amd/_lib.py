@@ -146,6 +146,8 @@ SIGNATURES = {
     'occ4d_interp_bwd_f32': (C.c_int, [_f, C.c_int64, _i, _f, C.c_int, C.c_int, C.c_int, _f, C.c_int64, _s]),
     'occ4d_segment_gather_sum_f32': (C.c_int, [_f, C.c_int64, _i, _i, _f, C.c_int, C.c_int, C.c_int, C.c_float, _f,
                                                C.c_int64, _s]),
+    'occ4d_segments_workspace_ints': (C.c_int64, [C.c_int]),
+    'occ4d_segments_build_i32': (C.c_int, [_i, C.c_int64, C.c_int, _i, _i, _i, _s]),
     'occ4d_segment_sum_sorted_f32': (C.c_int, [_f, C.c_int64, _i, _i, C.c_int, C.c_int, C.c_int, C.c_float, _f, C.c_int64,
                                                _s]),
     'occ4d_pt_pos_hidden_bwd_det_workspace': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),

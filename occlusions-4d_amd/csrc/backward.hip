@@ -266,6 +266,72 @@ __global__ __launch_bounds__(TPB) void segment_sum_sorted_kernel(const float* __
   atomicAdd(o + 3, scale * s.w);
 }
 
+// Segments of a scatter (pair p -> target row idx[p]) by a multi-block counting sort, kernels only (capturable; torch.sort
+// inside a captured graph clears its digit counters with memset nodes that this stack does not replay):
+//   count: block b histograms its contiguous slice of the pairs in LDS            -> bh[b][row]
+//   base : per row, exclusive prefix of bh[.][row] over the blocks                -> bh[b][row] = block b's base in the row; tot[row]
+//   scan : exclusive prefix of tot over the rows (one workgroup)                  -> off[0 .. n_out]
+//   fill : block b replays its slice: order[off[row] + bh[b][row] + (arrival rank in LDS)] = p
+// Within a (block, row) pair the order is the LDS atomics' arrival order: a valid segmentation for sums whose order
+// does not matter (the deterministic mode keeps its stable sort).
+constexpr int SEG_BLOCKS = 128;
+constexpr int SEG_MAX_ROWS = 16384;          // 64 KB of LDS counters
+__global__ __launch_bounds__(TPB) void seg_count_kernel(const int32_t* __restrict__ idx, int64_t n, int n_out,
+                                                        int32_t* __restrict__ bh) {
+  extern __shared__ int s_cnt[];
+  for (int r = threadIdx.x; r < n_out; r += TPB) s_cnt[r] = 0;
+  __syncthreads();
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = per * blockIdx.x, hi = min(n, lo + per);
+  for (int64_t p = lo + threadIdx.x; p < hi; p += TPB) atomicAdd(&s_cnt[idx[p]], 1);
+  __syncthreads();
+  for (int r = threadIdx.x; r < n_out; r += TPB) bh[(int64_t)blockIdx.x * n_out + r] = s_cnt[r];
+}
+__global__ __launch_bounds__(TPB) void seg_base_kernel(int32_t* __restrict__ bh, int n_blocks, int n_out,
+                                                       int32_t* __restrict__ tot) {
+  const int r = blockIdx.x * TPB + threadIdx.x;
+  if (r >= n_out) return;
+  int run = 0;
+  for (int b = 0; b < n_blocks; ++b) {
+    const int c = bh[(int64_t)b * n_out + r];
+    bh[(int64_t)b * n_out + r] = run;
+    run += c;
+  }
+  tot[r] = run;
+}
+__global__ __launch_bounds__(1024) void seg_scan_kernel(const int32_t* __restrict__ tot, int n_out, int32_t* __restrict__ off) {
+  __shared__ int s_part[1024];
+  const int t = threadIdx.x;
+  const int per = (n_out + 1023) / 1024;
+  const int lo = min(n_out, t * per), hi = min(n_out, lo + per);
+  int sum = 0;
+  for (int r = lo; r < hi; ++r) sum += tot[r];
+  s_part[t] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {                 // inclusive Hillis-Steele scan of the thread sums
+    const int v = t >= o ? s_part[t - o] : 0;
+    __syncthreads();
+    s_part[t] += v;
+    __syncthreads();
+  }
+  int run = s_part[t] - sum;
+  for (int r = lo; r < hi; ++r) {
+    off[r] = run;
+    run += tot[r];
+  }
+  if (t == 1023) off[n_out] = s_part[1023];
+}
+__global__ __launch_bounds__(TPB) void seg_fill_kernel(const int32_t* __restrict__ idx, int64_t n, int n_out,
+                                                       const int32_t* __restrict__ bh, const int32_t* __restrict__ off,
+                                                       int32_t* __restrict__ order) {
+  extern __shared__ int s_cnt[];
+  for (int r = threadIdx.x; r < n_out; r += TPB) s_cnt[r] = off[r] + bh[(int64_t)blockIdx.x * n_out + r];
+  __syncthreads();
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = per * blockIdx.x, hi = min(n, lo + per);
+  for (int64_t p = lo + threadIdx.x; p < hi; p += TPB) order[atomicAdd(&s_cnt[idx[p]], 1)] = (int32_t)p;
+}
+
 // pos_hidden_bwd with the block partials written out (blocks x 4 slices x h x 4 floats) instead of atomics ...
 __global__ __launch_bounds__(TPB) void pos_hidden_bwd_partials_kernel(const float* __restrict__ pos, int64_t ps,
                                                                       const float* __restrict__ pos2, int64_t p2s,
@@ -711,16 +777,30 @@ int occ4d_segment_gather_sum_f32(const float* src, int64_t lds, const int32_t* o
   return occ4d::check_launch("occ4d_segment_gather_sum_f32");
 }
 
+int64_t occ4d_segments_workspace_ints(int n_out) { return (int64_t)(SEG_BLOCKS + 1) * n_out; }
+
+int occ4d_segments_build_i32(const int32_t* idx, int64_t n, int n_out, int32_t* order, int32_t* offsets, int32_t* workspace,
+                             void* stream) {
+  OCC4D_REQUIRE(idx && order && offsets && workspace && n >= 0 && n < (int64_t)1 << 31 && n_out >= 1 && n_out <= SEG_MAX_ROWS,
+                "occ4d_segments_build_i32: bad arguments (1 <= n_out <= %d)", SEG_MAX_ROWS);
+  hipStream_t st = (hipStream_t)stream;
+  int32_t* bh = workspace;
+  int32_t* tot = workspace + (int64_t)SEG_BLOCKS * n_out;
+  const size_t lds = sizeof(int) * (size_t)n_out;
+  seg_count_kernel<<<SEG_BLOCKS, TPB, lds, st>>>(idx, n, n_out, bh);
+  seg_base_kernel<<<occ4d::cdiv(n_out, TPB), TPB, 0, st>>>(bh, SEG_BLOCKS, n_out, tot);
+  seg_scan_kernel<<<1, 1024, 0, st>>>(tot, n_out, offsets);
+  seg_fill_kernel<<<SEG_BLOCKS, TPB, lds, st>>>(idx, n, n_out, bh, offsets, order);
+  return occ4d::check_launch("occ4d_segments_build_i32");
+}
+
 int occ4d_segment_sum_sorted_f32(const float* src, int64_t lds, const int32_t* order, const int32_t* offsets, int n_out,
                                  int d, int parts, float scale, float* out, int64_t ldo, void* stream) {
   OCC4D_REQUIRE(src && order && offsets && out && n_out >= 0 && d >= 4 && d % 4 == 0 && parts >= 1 && lds >= d && ldo >= d &&
                     lds % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)out % 16) == 0,
                 "occ4d_segment_sum_sorted_f32: bad arguments (d, lds, ldo multiples of 4; src, out 16-byte aligned)");
   if (!n_out) return OCC4D_OK;
-  if (hipMemset2DAsync(out, ldo * sizeof(float), 0, d * sizeof(float), n_out, (hipStream_t)stream) != hipSuccess) {
-    occ4d::set_error("occ4d_segment_sum_sorted_f32: clearing the output failed");
-    return OCC4D_ELAUNCH;
-  }
+  if (int rc = occ4d::zero_rows(out, ldo, n_out, d, (hipStream_t)stream)) return rc;
   const int64_t total = (int64_t)n_out * parts * (d / 4);
   segment_sum_sorted_kernel<<<grid1d(total), TPB, 0, (hipStream_t)stream>>>(src, lds, order, offsets, total, d / 4, parts,
                                                                             scale, out, ldo);

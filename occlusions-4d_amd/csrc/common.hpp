@@ -45,6 +45,11 @@ bool wgrad16_plan(int M, int N, int K, int* splits, int* m_per_split);
 int wgrad16_launch(const float* g, int64_t ldg, const float* x, int64_t ldx, int M, int N, int K, int splits,
                    int m_per_split, float* part, float* part_b, int relu_x, hipStream_t stream);
 
+// memops.hip: dst[i][0 .. d) = 0 / = src[i][0 .. d) for n rows with row strides (kernels, never hipMemset / hipMemcpy: those
+// are not reliably replayed from a captured graph on this stack)
+int zero_rows(float* dst, int64_t ld, int64_t n, int d, hipStream_t st);
+int copy_rows(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t n, int d, hipStream_t st);
+
 // path.hip: phase offset of the paired attention workgroups (units of s_sleep(127); OCC4D_CA16P_SKEW, default 6)
 int attn16p_skew();
 

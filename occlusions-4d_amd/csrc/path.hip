@@ -577,13 +577,12 @@ int decoder_forward(const occ4d_decoder_weights& w, const DecoderLayout& L, cons
       const float* emb = q;
       int64_t ld_emb = qs;
       if (w.n_freq > 0) {
-        if (L.P4 != L.P) (void)hipMemsetAsync(pe, 0, sizeof(float) * (size_t)c * L.P4, st);
+        if (L.P4 != L.P) TRY(occ4d::zero_rows(pe, L.P4, c, L.P4, st));
         TRY(occ4d_posenc_f32(q, qs, c, w.d_in, w.n_freq, (double)w.base_frequency, pe, L.P4, st));
         emb = pe; ld_emb = L.P4;
       } else {
-        (void)hipMemsetAsync(pe, 0, sizeof(float) * (size_t)c * L.P4, st);
-        (void)hipMemcpy2DAsync(pe, sizeof(float) * L.P4, q, sizeof(float) * qs, sizeof(float) * w.d_in, c,
-                               hipMemcpyDeviceToDevice, st);
+        TRY(occ4d::zero_rows(pe, L.P4, c, L.P4, st));
+        TRY(occ4d::copy_rows(pe, L.P4, q, qs, c, w.d_in, st));
         emb = pe; ld_emb = L.P4;
       }
       TRY(lin(emb, ld_emb, w.lin_in_w, w.lin_in_ld, w.lin_in_b, x, ldx, c, L.P4, H, 0, 0, nullptr, 0, st));
@@ -796,11 +795,7 @@ extern "C" int occ4d_decoder_prepare_scene_f32(const occ4d_decoder_weights* w, c
   hipStream_t st = (hipStream_t)stream;
   const int H = L.H;
   OCC4D_REQUIRE(L.dg == 0 || (fglobal && al16(fglobal)), "%s: features_global missing or misaligned", who);
-  if (hipMemcpy2DAsync(scene + S.xyz, 3 * sizeof(float), xyz, xyz_stride * sizeof(float), 3 * sizeof(float), m,
-                       hipMemcpyDeviceToDevice, st) != hipSuccess) {
-    occ4d::set_error("%s: copy of the abstract coordinates failed", who);
-    return OCC4D_ELAUNCH;
-  }
+  TRY(occ4d::copy_rows(scene + S.xyz, 3, xyz, xyz_stride, m, 3, st));
   for (int i = 0; i < L.nB; ++i) {
     // Z[:, i] = F (W_z_i^local)^T (m, H): the local columns of lin_z[i].weight are a strided view of the parameter
     TRY(lin(feats, ld_feats, w->lin_z_w[i] + L.dg, w->d_latent, nullptr, scene + S.ztab + (int64_t)i * H, (int64_t)L.nB * H, m,
@@ -810,7 +805,7 @@ extern "C" int occ4d_decoder_prepare_scene_f32(const occ4d_decoder_weights* w, c
       TRY(lin(fglobal, L.dg, w->lin_z_w[i], w->d_latent, w->lin_z_b[i], scene + S.zconst + (int64_t)i * H, H, 1, L.dg, H, 0, 0,
               nullptr, 0, st));
     else
-      (void)hipMemcpyAsync(scene + S.zconst + (int64_t)i * H, w->lin_z_b[i], sizeof(float) * H, hipMemcpyDeviceToDevice, st);
+      TRY(occ4d::copy_rows(scene + S.zconst + (int64_t)i * H, H, w->lin_z_b[i], H, 1, H, st));
   }
   for (int j = 0; j < L.nC; ++j)
     TRY(layer_scene(w->cross[j], L.cl[j], prepared + L.cross[j], feats, ld_feats, m, scene + S.layer[j], st));

@@ -52,12 +52,19 @@ class PointCompletionNetV3(torch.nn.Module):
         self.blocks = torch.nn.ModuleList(blocks)
 
     def _geometry_chain(self, pos, full=False, ready=None):
-        """FPS -> sub-cloud of every DownTransition, for all levels, enqueued on a side stream: they depend on
-        coordinates only, and the FPS steps are a ~10 ms single-CU dependent chain that would otherwise serialise the
-        whole encode.  Returns {block index: (per-batch geometry, clouds, event)}; the main stream waits on the event
-        right before the block needs it.  full=True (prefetch_geometry) also runs every kNN of the encoder there: the
-        pooling neighbours of the DownTransitions and the self-kNN of the PointTransformerBlocks.  `ready`: an event
-        after which `pos` is complete; without it the side stream waits for everything queued on the current stream."""
+        """The coordinate-only work of the encoder on a side stream: FPS -> sub-cloud of every DownTransition (the FPS
+        steps are a multi-ms single-CU dependent chain that would otherwise serialise the whole encode) and the kNNs of
+        the levels that only exist once the FPS has run.  Returns {block index: (per-batch geometry, clouds, event)}; the
+        main stream waits on the event right before the block needs it.
+          DownTransition i   -> [(inds, p_sub[, nn_idx])]: the pooling neighbours are included when they can be derived
+                                here -- a row gather of the preceding block's self-kNN lists
+                                (modules.pool_neighbours_from_self_knn: no kNN launch) -- or, full=True, computed here.
+          PointTransformerBlock i -> [self-kNN (N_l, K) int32] for every level BELOW the first (their clouds come out of
+                                the FPS; with the nested levels of DESIGN.md 4 (iv) all of them right after level 0's
+                                launch, so these kNNs run beside the feature chain instead of inside it), and for the
+                                first level too when full=True (prefetch_geometry: nothing of it is left to forward()).
+        `ready`: an event after which `pos` is complete; without it the side stream waits for everything queued on the
+        current stream."""
         main = torch.cuda.current_stream()
         if self._geom_stream is None:
             self._geom_stream = torch.cuda.Stream()
@@ -67,35 +74,42 @@ class PointCompletionNetV3(torch.nn.Module):
         else:
             side.wait_stream(main)
         out = {}
+
+        def publish(i, payload, clouds):
+            for item in payload:                # produced on `side`, consumed on `main`
+                for t in (item if isinstance(item, tuple) else (item,)):
+                    t.record_stream(main)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            out[i] = (payload, clouds, ev)
         with torch.cuda.stream(side):
             cur = [pos[b].contiguous() for b in range(pos.shape[0])]
             nested = [modules.NestedFps() for _ in cur]      # (the levels' farthest-point subsets are prefixes of level 0's)
             for c in cur:
-                # allocated on the side stream, read by the pooling kNN on the main stream: without this the block
-                # could be recycled by a later side-stream allocation while that kNN is still queued
+                # allocated on the side stream, read by kernels on the main stream: without this the block could be
+                # recycled by a later side-stream allocation while such a kernel is still queued
                 c.record_stream(main)
+            self_idx = None                     # self-kNN lists of `cur` when they were computed on this stream
+            deferred = []                       # (block index, clouds) of the levels' self-kNNs: issued after ALL sampling
             for i, block in enumerate(self.blocks):
                 if isinstance(block, modules.DownTransition):
-                    # only the FPS subsets chain on the side stream; the down-kNN of a level (which the next level's
-                    # FPS does not need) is issued on the main stream when the level is consumed -- queued behind the
-                    # FPS it used to delay the whole chain by 0.45 ms per encode
                     g = [block.sample(c, nested=nf) for c, nf in zip(cur, nested)]
-                    if full:
+                    if modules.POOL_FROM_SELF_KNN and self_idx is not None and self_idx[0].shape[1] >= block.knn_k:
+                        g = [(inds, p_sub, modules.pool_neighbours_from_self_knn(sx, inds, block.knn_k))
+                             for (inds, p_sub), sx in zip(g, self_idx)]
+                    elif full:
                         g = [(inds, p_sub, block.neighbours(p_sub, c)) for (inds, p_sub), c in zip(g, cur)]
-                    for tup in g:               # produced on `side`, consumed on `main`
-                        for t in tup:
-                            t.record_stream(main)
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    out[i] = (g, cur, ev)
+                    publish(i, g, cur)
                     cur = [t[1] for t in g]
+                    self_idx = None
                 elif full:
-                    idx = [ops.knn(c, c, block.num_neighbors, metric=0) for c in cur]
-                    for t in idx:
-                        t.record_stream(main)
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    out[i] = (idx, cur, ev)
+                    self_idx = [ops.knn(c, c, block.num_neighbors, metric=0) for c in cur]
+                    publish(i, self_idx, cur)
+                elif i > 0:
+                    deferred.append((i, block, cur))
+            # forward() path: the sampling chain first (nothing may delay the FPS), then the self-kNNs of the lower levels
+            for i, block, clouds in deferred:
+                publish(i, [ops.knn(c, c, block.num_neighbors, metric=0) for c in clouds], clouds)
         return out
 
     def prefetch_geometry(self, pcl, ready=None):
@@ -143,21 +157,29 @@ class PointCompletionNetV3(torch.nn.Module):
             geom = pre[1]
         else:
             geom = self._geometry_chain(pos)
+        self_idx = None          # self-kNN lists of the current level (the next DownTransition's pooling lists are a prefix)
         for i, block in enumerate(self.blocks):
             if isinstance(block, modules.DownTransition):
                 g, clouds, ev = geom[i]
                 if ev is not None:
                     torch.cuda.current_stream().wait_event(ev)
                 if len(g[0]) == 2:
-                    g = [(inds, p_sub, block.neighbours(p_sub, c)) for (inds, p_sub), c in zip(g, clouds)]
+                    if modules.POOL_FROM_SELF_KNN and self_idx is not None and self_idx[0].shape[1] >= block.knn_k:
+                        g = [(inds, p_sub, modules.pool_neighbours_from_self_knn(sx, inds, block.knn_k))
+                             for (inds, p_sub), sx in zip(g, self_idx)]
+                    else:
+                        g = [(inds, p_sub, block.neighbours(p_sub, c)) for (inds, p_sub), c in zip(g, clouds)]
                 (x, pos) = block(x, pos, geometry=g)
-            elif i in geom:
-                idx, _, ev = geom[i]
-                if ev is not None:
-                    torch.cuda.current_stream().wait_event(ev)
-                (x, pos) = block(x, pos, knn_idx=idx)
+                self_idx = None
             else:
-                (x, pos) = block(x, pos)
+                if i in geom:
+                    self_idx, _, ev = geom[i]
+                    if ev is not None:
+                        torch.cuda.current_stream().wait_event(ev)
+                else:
+                    # (the first level's lists: on the main stream, beside the FPS of the geometry stream)
+                    self_idx = [ops.knn(pos[b], pos[b], block.num_neighbors, metric=0) for b in range(B)]
+                (x, pos) = block(x, pos, knn_idx=self_idx)
             if self.output_global_emb and i == self.center_block_idx:
                 g0, g2 = self.global_mlp[0], self.global_mlp[2]
                 if train:

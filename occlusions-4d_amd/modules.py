@@ -80,6 +80,22 @@ class NestedFps:
         return inds.to(torch.int32)
 
 
+POOL_FROM_SELF_KNN = os.environ.get('OCC4D_POOL_FROM_SELF_KNN', '1') != '0'      # (0: one kNN launch per DownTransition)
+
+
+def pool_neighbours_from_self_knn(self_idx, inds, k):
+    """The pooling neighbours of a DownTransition from the self-kNN lists of the block before it (exact): the k nearest
+    full-cloud points of a SAMPLED point (torch_cluster.knn(x=p, y=p_sub, k), model/modules.py:142-146) are the first k
+    entries of that point's own nearest-first list over the same cloud (kNN_torch(p, p, K), K >= k,
+    model/point_transformer_layer.py:167) -- same distance expression ((dx*dx + dy*dy) + dz*dz, same tie rule (distance,
+    then lowest index: a strict total order, so the top k is a prefix of the top K), and p_sub's coordinates are copies of
+    p's.  self_idx (N, K) int32, inds (n_new) int32 -> (n_new, k) int32: a row gather instead of a kNN launch (the int32
+    bit patterns travel through the fp32 gather kernel untouched)."""
+    assert self_idx.dtype == torch.int32 and self_idx.is_contiguous() and self_idx.shape[1] >= k
+    rows = ops.gather_rows(self_idx.view(torch.float32), inds).view(torch.int32)
+    return rows[:, :k].contiguous()
+
+
 class DownTransition(torch.nn.Module):
     """Farthest point sampling + kNN + Linear[/LayerNorm]/ReLU on all points + K-way max pool."""
 

@@ -974,21 +974,39 @@ class deterministic:
 _SEGMENTS = []       # a few recent (key, base tensor, order, offsets): one neighbour list serves several scatters
 
 
-def _segments(idx_flat, n_out):
-    """Pair indices sorted stably by target row (int32) and the (n_out + 1) segment bounds.  Cached on the STORAGE the
+def _segments(idx_flat, n_out, stable=True):
+    """Pair indices sorted stably by target row (int32) and the (n_out + 1) segment bounds (stable=False: grouped by target
+    row in unspecified order inside a group, built by the library's counting sort -- kernels only, so it can be captured;
+    torch.sort inside a captured graph is not replayed correctly on this stack).  Cached on the STORAGE the
     indices live in (+ offset, version, length) -- callers hand in a fresh `.view(-1)` object every time, so the tensor
-    object's identity says nothing; the storage's owner is kept alive so that its address cannot be recycled."""
+    object's identity says nothing; the storage's owner is kept alive so that its address cannot be recycled.
+    While a stream is being captured the cache is neither read nor written: a hit would bake tensors of an EARLIER
+    (eager) call into the graph -- constants of the normal memory pool that the cache frees on its next eviction while
+    every replay still reads them -- and an entry made during the capture would hand graph-pool tensors to later eager
+    calls."""
+    capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+    stable = bool(stable) or n_out > 16384
+    assert not (capturing and stable), 'the stable (deterministic) segmentation sorts with torch: eager steps only'
     key = (idx_flat.untyped_storage().data_ptr(), idx_flat.storage_offset(), idx_flat._version, idx_flat.numel(),
-           idx_flat.stride(0) if idx_flat.numel() > 1 else 1, n_out)
-    for k, keep, order, off in _SEGMENTS:
-        if k == key:
-            return order, off
-    keys, order = torch.sort(idx_flat.long(), stable=True)
-    order = order.to(torch.int32)
-    # segment bounds by binary search in the sorted keys (no host read, no data-dependent shape: capturable)
-    off = torch.searchsorted(keys, torch.arange(n_out + 1, device=idx_flat.device)).to(torch.int32)
-    _SEGMENTS.append((key, idx_flat, order, off))
-    del _SEGMENTS[:-4]
+           idx_flat.stride(0) if idx_flat.numel() > 1 else 1, n_out, stable)
+    if not capturing:
+        for k, keep, order, off in _SEGMENTS:
+            if k == key:
+                return order, off
+    if stable:
+        keys, order = torch.sort(idx_flat.long(), stable=True)
+        order = order.to(torch.int32)
+        off = torch.searchsorted(keys, torch.arange(n_out + 1, device=idx_flat.device)).to(torch.int32)
+    else:
+        idx_c = idx_flat if idx_flat.is_contiguous() else idx_flat.contiguous()
+        order = torch.empty((idx_c.numel(),), dtype=torch.int32, device=idx_c.device)
+        off = torch.empty((n_out + 1,), dtype=torch.int32, device=idx_c.device)
+        ws = torch.empty((int(_lib.lib().occ4d_segments_workspace_ints(n_out)),), dtype=torch.int32, device=idx_c.device)
+        _lib.check(_lib.lib().occ4d_segments_build_i32(_ptr(idx_c), idx_c.numel(), n_out, _ptr(order), _ptr(off), _ptr(ws),
+                                                      _stream()))
+    if not capturing:
+        _SEGMENTS.append((key, idx_flat, order, off))
+        del _SEGMENTS[:-4]
     return order, off
 
 
@@ -1011,6 +1029,7 @@ def segment_gather_sum(src, idx_flat, n_out, scale=1.0, weights=None, div=1):
 # neighbour list serves both attention layers (segment cache).  OCC4D_SORTED_SCATTER=0: atomics everywhere.
 SORTED_SCATTER = os.environ.get('OCC4D_SORTED_SCATTER', '1') != '0'
 SORTED_SCATTER_PARTS = int(os.environ.get('OCC4D_SORTED_SCATTER_PARTS', '8'))
+SORTED_SCATTER_RATIO = int(os.environ.get('OCC4D_SORTED_SCATTER_RATIO', '16'))
 
 
 def scatter_add_rows(src, idx, n_out, scale=1.0):
@@ -1020,9 +1039,9 @@ def scatter_add_rows(src, idx, n_out, scale=1.0):
     assert idx.numel() == n
     if DETERMINISTIC:
         return segment_gather_sum(src, idx, n_out, scale=scale)
-    if SORTED_SCATTER and n >= 65536 and 16 * n_out <= n and d >= 64 and d % 4 == 0 and lds % 4 == 0 \
-            and src.data_ptr() % 16 == 0:
-        order, off = _segments(idx, n_out)
+    if SORTED_SCATTER and n >= 65536 and SORTED_SCATTER_RATIO * n_out <= n and d >= 64 and d % 4 == 0 and lds % 4 == 0 \
+            and src.data_ptr() % 16 == 0 and n_out <= 16384:
+        order, off = _segments(idx, n_out, stable=False)
         out = torch.empty((n_out, d), dtype=torch.float32, device=src.device)
         _lib.check(_lib.lib().occ4d_segment_sum_sorted_f32(_ptr(src), lds, _ptr(order), _ptr(off), n_out, d, SORTED_SCATTER_PARTS,
                                                           float(scale), _ptr(out), d, _stream()))

@@ -347,6 +347,13 @@ def test_sorted_segment_scatter_matches_the_atomic_scatter(n, k, m, d):
         pk.ops.SORTED_SCATTER = old
     assert rel_err(got, ref.float()) < 2e-5 and rel_err(atomic, ref.float()) < 2e-5
     assert torch.all(got[m - 3:] == 0)
+    # the segments themselves (the library's counting sort): every group holds exactly the pairs of its row
+    pk.ops._SEGMENTS.clear()
+    order, off = pk.ops._segments(idx_t.view(-1), m, stable=False)
+    so, sf = pk.ops._segments(idx_t.view(-1), m, stable=True)
+    assert torch.equal(off, sf) and int(off[-1]) == n * k
+    assert torch.equal(idx_t.view(-1)[order.long()], idx_t.view(-1)[so.long()])          # grouped by row, ascending rows
+    assert torch.equal(torch.sort(order)[0], torch.arange(n * k, device='cuda', dtype=torch.int32))   # a permutation
 
 
 def test_deterministic_reductions_match_the_atomic_ones_and_repeat_bit_for_bit():
@@ -596,11 +603,11 @@ def test_geometry_prefetch_is_used_and_changes_nothing():
                 res = fn()
                 return res, {k: calls[k] - before[k] for k in calls}
             (ref, ref_g, _), per_forward = delta(lambda: enc(pcl, False))
-            # (a forward issues the FPS chain and the pooling kNNs from the host; the self-attention kNNs run inside the
-            # library's block call unless a prefetch hands them over)
-            assert per_forward['fps'] >= 1 and per_forward['knn'] >= 2
+            # (one FPS launch: the lower levels are prefixes of its selection order; one self-kNN per level: the pooling
+            # neighbours of a DownTransition are a prefix of the preceding block's lists -- DESIGN.md 4 (iv), (v))
+            assert per_forward == {'fps': 1, 'knn': pa['down_blocks'] + 1}
             _, per_prefetch = delta(lambda: enc.prefetch_geometry(pcl))
-            assert per_prefetch['fps'] == per_forward['fps'] and per_prefetch['knn'] >= per_forward['knn'] + 3
+            assert per_prefetch == per_forward
             (out, out_g, _), d = delta(lambda: enc(pcl, False))
             assert d == {'fps': 0, 'knn': 0}                                     # all of it ran in the prefetch
             assert torch.equal(out, ref) and torch.equal(out_g, ref_g)
