@@ -196,3 +196,54 @@ def test_nested_levels_are_prefixes_of_the_first_selection_order(kind, n):
     torch.manual_seed(3)
     rnd.sample(p, nested=chain)
     assert chain.order is None
+
+
+@pytest.mark.parametrize('kind,n', [('uniform', 14336), ('uniform', 3584), ('lattice', 4096), ('padded', 2048),
+                                    ('duplicates', 3000), ('uniform', 50)])
+def test_pooling_neighbours_are_a_prefix_of_the_self_knn_lists(kind, n):
+    """Exact-in-R refactoring (v): the knn_k nearest full-cloud points of a SAMPLED point (DownTransition.neighbours, one
+    kNN launch) = the first knn_k entries of that point's row of the preceding block's self-kNN lists (K = 16), bit for
+    bit -- also where distances tie (lattices, coincident points, the zero padding rows: lowest index first in both)."""
+    import occlusions4d_amd as pk
+    rng = np.random.default_rng(2000 + n)
+    if kind == 'uniform':
+        p = rng.uniform(-5, 5, size=(n, 3))
+    elif kind == 'lattice':
+        p = rng.integers(0, 12, size=(n, 3)).astype(np.float64)
+    elif kind == 'padded':
+        p = np.concatenate([rng.uniform(-5, 5, size=(n - n // 4, 3)), np.zeros((n // 4, 3))])
+    else:
+        base = rng.uniform(-5, 5, size=(n // 3, 3))
+        p = np.concatenate([base, base, base])[rng.permutation(3 * (n // 3))]
+    p = torch.from_numpy(p.astype(np.float32)).cuda()
+    for k_self, k_pool, factor in ((16, 12, 4), (16, 16, 3), (8, 3, 2)):
+        down = pk.modules.DownTransition(8, 16, factor=factor, knn_k=k_pool, fps_random_start=False)
+        inds, p_sub = down.sample(p)
+        launched = down.neighbours(p_sub, p)
+        self_idx = pk.ops.knn(p, p, k_self, metric=0)
+        derived = pk.modules.pool_neighbours_from_self_knn(self_idx, inds, k_pool)
+        assert derived.dtype == launched.dtype == torch.int32 and derived.shape == launched.shape
+        assert torch.equal(derived, launched)
+
+
+def test_encoder_with_and_without_the_derived_geometry_is_bit_identical():
+    """PointCompletionNetV3.forward with refactorings (iv) and (v) on (default) and off: the same floats."""
+    import occlusions4d_amd as pk
+    torch.manual_seed(5)
+    net = pk.model.PointCompletionNetV3(n_input=2048, d_in=8, d_feat=16, down_blocks=3, transition_factor=3,
+                                        pt_num_neighbors=16, down_neighbors=12, abstract_levels=2,
+                                        fps_random_start=False).cuda().eval()
+    pcl = torch.randn(2, 2048, 8, device='cuda')
+    pcl[1, 1500:] = 0.0
+    old = (pk.modules.NESTED_FPS, pk.modules.POOL_FROM_SELF_KNN)
+    try:
+        outs = []
+        for on in (True, False):
+            pk.modules.NESTED_FPS = pk.modules.POOL_FROM_SELF_KNN = on
+            with torch.no_grad():
+                (a, g, coords) = net(pcl, True)
+            outs.append((a.clone(), g.clone(), [c.clone() for c in coords]))
+    finally:
+        (pk.modules.NESTED_FPS, pk.modules.POOL_FROM_SELF_KNN) = old
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert all(torch.equal(x, y) for x, y in zip(outs[0][2], outs[1][2]))
