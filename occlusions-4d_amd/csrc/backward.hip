@@ -509,6 +509,86 @@ __global__ __launch_bounds__(TPB) void softmax_agg_bwd_kernel(const float* __res
     }
 }
 
+// The same for d % 4 == 0 and a compile-time neighbour count: a thread owns FOUR consecutive channels of one query, so
+// every pair-tensor access is 16 bytes per lane (1 KB per wave instruction) and all 2 K + 1 loads of a thread are
+// independent and issued before the first use: 5.3-5.5 TB/s on the 3 GB of a training chunk (32768 queries x 14
+// neighbours x 416 channels, four pair tensors) against 2.1 TB/s for the scalar kernel above.  Without the value-table
+// atomics: 16-byte lanes make them sparse (2.5 ms with, 0.57 ms without; profiles/r04_time_softmax_bwd.txt) -- the caller
+// reduces the per-pair value gradients `dval` (= dpe) itself (sorted-segment sum, occ4d_segment_sum_sorted_f32).
+// exp through v_exp_f32 on pre-scaled arguments (as the forward kernels do).
+typedef float sm_f4 __attribute__((ext_vector_type(4)));
+template <int K, bool HAS_PE>
+__global__ __launch_bounds__(256) void softmax_agg_bwd4_kernel(const float* __restrict__ logits,
+                                                               const float* __restrict__ v, int ldv,
+                                                               const float* __restrict__ pe,
+                                                               const int32_t* __restrict__ idx, int total4, int d4,
+                                                               float inv_div, const float* __restrict__ dagg, int ldda,
+                                                               float* __restrict__ dlogits, float* __restrict__ dval) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= total4) return;
+  const int i = e / d4, c = 4 * (e - i * d4);
+  const int64_t row0 = (int64_t)i * K;                                 // first pair row of the query
+  const int64_t ld = 4 * (int64_t)d4;
+  const float* lp = logits + row0 * ld + c;
+  sm_f4 l[K], val[K];
+  int id[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) l[j] = *reinterpret_cast<const sm_f4*>(lp + j * ld);
+#pragma unroll
+  for (int j = 0; j < K; ++j) id[j] = idx[row0 + j];
+  const sm_f4 go = *reinterpret_cast<const sm_f4*>(dagg + (int64_t)i * ldda + c);
+  if (HAS_PE) {
+    const float* pp = pe + row0 * ld + c;
+#pragma unroll
+    for (int j = 0; j < K; ++j) val[j] = *reinterpret_cast<const sm_f4*>(pp + j * ld);
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const sm_f4 vv = *reinterpret_cast<const sm_f4*>(v + (int64_t)id[j] * ldv + c);
+    val[j] = HAS_PE ? val[j] + vv : vv;
+  }
+  constexpr float LOG2E = 1.44269504088896f;
+  const float sc = inv_div * LOG2E;
+  sm_f4 mx = l[0];
+#pragma unroll
+  for (int j = 1; j < K; ++j) {
+    mx.x = fmaxf(mx.x, l[j].x); mx.y = fmaxf(mx.y, l[j].y); mx.z = fmaxf(mx.z, l[j].z); mx.w = fmaxf(mx.w, l[j].w);
+  }
+  sm_f4 den = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    l[j].x = __builtin_amdgcn_exp2f((l[j].x - mx.x) * sc); l[j].y = __builtin_amdgcn_exp2f((l[j].y - mx.y) * sc);
+    l[j].z = __builtin_amdgcn_exp2f((l[j].z - mx.z) * sc); l[j].w = __builtin_amdgcn_exp2f((l[j].w - mx.w) * sc);
+    den += l[j];
+  }
+  const sm_f4 rden = {1.f / den.x, 1.f / den.y, 1.f / den.z, 1.f / den.w};
+  sm_f4 dot = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    l[j] *= rden;                                                      // a_j
+    val[j] *= go;                                                      // da_j = val_j dagg
+    dot += l[j] * val[j];
+  }
+  float* dlp = dlogits + row0 * ld + c;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const sm_f4 dl = l[j] * (val[j] - dot) * inv_div;
+    *reinterpret_cast<sm_f4*>(dlp + j * ld) = dl;
+  }
+  float* dpp = dval + row0 * ld + c;
+#pragma unroll
+  for (int j = 0; j < K; ++j) *reinterpret_cast<sm_f4*>(dpp + j * ld) = l[j] * go;
+}
+
+template <int K>
+static void softmax_agg_bwd4_launch(const float* logits, const float* v, int ldv, const float* pe, const int32_t* idx,
+                                    int total4, int d4, float inv_div, const float* dagg, int ldda, float* dlogits,
+                                    float* dval, hipStream_t st) {
+  const dim3 grid((total4 + 255) / 256);
+  if (pe) softmax_agg_bwd4_kernel<K, true><<<grid, 256, 0, st>>>(logits, v, ldv, pe, idx, total4, d4, inv_div, dagg, ldda, dlogits, dval);
+  else softmax_agg_bwd4_kernel<K, false><<<grid, 256, 0, st>>>(logits, v, ldv, pe, idx, total4, d4, inv_div, dagg, ldda, dlogits, dval);
+}
+
 // pos-MLP first layer backward: r = relu(P1 delta + c1); gr = dL/dr (n*k, h)
 // dP1[m][:] += sum_p [r>0] gr[p][m] delta_p ; dc1[m] += sum_p [r>0] gr[p][m]      (block partials + atomics)
 __global__ __launch_bounds__(TPB) void pos_hidden_bwd_kernel(const float* __restrict__ pos, int64_t ps,
@@ -738,6 +818,23 @@ int occ4d_pt_softmax_agg_bwd_f32(const float* logits, const float* v, int64_t ld
   OCC4D_REQUIRE(n >= 0 && k >= 1 && k <= 16 && d >= 1 && divisor > 0.f, "occ4d_pt_softmax_agg_bwd_f32: bad sizes");
   const int64_t total = (int64_t)n * d;
   if (!total) return OCC4D_OK;
+  static const bool wide = [] { const char* e = getenv("OCC4D_SOFTMAX_BWD4"); return !e || e[0] != '0'; }();
+  const bool al = d % 4 == 0 && ldv % 4 == 0 && ldda % 4 == 0 && total / 4 < ((int64_t)1 << 31) &&
+                  ldv < ((int64_t)1 << 31) && ldda < ((int64_t)1 << 31) &&
+                  (((uintptr_t)logits | (uintptr_t)v | (uintptr_t)pe | (uintptr_t)dagg | (uintptr_t)dlogits |
+                    (uintptr_t)dpe) % 16) == 0;
+  if (wide && al && !dv && (k == 16 || k == 14 || k == 12 || k == 8)) {      // (dpe != null by the check above)
+    const int total4 = (int)(total / 4), d4 = d / 4;
+    const float inv_div = 1.f / divisor;
+    hipStream_t st = (hipStream_t)stream;
+    switch (k) {
+      case 16: softmax_agg_bwd4_launch<16>(logits, v, (int)ldv, pe, idx, total4, d4, inv_div, dagg, (int)ldda, dlogits, dpe, st); break;
+      case 14: softmax_agg_bwd4_launch<14>(logits, v, (int)ldv, pe, idx, total4, d4, inv_div, dagg, (int)ldda, dlogits, dpe, st); break;
+      case 12: softmax_agg_bwd4_launch<12>(logits, v, (int)ldv, pe, idx, total4, d4, inv_div, dagg, (int)ldda, dlogits, dpe, st); break;
+      default: softmax_agg_bwd4_launch<8>(logits, v, (int)ldv, pe, idx, total4, d4, inv_div, dagg, (int)ldda, dlogits, dpe, st); break;
+    }
+    return occ4d::check_launch("occ4d_pt_softmax_agg_bwd_f32");
+  }
   softmax_agg_bwd_kernel<16><<<grid1d(total), TPB, 0, (hipStream_t)stream>>>(logits, v, ldv, pe, idx, total, k, d,
                                                                              divisor, dagg, ldda, dlogits, dpe, dv, lddv);
   return occ4d::check_launch("occ4d_pt_softmax_agg_bwd_f32");

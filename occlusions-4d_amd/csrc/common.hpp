@@ -50,6 +50,9 @@ int wgrad16_launch(const float* g, int64_t ldg, const float* x, int64_t ldx, int
 int zero_rows(float* dst, int64_t ld, int64_t n, int d, hipStream_t st);
 int copy_rows(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t n, int d, hipStream_t st);
 
+// memops.hip: compute units of the current device (cached; 256 if the query fails)
+int cu_count();
+
 // path.hip: phase offset of the paired attention workgroups (units of s_sleep(127); OCC4D_CA16P_SKEW, default 6)
 int attn16p_skew();
 

@@ -644,18 +644,7 @@ __global__ __launch_bounds__(256, 2) void pair_mlp_kernel(const PairMlpArgs a) {
   }
 }
 
-int cu_count() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-      n = v;
-    else
-      n = 256;
-  }
-  return n;
-}
+using occ4d::cu_count;
 
 }  // namespace
 

@@ -35,4 +35,17 @@ int copy_rows(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t n,
   return check_launch("copy_rows");
 }
 
+int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      n = v;
+    else
+      n = 256;
+  }
+  return n;
+}
+
 }  // namespace occ4d

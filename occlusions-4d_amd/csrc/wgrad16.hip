@@ -7,12 +7,16 @@
 // one wave per SIMD (13 accumulator tiles of 32 x 32 = 208 registers), operand tiles staged through registers with
 // per-element selects (VALU, which on gfx950 shares the vector issue with the fp32 MFMAs), 128-row blocks of N = 416
 // (19 % of the rows idle).  Here:
-//   * v_mfma_f32_16x16x4_f32; a workgroup of 4 waves covers ALL 416 rows of an N chunk (as 28 tile rows of 16 = 448,
-//     7 per wave: 93 % live) and 64 (or 32) columns of K: 28 (14) accumulator tiles = 112 registers per wave, so two
-//     workgroups share a CU and cover each other's barrier / DMA waits;
+//   * v_mfma_f32_16x16x4_f32; a workgroup of 4 waves covers ALL 416 rows of an N chunk (26 tile rows of 16) and 64
+//     columns of K (4 tiles): wave (nh, kh) owns the tile rows 13 nh .. 13 nh + 12 and the column tiles 2 kh, 2 kh + 1 --
+//     26 accumulator tiles = 104 registers, every MFMA row live (round 3 gave each wave 7 of 28 tile rows: 7 % of the
+//     MFMAs computed rows 416 .. 447, which do not exist), so two workgroups share a CU and cover each other's barrier /
+//     DMA waits (the attention kernels' phase skew between the two was tried here: no effect, profiles/r04_time_wgrad.txt);
 //   * both operand tiles arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no VALU), exactly as
 //     they lie in memory ([16 m][416 n] and [16 m][64 k], rows contiguous), double buffered, one barrier per 16 rows
-//     of M; per 4-row MFMA step a wave reads 7 + 4 operand dwords from LDS for 28 MFMAs;
+//     of M; per 4-row MFMA step a wave reads 13 + 2 operand dwords from LDS for 26 MFMAs;
+//   * the bias gradient (column sums of g) is accumulated by the workgroups of K column 0 only (a workgroup-uniform
+//     specialisation of the stage loop: 13 VALU adds per step there, none in the other columns);
 //   * M is split over workgroups; the workgroups of one M slice (all K columns) are placed on the same XCD, so g is
 //     read from HBM once per slice and from that XCD's L2 by the others.
 // Partials [split][N][K] (+ [split][N] for the bias gradient) are summed by backward.hip's wgrad_reduce_kernel.
@@ -27,10 +31,10 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WN = 416;                  // rows of an N chunk
-constexpr int WTA = 7;                   // tile rows (16 n) per wave: 4 waves x 7 x 16 = 448 >= 416
+constexpr int WTA = 13;                  // tile rows (16 n) per wave: 2 wave rows x 13 x 16 = 416
+constexpr int WTB = 2;                   // column tiles (16 k) per wave: 2 wave columns x 2 x 16 = 64
 constexpr int WBM = 16;                  // rows of M per stage
 constexpr int WGS = WBM * WN;            // floats of a g tile (26 KB = 26 DMA chunks of 1 KB)
-constexpr int WSLACK = 32;               // the last wave's tile rows reach 32 floats past a row (never stored)
 
 struct W16Args {
   const float* g; int64_t ldg;
@@ -58,12 +62,13 @@ __device__ __forceinline__ void dma_wait_w() { asm volatile("s_waitcnt vmcnt(0)"
 template <int NTB, bool RELU, bool BIAS>
 __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const W16Args a) {
   constexpr int XROW = 16 * NTB;                       // floats per x tile row
-  __shared__ __attribute__((aligned(16))) float gs0[WGS + WSLACK];
-  __shared__ __attribute__((aligned(16))) float gs1[WGS + WSLACK];
+  __shared__ __attribute__((aligned(16))) float gs0[WGS];
+  __shared__ __attribute__((aligned(16))) float gs1[WGS];
   __shared__ __attribute__((aligned(16))) float xs0[WBM * XROW];
   __shared__ __attribute__((aligned(16))) float xs1[WBM * XROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4;
+  const int nh = wave >> 1, kh = wave & 1;
   // ---- which (M slice, N chunk, K column): workgroup b runs on XCD b % 8; the ncol x nchunk workgroups of a slice
   // are consecutive multiples of 8 apart, i.e. on one XCD
   const int cc_n = a.ncol * a.nchunk;
@@ -111,17 +116,17 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const W16Args a) {
   const bool extra = wave < 2;
   const unsigned w1k = (unsigned)wave * 1024u;
   // slot `slot` of the stage whose first rows are at (gsrc, xsrc), into the buffers (gdst, xdst)
-  auto dma_slot = [&](int slot, const float* gsrc, const float* xsrc, float* gdst, float* xdst) {
+  auto dma_slot = [&](int slot, const float* gsrc, const float* xsrc, float* gdst, float* xdst) __attribute__((always_inline)) {
     if (slot < GSL) dma_w(gsrc, voff[slot], lds_addr_w(gdst) + w1k + (unsigned)slot * 4096u);
     else if (slot == GSL) dma_w(xsrc, voff[GSL], lds_addr_w(xdst) + w1k);
     else if (extra) dma_w(gsrc, voff[GSL + 1], lds_addr_w(gdst) + 24u * 1024u + w1k);
   };
 
-  f32x4 acc[WTA][NTB];
+  f32x4 acc[WTA][WTB];
 #pragma unroll
   for (int ta = 0; ta < WTA; ++ta)
 #pragma unroll
-    for (int tb = 0; tb < NTB; ++tb) acc[ta][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int tb = 0; tb < WTB; ++tb) acc[ta][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum[WTA];
 #pragma unroll
   for (int ta = 0; ta < WTA; ++ta) bsum[ta] = 0.f;
@@ -131,19 +136,20 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const W16Args a) {
   dma_wait_w();
   __syncthreads();
 
-  // one stage = 4 MFMA steps of 4 rows of M: per step 7 A dwords (g, this wave's tile rows) + NTB B dwords (x) from
-  // LDS, 7 x NTB MFMAs; the operands of step s + 1 are read before the MFMAs of step s (fenced)
+  // one stage = 4 MFMA steps of 4 rows of M: per step 13 A dwords (g, this wave's tile rows) + 2 B dwords (x) from
+  // LDS, 26 MFMAs; the operands of step s + 1 are read before the MFMAs of step s (fenced)
   // (the next stage's DMA slots are issued INSIDE the step, between MFMAs: a burst of them at the top of a stage is
   // ~100 scalar instructions with the matrix pipe idle)
-  auto stage = [&](const float* __restrict__ gt, const float* __restrict__ xt, const float* gsrc, const float* xsrc,
-                   float* gdst, float* xdst) {
-    const float* ga = gt + kq * WN + 16 * WTA * wave + li;
-    const float* xb = xt + kq * XROW + li;
-    float av[2][WTA], bv[2][NTB];                         // operand registers of the current / next step (no copies)
+  auto stage = [&](auto with_bias, const float* __restrict__ gt, const float* __restrict__ xt, const float* gsrc,
+                   const float* xsrc, float* gdst, float* xdst) __attribute__((always_inline)) {
+    constexpr bool SUMS = decltype(with_bias)::value;
+    const float* ga = gt + kq * WN + 16 * WTA * nh + li;
+    const float* xb = xt + kq * XROW + 16 * WTB * kh + li;
+    float av[2][WTA], bv[2][WTB];                         // operand registers of the current / next step (no copies)
 #pragma unroll
     for (int ta = 0; ta < WTA; ++ta) av[0][ta] = ga[16 * ta];
 #pragma unroll
-    for (int tb = 0; tb < NTB; ++tb) bv[0][tb] = xb[16 * tb];
+    for (int tb = 0; tb < WTB; ++tb) bv[0][tb] = xb[16 * tb];
 #pragma unroll
     for (int s = 0; s < WBM / 4; ++s) {
       const int cur = s & 1, nxt = cur ^ 1;
@@ -151,23 +157,24 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const W16Args a) {
 #pragma unroll
         for (int ta = 0; ta < WTA; ++ta) av[nxt][ta] = ga[(4 * (s + 1)) * WN + 16 * ta];
 #pragma unroll
-        for (int tb = 0; tb < NTB; ++tb) bv[nxt][tb] = xb[(4 * (s + 1)) * XROW + 16 * tb];
+        for (int tb = 0; tb < WTB; ++tb) bv[nxt][tb] = xb[(4 * (s + 1)) * XROW + 16 * tb];
       }
       if (RELU) {
 #pragma unroll
-        for (int tb = 0; tb < NTB; ++tb) bv[cur][tb] = fmaxf(bv[cur][tb], 0.f);
+        for (int tb = 0; tb < WTB; ++tb) bv[cur][tb] = fmaxf(bv[cur][tb], 0.f);
       }
-      if (BIAS) {
+      if (SUMS) {
 #pragma unroll
         for (int ta = 0; ta < WTA; ++ta) bsum[ta] += av[cur][ta];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ta = 0; ta < WTA; ++ta) {
-        // two DMA slots per step, behind the 1st and the 4th row of MFMAs
-        if (ta == 1 || ta == 4) dma_slot(2 * s + (ta == 4), gsrc, xsrc, gdst, xdst);
+        // the next stage's 8 DMA slots in the first two steps (four each, three MFMA rows apart): the last of them
+        // has two steps of MFMAs to land before the stage's closing wait
+        if (s < 2 && ta % 3 == 1) dma_slot(4 * s + ta / 3, gsrc, xsrc, gdst, xdst);
 #pragma unroll
-        for (int tb = 0; tb < NTB; ++tb)
+        for (int tb = 0; tb < WTB; ++tb)
           acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][ta], bv[cur][tb], acc[ta][tb], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -175,43 +182,47 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const W16Args a) {
   };
   asm volatile("; OCC4D_MARK loop");
   // (the last stage has no successor: it re-loads itself into the idle buffer instead of branching around the DMA)
-  const float* gnext = gbase;
-  const float* xnext = xbase;
+  auto run = [&](auto with_bias) __attribute__((always_inline)) {
+    const float* gnext = gbase;
+    const float* xnext = xbase;
 #pragma clang loop unroll(disable)
-  for (int st = 0; st < n_stage; st += 2) {
-    if (st + 1 < n_stage) { gnext += gstep; xnext += xstep; }
-    stage(gs0, xs0, gnext, xnext, gs1, xs1);
-    dma_wait_w();
-    __syncthreads();
-    if (st + 1 >= n_stage) break;
-    if (st + 2 < n_stage) { gnext += gstep; xnext += xstep; }
-    stage(gs1, xs1, gnext, xnext, gs0, xs0);
-    dma_wait_w();
-    __syncthreads();
-  }
+    for (int st = 0; st < n_stage; st += 2) {
+      if (st + 1 < n_stage) { gnext += gstep; xnext += xstep; }
+      stage(with_bias, gs0, xs0, gnext, xnext, gs1, xs1);
+      dma_wait_w();
+      __syncthreads();
+      if (st + 1 >= n_stage) break;
+      if (st + 2 < n_stage) { gnext += gstep; xnext += xstep; }
+      stage(with_bias, gs1, xs1, gnext, xnext, gs0, xs0);
+      dma_wait_w();
+      __syncthreads();
+    }
+  };
+  if (BIAS && col == 0) run(std::true_type{});           // (workgroup-uniform: one scalar branch per workgroup)
+  else run(std::false_type{});
 
   asm volatile("; OCC4D_MARK epilogue");
   // ---- partial tile to memory: C/D lane (column j = li, rows 4 kq + reg)
 #pragma unroll
   for (int ta = 0; ta < WTA; ++ta) {
-    const int nrow = 16 * (WTA * wave + ta) + 4 * kq;
-    if (nrow >= WN) continue;                             // (tile rows 26, 27 of the chunk do not exist)
+    const int nrow = 16 * (WTA * nh + ta) + 4 * kq;
 #pragma unroll
-    for (int tb = 0; tb < NTB; ++tb) {
-      if (16 * tb < kskip) continue;                      // (columns the neighbouring block owns)
+    for (int tb = 0; tb < WTB; ++tb) {
+      const int kc = 16 * (WTB * kh + tb);
+      if (kc < kskip) continue;                           // (columns the neighbouring block owns)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) P[(int64_t)(n0 + nrow + r) * a.K + k0 + 16 * tb + li] = acc[ta][tb][r];
+      for (int r = 0; r < 4; ++r) P[(int64_t)(n0 + nrow + r) * a.K + k0 + kc + li] = acc[ta][tb][r];
     }
   }
-  if (BIAS && col == 0) {
-    // bias gradient (every column sums its A operands -- 7 VALU per 28 MFMAs -- column 0 stores): this lane summed g[m][n] over its m residue class kq; add the four classes (lanes li + 16 kq)
+  if (BIAS && col == 0 && kh == 0) {
+    // bias gradient: this lane summed g[m][n] over its m residue class kq; add the four classes (lanes li + 16 kq)
 #pragma unroll
     for (int ta = 0; ta < WTA; ++ta) {
       float v = bsum[ta];
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
-      const int n = 16 * (WTA * wave + ta) + li;
-      if (kq == 0 && n < WN) a.part_b[(int64_t)z * a.N + n0 + n] = v;
+      const int n = 16 * (WTA * nh + ta) + li;
+      if (kq == 0) a.part_b[(int64_t)z * a.N + n0 + n] = v;
     }
   }
 }

@@ -1099,6 +1099,9 @@ def layernorm_bwd(x, gamma, g, eps):
     return dx, dgamma, dbeta
 
 
+SOFTMAX_BWD_SPLIT = os.environ.get('OCC4D_SOFTMAX_BWD4', '1') != '0'
+
+
 def pt_softmax_agg_bwd(logits, v, pe, idx, dagg):
     logits = _cont(logits, 'logits')
     v, ldv = _rows(_dev(v, name='v'), 'v')
@@ -1118,6 +1121,15 @@ def pt_softmax_agg_bwd(logits, v, pe, idx, dagg):
                                                            divisor, _ptr(dagg), ldda, _ptr(dlogits), _ptr(dval), None, d,
                                                            _stream()))
         dv = segment_gather_sum(dval, idx32.contiguous().view(-1), v.shape[0])
+        return dlogits, (dval if pe is not None else None), dv
+    if SOFTMAX_BWD_SPLIT and k in (8, 12, 14, 16) and d % 4 == 0 and ldv % 4 == 0 and ldda % 4 == 0:
+        # 16-byte-lane kernel (5.4 TB/s over the four pair tensors) writes the per-pair value gradients; their sum per
+        # abstract point is a separate reduction (its own atomics from 16-byte lanes cost more than the kernel)
+        dval = torch.empty_like(logits)
+        _lib.check(_lib.lib().occ4d_pt_softmax_agg_bwd_f32(_ptr(logits), _ptr(v), ldv, _ptr(pe), _ptr(idx32), n, k, d,
+                                                           divisor, _ptr(dagg), ldda, _ptr(dlogits), _ptr(dval), None, d,
+                                                           _stream()))
+        dv = scatter_add_rows(dval, idx32, v.shape[0])
         return dlogits, (dval if pe is not None else None), dv
     dpe = torch.empty_like(logits) if pe is not None else None
     dv = torch.zeros((v.shape[0], d), dtype=torch.float32, device=logits.device)
