@@ -139,12 +139,49 @@ __global__ __launch_bounds__(TPB) void wgrad_reduce_kernel(const float* __restri
   const int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
   if (e >= nk) return;
   float s = accumulate ? dw[e] : 0.f;
-  for (int z = 0; z < splits; ++z) s += part[(int64_t)z * nk + e];
+  int z = 0;
+  for (; z + 8 <= splits; z += 8) {            // (eight independent loads in flight: a serial loop is one HBM latency per partial)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(z + u) * nk + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; z < splits; ++z) s += part[(int64_t)z * nk + e];
   dw[e] = s;
 }
-
-// the same sum (same order per element: z ascending) four elements per thread with eight partial planes in flight:
-// the scalar loop above ran the 40 .. 73 planes of the large weight gradients at 0.5 TB/s
+// The same sum for SHORT vectors (the bias gradient: N = 416 .. 832 elements, up to 113 partials): with one thread per
+// element the launch is two workgroups walking 113 dependent-latency loads each (measured 28 us average, 121 us at 113
+// partials, 70 launches per training step).  Here 64 elements per workgroup x 4 waves, wave w takes the partials
+// z = w (mod 4) with 8 loads in flight; the four sums meet in LDS and are added in a fixed order (deterministic).
+__global__ __launch_bounds__(TPB) void short_reduce_kernel(const float* __restrict__ part, int splits, int nk,
+                                                           float* __restrict__ dw, int accumulate) {
+  __shared__ float sh[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (e < nk) {
+    int z = w;
+    for (; z + 28 < splits; z += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(z + 4 * u) * nk + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; z < splits; z += 4) s += part[(int64_t)z * nk + e];
+  }
+  sh[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && e < nk) {
+    float t = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+    if (accumulate) t += dw[e];
+    dw[e] = t;
+  }
+}
+static void launch_short_reduce(const float* part, int splits, int nk, float* dw, int accumulate, hipStream_t st) {
+  short_reduce_kernel<<<(nk + 63) / 64, TPB, 0, st>>>(part, splits, nk, dw, accumulate);
+}
 __global__ __launch_bounds__(TPB) void wgrad_reduce4_kernel(const float* __restrict__ part, int splits, int64_t nk4,
                                                             float* __restrict__ dw, int accumulate) {
   typedef float f4 __attribute__((ext_vector_type(4)));
@@ -373,6 +410,23 @@ __global__ __launch_bounds__(TPB) void segment_sum_kernel(const float* __restric
   float s = 0.f;
   for (int j = 0; j < k; ++j) s += src[(i * k + j) * d + c];
   out[i * ldo + c] = s;
+}
+// the same on 16-byte lanes, the k <= 16 loads of a thread independent (the scalar kernel above: 3.5 TB/s on the 1.5 GB
+// pair gradient of a training chunk)
+__global__ __launch_bounds__(TPB) void segment_sum4_kernel(const float* __restrict__ src, int total4, int k, int d4,
+                                                           float* __restrict__ out, int64_t ldo) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int e = blockIdx.x * TPB + threadIdx.x;
+  if (e >= total4) return;
+  const int i = e / d4, c = e - i * d4;
+  const f4* p = reinterpret_cast<const f4*>(src) + (int64_t)i * k * d4 + c;
+  f4 v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = j < k ? p[(int64_t)j * d4] : f4{0.f, 0.f, 0.f, 0.f};
+  f4 s = v[0];
+#pragma unroll
+  for (int j = 1; j < 16; ++j) s += v[j];
+  *reinterpret_cast<f4*>(out + (int64_t)i * ldo + 4 * c) = s;
 }
 
 // max pool backward: dy[idx[i][j*]][c] += dz[i][c], j* = first argmax_j y[idx[i][j]][c]
@@ -699,8 +753,11 @@ int occ4d_linear_wgrad_workspace(int M, int N, int K, int* splits_out, int64_t* 
     return OCC4D_OK;                                                            // last full 16-row tile)
   }
   // enough m-chunks to give every CU a workgroup, each at least 256 rows deep
+  // (K <= 64: the launch is HBM-bound -- one 16-row tile in flight per workgroup -- and wants more workgroups in flight:
+  // 458752 x 832 x 32 at 518 workgroups ran at 3 TB/s)
   const int tiles = occ4d::cdiv(N, 128) * occ4d::cdiv(K, 416);
-  int splits = occ4d::cdiv(512, tiles);
+  static const int narrow_target = [] { const char* e = getenv("OCC4D_WGRAD_NARROW_WGS"); return e ? atoi(e) : 2048; }();
+  int splits = occ4d::cdiv(K <= 64 ? narrow_target : 512, tiles);
   const int cap = M / 256 > 1 ? M / 256 : 1;
   if (splits > cap) splits = cap;
   *splits_out = splits > 1 ? splits : 1;
@@ -734,7 +791,7 @@ int occ4d_linear_wgrad_bias_f32(const float* g, int64_t ldg, const float* x, int
       wgrad_reduce4_kernel<<<grid1d(nk / 4), TPB, 0, st>>>(workspace, splits + 1, nk / 4, dw, accumulate);
     else
       wgrad_reduce_kernel<<<grid1d(nk), TPB, 0, st>>>(workspace, splits + 1, nk, dw, accumulate);
-    if (db) wgrad_reduce_kernel<<<grid1d(N), TPB, 0, st>>>(pb16, splits + 1, N, db, accumulate);
+    if (db) launch_short_reduce(pb16, splits + 1, N, db, accumulate, st);
     return occ4d::check_launch("occ4d_linear_wgrad_f32(reduce)");
   }
 #define OCC4D_WGRAD(NT) launch_wgrad<NT>(g, ldg, x, ldx, M, N, K, splits, mps, workspace, part_b, relu_x, st)
@@ -751,7 +808,7 @@ int occ4d_linear_wgrad_bias_f32(const float* g, int64_t ldg, const float* x, int
     wgrad_reduce4_kernel<<<grid1d(nk / 4), TPB, 0, st>>>(workspace, splits, nk / 4, dw, accumulate);
   else
     wgrad_reduce_kernel<<<grid1d(nk), TPB, 0, st>>>(workspace, splits, nk, dw, accumulate);
-  if (db) wgrad_reduce_kernel<<<grid1d(N), TPB, 0, st>>>(part_b, splits, N, db, accumulate);
+  if (db) launch_short_reduce(part_b, splits, N, db, accumulate, st);
   return occ4d::check_launch("occ4d_linear_wgrad_f32(reduce)");
 }
 
@@ -761,7 +818,7 @@ int occ4d_colsum_f32(const float* x, int64_t ldx, int n, int d, float* out, int 
   hipStream_t st = (hipStream_t)stream;
   const int rpc = occ4d::cdiv(n, chunks);
   colsum_partial_kernel<<<dim3(occ4d::cdiv(d, 64), chunks), TPB, 0, st>>>(x, ldx, n, d, rpc, workspace);
-  wgrad_reduce_kernel<<<grid1d(d), TPB, 0, st>>>(workspace, chunks, d, out, accumulate);
+  launch_short_reduce(workspace, chunks, d, out, accumulate, st);
   return occ4d::check_launch("occ4d_colsum_f32");
 }
 
@@ -787,6 +844,11 @@ int occ4d_segment_sum_f32(const float* src, int n, int k, int d, float* out, int
   OCC4D_REQUIRE(src && out && n >= 0 && k >= 1 && d >= 1 && ldo >= d, "occ4d_segment_sum_f32: bad arguments");
   const int64_t total = (int64_t)n * d;
   if (!total) return OCC4D_OK;
+  if (k <= 16 && d % 4 == 0 && ldo % 4 == 0 && total / 4 < ((int64_t)1 << 31) &&
+      (((uintptr_t)src | (uintptr_t)out) % 16) == 0) {
+    segment_sum4_kernel<<<grid1d(total / 4), TPB, 0, (hipStream_t)stream>>>(src, (int)(total / 4), k, d / 4, out, ldo);
+    return occ4d::check_launch("occ4d_segment_sum_f32");
+  }
   segment_sum_kernel<<<grid1d(total), TPB, 0, (hipStream_t)stream>>>(src, total, k, d, out, ldo);
   return occ4d::check_launch("occ4d_segment_sum_f32");
 }
