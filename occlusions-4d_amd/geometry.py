@@ -232,6 +232,18 @@ def _gap_rows(to_filter, target_coords, radius, grid=None):
     return ops.compact_rows(to_filter, far, 0.5, strict=True)[0]
 
 
+# '1' (default): GuidedImplicitPointSampler reads device-side counts three times per batch element instead of once per
+# selection (same draws, same points: tests/test_gpu_sampler.py); '0': the step-by-step path everywhere.
+SAMPLER_FAST = os.environ.get('OCC4D_SAMPLER_FAST', '1') == '1'
+_SEGM_BINS = 64            # semantic ids the fast path groups rows by (CARLA has 23); others take the step-by-step path
+
+
+def _upload(cpu_tensor, device):
+    """Host->device copy of a freshly drawn CPU tensor (pageable: staging it through pinned memory costs more than the
+    copy of these ~100 KB)."""
+    return cpu_tensor.to(device)
+
+
 def _take(rows, cpu_inds):
     """rows[cpu_inds] for a CPU LongTensor of indices, on the gather kernel."""
     return ops.gather_rows(rows, cpu_inds.to(torch.int32).to(rows.device))
@@ -270,37 +282,276 @@ class GuidedImplicitPointSampler(torch.nn.Module):
             if other_time == time_idx:
                 other_time += 1
             other, other_sizes = pcl_target[other_time], pcl_target_size[other_time]
-        carla = self.data_kind == 'carla'
+        fast = (SAMPLER_FAST and GRID_GAP_FILTER and frame.is_cuda and 'ivalo' not in self.point_sample_bias
+                and self.num_solid > 0 and self.num_air > 0)
+        if not fast:
+            assert torch.all(sizes <= M)
         outs = [[] for _ in range(6)]
         for i in range(B):
-            tgt = frame[i, :int(sizes[i].item())]
-            ids = sorted(list(valo_ids[i, :int(num_valo_ids[i].item())].detach().cpu().numpy()))
-            if carla:
-                tgt = filter_pcl_bounds_carla_output_torch(tgt, min_z=self.min_z, other_bounds=self.cube_bounds,
-                                                           cube_mode=self.cube_mode)
-            if tgt.shape[0] < 256:
-                raise RuntimeError(f'Invalid due to cur_tgt_pcl_count: {tgt.shape[0]}')
-            max_slice = int((2 ** 27) // self.num_air)
-            used = tgt.shape[0] // int(np.ceil(tgt.shape[0] / max_slice)) + 1
-            tgt_unique = other_unique = None
-            if 'moving' in self.point_sample_bias:
-                oth_count = int(other_sizes[i].item())
-                oth = other[i, :oth_count]
-                if carla:
-                    oth = filter_pcl_bounds_carla_output_torch(oth, min_z=self.min_z, other_bounds=self.cube_bounds,
-                                                               cube_mode=self.cube_mode)
-                    oth_count = tgt.shape[0]            # sic (utils/geometry.py:704)
-                if oth_count < 256:
-                    raise RuntimeError(f'Invalid due to cur_other_pcl_count: {oth_count}')
-                tgt_sub, oth_sub = tgt[:used], oth[:used]
-                r2 = self.point_occupancy_radius * 2.0
-                tgt_unique = _gap_rows(tgt_sub, oth_sub[..., :3], r2)
-                other_unique = _gap_rows(oth_sub, tgt_sub[..., :3], r2)
-            (sq, st, ss) = self.construct_solid_input_target(tgt, tgt_unique, ids, time_idx)
-            (aq, at, as_) = self.construct_air_input_target(tgt, other_unique, sq, ids, time_idx)
-            for lst, v in zip(outs, (sq, aq, st, at, ss, as_)):
+            res = self._element_fast(frame, sizes, other, other_sizes, i, time_idx) if fast else None
+            if res is None:
+                res = self._element(frame, sizes, other, other_sizes, valo_ids, num_valo_ids, i, time_idx)
+            for lst, v in zip(outs, res):
                 lst.append(v)
         return tuple(torch.stack(v) for v in outs)
+
+    def _element(self, frame, sizes, other, other_sizes, valo_ids, num_valo_ids, i, time_idx):
+        """One batch element, step by step as the reference does it (utils/geometry.py:650-760): every selection sizes
+        its result through a device->host read."""
+        carla = self.data_kind == 'carla'
+        tgt = frame[i, :int(sizes[i].item())]
+        ids = sorted(list(valo_ids[i, :int(num_valo_ids[i].item())].detach().cpu().numpy()))
+        if carla:
+            tgt = filter_pcl_bounds_carla_output_torch(tgt, min_z=self.min_z, other_bounds=self.cube_bounds,
+                                                       cube_mode=self.cube_mode)
+        if tgt.shape[0] < 256:
+            raise RuntimeError(f'Invalid due to cur_tgt_pcl_count: {tgt.shape[0]}')
+        max_slice = int((2 ** 27) // self.num_air)
+        used = tgt.shape[0] // int(np.ceil(tgt.shape[0] / max_slice)) + 1
+        tgt_unique = other_unique = None
+        if 'moving' in self.point_sample_bias:
+            oth_count = int(other_sizes[i].item())
+            oth = other[i, :oth_count]
+            if carla:
+                oth = filter_pcl_bounds_carla_output_torch(oth, min_z=self.min_z, other_bounds=self.cube_bounds,
+                                                           cube_mode=self.cube_mode)
+                oth_count = tgt.shape[0]            # sic (utils/geometry.py:704)
+            if oth_count < 256:
+                raise RuntimeError(f'Invalid due to cur_other_pcl_count: {oth_count}')
+            tgt_sub, oth_sub = tgt[:used], oth[:used]
+            r2 = self.point_occupancy_radius * 2.0
+            tgt_unique = _gap_rows(tgt_sub, oth_sub[..., :3], r2)
+            other_unique = _gap_rows(oth_sub, tgt_sub[..., :3], r2)
+        (sq, st, ss) = self.construct_solid_input_target(tgt, tgt_unique, ids, time_idx)
+        (aq, at, as_) = self.construct_air_input_target(tgt, other_unique, sq, ids, time_idx)
+        return (sq, aq, st, at, ss, as_)
+
+    def _bounds_key(self, rows, size):
+        """1.0 for the rows of one padded cloud (M, E) that the reference keeps: index < size and, for CARLA, inside the
+        output cuboid (filter_pcl_bounds_carla_output_torch's comparisons) -- as a key for the compaction kernel."""
+        keep = torch.arange(rows.shape[0], device=rows.device) < size
+        if self.data_kind == 'carla':
+            sx, sy, sz = _CARLA_OUTPUT_SCALE[self.cube_mode]
+            ob = self.cube_bounds
+            for col, lo, hi in ((0, 0.0, ob * sx), (1, -ob * sy, ob * sy), (2, self.min_z, ob * sz)):
+                keep = keep & (lo <= rows[:, col]) & (rows[:, col] <= hi)
+        return keep.to(torch.float32)
+
+    def _element_fast(self, frame, sizes, other, other_sizes, i, time_idx):
+        """The same element with THREE device->host reads instead of ~25: every selection writes into a buffer sized for
+        the worst case and leaves its count on the device (ops.compact_rows_nosync); the counts of a stage are read in
+        one transfer, all of the element's host-generator draws are then made -- in the reference's call order, with the
+        reference's arguments (golden G13 pins both) -- and uploaded in two copies.  Returns None (before any draw) when
+        the element needs the step-by-step path (semantic ids outside 0..63 or not integral)."""
+        dev = frame.device
+        carla = self.data_kind == 'carla'
+        inst_idx, segm_idx, view_idx = (4, 5, 6) if carla else (3, 3, 4)
+        bias = self.point_sample_bias
+        moving = 'moving' in bias
+        r = self.point_occupancy_radius
+        M = frame.shape[1]
+
+        # ---- stage A: the two clouds of the element, compacted; their sizes
+        tgt_buf, tgt_cnt = ops.compact_rows_nosync(frame[i], self._bounds_key(frame[i], sizes[i]), 0.5)
+        heads = [tgt_cnt.to(torch.int64), sizes.reshape(-1).to(torch.int64)]
+        if moving:
+            oth_buf, oth_cnt = ops.compact_rows_nosync(other[i], self._bounds_key(other[i], other_sizes[i]), 0.5)
+            heads += [oth_cnt.to(torch.int64), other_sizes[i].reshape(1).to(torch.int64)]
+        host = torch.cat(heads).cpu().tolist()                                         # (sync 1)
+        tgt_n = host[0]
+        assert all(z <= M for z in host[1:1 + sizes.numel()])
+        if tgt_n < 256:
+            raise RuntimeError(f'Invalid due to cur_tgt_pcl_count: {tgt_n}')
+        tgt = tgt_buf[:tgt_n]
+        max_slice = int((2 ** 27) // self.num_air)
+        used = tgt_n // int(np.ceil(tgt_n / max_slice)) + 1
+
+        # ---- stage B: every selection the biases need, counts left on the device
+        counts = []                                           # device tensors, read together
+        if moving:
+            oth_n = host[-2]
+            oth_count = tgt_n if carla else host[-1]          # sic (utils/geometry.py:704)
+            if oth_count < 256:
+                raise RuntimeError(f'Invalid due to cur_other_pcl_count: {oth_count}')
+            tgt_sub, oth_sub = tgt[:used], oth_buf[:oth_n][:used]
+            r2 = r * 2.0
+            uq_buf, uq_cnt = ops.compact_rows_nosync(tgt_sub, ops.RadiusGrid(oth_sub[..., :3], r2).far(tgt_sub, r2), 0.5)
+            ou_buf, ou_cnt = ops.compact_rows_nosync(oth_sub, ops.RadiusGrid(tgt_sub[..., :3], r2).far(oth_sub, r2), 0.5)
+            counts += [uq_cnt, ou_cnt]
+        if 'low' in bias:
+            z = tgt[:, 2]
+            low_buf, low_cnt = ops.compact_rows_nosync(
+                tgt, torch.logical_and(self.low_prefer_min_z <= z, z <= self.low_prefer_max_z).to(torch.float32), 0.5)
+            counts.append(low_cnt)
+        by_class = 'vehped' in bias or 'sembal' in bias
+        if by_class:
+            assert carla
+            segm = tgt[:, segm_idx]
+            segm_i = segm.to(torch.int32)
+            # rows grouped by semantic id, original order inside a group (= tgt[segm == id] for every id at once)
+            sorted_ids, order = torch.sort(segm_i, stable=True)
+            order = order.to(torch.int32)
+            # first position of every id 0 .. _SEGM_BINS in the sorted list (a histogram by atomics on 64 addresses costs
+            # milliseconds): [0] = rows with negative ids, tgt_n - [-1] = rows with ids too large
+            first = torch.searchsorted(sorted_ids, torch.arange(_SEGM_BINS + 1, device=dev, dtype=torch.int32))
+            odd = (segm != segm_i.to(torch.float32)).any().reshape(1)
+        parts = [c.to(torch.float32) for c in counts]
+        if by_class:
+            parts += [first.to(torch.float32), odd.to(torch.float32)]
+        stage = torch.cat(parts).cpu().tolist() if parts else []                         # (sync 2)
+        it = iter(stage)
+        uq_n = ou_n = low_n = 0
+        if moving:
+            uq_n, ou_n = int(next(it)), int(next(it))
+        if 'low' in bias:
+            low_n = int(next(it))
+        if by_class:
+            seg_off = np.array([int(next(it)) for _ in range(_SEGM_BINS + 1)], dtype=np.int64)
+            if seg_off[0] or seg_off[-1] != tgt_n or next(it):
+                return None
+            seg_count = [int(c) for c in np.diff(seg_off)]
+
+        # ---- host: shares, counts and EVERY draw of the element, in the reference's order
+        shares = torch.tensor([1.0, 0.0, 0.0, 0.0, 0.0, 0.0])     # regular, low, moving, vehped, ivalo, sembal
+        if 'low' in bias and low_n >= 256:
+            shares[1] += 1.0
+        if moving:
+            if uq_n >= 256:
+                shares[2] += 0.4
+            elif uq_n >= 16:
+                shares[2] += uq_n * 0.4 / 256.0
+        if 'vehped' in bias:
+            vehped_n = seg_count[4] + seg_count[10]
+            if vehped_n >= 256:
+                shares[3] += 0.2
+            elif vehped_n >= 16:
+                shares[3] += vehped_n * 0.2 / 256.0
+        if 'sembal' in bias:
+            shares[5] += 0.4
+        shares /= shares.sum()
+        n_low, n_moving, n_vehped, n_ivalo, n_sembal = [int(shares[j] * self.num_solid) for j in range(1, 6)]
+        assert n_ivalo == 0
+        ints = []                                             # (what the indices address, CPU LongTensor)
+        if n_low > 0:
+            ints.append(('low', torch.randint(0, low_n, (n_low, ))))
+        if n_moving > 0:
+            ints.append(('uq', torch.randint(0, uq_n, (n_moving, ))))
+        if n_vehped > 0:
+            pick = torch.randint(0, vehped_n, (n_vehped, ))
+            c4 = seg_count[4]                                 # (get_vehped_points: the rows of class 4, then of class 10)
+            ints.append(('order', torch.where(pick < c4, pick + int(seg_off[4]), pick - c4 + int(seg_off[10]))))
+        if n_sembal > 0:
+            seg_ids = [sid for sid in range(_SEGM_BINS) if seg_count[sid] > 0]
+            taken = 0
+            for sid in seg_ids:
+                if seg_count[sid] >= 16:
+                    per = n_sembal // len(seg_ids)
+                    ints.append(('order', torch.randint(0, seg_count[sid], (per, )) + int(seg_off[sid])))
+                    taken += per
+            n_sembal = taken
+        n_regular = self.num_solid - n_low - n_moving - n_vehped - n_ivalo - n_sembal
+        if n_regular > 0:
+            ints.append(('tgt', torch.randint(0, tgt_n, (n_regular, ))))
+        floats = [sample_random_uniform_3ball(self.num_solid, r / 2.0)]
+        air_shares = torch.tensor([0.5, 0.0, 0.3, 0.2])       # regular, moving, hard_solid_query, hard_target
+        if moving:
+            if ou_n >= 256:
+                air_shares[1] += 0.4
+            elif ou_n >= 16:
+                air_shares[1] += ou_n * 0.4 / 256.0
+        air_shares /= air_shares.sum()
+        a_moving = int(air_shares[1] * self.num_air)
+        a_hsq = int(air_shares[2] * self.num_air)
+        a_ht = int(air_shares[3] * self.num_air)
+        a_regular = self.num_air - a_moving - a_hsq - a_ht
+        air = []                                              # (source, rows wanted, warn)
+        if a_moving > 0:
+            draw = int(a_moving * 1.6)
+            ints.append(('ou', torch.randint(0, ou_n, (draw, ))))
+            floats.append(sample_random_uniform_3ball(draw, r * 2.0))
+            air.append(('ou', a_moving, False))
+        if a_hsq > 0:
+            draw = int(a_hsq * 2.0)
+            ints.append(('solid', torch.randint(0, self.num_solid, (draw, ))))
+            floats.append(sample_random_uniform_3ball(draw, max_radius=r * 3.0, min_radius=r))
+            air.append(('solid', a_hsq, True))
+        if a_ht > 0:
+            draw = int(a_ht * 2.0)
+            ints.append(('tgt', torch.randint(0, tgt_n, (draw, ))))
+            floats.append(sample_random_uniform_3ball(draw, max_radius=r * 3.0, min_radius=r))
+            air.append(('tgt', a_ht, True))
+        if a_regular > 0:
+            draw = int(a_regular * (1.3 if self.data_kind == 'greater' else 1.1))
+            floats.append(sample_implicit_points_blind_torch(self.data_kind, draw, self.cube_mode, self.cube_bounds,
+                                                             self.min_z, 'cpu'))
+            air.append(('blind', a_regular, True))
+        n_solid_ints = len(ints) - sum(1 for a in air if a[0] != 'blind')
+        idx_dev = _upload(torch.cat([t for _, t in ints]).to(torch.int32), dev) if ints else None
+        flt_dev = _upload(torch.cat(floats), dev)
+        idx_parts, at = [], 0
+        for _, t in ints:
+            idx_parts.append(idx_dev[at:at + t.numel()])
+            at += t.numel()
+        flt_parts, at = [], 0
+        for t in floats:
+            flt_parts.append(flt_dev[at:at + t.shape[0]])
+            at += t.shape[0]
+
+        # ---- solid points: gathers in pool order, no host read
+        sources = {'tgt': tgt}
+        if moving:
+            sources.update(uq=uq_buf, ou=ou_buf)
+        if 'low' in bias:
+            sources['low'] = low_buf
+
+        def rows_of(kind, ix):
+            if kind == 'order':
+                return ops.gather_rows(tgt, order[ix.long()])
+            return ops.gather_rows(sources[kind], ix)
+        chosen = torch.cat([rows_of(kind, ix) for (kind, _), ix in zip(ints[:n_solid_ints], idx_parts)], dim=0)
+        assert chosen.shape[0] == self.num_solid
+        xyz = ops.add_rows(chosen[..., :3], flt_parts[0])
+        sq = torch.cat([xyz, torch.ones_like(xyz[..., 0:1]) * time_idx], dim=-1)
+        st = torch.cat([torch.ones_like(xyz[..., 0:1]), chosen[..., -4:]], dim=-1)
+        if self.predict_segmentation:
+            sg = chosen[..., segm_idx:segm_idx + 1].clone()
+            sg[sg >= self.semantic_classes] = 3            # = Other
+            st = torch.cat([st, sg], dim=-1)
+        else:
+            st = torch.cat([st, -torch.ones_like(st[..., 0:1])], dim=-1)
+
+        # ---- air points: ONE radius test of all candidates against the target frame, then per-source compaction
+        sources['solid'] = sq
+        cands = []
+        for j, (kind, _, _) in enumerate(air):
+            if kind == 'blind':
+                cands.append(flt_parts[1 + j])
+            else:
+                cands.append(ops.add_rows(ops.gather_rows(sources[kind], idx_parts[n_solid_ints + j])[..., :3],
+                                          flt_parts[1 + j]))
+        allc = torch.cat(cands, dim=0)
+        far = ops.RadiusGrid(tgt[..., :3], r).far(allc, r)
+        points, kept_counts, at = [], [], 0
+        for cand, (_, want, _) in zip(cands, air):
+            kept, cnt = ops.compact_rows_nosync(allc[at:at + cand.shape[0]], far[at:at + cand.shape[0]], 0.5)
+            at += cand.shape[0]
+            # select_safely without the read: a too-short tensor doubled until it suffices = its rows repeated cyclically
+            cyc = torch.remainder(torch.arange(want, device=dev, dtype=torch.int32), cnt.clamp(min=1))
+            points.append(ops.gather_rows(kept, cyc))
+            kept_counts.append(cnt)
+        axyz = torch.cat(points, dim=0)
+        assert axyz.shape[0] == self.num_air
+        aq = torch.cat([axyz, torch.ones_like(axyz[..., 0:1]) * time_idx], dim=-1)
+        atg = -torch.ones((self.num_air, 6), device=dev, dtype=tgt.dtype)
+        atg[..., 0] = 0.0
+        for c, (_, want, warn) in zip(torch.cat(kept_counts).cpu().tolist(), air):          # (sync 3)
+            if c == 0:
+                raise RuntimeError('select_safely: no candidate survived the air / solid gap filter')
+            while c < want:
+                if warn and self.logger is not None:
+                    self.logger.warning(f'Size {c} is insufficient for {want}!')
+                c *= 2
+        return (sq, aq, st, atg, shares, air_shares)
 
     def construct_solid_input_target(self, cur_tgt_pcl, cur_tgt_unique, cur_valo_ids, time_idx):
         tgt = cur_tgt_pcl

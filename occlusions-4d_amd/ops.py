@@ -869,6 +869,29 @@ def compact_rows(rows, key, threshold, strict=True):
     return out_rows, out_key
 
 
+def compact_rows_nosync(rows, key, threshold, strict=True):
+    """compact_rows without the device->host read: -> (buffer (n, d) whose first `count` rows are rows[key > threshold] in
+    order -- the rest is uninitialised --, count (1,) int32 ON THE DEVICE).  For callers that collect several counts and
+    read them in one transfer (the point sampler: one synchronisation per stage instead of one per selection)."""
+    r, ld = _rows(_dev(rows, name='rows'), 'rows')
+    k = _dev(key, name='key')
+    assert k.dim() == 1 and k.shape[0] == r.shape[0]
+    n, d = r.shape
+    if n == 0:
+        return r.new_empty((0, d)), torch.zeros((1,), dtype=torch.int32, device=r.device)
+    lk = k.stride(0) if n > 1 else 1
+    nb = (n + 255) // 256
+    scratch = torch.empty(nb + 1, dtype=torch.int32, device=r.device)
+    st = _stream()
+    _lib.check(_lib.lib().occ4d_compact_count_f32(_ptr(k), lk, n, float(threshold), int(strict), _ptr(scratch),
+                                                  _ptr(scratch[nb:]), st))
+    out_rows = torch.empty((n, d), dtype=torch.float32, device=r.device)
+    out_key = torch.empty((n,), dtype=torch.float32, device=r.device)
+    _lib.check(_lib.lib().occ4d_compact_rows_f32(_ptr(r), ld, n, d, _ptr(k), lk, float(threshold), int(strict),
+                                                 _ptr(scratch), _ptr(out_rows), _ptr(out_key), st))
+    return out_rows, scratch[nb:nb + 1]
+
+
 def add_rows(a, b):
     """a + b for two (n, d) tensors (exact fp32 add; the sampler's query = target point + offset)."""
     a, lda = _rows(_dev(a, name='a'), 'a')

@@ -123,6 +123,81 @@ def test_sampler_grid_filter_switch_changes_nothing(pk, monkeypatch):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('kind,bias,batch,segm', [
+    ('carla', 'low_moving_vehped_sembal', 1, True), ('carla', 'low_moving_vehped_sembal', 2, False),
+    ('carla', 'sembal', 1, True), ('carla', 'vehped', 2, True), ('carla', 'low', 1, True), ('carla', 'moving', 1, True),
+    ('carla', 'none', 1, True), ('greater', 'none', 2, False), ('greater', 'low_moving', 1, False)])
+def test_sampler_few_reads_path_equals_the_step_by_step_path(pk, monkeypatch, kind, bias, batch, segm):
+    """geometry.SAMPLER_FAST (three device->host reads per element, every draw made up front) returns the points of the
+    step-by-step path (G13: the reference's) bit for bit and leaves both host generators in the same state."""
+    case = dict(name='fast', kind=kind, bias=bias, frames=3, m=9000, num_solid=1536, num_air=2200, time_idx=1, segm=segm,
+                seed=81, batch=batch)
+    frames, sizes, valo, num_valo = gc.sampler_inputs(case)
+    cfg = gc.sampler_config(case)
+    dev = ([torch.from_numpy(f).cuda() for f in frames], [torch.from_numpy(z).cuda() for z in sizes],
+           torch.from_numpy(valo).cuda(), torch.from_numpy(num_valo).cuda())
+    outs, tails = [], []
+    for fast in (True, False):
+        monkeypatch.setattr(pk.geometry, 'SAMPLER_FAST', fast)
+        sampler = pk.geometry.GuidedImplicitPointSampler(_Log(), **cfg)
+        if fast:            # the few-reads path must not fall back for these inputs
+            monkeypatch.setattr(sampler, '_element', lambda *a, **k: (_ for _ in ()).throw(AssertionError('fell back')))
+        np.random.seed(6)
+        torch.manual_seed(6)
+        outs.append([sampler(*dev, t) for t in range(3)])
+        tails.append((np.random.rand(), float(torch.rand(1))))
+    for ra, rb in zip(*outs):
+        for a, b in zip(ra, rb):
+            assert a.shape == b.shape and a.device == b.device and torch.equal(a, b)
+    assert tails[0] == tails[1]
+
+
+def test_sampler_few_reads_path_falls_back_and_reports_like_the_step_by_step_path(pk, monkeypatch):
+    """Semantic ids the grouped selection does not cover (negative / non-integral) send the element to the step-by-step
+    path before any draw; a cloud that is too small raises the reference's error; a gap filter that keeps too few
+    candidates warns once per doubling."""
+    case = dict(name='fb', kind='carla', bias='low_moving_vehped_sembal', frames=3, m=6000, num_solid=512, num_air=800,
+                time_idx=1, segm=True, seed=82)
+    frames, sizes, valo, num_valo = gc.sampler_inputs(case)
+    cfg = gc.sampler_config(case)
+    for f in frames:
+        f[0, :40, 5] = -2.0
+        f[0, 40:60, 5] = 3.5
+    dev = ([torch.from_numpy(f).cuda() for f in frames], [torch.from_numpy(z).cuda() for z in sizes],
+           torch.from_numpy(valo).cuda(), torch.from_numpy(num_valo).cuda())
+    outs = []
+    for fast in (True, False):
+        monkeypatch.setattr(pk.geometry, 'SAMPLER_FAST', fast)
+        sampler = pk.geometry.GuidedImplicitPointSampler(_Log(), **cfg)
+        np.random.seed(7)
+        torch.manual_seed(7)
+        outs.append(sampler(*dev, 1))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    monkeypatch.setattr(pk.geometry, 'SAMPLER_FAST', True)
+    small = [f[:, :200].contiguous() for f in dev[0]]
+    with pytest.raises(RuntimeError, match='cur_tgt_pcl_count'):
+        pk.geometry.GuidedImplicitPointSampler(_Log(), **cfg)(small, [z.clamp(max=200) for z in dev[1]], dev[2], dev[3], 1)
+    # dense target cloud, large radius: few air candidates survive -> doublings are reported, counts still exact
+    dense = dict(cfg, point_occupancy_radius=1.2)
+    warns = []
+    for fast in (True, False):
+        monkeypatch.setattr(pk.geometry, 'SAMPLER_FAST', fast)
+        log = _Log()
+        np.random.seed(8)
+        torch.manual_seed(8)
+        try:
+            res = pk.geometry.GuidedImplicitPointSampler(log, **dense)(*dev, 1)
+            warns.append((log.warnings, [r.clone() for r in res]))
+        except RuntimeError as e:
+            warns.append((str(e), None))
+    assert warns[0][0] == warns[1][0]
+    if warns[0][1] is not None:
+        assert warns[0][0] > 0
+        for a, b in zip(warns[0][1], warns[1][1]):
+            assert torch.equal(a, b)
+
+
 def test_side_stream_sampler_draws_the_same_points(pk):
     """training.SideStreamSampler (the next step's points drawn on a side stream) consumes the random stream exactly as
     direct calls do: two consecutive draws equal two consecutive rounds of direct sampler calls."""
