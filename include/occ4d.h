@@ -135,6 +135,19 @@ int occ4d_pt_softmax_agg_f32(const float* logits, const float* v, int64_t ldv, c
                              const int32_t* idx, int n, int k, int d, float divisor,
                              float* agg, int64_t ld_agg, void* stream);
 
+/* Fused vector attention over k = 16 neighbours for the encoder widths (d a multiple of 4, d <= 288;
+ * model/point_transformer_layer.py:168-179 as ONE kernel: the (n 16, 2d) hidden, (n 16, d) logits and (n 16, d)
+ * positional encodings never reach HBM).  Replaces pos_hidden -> linear -> linear -> linear -> softmax_agg.
+ * Merged form: aq (n, 2d) = (W1 Wq) x + bias, kt (m, 2d) = (W1 Wk) x2, vt (m, d) = to_v(x2),
+ * wp (2d, 32) = W1 P2 row-major, w2 (d, 2d) = attn_mlp[2].weight, p2 (d, 32) / c2 (d) = pos_mlp[2], P1 (32, 3) / c1 (32)
+ * = pos_mlp[0]; all in the reference's row-major layout (the kernel pads to its tile grid itself).
+ * attn_mlp[2].bias is not an argument: constant over the neighbour axis, it cancels in the softmax. */
+int occ4d_pt_self_attn16_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t qs, const float* apos,
+                             int64_t as, const int32_t* idx, const float* kt, int64_t ld_kt, const float* vt,
+                             int64_t ld_vt, const float* P1, const float* c1, const float* wp, const float* w2,
+                             const float* p2, const float* c2, float* agg, int64_t ld_agg, int n, int m, int k, int d,
+                             float divisor, void* stream);
+
 /* Fused vector attention for d in {288, 416} (model/point_transformer_layer.py:168-179 in one
  * kernel; the (n*k, 2d) hidden, (n*k, d) logits and (n*k, d) positional encodings never
  * reach HBM).  With r_p = relu(P1 (qpos_i - apos_j) + c1), j = idx[i,s], p = (i,s):

@@ -80,6 +80,9 @@ SIGNATURES = {
     'occ4d_pt_cross_attn_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, C.c_int64, _i, _f, C.c_int64, _f,
                                           C.c_int64, _f, _f, _f, _f, _f, _f, _f, _f, C.c_int64, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_float, _s]),
+    'occ4d_pt_self_attn16_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, C.c_int64, _i, _f, C.c_int64, _f,
+                                           C.c_int64, _f, _f, _f, _f, _f, _f, _f, C.c_int64, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_float, _s]),
     'occ4d_pt_cross_attn_bf16x3_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, C.c_int64, _i, _f, C.c_int64, _f,
                                                  C.c_int64, _f, _f, _f, _f, _f, _f, _f, _f, C.c_int64, C.c_int,
                                                  C.c_int, C.c_int, C.c_int, C.c_float, _s]),

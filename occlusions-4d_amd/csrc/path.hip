@@ -210,7 +210,7 @@ bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 // ----------------------------------------------------------------------------------------------------------------
 struct LayerLayout {
   int D, D2, h, Kq;                 // Kq: input width of the merged query projection (d_in when layer1 is folded in)
-  bool fold_pre, fused16p, fused_first, bf16x3, wq_rows, w3_rows, trunk4;
+  bool fold_pre, fused16p, fused_first, fused_self16, bf16x3, wq_rows, w3_rows, trunk4;
   int64_t wq, bq, wk, wp, wq_packed, stream, w2_bf, wp_bf, w3_packed, scratch, total;
   int64_t s_A, s_B, s_C, s_C2, s_v, s_bq;      // doubles, inside the scratch region
 };
@@ -243,6 +243,7 @@ LayerLayout layer_layout(const occ4d_pt_layer_weights& w, int flags) {
   L.bf16x3 = fusable && (flags & OCC4D_PATH_BF16X3);
   L.fused16p = fusable && L.D == 416 && !(flags & (OCC4D_PATH_FIRST_GEN | OCC4D_PATH_BF16X3));
   L.fused_first = fusable && !L.fused16p;
+  L.fused_self16 = L.h == 32 && L.D % 4 == 0 && L.D <= 288 && !(flags & OCC4D_PATH_UNFUSED);   // (used when k == 16)
   L.trunk4 = flags & OCC4D_PATH_TRUNK4;
   const bool trunk = !(flags & OCC4D_PATH_GENERIC_LINEAR);
   L.wq_rows = trunk && w.cross && L.Kq == TRUNK && (2 * L.D) % 32 == 0;
@@ -434,6 +435,11 @@ int layer_forward(const occ4d_pt_layer_weights& w, const LayerLayout& L, const f
         E.after(OCC4D_PROFILE_CROSS_ATTN);
         TRY(rc);
       }
+    } else if (L.fused_self16 && k == 16) {
+      // the encoder's widths, 16 neighbours: one kernel, no pair tensor in HBM (csrc/selfattn16.hip)
+      if (!dry)
+        TRY(occ4d_pt_self_attn16_f32(aq, 2 * D, qp, ps, pos2, p2s, idx, kt, 2 * D, vt, D, w.pos0_w, w.pos0_b, prep + L.wp,
+                                     w.attn2_w, w.pos2_w, w.pos2_b, agg_c, ld_agg, c, m, k, D, divisor, st));
     } else {
       // unfused chain: r = relu(P1 (p_i - p_j) + c1); hid = relu(aq_i - kt_j + Wp r); logits = W2 hid + b2; pe = P2 r + c2
       const int64_t rows = (int64_t)c * k;

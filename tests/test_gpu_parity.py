@@ -323,6 +323,32 @@ def test_fused_attention_matches_unfused_chain(pk, k, n, dim, dim2, generation):
     close(fused, chain, 2e-5)
 
 
+@pytest.mark.parametrize('n,dim', [(14336, 36), (3584, 72), (896, 144), (224, 288), (16, 36), (21, 72), (1001, 20), (333, 100),
+                                   (62, 260), (4099, 4)])
+def test_fused_self_attention_matches_unfused_chain(pk, n, dim):
+    """The encoder's self-attention as one kernel (csrc/selfattn16.hip: a wave per query, its 16 neighbours = the 16 MFMA
+    columns, weights staged through LDS and padded to the tile grid in the kernel) against the unfused five-launch
+    chain: every encoder width of the two published configurations, widths that are not multiples of 16 (padding in
+    channels AND hidden units), row counts that are not multiples of the 4 queries of a workgroup, exactly as many points
+    as neighbours."""
+    rng = np.random.default_rng(n + dim)
+    x = rng.normal(size=(n, dim)).astype(np.float32)
+    pos = rng.uniform(-5, 5, size=(n, 3)).astype(np.float32)
+    ptl = pk.point_transformer_layer
+    layer = ptl.PointTransformerLayer(dim, num_neighbors=16).cuda()
+    layer.load_state_dict(pk.configs.fill_state_dict(layer, 77 + dim))
+    args = (dev(x)[None], dev(pos)[None])
+    with torch.no_grad():
+        try:
+            fused = layer(*args)[0]
+            ptl.USE_FUSED_ATTENTION = False
+            chain = layer(*args)[0]
+        finally:
+            ptl.USE_FUSED_ATTENTION = True
+    assert torch.isfinite(fused).all() and fused.shape == (n, dim)
+    close(fused, chain, 2e-5)
+
+
 @pytest.mark.parametrize('case', gc.TRACK_CASES, ids=lambda c: c['name'])
 def test_perform_inference_tracks_and_gt_labels(pk, case):
     """D8 branches: track_mode 'all' and ground-truth 1-NN labelling, against the reference's vectors."""
