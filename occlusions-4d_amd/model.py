@@ -106,8 +106,14 @@ class PointCompletionNetV3(torch.nn.Module):
                     self_idx = [ops.knn(c, c, block.num_neighbors, metric=0) for c in cur]
                     publish(i, self_idx, cur)
                 elif i > 0:
-                    deferred.append((i, block, cur))
-            # forward() path: the sampling chain first (nothing may delay the FPS), then the self-kNNs of the lower levels
+                    if all(nf.order is not None for nf in nested):
+                        # nested levels: no FPS launch is left behind this point (the further subsets are index arithmetic),
+                        # and this level's lists are what the feature chain waits for next
+                        publish(i, [ops.knn(c, c, block.num_neighbors, metric=0) for c in cur], cur)
+                    else:
+                        deferred.append((i, block, cur))
+            # forward() path with one FPS launch per level: the sampling chain first (nothing may delay an FPS), then the
+            # self-kNNs of the lower levels
             for i, block, clouds in deferred:
                 publish(i, [ops.knn(c, c, block.num_neighbors, metric=0) for c in clouds], clouds)
         return out

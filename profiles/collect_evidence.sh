@@ -26,6 +26,9 @@ for flags in "--graph" "--sampler --graph" "--sampler" "--sampler --sampler-seri
   python bench_train.py --steps 5 --warmup 2 $flags 2>/dev/null | tail -1 >> "$OUT/bench_train_sampler.jsonl"
 done
 python profiles/time_pair_mlp.py > "$OUT/time_pair_mlp.txt" 2>/dev/null
+python profiles/time_wgrad.py 2>/dev/null | grep -v amdgpu.ids > "$OUT/time_wgrad.txt"
+( echo "16-byte-lane kernel (default):"; python profiles/time_softmax_bwd.py 2>/dev/null | grep -v amdgpu.ids;
+  echo "scalar kernel (OCC4D_SOFTMAX_BWD4=0):"; OCC4D_SOFTMAX_BWD4=0 python profiles/time_softmax_bwd.py 2>/dev/null | grep -v amdgpu.ids ) > "$OUT/time_softmax_bwd.txt"
 python profiles/profile_sampler.py 2>/dev/null | head -3 > "$OUT/profile_sampler.txt"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof3" -- python bench_train.py --steps 4 --warmup 2 > /dev/null 2>&1
 cp "$(find "$OUT/prof3" -name '*kernel_stats.csv' | head -1)" "$OUT/train_kernel_stats.csv"

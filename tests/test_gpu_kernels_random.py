@@ -274,6 +274,45 @@ def test_attention_chain_gradients_random(pk):
         assert _rel(dx, xt.grad) <= 2e-5 and _rel(dg, gt.grad) <= 2e-5 and _rel(dbeta, bt.grad) <= 2e-5
 
 
+@pytest.mark.parametrize('k', [8, 12, 14, 16, 13])
+@pytest.mark.parametrize('d,with_pe,scale', [(416, True, 1.0), (36, True, 1.0), (288, False, 1.0), (416, True, 300.0), (38, True, 1.0)])
+def test_softmax_aggregate_backward_wide_and_scalar_kernels(pk, k, d, with_pe, scale):
+    """The 16-byte-lane kernel (compile-time k in {8, 12, 14, 16}, d % 4 == 0: pair tensors as dwordx4, value gradients
+    reduced by a separate segment sum) and the scalar kernel (any k, d) against torch autograd in fp64: with and without
+    positional encodings, logits far outside the exp range (one neighbour takes all the weight, the others underflow), a
+    width that is not a multiple of 4, query counts that do not fill a workgroup."""
+    rng = np.random.default_rng(1000 * k + d)
+    for n, m in ((1, 14), (257, 76), (3000, 531)):
+        idx = rng.integers(0, m, size=(n, k)).astype(np.int32)
+        logits = (scale * rng.normal(size=(n * k, d))).astype(np.float32)
+        v = rng.normal(size=(m, d)).astype(np.float32)
+        pe = rng.normal(size=(n * k, d)).astype(np.float32)
+        dagg = rng.normal(size=(n, d)).astype(np.float32)
+        lt, vt, pt = (torch.from_numpy(a).double().requires_grad_(True) for a in (logits, v, pe))
+        att = torch.softmax(lt.view(n, k, d) / float(np.float32(np.sqrt(d))), dim=1)
+        val = vt[torch.from_numpy(idx).long()] + (pt.view(n, k, d) if with_pe else 0.0)
+        (att * val).sum(dim=1).backward(torch.from_numpy(dagg).double())
+        dl, dpe, dv = pk.ops.pt_softmax_agg_bwd(C(logits), C(v), C(pe) if with_pe else None, C(idx), C(dagg))
+        assert _rel(dl, lt.grad) <= 1e-5 and _rel(dv, vt.grad) <= 1e-5
+        if with_pe:
+            assert _rel(dpe, pt.grad) <= 1e-5
+        else:
+            assert dpe is None
+
+
+def test_short_vector_reduce_of_the_bias_gradient(pk):
+    """The bias gradient of a wide layer = sum of up to 113 per-slice partials, by the 4-wave short-vector reduce:
+    against fp64 column sums at the training shapes (N = 416 / 832, many slices) and for a ragged N."""
+    rng = np.random.default_rng(5)
+    for (M, N, K) in ((68812, 416, 416), (40000, 832, 416), (4100, 420, 64), (300, 36, 36)):
+        g = rng.normal(size=(M, N)).astype(np.float32)
+        x = rng.normal(size=(M, K)).astype(np.float32)
+        dw, db = pk.ops.linear_wgrad(C(g), C(x), bias=True)
+        assert _rel(db, g.astype(np.float64).sum(axis=0)) <= 3e-6
+        assert _rel(dw, g.astype(np.float64).T @ x.astype(np.float64)) <= 3e-6
+        assert _rel(pk.ops.colsum(C(g)), g.astype(np.float64).sum(axis=0)) <= 3e-6
+
+
 @pytest.mark.parametrize('n,k,m,h', [(5, 3, 9, 32), (3000, 14, 700, 32), (9000, 16, 300, 24), (700, 7, 50, 64), (2000, 14, 90, 48),
                                      (40000, 14, 1062, 32)])
 def test_pos_hidden_backward_sizes_and_widths(pk, n, k, m, h):
