@@ -9,14 +9,11 @@ def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     n_enc = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
-    # one encode = everything from one fps_kernel<28 (level 0) launch's neighbourhood to the next; split on level-0 FPS
-    starts = [i for i, r in enumerate(rows) if 'fps_bucket_kernel<7' in r['Kernel_Name'] or 'fps_kernel<28' in r['Kernel_Name']]
-    assert len(starts) >= 2, 'need at least two encodes in the trace'
-    # an encode begins a few kernels before its level-0 FPS: take the first kernel after the previous encode's last one
-    a = starts[-1]
-    while a > 0 and int(rows[a]['Start_Timestamp']) - int(rows[a - 1]['End_Timestamp']) < 200000:
-        a -= 1
-    seg = rows[a:]
+    # one encode ends with the torch.cat of its outputs (CatArrayBatchedCopy): the last encode = the kernels behind the
+    # second-to-last of them (encodes are issued back to back, so gaps do not delimit them)
+    ends = [i for i, r in enumerate(rows) if 'CatArrayBatchedCopy' in r['Kernel_Name']]
+    assert len(ends) >= 2, 'need at least two encodes in the trace'
+    seg = rows[ends[-2] + 1:ends[-1] + 1]
     t0 = int(seg[0]['Start_Timestamp'])
     end = max(int(r['End_Timestamp']) for r in seg)
     print('last encode: %d kernels, %.3f ms from first start to last end' % (len(seg), (end - t0) / 1e6))
