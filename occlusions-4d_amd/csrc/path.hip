@@ -21,7 +21,15 @@ using occ4d::cdiv;
   } while (0)
 
 constexpr int TRUNK = 416;            // width the row-resident kernels are built for (occ4d_trunk_width)
-constexpr int ROW_CHUNK = 32768;      // query rows per pass (bounds the per-pair workspace of the unfused chain)
+constexpr int ROW_CHUNK = 32768;      // most query rows per pass (bounds the per-pair workspace of the unfused chain)
+// Rows per pass for n rows: passes of EQUAL size (a multiple of the attention kernels' 9 queries per workgroup) instead
+// of full passes + a short one -- 68812 training queries = 3 x 22941, not 2 x 32768 + 3276 whose last launch fills a
+// third of the machine.  n <= ROW_CHUNK: one pass.
+inline int row_step(int n) {
+  static const bool balance = [] { const char* e = getenv("OCC4D_ROW_BALANCE"); return !e || e[0] != '0'; }();
+  const int passes = (n + ROW_CHUNK - 1) / ROW_CHUNK;
+  return passes <= 1 || !balance ? ROW_CHUNK : ((n + passes - 1) / passes + 8) / 9 * 9;
+}
 constexpr int64_t ALIGN = 64;         // floats: every sub-buffer starts on a 256-byte boundary
 
 inline int64_t up(int64_t v) { return (v + ALIGN - 1) / ALIGN * ALIGN; }
@@ -393,8 +401,9 @@ int layer_forward(const occ4d_pt_layer_weights& w, const LayerLayout& L, const f
   if (w.post_w) { agg = ws.take((int64_t)n * D); ld_agg = D; }
   const bool fused = (L.fused16p || L.fused_first) && k <= 14;
   const float divisor = sqrtf((float)D);          // fp32(sqrt(d)), as torch.tensor(math.sqrt(d), float32)
-  for (int lo = 0; lo < n; lo += ROW_CHUNK) {
-    const int c = std::min(ROW_CHUNK, n - lo);
+  const int step = row_step(n);
+  for (int lo = 0; lo < n; lo += step) {
+    const int c = std::min(step, n - lo);
     const int64_t cmark = ws.mark();
     const int32_t* idx = knn_idx ? knn_idx + (int64_t)lo * k : nullptr;
     if (!idx) {
@@ -562,8 +571,9 @@ int decoder_forward(const occ4d_decoder_weights& w, const DecoderLayout& L, cons
   const DecoderScene S = decoder_scene_layout(w, m);
   const float* xyz = scene ? scene + S.xyz : nullptr;
   const int act = w.activation == 1 ? 2 : 1;           // linear's act_in code: 1 relu, 2 swish
-  for (int lo = 0; lo < n; lo += ROW_CHUNK) {
-    const int c = std::min(ROW_CHUNK, n - lo);
+  const int step = row_step(n);
+  for (int lo = 0; lo < n; lo += step) {
+    const int c = std::min(step, n - lo);
     const int64_t mark = ws.mark();
     const float* q = queries + (int64_t)lo * qs;
     float* x = penult ? penult + (int64_t)lo * ld_pen : ws.take((int64_t)c * H);

@@ -620,7 +620,15 @@ def rowlin(x, w_packed, b, n_out, relu_in=False, residual=None, out=None, interp
 # reference forward.  The nn.Module mirrors build the weight structs from their parameters (reference layout) and call
 # these; `prepared` / `scene` buffers are cached by the modules, the per-call workspace comes from torch's caching allocator.
 # --------------------------------------------------------------------------------------
-PATH_ROW_CHUNK = 32768          # rows per pass inside the library (csrc/path.hip ROW_CHUNK)
+PATH_ROW_CHUNK = 32768          # most rows per pass inside the library (csrc/path.hip ROW_CHUNK)
+
+
+def path_row_chunks(n):
+    """The passes the library cuts n query rows into (csrc/path.hip row_step): equal sizes, multiples of 9."""
+    passes = -(-n // PATH_ROW_CHUNK)
+    balance = os.environ.get('OCC4D_ROW_BALANCE', '1') != '0'
+    step = PATH_ROW_CHUNK if passes <= 1 or not balance else (-(-n // passes) + 8) // 9 * 9
+    return [min(step, n - lo) for lo in range(0, n, step)]
 
 
 def _attn_flops(c, k, d):
@@ -686,7 +694,7 @@ def pt_layer_fwd(w, prepared, x, pos, x2, pos2, k, flags=0, knn_idx=None, out=No
         _lib.check(_lib.EINVAL)
     ws = torch.empty((nws,), dtype=torch.float32, device=x.device)
     fused = w.dim in FUSED_ATTN_DIMS and k <= FUSED_ATTN_MAX_K and w.pos_hidden == 32 and not (flags & _lib.PATH_UNFUSED)
-    chunks = [min(PATH_ROW_CHUNK, n - lo) for lo in range(0, n, PATH_ROW_CHUNK)] if fused else []
+    chunks = path_row_chunks(n) if fused else []
     t = _timer
     ev, finish = (None, lambda: None)
     if t is not None and chunks and t.want('cross_attn', n=chunks[0], k=k, d=w.dim):
@@ -755,7 +763,7 @@ def decoder_query_fwd(w, prepared, scene, m, queries, flags=0, out=None, penult=
     if penult is not None:
         pp, ldp = _rows(_dev(penult, name='penult'), 'penult')
         assert pp is penult and tuple(pp.shape) == (n, w.d_hidden)
-    nws = int(_lib.lib().occ4d_decoder_query_workspace_floats(C.byref(w), min(n, PATH_ROW_CHUNK), m, flags))
+    nws = int(_lib.lib().occ4d_decoder_query_workspace_floats(C.byref(w), n, m, flags))
     if nws < 0:
         _lib.check(_lib.EINVAL)
     ws = torch.empty((nws,), dtype=torch.float32, device=q.device)
@@ -765,10 +773,10 @@ def decoder_query_fwd(w, prepared, scene, m, queries, flags=0, out=None, penult=
     t = _timer
     ev, finish = (None, lambda: None)
     if t is not None and fused and n and t.want('cross_attn', n=min(n, PATH_ROW_CHUNK), k=k, d=d):
-        chunks = [min(PATH_ROW_CHUNK, n - lo) for lo in range(0, n, PATH_ROW_CHUNK)]
+        chunks = path_row_chunks(n)
         ev, finish = _path_timing('cross_attn', [_attn_flops(c, k, d) for c in chunks for _ in range(w.n_cross)])
     elif t is not None and n and t.want('resblock', n=min(n, PATH_ROW_CHUNK)):
-        chunks = [min(PATH_ROW_CHUNK, n - lo) for lo in range(0, n, PATH_ROW_CHUNK)]
+        chunks = path_row_chunks(n)
         ev, finish = _path_timing('resblock', [4.0 * c * d * d for c in chunks for _ in range(w.n_blocks)])
     _lib.check(_lib.lib().occ4d_decoder_query_fwd_f32(
         C.byref(w), _ptr(prepared), _ptr(scene), m, _ptr(q), qs, n, _ptr(o), ldo, _ptr(penult), ldp, _ptr(ws), flags,
