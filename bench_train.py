@@ -231,17 +231,22 @@ def main():
         def run_step():
             return step(pcl, q, target, **nxt)
 
+    # The loss of an eager step is a device scalar: it is read after the timed region (a loop that logs every step's loss
+    # with .item() stalls the host once per step; the usual loop logs every N-th).  A replayed step leaves its loss in a
+    # static tensor that the next replay overwrites, so that one is read per step.
+    read = (lambda t: float(t)) if args.graph else (lambda t: t)
     losses = []
     for _ in range(args.warmup):
-        losses.append(float(run_step()))
+        losses.append(read(run_step()))
     fence()
     if args.sampler:
         sampler_time[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses.append(float(run_step()))
+        losses.append(read(run_step()))
     fence()
     elapsed = time.perf_counter() - t0
+    losses = [float(t) for t in losses]
     if args.sampler:
         sampler_ms = 1e3 * sampler_time[0] / args.steps
     per_rank = [elapsed]
@@ -290,7 +295,7 @@ def main():
             'metric': 'training step (BASELINE config 5: CARLA-4D, batch 1/GPU, n_points=28672, 4 x 17203 queries)',
             'value': world * args.steps / elapsed, 'unit': 'examples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'dtype': 'f32', 'data': 'synthetic', 'losses': losses, 'sampler_ms_per_step': sampler_ms, 'sampler': (None if not args.sampler else 'in front of the step (serial)' if args.sampler_serial else "next step's points drawn on a side stream beside this step (host time per step in sampler_ms_per_step)"), 'graph': bool(args.graph), 'geometry_prefetch': bool(nxt), 'frames_batched': bool(step.batch_frames), 'attention_backward': ('stored pair tensors (%s form)' % pk.point_transformer_layer.STORED_ATTENTION_FORM) if args.no_checkpoint else 'recompute in backward (equal chunks of at most %d queries)' % pk.point_transformer_layer._CHECKPOINT_CHUNK,
+            'scaling': 'weak', 'dtype': 'f32', 'data': 'synthetic', 'losses': losses, 'sampler_ms_per_step': sampler_ms, 'sampler': (None if not args.sampler else 'in front of the step (serial)' if args.sampler_serial else "next step's points drawn on a side stream beside this step (host time per step in sampler_ms_per_step)"), 'graph': bool(args.graph), 'loss_read': 'per step (static tensor of the replay)' if args.graph else 'after the timed region', 'geometry_prefetch': bool(nxt), 'frames_batched': bool(step.batch_frames), 'attention_backward': ('stored pair tensors (%s form)' % pk.point_transformer_layer.STORED_ATTENTION_FORM) if args.no_checkpoint else 'recompute in backward (equal chunks of at most %d queries)' % pk.point_transformer_layer._CHECKPOINT_CHUNK,
             'peak_mem_gb': torch.cuda.max_memory_allocated() / 2 ** 30,
             'roofline': roof,
             'config': {'workload': 'CARLA-4D training step (BASELINE configs[4]): batch 1 per GPU, n_points=%d, %d x %d '

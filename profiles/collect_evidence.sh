@@ -18,12 +18,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof2" -- \
 cp "$(find "$OUT/prof2" -name '*kernel_stats.csv' | head -1)" "$OUT/bench_kernel_stats.csv"
 : > "$OUT/bench_train.jsonl"
 for flags in "" "--graph" "--no-checkpoint" "--graph --no-checkpoint"; do
-  python bench_train.py --steps 5 --warmup 2 $flags 2>/dev/null | tail -1 >> "$OUT/bench_train.jsonl"
+  python bench_train.py --steps 20 --warmup 3 $flags 2>/dev/null | tail -1 >> "$OUT/bench_train.jsonl"
 done
-OCC4D_PAIR_MLP=0 OCC4D_TRAIN_ROWLIN_HALF_CU=0 python bench_train.py --steps 5 --warmup 2 --graph 2>/dev/null | tail -1 >> "$OUT/bench_train.jsonl"
+OCC4D_PAIR_MLP=0 OCC4D_TRAIN_ROWLIN_HALF_CU=0 python bench_train.py --steps 20 --warmup 3 --graph 2>/dev/null | tail -1 >> "$OUT/bench_train.jsonl"
 : > "$OUT/bench_train_sampler.jsonl"
 for flags in "--graph" "--sampler --graph" "--sampler" "--sampler --sampler-serial"; do
-  python bench_train.py --steps 5 --warmup 2 $flags 2>/dev/null | tail -1 >> "$OUT/bench_train_sampler.jsonl"
+  python bench_train.py --steps 20 --warmup 3 $flags 2>/dev/null | tail -1 >> "$OUT/bench_train_sampler.jsonl"
 done
 python profiles/time_pair_mlp.py > "$OUT/time_pair_mlp.txt" 2>/dev/null
 python profiles/time_wgrad.py 2>/dev/null | grep -v amdgpu.ids > "$OUT/time_wgrad.txt"
