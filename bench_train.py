@@ -168,7 +168,10 @@ def main():
                              np.zeros((FRAMES, QUERIES, 1)), rng.integers(-1, 13, size=(FRAMES, QUERIES, 1))], -1)
     q = torch.from_numpy(q.astype(np.float32)).to(device)
     target = torch.from_numpy(target.astype(np.float32)).to(device)
-    lkw = dict(density_lw=1.0, segmentation_lw=0.6)
+    # static_shapes: the loss's masked means by weighting instead of boolean indexing (training.implicit_loss) -- the
+    # form GraphedTrainStep always uses; in the eager step it removes the 12 device->host reads (one per boolean index) that
+    # stall the host between forward and backward.  OCC4D_BENCH_INDEXED_LOSS=1: the reference's indexing form.
+    lkw = dict(density_lw=1.0, segmentation_lw=0.6, static_shapes=os.environ.get('OCC4D_BENCH_INDEXED_LOSS') != '1')
     if args.graph:
         # (the guided sampler draws on the host: it is not part of the captured step -- it runs beside the replay)
         step = pk.training.GraphedTrainStep(enc, dec, lr=1e-3, grad_clip=0.2, loss_kwargs=lkw,

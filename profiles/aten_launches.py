@@ -1,0 +1,48 @@
+"""Which ATen operators of one eager training step (BASELINE config 5) launch kernels, how often and on which shapes
+(torch.profiler; the library's own launches go through ctypes and do not appear here)."""
+import os
+import sys
+
+import numpy as np
+import torch
+from torch.profiler import ProfilerActivity, profile
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import occlusions4d_amd as pk  # noqa: E402
+
+N_POINTS, FRAMES, QUERIES, SEED = 28672, 4, 17203, 2030
+dev = torch.device('cuda:0')
+pa, ia, inf = pk.configs.model_args('carla', N_POINTS)
+esd, dsd = pk.configs.synthetic_weights(pa, ia, SEED)
+enc = pk.model.PointCompletionNetV3(**pa).to(dev).train()
+dec = pk.implicit.LocalPclResnetFC(**ia).to(dev).train()
+enc.load_state_dict(esd)
+dec.load_state_dict(dsd)
+pcl = pk.configs.synthetic_pcl('carla', N_POINTS, 12, SEED).to(dev)
+rng = np.random.default_rng(SEED + 100)
+q = np.concatenate([rng.uniform([0, -16, -1], [40, 16, 6.4], size=(FRAMES, QUERIES, 3)),
+                    np.broadcast_to(np.arange(FRAMES, dtype=np.float64)[:, None, None], (FRAMES, QUERIES, 1))], -1)
+target = np.concatenate([rng.integers(0, 2, size=(FRAMES, QUERIES, 1)), rng.uniform(size=(FRAMES, QUERIES, 3)),
+                         np.zeros((FRAMES, QUERIES, 1)), rng.integers(-1, 13, size=(FRAMES, QUERIES, 1))], -1)
+q = torch.from_numpy(q.astype(np.float32)).to(dev)
+target = torch.from_numpy(target.astype(np.float32)).to(dev)
+step = pk.training.TrainStep(enc, dec, lr=1e-3, grad_clip=0.2, loss_kwargs=dict(density_lw=1.0, segmentation_lw=0.6))
+step.batch_frames = True
+for _ in range(2):
+    step(pcl, q, target, next_pcl_input=pcl)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    step(pcl, q, target, next_pcl_input=pcl)
+    torch.cuda.synchronize()
+rows = []
+for e in prof.key_averages(group_by_input_shape=True):
+    dt = getattr(e, 'self_device_time_total', None)
+    if dt is None:
+        dt = getattr(e, 'self_cuda_time_total', 0)
+    if dt > 0:
+        rows.append((dt, e.count, e.key, str(e.input_shapes)[:110]))
+rows.sort(reverse=True)
+print('self device time (us), count, op, input shapes')
+for dt, cnt, key, shp in rows[:70]:
+    print('%9.0f %5d  %-28s %s' % (dt, cnt, key, shp))
+print('total', sum(r[0] for r in rows))
