@@ -341,6 +341,22 @@ class MeanRowsFn(Function):
         return ops.broadcast_rows(dout.contiguous(), ctx.n, 1.0 / ctx.n)
 
 
+class ExpandRowsFn(Function):
+    """v (d) -> (n, d), every row = v: `v[None].expand(n, d)` with a backward on the library's column-sum kernels.
+    torch's own backward of expand is a multi-block reduction whose completion counters are cleared by a cudaMemsetAsync:
+    inside a captured step that is a MEMSET NODE, and on this HIP runtime memset nodes are not ordered reliably against
+    the kernel nodes around them (profiles/r04_graph_replay_probe.txt: the replayed step computed a wrong gradient for the
+    global embedding whenever an eager kernel had run since the last device-wide synchronisation)."""
+
+    @staticmethod
+    def forward(ctx, v, n):
+        return ops.broadcast_rows(v, n, 1.0)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return ops.colsum(dout), None
+
+
 class InterpFn(Function):
     """y[i] = sum_j w[i,j] table[idx[i,j]]  (inverse-distance feature interpolation)."""
 

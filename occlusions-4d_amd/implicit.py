@@ -346,7 +346,7 @@ class LocalPclResnetFC(ResnetFC):
         idx8, dist = ops.knn(q, pa, self.num_local_features, metric=1, return_dist=True)
         w8 = ops.interp_weights(dist)
         f_local = autograd.InterpFn.apply(fa, idx8, w8)                                   # (n, E)
-        f_query = torch.cat([fg[None, :].expand(n, dg), f_local], dim=-1)                 # (n, D)
+        f_query = torch.cat([autograd.ExpandRowsFn.apply(fg, n), f_local], dim=-1)         # (n, D)
         x = autograd.linear(ops.posenc(q, self.pos_encoding_freqs, 0.1), self.lin_in)
         qxyz = q[:, :3].detach()
         idx_att = None

@@ -26,7 +26,7 @@ target = np.concatenate([rng.integers(0, 2, size=(FRAMES, QUERIES, 1)), rng.unif
                          np.zeros((FRAMES, QUERIES, 1)), rng.integers(-1, 13, size=(FRAMES, QUERIES, 1))], -1)
 q = torch.from_numpy(q.astype(np.float32)).to(dev)
 target = torch.from_numpy(target.astype(np.float32)).to(dev)
-step = pk.training.TrainStep(enc, dec, lr=1e-3, grad_clip=0.2, loss_kwargs=dict(density_lw=1.0, segmentation_lw=0.6))
+step = pk.training.TrainStep(enc, dec, lr=1e-3, grad_clip=0.2, loss_kwargs=dict(density_lw=1.0, segmentation_lw=0.6, static_shapes=True))
 step.batch_frames = True
 for _ in range(2):
     step(pcl, q, target, next_pcl_input=pcl)
@@ -46,3 +46,11 @@ print('self device time (us), count, op, input shapes')
 for dt, cnt, key, shp in rows[:70]:
     print('%9.0f %5d  %-28s %s' % (dt, cnt, key, shp))
 print('total', sum(r[0] for r in rows))
+print('reductions (aten::sum / mean / norm) by input shape:')
+for e in prof.key_averages(group_by_input_shape=True):
+    if e.key in ('aten::sum', 'aten::mean', 'aten::linalg_vector_norm', 'aten::norm', 'aten::_foreach_norm', 'aten::amax', 'aten::max', 'aten::any', 'aten::all', 'aten::cumsum', 'aten::sort', 'aten::nonzero', 'aten::index_add_', 'aten::bincount', 'aten::unique'):
+        print('   %-26s x%-4d %s' % (e.key, e.count, str(e.input_shapes)[:120]))
+print('memset activities (each would be a MEMSET NODE of a captured step):')
+for dt, cnt, key, shp in rows:
+    if 'emset' in key:
+        print('%9.0f %5d  %s' % (dt, cnt, key))
