@@ -123,7 +123,9 @@ class DownTransition(torch.nn.Module):
         one long chain on a single CU) back to back on a side stream (model.py).  `nested`: the NestedFps of the chain
         this cloud belongs to; with a deterministic start the subset then comes from the first level's selection order."""
         n_new = int(np.ceil(p.shape[0] / self.factor))
-        if nested is not None and NESTED_FPS and not self.fps_random_start:
+        # (not while a stream is being captured: the prefix arithmetic sorts with torch, and only kernels of this library
+        # are safe inside a captured region on this runtime -- DESIGN.md 7b)
+        if nested is not None and NESTED_FPS and not self.fps_random_start and not torch.cuda.is_current_stream_capturing():
             if nested.usable(p.shape[0], n_new):
                 inds = nested.next_level(n_new)
                 return (inds, ops.gather_rows(p, inds))
