@@ -351,6 +351,13 @@ int64_t occ4d_radius_grid_workspace_bytes(int n);
 int occ4d_radius_grid_build_f32(const float* xyz, int64_t stride, int n, float radius_max, void* workspace, void* stream);
 int occ4d_radius_far_f32(const float* query, int64_t q_stride, int n_query, const void* workspace, float radius,
                          float* far, void* stream);
+/* Exact k nearest neighbours through a uniform grid of `data` (built inside the call, in `workspace` of
+ * occ4d_radius_grid_workspace_bytes(n_data) bytes, 16-byte aligned): the contract and the results of occ4d_knn_f32 with
+ * int32 indices, bit for bit (same distance expressions, (distance, index) lexicographic order), for large searches --
+ * a query visits the cells around its own in growing rings until its k-th distance is proven (csrc/gridrad.hip) instead of
+ * all n_data points.  The caller chooses: the brute-force kernel wins below ~128 M pairs. */
+int occ4d_knn_grid_f32(const float* query, int64_t q_stride, int n_query, const float* data, int64_t d_stride, int n_data,
+                       int k, int metric, int32_t* out_idx, float* out_dist, void* workspace, void* stream);
 
 /* Generic order-preserving row compaction (training-time sampler, filter_air_solid_gap utils/geometry.py:1190-1194):
  * keep row i when key[i] >= threshold (key[i] > threshold when strict).  compact_count fills block_counts

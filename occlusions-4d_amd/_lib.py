@@ -123,6 +123,7 @@ SIGNATURES = {
     'occ4d_radius_grid_workspace_bytes': (C.c_int64, [C.c_int]),
     'occ4d_radius_grid_build_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_float, _f, _s]),
     'occ4d_radius_far_f32': (C.c_int, [_f, C.c_int64, C.c_int, _f, C.c_float, _f, _s]),
+    'occ4d_knn_grid_f32': (C.c_int, [_f, C.c_int64, C.c_int, _f, C.c_int64, C.c_int, C.c_int, C.c_int, _i, _f, _f, _s]),
     'occ4d_compact_count_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_float, C.c_int, _i, _i, _s]),
     'occ4d_compact_rows_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, _f, C.c_int64, C.c_float, C.c_int, _i, _f, _f,
                                          _s]),

@@ -16,6 +16,8 @@
 // Build (per target cloud): bounding box + cell size on the device (no host round trip), cell histogram with atomics,
 // one-workgroup exclusive scan, scatter of the points (as float4) into cell order.  GD^3 cells at most: a cloud larger
 // than GD cells along an axis gets coarser cells (more candidates per query, same answers).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -54,8 +56,12 @@ __device__ __forceinline__ float block_minmax(float v, bool is_max, float* red, 
   return r;
 }
 
+// h_min > 0: the cell edge is at least h_min (radius tests).  per_cell > 0 (exact kNN): the edge that puts ~per_cell
+// points into a cell of the cloud's box, cbrt(volume x per_cell / n) with degenerate extents widened to 0.1 % of the
+// longest one -- a guess that only sets the speed: the search below widens its ring until the answer is proven.
 __global__ __launch_bounds__(GT) void grid_plan_kernel(const float* __restrict__ xyz, int64_t stride, int n, float h_min,
-                                                       GridPlan* __restrict__ plan, int* __restrict__ counts) {
+                                                       float per_cell, GridPlan* __restrict__ plan,
+                                                       int* __restrict__ counts) {
   __shared__ float red[GT / 64];
   const int t = threadIdx.x;
   float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
@@ -73,6 +79,11 @@ __global__ __launch_bounds__(GT) void grid_plan_kernel(const float* __restrict__
     ext = fmaxf(ext, hi[a] - lo[a]);
   }
   // cell edge: at least h_min, and large enough that the longest axis fits GD cells (every thread computes the same plan)
+  if (per_cell > 0.f) {
+    const float eps = fmaxf(ext, 1e-30f) * 1e-3f;
+    const float vol = fmaxf(hi[0] - lo[0], eps) * fmaxf(hi[1] - lo[1], eps) * fmaxf(hi[2] - lo[2], eps);
+    h_min = cbrtf(vol * per_cell / (float)n);
+  }
   float h = fmaxf(h_min, ext / (float)(GD - 1));
   if (!(h > 0.f) || !(h < __builtin_inff())) h = 1.f;            // (degenerate / non-finite clouds: one coarse grid)
   GridPlan g;
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(256) void grid_fill_kernel(const float* __restrict_
   const float* p = xyz + (int64_t)i * stride;
   const int c = cell_of(g, p[0], p[1], p[2]);
   const int slot = atomicAdd(cursors + c, 1);
-  pts[starts[c] + slot] = float4{p[0], p[1], p[2], 0.f};
+  pts[starts[c] + slot] = float4{p[0], p[1], p[2], __int_as_float(i)};        // (.w: the point's index, for the kNN search)
 }
 
 // far[i] = 1.0f when no target lies within r of query i (the rows the gap filter keeps), else 0.0f.
@@ -182,6 +193,93 @@ __global__ __launch_bounds__(256) void grid_far_kernel(const float* __restrict__
   if (live && sub == 0) far[i] = any ? 0.f : 1.f;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Exact k nearest neighbours on the same grid (csrc/knn.hip's contract: the k smallest (distance, index) pairs in
+// lexicographic order, distances by that file's METRIC 0 / 1 expressions, so the lists are bit-identical to the
+// brute-force scan's).  One thread per query walks the cells around its own in rings of growing Chebyshev radius and keeps
+// its k best in registers; after ring rho every unvisited point lies beyond one of the faces of the visited block that
+// still has cells behind it, i.e. at least lb = (smallest distance from the query to such a face) away.  The search ends
+// when the k-th best distance is STRICTLY below lb minus a margin of 1e-2 cell edges (cell coordinates are
+// floor((p - origin) / h) in fp32: their rounding, ~1e-5 cells for coordinates of this size, is far inside the margin; strict, so that an unvisited
+// point at exactly the k-th distance with a lower index cannot be missed), or when the block covers the grid.  A query
+// outside the cloud's box starts from the clamped cell; its distances to the faces are then simply larger.
+// Order inside a cell is arbitrary (atomics at build time): the comparison is lexicographic, so it does not matter.
+// The brute-force kernel scans n_query x n_data pairs (28672 x 28672 of a training cloud: 2 ms on the whole chip); here
+// a query sees a few hundred candidates.
+template <int KT, int METRIC>
+__global__ __launch_bounds__(64) void knn_grid_kernel(const float* __restrict__ query, int64_t qs, int nq,
+                                                      const GridPlan* __restrict__ plan, const int* __restrict__ starts,
+                                                      const float4* __restrict__ pts, int k, int32_t* __restrict__ out_idx,
+                                                      float* __restrict__ out_dist) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= nq) return;
+  const GridPlan g = *plan;
+  const float h = 1.0f / g.inv_h;
+  const float* q = query + (int64_t)i * qs;
+  const float qx = q[0], qy = q[1], qz = q[2];
+  const int cx = max(0, min(g.nx - 1, (int)floorf((qx - g.ox) * g.inv_h)));
+  const int cy = max(0, min(g.ny - 1, (int)floorf((qy - g.oy) * g.inv_h)));
+  const int cz = max(0, min(g.nz - 1, (int)floorf((qz - g.oz) * g.inv_h)));
+  float bd[KT];
+  int bi[KT];
+#pragma unroll
+  for (int s = 0; s < KT; ++s) { bd[s] = __builtin_inff(); bi[s] = 0x7fffffff; }
+  auto visit = [&](int s0, int s1) {
+    for (int t = s0; t < s1; ++t) {
+      const float4 p = pts[t];
+      const int id = __float_as_int(p.w);
+      const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+      const float d = METRIC == 0 ? (dx * dx + dy * dy) + dz * dz : sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+      if (d < bd[KT - 1] || (d == bd[KT - 1] && id < bi[KT - 1])) {
+        bd[KT - 1] = d;
+        bi[KT - 1] = id;
+#pragma unroll
+        for (int s = KT - 1; s > 0; --s) {
+          if (bd[s] < bd[s - 1] || (bd[s] == bd[s - 1] && bi[s] < bi[s - 1])) {
+            const float td = bd[s]; bd[s] = bd[s - 1]; bd[s - 1] = td;
+            const int ti = bi[s]; bi[s] = bi[s - 1]; bi[s - 1] = ti;
+          }
+        }
+      }
+    }
+  };
+  const int rings = max(g.nx, max(g.ny, g.nz));
+  for (int rho = 0; rho < rings; ++rho) {
+    const int z0 = max(0, cz - rho), z1 = min(g.nz - 1, cz + rho);
+    const int y0 = max(0, cy - rho), y1 = min(g.ny - 1, cy + rho);
+    const int x0 = max(0, cx - rho), x1 = min(g.nx - 1, cx + rho);
+    for (int z = z0; z <= z1; ++z) {
+      for (int y = y0; y <= y1; ++y) {
+        const int row = (z * g.ny + y) * g.nx;
+        if (z - cz == rho || cz - z == rho || y - cy == rho || cy - y == rho) {
+          visit(starts[row + x0], starts[row + x1 + 1]);              // a face of the block: the whole x range
+        } else {                                                        // inside: only the two end cells of the row
+          if (cx - rho >= 0) visit(starts[row + cx - rho], starts[row + cx - rho + 1]);
+          if (rho > 0 && cx + rho <= g.nx - 1) visit(starts[row + cx + rho], starts[row + cx + rho + 1]);
+        }
+      }
+    }
+    float lb = __builtin_inff();
+    if (cx - rho > 0) lb = fminf(lb, qx - (g.ox + (float)(cx - rho) * h));
+    if (cx + rho < g.nx - 1) lb = fminf(lb, (g.ox + (float)(cx + rho + 1) * h) - qx);
+    if (cy - rho > 0) lb = fminf(lb, qy - (g.oy + (float)(cy - rho) * h));
+    if (cy + rho < g.ny - 1) lb = fminf(lb, (g.oy + (float)(cy + rho + 1) * h) - qy);
+    if (cz - rho > 0) lb = fminf(lb, qz - (g.oz + (float)(cz - rho) * h));
+    if (cz + rho < g.nz - 1) lb = fminf(lb, (g.oz + (float)(cz + rho + 1) * h) - qz);
+    if (lb == __builtin_inff()) break;                                // the block covers the grid
+    lb = fmaxf(0.f, lb - 1e-2f * h);
+    const float kth = bd[k - 1];
+    if (METRIC == 0 ? kth < lb * lb : kth < lb) break;
+  }
+#pragma unroll
+  for (int s = 0; s < KT; ++s) {
+    if (s < k) {
+      out_idx[(int64_t)i * k + s] = min(bi[s], g.n - 1);               // (unfilled slot -- NaN / inf input --: in bounds)
+      if (out_dist) out_dist[(int64_t)i * k + s] = bd[s];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int64_t occ4d_radius_grid_workspace_bytes(int n) { return (int64_t)off_points() + (int64_t)(n > 0 ? n : 0) * 16; }
@@ -197,7 +295,7 @@ extern "C" int occ4d_radius_grid_build_f32(const float* xyz, int64_t stride, int
   int* counts = (int*)(ws + off_counts());
   int* starts = (int*)(ws + off_starts());
   float4* pts = (float4*)(ws + off_points());
-  grid_plan_kernel<<<1, GT, 0, st>>>(xyz, stride, n, radius_max / 0.95f, plan, counts);
+  grid_plan_kernel<<<1, GT, 0, st>>>(xyz, stride, n, radius_max / 0.95f, 0.f, plan, counts);
   grid_count_kernel<<<occ4d::cdiv(n, 256), 256, 0, st>>>(xyz, stride, n, plan, counts);
   grid_scan_kernel<<<1, GT, 0, st>>>(plan, counts, starts);
   grid_fill_kernel<<<occ4d::cdiv(n, 256), 256, 0, st>>>(xyz, stride, n, plan, counts, starts, pts);
@@ -213,4 +311,35 @@ extern "C" int occ4d_radius_far_f32(const float* query, int64_t qs, int nq, cons
   grid_far_kernel<<<occ4d::cdiv((int64_t)nq * FAR_TPQ, 256), 256, 0, (hipStream_t)stream>>>(
       query, qs, nq, (const GridPlan*)ws, (const int*)(ws + off_starts()), (const float4*)(ws + off_points()), radius, far);
   return occ4d::check_launch("occ4d_radius_far_f32");
+}
+
+// Exact kNN through the grid: builds the grid of `data` in `workspace` (occ4d_radius_grid_workspace_bytes(n_data)) and
+// searches it.  Same results as occ4d_knn_f32 (int32 indices), bit for bit.
+extern "C" int occ4d_knn_grid_f32(const float* query, int64_t q_stride, int n_query, const float* data, int64_t d_stride,
+                                  int n_data, int k, int metric, int32_t* out_idx, float* out_dist, void* workspace,
+                                  void* stream) {
+  OCC4D_REQUIRE(k >= 1 && k <= 16, "occ4d_knn_grid_f32: k=%d outside [1,16]", k);
+  OCC4D_REQUIRE(n_data >= k, "occ4d_knn_grid_f32: n_data=%d < k=%d", n_data, k);
+  OCC4D_REQUIRE(metric == 0 || metric == 1, "occ4d_knn_grid_f32: metric=%d", metric);
+  OCC4D_REQUIRE(n_query >= 0 && q_stride >= 3 && d_stride >= 3, "occ4d_knn_grid_f32: bad sizes/strides");
+  OCC4D_REQUIRE(query && data && out_idx && workspace && ((uintptr_t)workspace % 16) == 0,
+                "occ4d_knn_grid_f32: null pointer or workspace not 16-byte aligned");
+  if (n_query == 0) return OCC4D_OK;
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  GridPlan* plan = (GridPlan*)ws;
+  int* counts = (int*)(ws + off_counts());
+  int* starts = (int*)(ws + off_starts());
+  float4* pts = (float4*)(ws + off_points());
+  static const float per_cell = [] { const char* e = getenv("OCC4D_KNN_GRID_PER_CELL"); return e ? (float)atof(e) : 4.f; }();
+  grid_plan_kernel<<<1, GT, 0, st>>>(data, d_stride, n_data, 0.f, per_cell, plan, counts);
+  grid_count_kernel<<<occ4d::cdiv(n_data, 256), 256, 0, st>>>(data, d_stride, n_data, plan, counts);
+  grid_scan_kernel<<<1, GT, 0, st>>>(plan, counts, starts);
+  grid_fill_kernel<<<occ4d::cdiv(n_data, 256), 256, 0, st>>>(data, d_stride, n_data, plan, counts, starts, pts);
+  const int grid = occ4d::cdiv(n_query, 64);
+#define OCC4D_KG(KT, M) knn_grid_kernel<KT, M><<<grid, 64, 0, st>>>(query, q_stride, n_query, plan, starts, pts, k, out_idx, out_dist)
+  if (k <= 8) { if (metric == 0) OCC4D_KG(8, 0); else OCC4D_KG(8, 1); }
+  else { if (metric == 0) OCC4D_KG(16, 0); else OCC4D_KG(16, 1); }
+#undef OCC4D_KG
+  return occ4d::check_launch("occ4d_knn_grid_f32");
 }

@@ -113,6 +113,14 @@ def _aligned_rows(t, name, k_pad=None):
 
 
 # --------------------------------------------------------------------------------------
+# Searches of at least KNN_GRID_MIN_PAIRS query x data pairs (2^27: where the brute-force scan passes ~0.4 ms, the grid
+# search's latency floor -- profiles/r04_time_knn_grid.txt) over at least KNN_GRID_MIN_DATA points go through the grid
+# (OCC4D_KNN_GRID=0: the brute-force kernel everywhere; both give the same lists).
+KNN_GRID = os.environ.get('OCC4D_KNN_GRID', '1') != '0'
+KNN_GRID_MIN_DATA = int(os.environ.get('OCC4D_KNN_GRID_MIN_DATA', '1024'))
+KNN_GRID_MIN_PAIRS = int(os.environ.get('OCC4D_KNN_GRID_MIN_PAIRS', str(1 << 27)))
+
+
 def knn(query, data, k, metric=0, return_dist=False, int64=False):
     """query (N0,>=3), data (N1,>=3) -> idx (N0,k) [, dist (N0,k)].  metric 0 = squared
     sum (kNN_torch arithmetic), 1 = Euclidean norm (my_knn_torch arithmetic)."""
@@ -122,6 +130,14 @@ def knn(query, data, k, metric=0, return_dist=False, int64=False):
     n0 = q.shape[0]
     idx = torch.empty((n0, k), dtype=torch.int64 if int64 else torch.int32, device=q.device)
     dist = torch.empty((n0, k), dtype=torch.float32, device=q.device) if return_dist else None
+    if KNN_GRID and not int64 and d.shape[0] >= KNN_GRID_MIN_DATA and n0 * d.shape[0] >= KNN_GRID_MIN_PAIRS:
+        # large searches (the self-kNNs of a cloud, the decoder's query -> abstract-cloud lists of a training step):
+        # exact search on a uniform grid of `data`, same lists bit for bit (csrc/gridrad.hip)
+        ws = torch.empty(((int(_lib.lib().occ4d_radius_grid_workspace_bytes(d.shape[0])) + 3) // 4,), dtype=torch.float32,
+                         device=q.device)
+        _lib.check(_lib.lib().occ4d_knn_grid_f32(_ptr(q), qs, n0, _ptr(d), ds, d.shape[0], k, metric, _ptr(idx), _ptr(dist),
+                                                 _ptr(ws), _stream()))
+        return (idx, dist) if return_dist else idx
     _lib.check(_lib.lib().occ4d_knn_f32(_ptr(q), qs, n0, _ptr(d), ds, d.shape[0], k, metric, _ptr(idx),
                                         1 if int64 else 0, _ptr(dist), _stream()))
     return (idx, dist) if return_dist else idx
