@@ -355,7 +355,7 @@ int occ4d_radius_far_f32(const float* query, int64_t q_stride, int n_query, cons
  * occ4d_radius_grid_workspace_bytes(n_data) bytes, 16-byte aligned): the contract and the results of occ4d_knn_f32 with
  * int32 indices, bit for bit (same distance expressions, (distance, index) lexicographic order), for large searches --
  * a query visits the cells around its own in growing rings until its k-th distance is proven (csrc/gridrad.hip) instead of
- * all n_data points.  The caller chooses: the brute-force kernel wins below ~128 M pairs. */
+ * all n_data points.  The caller chooses: the brute-force kernel wins below ~64 M pairs. */
 int occ4d_knn_grid_f32(const float* query, int64_t q_stride, int n_query, const float* data, int64_t d_stride, int n_data,
                        int k, int metric, int32_t* out_idx, float* out_dist, void* workspace, void* stream);
 

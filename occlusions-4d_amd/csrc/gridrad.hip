@@ -196,8 +196,8 @@ __global__ __launch_bounds__(256) void grid_far_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------------------------
 // Exact k nearest neighbours on the same grid (csrc/knn.hip's contract: the k smallest (distance, index) pairs in
 // lexicographic order, distances by that file's METRIC 0 / 1 expressions, so the lists are bit-identical to the
-// brute-force scan's).  One thread per query walks the cells around its own in rings of growing Chebyshev radius and keeps
-// its k best in registers; after ring rho every unvisited point lies beyond one of the faces of the visited block that
+// brute-force scan's).  A query walks the cells around its own in rings of growing Chebyshev radius and keeps its k best in
+// registers; after ring rho every unvisited point lies beyond one of the faces of the visited block that
 // still has cells behind it, i.e. at least lb = (smallest distance from the query to such a face) away.  The search ends
 // when the k-th best distance is STRICTLY below lb minus a margin of 1e-2 cell edges (cell coordinates are
 // floor((p - origin) / h) in fp32: their rounding, ~1e-5 cells for coordinates of this size, is far inside the margin; strict, so that an unvisited
@@ -206,8 +206,11 @@ __global__ __launch_bounds__(256) void grid_far_kernel(const float* __restrict__
 // Order inside a cell is arbitrary (atomics at build time): the comparison is lexicographic, so it does not matter.
 // The brute-force kernel scans n_query x n_data pairs (28672 x 28672 of a training cloud: 2 ms on the whole chip); here
 // a query sees a few hundred candidates.
+// The same search with ONE thread per query, for searches with so many queries that the machine is full without
+// splitting them (the decoder's 68812 queries of a training step): exact termination (the thread knows its own k-th
+// distance), no merge.  profiles/r04_time_knn_grid.txt has both on every shape.
 template <int KT, int METRIC>
-__global__ __launch_bounds__(64) void knn_grid_kernel(const float* __restrict__ query, int64_t qs, int nq,
+__global__ __launch_bounds__(64) void knn_grid1_kernel(const float* __restrict__ query, int64_t qs, int nq,
                                                       const GridPlan* __restrict__ plan, const int* __restrict__ starts,
                                                       const float4* __restrict__ pts, int k, int32_t* __restrict__ out_idx,
                                                       float* __restrict__ out_dist) {
@@ -280,6 +283,128 @@ __global__ __launch_bounds__(64) void knn_grid_kernel(const float* __restrict__ 
   }
 }
 
+constexpr int KG_TPQ = 16;                   // lanes per query
+constexpr int KG_BLOCK = 256;                // 16 queries per workgroup
+template <int KT, int METRIC>
+__global__ __launch_bounds__(KG_BLOCK) void knn_grid_kernel(const float* __restrict__ query, int64_t qs, int nq,
+                                                            const GridPlan* __restrict__ plan, const int* __restrict__ starts,
+                                                            const float4* __restrict__ pts, int k, int32_t* __restrict__ out_idx,
+                                                            float* __restrict__ out_dist) {
+  // Sixteen lanes per query (one thread per query is a chain of ~100 dependent L2 round trips with < 2 waves per CU to
+  // hide them: 0.3 ms whatever the size).  The lanes fetch the cell-row ranges of a ring in parallel and stride through
+  // every range together; each keeps the best KT of ITS points, sorted.  After a ring the k-th distance of the union is
+  // bounded from above without merging: by the smallest lane-level k-th, and -- every lane holding at least one point
+  // means sixteen points no farther than the largest lane minimum -- by that maximum (k <= 16).  The bound is
+  // conservative (a ring too many at worst), the answer exact: the sixteen lists are merged through LDS at the end.
+  __shared__ float m_d[KG_BLOCK * (KT + 1)];
+  __shared__ int m_i[KG_BLOCK * (KT + 1)];
+  const int i = (blockIdx.x * KG_BLOCK + threadIdx.x) / KG_TPQ, sub = threadIdx.x % KG_TPQ;
+  const bool live = i < nq;
+  const GridPlan g = *plan;
+  const float h = 1.0f / g.inv_h;
+  const float* q = query + (int64_t)(live ? i : 0) * qs;
+  const float qx = q[0], qy = q[1], qz = q[2];
+  const int cx = max(0, min(g.nx - 1, (int)floorf((qx - g.ox) * g.inv_h)));
+  const int cy = max(0, min(g.ny - 1, (int)floorf((qy - g.oy) * g.inv_h)));
+  const int cz = max(0, min(g.nz - 1, (int)floorf((qz - g.oz) * g.inv_h)));
+  float bd[KT];
+  int bi[KT];
+#pragma unroll
+  for (int s = 0; s < KT; ++s) { bd[s] = __builtin_inff(); bi[s] = 0x7fffffff; }
+  auto insert = [&](const float4 p) {
+    const int id = __float_as_int(p.w);
+    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+    const float d = METRIC == 0 ? (dx * dx + dy * dy) + dz * dz : sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+    if (d < bd[KT - 1] || (d == bd[KT - 1] && id < bi[KT - 1])) {
+      bd[KT - 1] = d;
+      bi[KT - 1] = id;
+#pragma unroll
+      for (int s = KT - 1; s > 0; --s) {
+        if (bd[s] < bd[s - 1] || (bd[s] == bd[s - 1] && bi[s] < bi[s - 1])) {
+          const float td = bd[s]; bd[s] = bd[s - 1]; bd[s - 1] = td;
+          const int ti = bi[s]; bi[s] = bi[s - 1]; bi[s - 1] = ti;
+        }
+      }
+    }
+  };
+  auto visit = [&](int s0, int s1) {
+    for (int t = s0 + sub; t < s1; t += KG_TPQ) insert(pts[t]);
+  };
+  const int rings = live ? max(g.nx, max(g.ny, g.nz)) : 0;
+  for (int rho = 0; rho < rings; ++rho) {              // (uniform over the sixteen lanes of a query)
+    const int z0 = max(0, cz - rho), z1 = min(g.nz - 1, cz + rho);
+    const int y0 = max(0, cy - rho), y1 = min(g.ny - 1, cy + rho);
+    const int x0 = max(0, cx - rho), x1 = min(g.nx - 1, cx + rho);
+    const int ny_cnt = y1 - y0 + 1, n_rows = (z1 - z0 + 1) * ny_cnt;
+    for (int base = 0; base < n_rows; base += KG_TPQ) {
+      const int r = base + sub;
+      int a0 = 0, a1 = 0, b0 = 0, b1 = 0;              // this lane's row: one range (a face of the block) or its two end cells
+      if (r < n_rows) {
+        const int z = z0 + r / ny_cnt, y = y0 + r % ny_cnt;
+        const int row = (z * g.ny + y) * g.nx;
+        if (z - cz == rho || cz - z == rho || y - cy == rho || cy - y == rho) {
+          a0 = starts[row + x0]; a1 = starts[row + x1 + 1];
+        } else {
+          if (cx - rho >= 0) { a0 = starts[row + cx - rho]; a1 = starts[row + cx - rho + 1]; }
+          if (rho > 0 && cx + rho <= g.nx - 1) { b0 = starts[row + cx + rho]; b1 = starts[row + cx + rho + 1]; }
+        }
+      }
+      const int cnt = min(KG_TPQ, n_rows - base);
+      for (int j = 0; j < cnt; ++j) {
+        const int sa = __shfl(a0, j, KG_TPQ), ea = __shfl(a1, j, KG_TPQ);
+        const int sb = __shfl(b0, j, KG_TPQ), eb = __shfl(b1, j, KG_TPQ);
+        visit(sa, ea);
+        visit(sb, eb);
+      }
+    }
+    float lb = __builtin_inff();
+    if (cx - rho > 0) lb = fminf(lb, qx - (g.ox + (float)(cx - rho) * h));
+    if (cx + rho < g.nx - 1) lb = fminf(lb, (g.ox + (float)(cx + rho + 1) * h) - qx);
+    if (cy - rho > 0) lb = fminf(lb, qy - (g.oy + (float)(cy - rho) * h));
+    if (cy + rho < g.ny - 1) lb = fminf(lb, (g.oy + (float)(cy + rho + 1) * h) - qy);
+    if (cz - rho > 0) lb = fminf(lb, qz - (g.oz + (float)(cz - rho) * h));
+    if (cz + rho < g.nz - 1) lb = fminf(lb, (g.oz + (float)(cz + rho + 1) * h) - qz);
+    if (lb == __builtin_inff()) break;                                // the block covers the grid
+    lb = fmaxf(0.f, lb - 1e-2f * h);
+    float lo = bd[k - 1], hi = bd[0];                                 // upper bounds of the union's k-th distance
+#pragma unroll
+    for (int o = KG_TPQ / 2; o > 0; o >>= 1) {
+      lo = fminf(lo, __shfl_xor(lo, o, KG_TPQ));
+      hi = fmaxf(hi, __shfl_xor(hi, o, KG_TPQ));
+    }
+    const float kth = fminf(lo, hi);
+    if (METRIC == 0 ? kth < lb * lb : kth < lb) break;
+  }
+  // ---- merge the sixteen sorted lists of each query (lexicographic on (distance, index)), as csrc/knn.hip does
+#pragma unroll
+  for (int s = 0; s < KT; ++s) {
+    m_d[threadIdx.x * (KT + 1) + s] = bd[s];
+    m_i[threadIdx.x * (KT + 1) + s] = bi[s];
+  }
+  __syncthreads();
+  if (live && sub == 0) {
+    int head[KG_TPQ];
+#pragma unroll
+    for (int u = 0; u < KG_TPQ; ++u) head[u] = 0;
+    const int t0 = threadIdx.x;
+    for (int s = 0; s < k; ++s) {
+      float best_d = __builtin_inff();
+      int best_i = 0x7fffffff, best_u = 0;
+#pragma unroll
+      for (int u = 0; u < KG_TPQ; ++u) {
+        const int hd = head[u];
+        const float d = hd < KT ? m_d[(t0 + u) * (KT + 1) + hd] : __builtin_inff();
+        const int id = hd < KT ? m_i[(t0 + u) * (KT + 1) + hd] : 0x7fffffff;
+        if (d < best_d || (d == best_d && id < best_i)) { best_d = d; best_i = id; best_u = u; }
+      }
+#pragma unroll
+      for (int u = 0; u < KG_TPQ; ++u) head[u] += (u == best_u) ? 1 : 0;
+      out_idx[(int64_t)i * k + s] = min(best_i, g.n - 1);              // (unfilled slot -- NaN / inf input --: in bounds)
+      if (out_dist) out_dist[(int64_t)i * k + s] = best_d;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int64_t occ4d_radius_grid_workspace_bytes(int n) { return (int64_t)off_points() + (int64_t)(n > 0 ? n : 0) * 16; }
@@ -331,15 +456,27 @@ extern "C" int occ4d_knn_grid_f32(const float* query, int64_t q_stride, int n_qu
   int* counts = (int*)(ws + off_counts());
   int* starts = (int*)(ws + off_starts());
   float4* pts = (float4*)(ws + off_points());
-  static const float per_cell = [] { const char* e = getenv("OCC4D_KNN_GRID_PER_CELL"); return e ? (float)atof(e) : 4.f; }();
+  static const int one_from = [] { const char* e = getenv("OCC4D_KNN_GRID_ONE_THREAD_FROM"); return e ? atoi(e) : 32768; }();
+  // points per cell (measured, profiles/r04_time_knn_grid.txt): sixteen lanes share a query's candidates, so coarser cells
+  // (fewer row visits) win there; a single thread wants few candidates
+  static const float forced = [] { const char* e = getenv("OCC4D_KNN_GRID_PER_CELL"); return e ? (float)atof(e) : 0.f; }();
+  const float per_cell = forced > 0.f ? forced : (n_query >= one_from ? 2.f : 8.f);
   grid_plan_kernel<<<1, GT, 0, st>>>(data, d_stride, n_data, 0.f, per_cell, plan, counts);
   grid_count_kernel<<<occ4d::cdiv(n_data, 256), 256, 0, st>>>(data, d_stride, n_data, plan, counts);
   grid_scan_kernel<<<1, GT, 0, st>>>(plan, counts, starts);
   grid_fill_kernel<<<occ4d::cdiv(n_data, 256), 256, 0, st>>>(data, d_stride, n_data, plan, counts, starts, pts);
-  const int grid = occ4d::cdiv(n_query, 64);
-#define OCC4D_KG(KT, M) knn_grid_kernel<KT, M><<<grid, 64, 0, st>>>(query, q_stride, n_query, plan, starts, pts, k, out_idx, out_dist)
-  if (k <= 8) { if (metric == 0) OCC4D_KG(8, 0); else OCC4D_KG(8, 1); }
-  else { if (metric == 0) OCC4D_KG(16, 0); else OCC4D_KG(16, 1); }
+  if (n_query >= one_from) {
+    const int grid = occ4d::cdiv(n_query, 64);
+#define OCC4D_KG(KT, M) knn_grid1_kernel<KT, M><<<grid, 64, 0, st>>>(query, q_stride, n_query, plan, starts, pts, k, out_idx, out_dist)
+    if (k <= 8) { if (metric == 0) OCC4D_KG(8, 0); else OCC4D_KG(8, 1); }
+    else { if (metric == 0) OCC4D_KG(16, 0); else OCC4D_KG(16, 1); }
 #undef OCC4D_KG
+  } else {
+    const int grid = occ4d::cdiv((int64_t)n_query * KG_TPQ, KG_BLOCK);
+#define OCC4D_KG(KT, M) knn_grid_kernel<KT, M><<<grid, KG_BLOCK, 0, st>>>(query, q_stride, n_query, plan, starts, pts, k, out_idx, out_dist)
+    if (k <= 8) { if (metric == 0) OCC4D_KG(8, 0); else OCC4D_KG(8, 1); }
+    else { if (metric == 0) OCC4D_KG(16, 0); else OCC4D_KG(16, 1); }
+#undef OCC4D_KG
+  }
   return occ4d::check_launch("occ4d_knn_grid_f32");
 }

@@ -113,12 +113,12 @@ def _aligned_rows(t, name, k_pad=None):
 
 
 # --------------------------------------------------------------------------------------
-# Searches of at least KNN_GRID_MIN_PAIRS query x data pairs (2^27: where the brute-force scan passes ~0.4 ms, the grid
+# Searches of at least KNN_GRID_MIN_PAIRS query x data pairs (2^26: where the brute-force scan passes ~0.25 ms, twice the grid
 # search's latency floor -- profiles/r04_time_knn_grid.txt) over at least KNN_GRID_MIN_DATA points go through the grid
 # (OCC4D_KNN_GRID=0: the brute-force kernel everywhere; both give the same lists).
 KNN_GRID = os.environ.get('OCC4D_KNN_GRID', '1') != '0'
 KNN_GRID_MIN_DATA = int(os.environ.get('OCC4D_KNN_GRID_MIN_DATA', '1024'))
-KNN_GRID_MIN_PAIRS = int(os.environ.get('OCC4D_KNN_GRID_MIN_PAIRS', str(1 << 27)))
+KNN_GRID_MIN_PAIRS = int(os.environ.get('OCC4D_KNN_GRID_MIN_PAIRS', str(1 << 26)))
 
 
 def knn(query, data, k, metric=0, return_dist=False, int64=False):

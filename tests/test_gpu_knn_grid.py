@@ -94,7 +94,7 @@ def test_grid_knn_is_what_large_searches_use_and_rejects_bad_arguments():
     import ctypes as C
     import occlusions4d_amd as pk
     ops, lib = pk.ops, pk._lib.lib()
-    assert ops.KNN_GRID and ops.KNN_GRID_MIN_PAIRS == 1 << 27
+    assert ops.KNN_GRID and ops.KNN_GRID_MIN_PAIRS == 1 << 26
     p = torch.rand(6000, 3, device='cuda')
     ws = torch.empty((int(lib.occ4d_radius_grid_workspace_bytes(6000)) + 3) // 4, device='cuda')
     idx = torch.empty((6000, 16), dtype=torch.int32, device='cuda')
