@@ -21,6 +21,8 @@ def cached(self, pcl, ready=None):
 
 
 MODE = os.environ.get('MODE', '')
+if MODE == 'coop':          # the 28672-point FPS on the cooperative multi-workgroup kernel (16 small workgroups) instead of one big one
+    pk.ops.FPS_COOP_MIN_POINTS = 20000
 if MODE in ('nofps', 'noknn'):     # only ONE kind of geometry kernel is cached (same cloud every step: same results)
     name = 'fps_auto' if MODE == 'nofps' else 'knn'
     real_op, memo = getattr(pk.ops, name), {}
@@ -34,7 +36,7 @@ if MODE in ('nofps', 'noknn'):     # only ONE kind of geometry kernel is cached 
             memo[key] = real_op(*a, **k)
         return memo[key]
     setattr(pk.ops, name, memoised)
-elif os.environ.get('REUSE', '1') == '1':
+elif MODE != 'coop' and os.environ.get('REUSE', '1') == '1':
     pk.model.PointCompletionNetV3.prefetch_geometry = cached
 sys.argv = ['bench_train.py', '--steps', '20', '--warmup', '3']
 runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench_train.py'), run_name='__main__')
