@@ -9,11 +9,14 @@
 //              wave 0 POLLS all 4 G words with one relaxed agent-scope 8-byte load per lane until every word
 //              carries this step's tag, reduces the G candidates on the DPP network, broadcasts the winner
 //              through LDS.  No fence, no counter, no read-modify-write: 8-byte agent atomics on both sides are
-//              a valid hand-off on gfx950 (MI355X_MICROARCH.md, inter-workgroup visibility), ~1 us per step.
+//              a valid hand-off on gfx950 (MI355X_MICROARCH.md, inter-workgroup visibility), ~1 us per exchange.
+//   rounds     (round 4) an exchange yields SEVERAL samples: a workgroup also publishes a floor (the second largest of
+//              its running minima) and every workgroup runs the same candidate round on the G candidates -- see the
+//              loop below; 2.1 -> 1.1 us per sample at 28672 points with 16 workgroups, indices unchanged.
 //   tags       two slot buffers alternate by step; the 1-bit tag flips each time a buffer is reused.  A slot
 //              can only ever hold this use's value or the previous use's (opposite tag): a workgroup cannot
 //              publish step j+2 before every workgroup has finished polling step j (it needs all of j+1).
-//              The workspace is reset (tag = 1 everywhere, status = 0) by a stream-ordered memset per call.
+//              The workspace is reset (tag = 1 everywhere, status = 0) by a small kernel per call.
 //   safety     every spin is bounded; on time-out the status word is set, the kernel finishes quickly with
 //              undefined indices and the host wrapper raises.  Workgroups that are not yet resident only delay
 //              the others (no deadlock as long as other kernels on the device terminate).
@@ -59,7 +62,6 @@ __global__ __launch_bounds__(T) void fps_coop_kernel(const float* __restrict__ x
   constexpr int NW = T / 64;
   __shared__ u64 s_key[NW];
   __shared__ float s_p[NW][4];
-  __shared__ float s_win[2][4];
   __shared__ unsigned s_flags[FLAG_WORDS];
   __shared__ int s_cnt[T];
 
@@ -86,61 +88,86 @@ __global__ __launch_bounds__(T) void fps_coop_kernel(const float* __restrict__ x
   if (g == 0)
     for (int w = t; w < FLAG_WORDS; w += T) s_flags[w] = 0u;
   __syncthreads();
-  float cx, cy, cz;
-  {
+  // ---- rounds.  A round = one all-to-all; it yields the next sample and every FURTHER sample that can be proven from
+  // what was exchanged (round 4; csrc/fps_bucket.hip's rule): beside its candidate (its point of largest running
+  // minimum, exact value) a workgroup publishes a FLOOR -- an upper bound of the running minima of all its OTHER points
+  // (the second largest, exactly).  After the exchange every workgroup holds the same G candidates and F = the largest
+  // floor, and runs the same candidate round: the best candidate is the next sample (as before); the others are lowered by
+  // their distance to it (the very expression the point update will compute), and the best of them is accepted too iff it
+  // is STRICTLY above F -- then it is above every point nobody has seen, whose minima only shrink -- and so on, lowest
+  // index first among equal candidates.  A tie with F ends the round (an unseen point of lower index could sit there).
+  // The accepted samples are applied to the points together at the start of the next round.
+  __shared__ float s_acc[2][MAX_WG][4];      // the samples accepted by a round (x, y, z), read by the next one
+  __shared__ int s_nacc[2];
+  __shared__ unsigned s_fl[NW];
+  if (t == 0) {
     const float* p = xyz + (int64_t)start * stride;
-    cx = p[0]; cy = p[1]; cz = p[2];
+    s_acc[0][0][0] = p[0]; s_acc[0][0][1] = p[1]; s_acc[0][0][2] = p[2];
+    s_nacc[0] = 1;
+    if (g == 0) {
+      s_flags[start >> 5] = 1u << (start & 31);
+      if (out_order) out_order[0] = start;
+    }
   }
-  if (g == 0 && t == 0) {
-    s_flags[start >> 5] = 1u << (start & 31);
-    if (out_order) out_order[0] = start;
-  }
+  __syncthreads();
   bool dead = false;   // wave-0 uniform: a poll timed out
+  auto enc = [](float d) { return d >= 0.f ? __float_as_uint(d) + 1u : 0u; };      // <= 0x7f800001: bit 31 is free (tag)
+  auto dec = [](unsigned b) { return b ? __uint_as_float(b - 1u) : -1.f; };
 
-  for (int it = 1; it < m; ++it) {
-    float bd = -1.f, bx = 0.f, by = 0.f, bz = 0.f;
+  int it = 1;                                   // samples chosen so far
+  for (int r = 0; it < m; ++r) {
+    const int par = r & 1;
+    const int na = s_nacc[par];
+    float b1 = -1.f, b2 = -1.f, bx = 0.f, by = 0.f, bz = 0.f;
     unsigned bi = 0xffffffffu;
-    const f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
 #pragma unroll
     for (int u = 0; u < PP; ++u) {
-      const f32x2 dx = px[u] - c2x, dy = py[u] - c2y, dz = pz[u] - c2z;
-      const f32x2 d = (dx * dx + dy * dy) + dz * dz;          // -ffp-contract=off: no FMA
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
-        const float old = md[u][v];
-        const float nv = d[v] < old ? d[v] : old;
+        const float x = px[u][v], y = py[u][v], z = pz[u][v];
+        float nv = md[u][v];
+        for (int a = 0; a < na; ++a) {
+          const float dx = x - s_acc[par][a][0], dy = y - s_acc[par][a][1], dz = z - s_acc[par][a][2];
+          const float d = (dx * dx + dy * dy) + dz * dz;          // -ffp-contract=off: no FMA
+          nv = d < nv ? d : nv;
+        }
         md[u][v] = nv;
-        const bool better = nv > bd;                            // strict: slots ascend in index
-        bd = better ? nv : bd;
+        const bool better = nv > b1;                              // strict: slots ascend in index
+        b2 = better ? b1 : (nv > b2 ? nv : b2);
+        b1 = better ? nv : b1;
         bi = better ? (unsigned)(base + t + T * (2 * u + v)) : bi;
-        bx = better ? px[u][v] : bx;
-        by = better ? py[u][v] : by;
-        bz = better ? pz[u][v] : bz;
+        bx = better ? x : bx;
+        by = better ? y : by;
+        bz = better ? z : bz;
       }
     }
-    const unsigned dbits = bd >= 0.f ? __float_as_uint(bd) + 1u : 0u;   // <= 0x7f800001: bit 31 is free (tag)
+    const unsigned dbits = enc(b1);
     const unsigned wmax = wave_reduce_u32<true>(dbits);
     const unsigned cand = (dbits == wmax) ? bi : 0xffffffffu;
     const unsigned wmin = wave_reduce_u32<false>(cand);
-    if (dbits == wmax && bi == wmin) {
+    const bool iswin = dbits == wmax && bi == wmin;
+    const unsigned wfl = wave_reduce_u32<true>(enc(iswin ? b2 : b1));    // everything of this wave but its winner
+    if (iswin) {
       s_key[wave] = ((u64)wmax << 32) | (u64)(0xffffffffu - wmin);
       s_p[wave][0] = bx; s_p[wave][1] = by; s_p[wave][2] = bz;
     }
+    if (lane == 0) s_fl[wave] = wfl;
     __syncthreads();
-    const int par = it & 1;
     if (wave == 0) {
-      // this workgroup's candidate
+      // this workgroup's candidate and floor
       const u64 k = lane < NW ? s_key[lane] : 0ull;
       const unsigned khi = (unsigned)(k >> 32), klo = (unsigned)k;
       const unsigned m1 = wave_reduce_u32<true>(khi);
       const unsigned m2 = wave_reduce_u32<true>(khi == m1 ? klo : 0u);
       const u64 hit = __ballot(lane < NW && khi == m1 && klo == m2);
       const int wv = hit ? __ffsll((long long)hit) - 1 : 0;
-      const int j = it - 1;
-      const u64 tag = (u64)((j >> 1) & 1) << 63;
-      u64* slots = ws + (j & 1) * SLOT_WORDS;
+      const unsigned fw = lane < NW ? max(s_fl[lane], lane == wv ? 0u : khi) : 0u;
+      const unsigned floor_wg = wave_reduce_u32<true>(fw);
+      const u64 tag = (u64)((r >> 1) & 1) << 63;
+      u64* slots = ws + (r & 1) * SLOT_WORDS;
       if (lane < 4) {
-        const u64 payload = lane == 0 ? (((u64)m1 << 32) | (u64)m2) : (u64)__float_as_uint(s_p[wv][lane - 1]);
+        u64 payload = lane == 0 ? (((u64)m1 << 32) | (u64)m2) : (u64)__float_as_uint(s_p[wv][lane - 1]);
+        if (lane == 1) payload |= (u64)floor_wg << 32;             // (31 free bits above the x coordinate)
         __hip_atomic_store(slots + 4 * g + lane, payload | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       // all-to-all: lane L watches word (L & 3) of workgroup (L >> 2)
@@ -159,28 +186,50 @@ __global__ __launch_bounds__(T) void fps_coop_kernel(const float* __restrict__ x
           }
         }
       }
-      const bool keylane = watch && (lane & 3) == 0;
-      const unsigned vhi = keylane ? ((unsigned)(v >> 32) & 0x7fffffffu) : 0u;
-      const unsigned vlo = keylane ? (unsigned)v : 0u;
-      const unsigned M1 = wave_reduce_u32<true>(vhi);
-      const unsigned M2 = wave_reduce_u32<true>((keylane && vhi == M1) ? vlo : 0u);
-      const u64 win = __ballot(keylane && vhi == M1 && vlo == M2);
-      const int lw = win ? __ffsll((long long)win) - 1 : 0;
-      const int w32 = (int)(unsigned)v;
-      const float wx = __int_as_float(__builtin_amdgcn_readlane(w32, lw + 1));
-      const float wy = __int_as_float(__builtin_amdgcn_readlane(w32, lw + 2));
-      const float wz = __int_as_float(__builtin_amdgcn_readlane(w32, lw + 3));
-      if (lane == 0) {
-        s_win[par][0] = wx; s_win[par][1] = wy; s_win[par][2] = wz;
-        if (g == 0) {
-          const unsigned gi = min(0xffffffffu - M2, (unsigned)(n - 1));   // clamp: only reachable after a time-out
-          s_flags[gi >> 5] |= 1u << (gi & 31);
-          if (out_order) out_order[it] = (int)gi;
+      // candidate round: lane i < G holds candidate i
+      const unsigned vhi32 = (unsigned)(v >> 32) & 0x7fffffffu, vlo32 = (unsigned)v;
+      const int src = min(4 * lane, 63);
+      unsigned ckey = (unsigned)__shfl((int)vhi32, src);            // encoded running minimum
+      const unsigned cidx = (unsigned)__shfl((int)vlo32, src);      // ~index
+      const unsigned cfl = (unsigned)__shfl((int)vhi32, min(src + 1, 63));
+      const float ccx = __int_as_float(__shfl((int)vlo32, min(src + 1, 63)));
+      const float ccy = __int_as_float(__shfl((int)vlo32, min(src + 2, 63)));
+      const float ccz = __int_as_float(__shfl((int)vlo32, min(src + 3, 63)));
+      const bool isc = lane < G;
+      if (!isc) ckey = 0u;
+      const unsigned F = wave_reduce_u32<true>(isc ? cfl : 0u);
+      float cm = dec(ckey);
+      int nacc = 0;
+      for (;;) {
+        const unsigned M1 = wave_reduce_u32<true>(ckey);
+        const unsigned M2 = wave_reduce_u32<true>((isc && ckey == M1) ? cidx : 0u);
+        if (nacc > 0 && !(M1 > F)) break;                           // (M1 == 0: no candidate left)
+        const u64 win = __ballot(isc && ckey == M1 && cidx == M2);
+        const int lw = win ? __ffsll((long long)win) - 1 : 0;
+        const float sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ccx), lw));
+        const float sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ccy), lw));
+        const float sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ccz), lw));
+        if (lane == 0) {
+          s_acc[par ^ 1][nacc][0] = sx; s_acc[par ^ 1][nacc][1] = sy; s_acc[par ^ 1][nacc][2] = sz;
+          if (g == 0) {
+            const unsigned gi = min(0xffffffffu - M2, (unsigned)(n - 1));   // clamp: only reachable after a time-out
+            s_flags[gi >> 5] |= 1u << (gi & 31);
+            if (out_order) out_order[it + nacc] = (int)gi;
+          }
         }
+        ++nacc;
+        if (it + nacc >= m || nacc >= G) break;
+        // the remaining candidates against the sample just accepted (the point update's own expression)
+        const float dx = ccx - sx, dy = ccy - sy, dz = ccz - sz;
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        cm = d < cm ? d : cm;
+        ckey = (isc && lane != lw && ckey != 0u) ? enc(cm) : 0u;
+        if (lane == lw) cm = -1.f;
       }
+      if (lane == 0) s_nacc[par ^ 1] = nacc;
     }
     __syncthreads();
-    cx = s_win[par][0]; cy = s_win[par][1]; cz = s_win[par][2];
+    it += s_nacc[par ^ 1];
   }
   if (g != 0) return;
   __syncthreads();
@@ -212,6 +261,10 @@ __global__ __launch_bounds__(T) void fps_coop_kernel(const float* __restrict__ x
       ++pos;
     }
   }
+}
+
+__global__ void fps_coop_reset_kernel(u64* __restrict__ ws) {
+  for (int i = threadIdx.x; i < WS_WORDS; i += blockDim.x) ws[i] = i < 2 * SLOT_WORDS ? ~0ull : 0ull;
 }
 
 template <int T>
@@ -251,12 +304,9 @@ int occ4d_fps_coop_f32(const float* xyz, int64_t stride, int n, int m, int start
   const int chunk = occ4d::cdiv(n, G);
   const int ppt = occ4d::cdiv(chunk, T);
   u64* ws = (u64*)workspace;
-  hipError_t e = hipMemsetAsync(ws, 0xFF, 2 * SLOT_WORDS * 8, st);     // every tag = 1: nothing published yet
-  if (e == hipSuccess) e = hipMemsetAsync(ws + 2 * SLOT_WORDS, 0, 8, st);   // status: 0 ok, 1 a poll timed out
-  if (e != hipSuccess) {
-    occ4d::set_error("occ4d_fps_coop_f32: workspace reset: %s", hipGetErrorString(e));
-    return OCC4D_ELAUNCH;
-  }
+  // every tag = 1 (nothing published yet), status = 0 (ok; 1 = a poll timed out) -- by a kernel, not hipMemsetAsync: a
+  // memset node is not replayed reliably from a captured graph on this runtime
+  fps_coop_reset_kernel<<<1, 256, 0, st>>>(ws);
   int rc = T == 512 ? launch<512>(G, ppt, xyz, stride, n, m, start, chunk, out_sorted, out_order, ws, st)
                     : launch<1024>(G, ppt, xyz, stride, n, m, start, chunk, out_sorted, out_order, ws, st);
   OCC4D_REQUIRE(rc == 0, "occ4d_fps_coop_f32: n=%d does not fit %d workgroups of %d threads", n, G, T);

@@ -204,11 +204,9 @@ def check_pending(wait=True):
         raise RuntimeError(_FPS_TIMEOUT)
 
 
-FPS_COOP_MIN_POINTS = 28673     # measured (profiles/time_fps.py, r02_fps_time.txt): one workgroup 1.17 us / step at
-                                # 14336 points (cooperative: 1.74 at best), 2.12 at 28672 (cooperative 2.03 .. 2.16).
-                                # Up to 28672 points (56 per lane at 512 threads) the single workgroup is as fast and
-                                # does not depend on several workgroups being co-resident -- which matters when the
-                                # chain is prefetched under another step's backward (model.prefetch_geometry)
+FPS_COOP_MIN_POINTS = 16385     # above the pruned single-workgroup kernel's range the cooperative kernel: since a round
+                                # of its all-to-all yields several samples (round 4) it takes 1.09 us per sample at 28672
+                                # points with 16 workgroups against the single workgroup's 2.10 (profiles/r04_time_fps_coop.txt)
 
 
 # A cloud above the pruned kernel's 16384 points that is sampled BESIDE other work (the next cloud's geometry under a
