@@ -93,7 +93,7 @@ class PointCompletionNetV3(torch.nn.Module):
             deferred = []                       # (block index, clouds) of the levels' self-kNNs: issued after ALL sampling
             for i, block in enumerate(self.blocks):
                 if isinstance(block, modules.DownTransition):
-                    g = [block.sample(c, nested=nf, concurrent=full) for c, nf in zip(cur, nested)]
+                    g = [block.sample(c, nested=nf) for c, nf in zip(cur, nested)]
                     if modules.POOL_FROM_SELF_KNN and self_idx is not None and self_idx[0].shape[1] >= block.knn_k:
                         g = [(inds, p_sub, modules.pool_neighbours_from_self_knn(sx, inds, block.knn_k))
                              for (inds, p_sub), sx in zip(g, self_idx)]

@@ -117,12 +117,11 @@ class DownTransition(torch.nn.Module):
         else:
             raise ValueError()
 
-    def sample(self, p, nested=None, concurrent=False):
+    def sample(self, p, nested=None):
         """Farthest-point subset of ONE cloud p (N,3): (ascending indices (n_new) int32, their coordinates (n_new,3)).
         Depends on coordinates only: the encoder runs the three levels of this dependent chain (the FPS steps are
         one long chain on a single CU) back to back on a side stream (model.py).  `nested`: the NestedFps of the chain
-        this cloud belongs to; with a deterministic start the subset then comes from the first level's selection order.
-        `concurrent`: the call is a prefetch beside compute-bound work (ops.fps_auto picks the kernel accordingly)."""
+        this cloud belongs to; with a deterministic start the subset then comes from the first level's selection order."""
         n_new = int(np.ceil(p.shape[0] / self.factor))
         # (not while a stream is being captured: the prefix arithmetic sorts with torch, and only kernels of this library
         # are safe inside a captured region on this runtime -- DESIGN.md 7b)
@@ -130,13 +129,13 @@ class DownTransition(torch.nn.Module):
             if nested.usable(p.shape[0], n_new):
                 inds = nested.next_level(n_new)
                 return (inds, ops.gather_rows(p, inds))
-            inds, order = ops.fps_auto(p, n_new, start=0, return_order=True, concurrent=concurrent)
+            inds, order = ops.fps_auto(p, n_new, start=0, return_order=True)
             nested.begin(order, inds)
             return (inds, ops.gather_rows(p, inds))
         # torch_cluster draws the first sample at random when random_start (training default); the reference
         # forces False at test time (eval/inference.py:59).  The draw uses torch's global CPU generator.
         start = int(torch.randint(p.shape[0], (1,)).item()) if self.fps_random_start else 0
-        inds = ops.fps_auto(p, n_new, start=start, concurrent=concurrent)     # ascending int32
+        inds = ops.fps_auto(p, n_new, start=start)                     # ascending int32
         return (inds, ops.gather_rows(p, inds))                        # (n_new), (n_new,3)
 
     def neighbours(self, p_sub, p):

@@ -209,20 +209,14 @@ FPS_COOP_MIN_POINTS = 16385     # above the pruned single-workgroup kernel's ran
                                 # points with 16 workgroups against the single workgroup's 2.10 (profiles/r04_time_fps_coop.txt)
 
 
-# A cloud above the pruned kernel's 16384 points that is sampled BESIDE other work (the next cloud's geometry under a
-# training step) goes to the cooperative kernel although one workgroup is as fast stand-alone: the single workgroup's 8
-# waves x 224 VGPRs hold a compute unit for 20 ms and cost the step 2.2 ms; sixteen small workgroups cost it 0.7
-# (profiles/r04_geometry_stream_cost.txt; same indices from both).  Its inter-workgroup spins are bounded (0.4 s) and a
-# time-out raises at the next check_pending(); profiles/stress_fps_coop.py screens it under saturating load.
-FPS_COOP_WHEN_CONCURRENT = os.environ.get('OCC4D_FPS_COOP_WHEN_CONCURRENT', '1') != '0'
-
-
-def fps_auto(xyz, m, start=0, return_order=False, concurrent=False):
+def fps_auto(xyz, m, start=0, return_order=False):
     """Ascending FPS indices [, the selection order] with the faster kernel for the cloud size: one workgroup with the
-    cloud in registers (fps) below FPS_COOP_MIN_POINTS points, the cooperative multi-workgroup kernel above (the
-    dataloader's whole clips).  `concurrent`: the call runs on a side stream beside compute-bound work."""
+    cloud in registers (fps: pruned, several samples per round) below FPS_COOP_MIN_POINTS points, the cooperative
+    multi-workgroup kernel above (the training clouds, the dataloader's whole clips).  Beside a training step the
+    cooperative kernel is also the cheaper neighbour: sixteen small workgroups cost the step 0.7 ms where one workgroup
+    of 8 waves x 224 VGPRs, holding a compute unit, cost 2.2 (profiles/r04_geometry_stream_cost.txt)."""
     n = xyz.shape[0]
-    if n < FPS_COOP_MIN_POINTS and not (concurrent and FPS_COOP_WHEN_CONCURRENT and n > 16384):
+    if n < FPS_COOP_MIN_POINTS:
         return fps(xyz, m, start=start, return_order=return_order)
     return fps_coop(xyz, m, start=start, n_workgroups=16, check=False, return_order=return_order)
 
