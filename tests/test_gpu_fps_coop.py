@@ -174,3 +174,21 @@ def test_down_transition_random_start_and_large_clouds(pk):
     b = pk.ops.fps(big, 9558)
     assert torch.equal(a, b)
     pk.ops.check_pending()
+
+
+@pytest.mark.parametrize('kind,n,m', [('lattice', 20000, 5000), ('half_lattice', 28672, 7168), ('planar', 18000, 4500),
+                                      ('clusters', 28672, 7168), ('all_equal', 17000, 300), ('line', 16500, 4000)])
+@pytest.mark.parametrize('wgs', [16, 5])
+def test_fps_coop_several_samples_per_exchange_on_tie_storms(pk, kind, n, m, wgs):
+    """Round 4: an exchange of the cooperative kernel yields every further sample it can PROVE (candidate + floor per
+    workgroup).  The proof rests on strict comparisons; clouds where almost every step is an exact tie (integer / half-
+    integer lattices with repeats, planar and collinear clouds, tight far-apart clusters with duplicates and padding rows,
+    a constant cloud) must give the single-workgroup kernel's selection order, index for index."""
+    from test_gpu_fps_pruned import _cloud as cloud
+    rng = np.random.default_rng(n + m + wgs)
+    p = torch.from_numpy(cloud(kind, n, rng).astype(np.float32)).cuda()
+    ref_idx, ref_order = pk.ops.fps(p, m, return_order=True)
+    idx, order = pk.ops.fps_coop(p, m, start=0, n_workgroups=wgs, return_order=True)
+    assert torch.equal(order, ref_order)
+    if int(torch.unique(order).numel()) == m:          # (once every distinct point is taken the rule re-picks: the sorted
+        assert torch.equal(idx, ref_idx)               # list then has fewer than m entries and an unspecified tail)
