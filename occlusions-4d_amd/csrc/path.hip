@@ -408,7 +408,13 @@ int layer_forward(const occ4d_pt_layer_weights& w, const LayerLayout& L, const f
     const int32_t* idx = knn_idx ? knn_idx + (int64_t)lo * k : nullptr;
     if (!idx) {
       int32_t* ib = reinterpret_cast<int32_t*>(ws.take((int64_t)c * k));
-      if (!dry) TRY(occ4d_knn_f32(pos + (int64_t)lo * ps, ps, c, pos2, p2s, m, k, 0, ib, 0, nullptr, st));
+      // large searches (the self-kNN of a 14336- / 28672-point cloud) on the exact grid search: the same lists
+      const bool grid = m >= 1024 && (int64_t)c * m >= ((int64_t)1 << 26);
+      float* gws = grid ? ws.take((occ4d_radius_grid_workspace_bytes(m) + 3) / 4) : nullptr;
+      if (!dry) {
+        if (grid) TRY(occ4d_knn_grid_f32(pos + (int64_t)lo * ps, ps, c, pos2, p2s, m, k, 0, ib, nullptr, gws, st));
+        else TRY(occ4d_knn_f32(pos + (int64_t)lo * ps, ps, c, pos2, p2s, m, k, 0, ib, 0, nullptr, st));
+      }
       idx = ib;
     }
     const float* aq;

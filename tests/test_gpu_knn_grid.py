@@ -104,3 +104,26 @@ def test_grid_knn_is_what_large_searches_use_and_rejects_bad_arguments():
     assert lib.occ4d_knn_grid_f32(P(p), 3, 6000, P(p), 3, 6000, 16, 2, P(idx), None, P(ws), None) == pk._lib.EINVAL
     assert lib.occ4d_knn_grid_f32(P(p), 3, 6000, P(p), 3, 6000, 16, 0, P(idx), None, None, None) == pk._lib.EINVAL
     assert lib.occ4d_knn_grid_f32(P(p), 3, 0, P(p), 3, 6000, 16, 0, P(idx), None, P(ws), None) == 0
+
+
+def test_library_layer_uses_the_grid_for_a_large_self_knn_and_gets_the_same_block():
+    """The path-level entry point computes the neighbour lists itself when none are passed (occ4d_pt_layer_fwd_f32 with
+    knn_idx = NULL: the C-ABI-only binder's case); from 2^26 pairs it takes the grid search.  Same output as with the
+    brute-force lists handed in."""
+    import occlusions4d_amd as pk
+    n, dim = 9000, 36
+    rng = np.random.default_rng(12)
+    x = torch.from_numpy(rng.normal(size=(1, n, dim)).astype(np.float32)).cuda()
+    pos = torch.from_numpy(rng.uniform([0, -16, -1], [40, 16, 6.4], size=(1, n, 3)).astype(np.float32)).cuda()
+    blk = pk.modules.PointTransformerBlock(dim, dim, dim, num_neighbors=16).cuda().eval()
+    blk.load_state_dict(pk.configs.fill_state_dict(blk, 99))
+    old = pk.ops.KNN_GRID
+    try:
+        pk.ops.KNN_GRID = False
+        idx = pk.ops.knn(pos[0], pos[0], 16, metric=0)
+    finally:
+        pk.ops.KNN_GRID = old
+    with torch.no_grad():
+        given = blk(x, pos, knn_idx=idx[None])[0]
+        own = blk(x, pos)[0]
+    assert torch.equal(given, own)
