@@ -115,12 +115,43 @@ def cpu_baseline_worker(kind):
     print(json.dumps(dict(stage='encode', t_enc=t_enc)), flush=True)
 
 
-def cpu_baseline(kind, budget_s=240.0):
-    """Runs cpu_baseline_worker in a child with a wall-clock budget (the child is killed by PID if the
-    encode overruns; the decode-only figure is then reported and said so)."""
+def cpu_baseline_start(kind):
+    """Starts cpu_baseline_worker in a child (16 host threads of the box's 256; the GPU legs that run meanwhile need one)."""
     import subprocess
-    child = subprocess.Popen([sys.executable, os.path.abspath(__file__), '--_cpu-worker', '--kind', kind],
-                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    return subprocess.Popen([sys.executable, os.path.abspath(__file__), '--_cpu-worker', '--kind', kind],
+                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+
+
+def secondary_leg(script, argv, pick, budget_s=150.0):
+    """One more BASELINE configuration on the driver-timed line: runs `script argv` in a child process on this GPU
+    (the parent is idle meanwhile), parses its JSON line and keeps the keys in `pick`.  A failure is recorded on the
+    line, it never fails the headline."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, script)] + argv
+    t0 = time.time()
+    try:
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=budget_s)
+    except subprocess.TimeoutExpired:
+        return dict(error='%s %s: no result within %.0f s' % (script, ' '.join(argv), budget_s))
+    rec = None
+    for ln in res.stdout.splitlines():
+        try:
+            rec = json.loads(ln)
+        except ValueError:
+            pass
+    if res.returncode != 0 or not isinstance(rec, dict):
+        return dict(error='%s %s: exit code %d: %s' % (script, ' '.join(argv), res.returncode, res.stderr.strip()[-300:]))
+    out = {k: rec.get(k) for k in pick}
+    out['command'] = 'python %s %s' % (script, ' '.join(argv))
+    out['wall_s'] = round(time.time() - t0, 1)
+    return out
+
+
+def cpu_baseline(kind, budget_s=240.0, child=None):
+    """Collects cpu_baseline_worker (started here unless the caller did) within a wall-clock budget (the child is killed
+    by PID if the encode overruns; the decode-only figure is then reported and said so)."""
+    import subprocess
+    child = child or cpu_baseline_start(kind)
     try:
         out, _ = child.communicate(timeout=budget_s)
     except subprocess.TimeoutExpired:
@@ -191,6 +222,8 @@ def main():
     ap.add_argument('--no-alt', action='store_true', help='skip the opt-in split-bf16 logits measurement')
     ap.add_argument('--no-extra', action='store_true', help='skip every informational leg (secondary grid, pipelined, '
                     'host boundary)')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the secondary BASELINE configurations '
+                    '(carla_config3 = configs[2], train_config5 = configs[4]) that the N = 1 line carries')
     ap.add_argument('--_cpu-worker', dest='cpu_worker', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
@@ -455,8 +488,22 @@ def main():
             line['pipelined'] = pipelined
         if host_boundary is not None:
             line['host_boundary'] = host_boundary
-        if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(args.kind)
+        # BASELINE configs[2] and configs[4] on the same driver-timed line: each leg is its own
+        # process on this GPU, K timed steps between fences exactly as above, its own `roofline` object.  The CPU
+        # baseline (16 host threads) runs beside them.
+        cpu_child = cpu_baseline_start(args.kind) if world == 1 and not args.no_cpu_baseline else None
+        if world == 1 and extra and not args.no_secondary and args.kind == 'greater':
+            del out
+            torch.cuda.empty_cache()
+            line['carla_config3'] = secondary_leg(
+                'bench.py', ['--kind', 'carla', '--steps', '10', '--warmup', '3', '--no-extra', '--no-cpu-baseline'],
+                ['metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'config', 'roofline', 'pipeline'])
+            line['train_config5'] = secondary_leg(
+                'bench_train.py', ['--steps', '10', '--warmup', '3'],
+                ['metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'scaling', 'graph',
+                 'attention_backward', 'geometry_prefetch', 'peak_mem_gb', 'roofline', 'config', 'losses'])
+        if cpu_child is not None:
+            line['cpu_baseline'] = cpu_baseline(args.kind, child=cpu_child)
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -32,7 +32,7 @@ extern "C" {
 #define OCC4D_EINVAL (-1)   /* bad argument (maps to AssertionError / ValueError) */
 #define OCC4D_ELAUNCH (-2)  /* HIP launch failure */
 
-#define OCC4D_ABI_VERSION 2
+#define OCC4D_ABI_VERSION 3
 
 int occ4d_abi_version(void);
 const char* occ4d_last_error(void);
@@ -54,6 +54,11 @@ int occ4d_knn_f32(const float* query, int64_t q_stride, int n_query,
                   const float* data, int64_t d_stride, int n_data,
                   int k, int metric, void* out_idx, int idx_is_i64,
                   float* out_dist, void* stream);
+/* Distances of caller-supplied neighbour lists idx (n_query, k) int32 in the same metric expressions (entries are
+ * clamped to [0, n_data)): what occ4d_knn_f32 would have written to out_dist beside these indices.  Used when the
+ * caller brings the reference's own lists (unstable-sort tie order, utils/geometry.py:484). */
+int occ4d_knn_dists_f32(const float* query, int64_t q_stride, int n_query, const float* data, int64_t d_stride,
+                        int n_data, const int32_t* idx, int k, int metric, float* out_dist, void* stream);
 
 /* ------------------------------------------------------------------------
  * K5  farthest point sampling (restated torch_cluster.fps with
@@ -79,11 +84,21 @@ int occ4d_fps_start_f32(const float* xyz, int64_t stride, int n, int m, int star
  * 28 672-point training clouds.  `start` = index of the first sample (torch_cluster's random_start draws
  * it; the caller passes the draw).  Indices are bit-identical to occ4d_fps_f32 for start = 0.
  * workspace: occ4d_fps_coop_workspace_bytes() bytes of device memory, 8-byte aligned, reset by the call
- * itself (stream-ordered); after completion its LAST 8-byte word is 0, or 1 if a bounded spin timed
- * out (results undefined).  n_workgroups 0 = automatic. */
+ * itself (stream-ordered); after completion its LAST 8-byte word (the status) is 0 = ok; 2 = a bounded
+ * inter-workgroup spin timed out and the selection was RECOMPUTED, in stream order, by the single-workgroup
+ * kernel (occ4d_fps_repair_f32, enqueued by this call for every n <= 32768: the results are valid, a
+ * consumer queued behind this call never sees a timed-out selection); 1 = timed out and not repaired
+ * (n > 32768 only: results undefined, relaunch).  n_workgroups 0 = automatic.
+ * occ4d_fps_repair_f32: the conditional launch itself -- does nothing when *status == 0, else overwrites
+ * out_sorted / out_order with occ4d_fps_start_f32's selection and stores 2.
+ * occ4d_fps_coop_debug (tests): spin_limit (0 = default 2^22 polls) and the round in which a time-out is
+ * declared regardless of the polls (-1 = never); process-wide. */
 int64_t occ4d_fps_coop_workspace_bytes(void);
 int occ4d_fps_coop_f32(const float* xyz, int64_t stride, int n, int m, int start, int n_workgroups,
                        int32_t* out_sorted, int32_t* out_order, void* workspace, void* stream);
+int occ4d_fps_repair_f32(const float* xyz, int64_t stride, int n, int m, int start, int32_t* out_sorted,
+                         int32_t* out_order, void* status, void* stream);
+int occ4d_fps_coop_debug(unsigned spin_limit, int fail_round);
 
 /* ------------------------------------------------------------------------
  * K3 / K11  torch.nn.Linear on row tiles with fused prologue/epilogue, exact
@@ -578,12 +593,20 @@ int occ4d_decoder_prepare_scene_f32(const occ4d_decoder_weights* w, const float*
                                     int64_t xyz_stride, const float* feats, int64_t ld_feats, const float* fglobal,
                                     int m, float* scene, int flags, void* stream);
 /* One mini-batch of queries (any n; processed in chunks of 32768 rows): queries (n, d_in) rows (x, y, z, t) ->
- * out (n, d_out) raw network outputs, penult (n, d_hidden) or NULL. */
+ * out (n, d_out) raw network outputs, penult (n, d_hidden) or NULL.
+ * knn_local (n, k_local) / knn_cross (n, k_cross) int32, each optional (NULL = searched here, lowest index first on
+ * equal distances): the caller's own neighbour lists of the abstract cloud -- my_knn_torch's `inds`
+ * (utils/geometry.py:484, model/implicit.py:328) and kNN_torch's `knn_idx` (model/point_transformer_layer.py:96-97,167;
+ * one list serves every cross layer: same coordinates, same K).  The reference orders equidistant points with an
+ * unstable sort, so on clouds with coincident points (CARLA's two-level abstract cloud, model/model.py:202-228) its
+ * choice at the k-th rank is implementation-defined; a caller that must reproduce one particular run passes that run's
+ * lists (tests/golden g10 / g8 `knn_local`, `knn_cross`).  The inverse-distance weights are recomputed from the given
+ * indices with the search kernel's distance expression (occ4d_knn_dists_f32). */
 int64_t occ4d_decoder_query_workspace_floats(const occ4d_decoder_weights* w, int n, int m, int flags);
 int occ4d_decoder_query_fwd_f32(const occ4d_decoder_weights* w, const float* prepared, const float* scene, int m,
-                                const float* queries, int64_t q_stride, int n, float* out, int64_t ld_out,
-                                float* penult, int64_t ld_pen, float* workspace, int flags, occ4d_launch_events* ev,
-                                void* stream);
+                                const float* queries, int64_t q_stride, int n, const int32_t* knn_local,
+                                const int32_t* knn_cross, float* out, int64_t ld_out, float* penult, int64_t ld_pen,
+                                float* workspace, int flags, occ4d_launch_events* ev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libocc4d.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK, EINVAL, ELAUNCH = 0, -1, -2
 
@@ -71,6 +71,8 @@ SIGNATURES = {
     'occ4d_fps_start_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, C.c_int, _i, _i, _s]),
     'occ4d_fps_coop_workspace_bytes': (C.c_int64, []),
     'occ4d_fps_coop_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _i, _i, _s, _s]),
+    'occ4d_fps_repair_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, C.c_int, _i, _i, _s, _s]),
+    'occ4d_fps_coop_debug': (C.c_int, [C.c_uint, C.c_int]),
     'occ4d_linear_f32': (C.c_int, [C.POINTER(LinearArgs), _s]),
     'occ4d_pt_pos_hidden_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _i, C.c_int, C.c_int, _f, _f, C.c_int,
                                           _f, _s]),
@@ -181,8 +183,9 @@ SIGNATURES = {
     'occ4d_decoder_scene_floats': (C.c_int64, [_DW, C.c_int]),
     'occ4d_decoder_prepare_scene_f32': (C.c_int, [_DW, _f, _f, C.c_int64, _f, C.c_int64, _f, C.c_int, _f, C.c_int, _s]),
     'occ4d_decoder_query_workspace_floats': (C.c_int64, [_DW, C.c_int, C.c_int, C.c_int]),
-    'occ4d_decoder_query_fwd_f32': (C.c_int, [_DW, _f, _f, C.c_int, _f, C.c_int64, C.c_int, _f, C.c_int64, _f, C.c_int64,
-                                              _f, C.c_int, _EV, _s]),
+    'occ4d_decoder_query_fwd_f32': (C.c_int, [_DW, _f, _f, C.c_int, _f, C.c_int64, C.c_int, _i, _i, _f, C.c_int64, _f,
+                                              C.c_int64, _f, C.c_int, _EV, _s]),
+    'occ4d_knn_dists_f32': (C.c_int, [_f, C.c_int64, C.c_int, _f, C.c_int64, C.c_int, _i, C.c_int, C.c_int, _f, _s]),
 }
 
 _lib = None

@@ -53,8 +53,10 @@ constexpr int tuple_len(int ppt) { return ppt <= 16 ? 16 : 32; }   // (tuples of
 template <int PPT, int T>
 __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, int64_t stride, int n, int m,
                                                 int start, int32_t* __restrict__ out_sorted,
-                                                int32_t* __restrict__ out_order) {
+                                                int32_t* __restrict__ out_order, u64* __restrict__ gate) {
   static_assert(PPT % 2 == 0, "PPT must be even");
+  // repair launch behind the cooperative kernel (fps_coop.hip): nothing to do unless its status word says "timed out"
+  if (gate && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) return;
   constexpr int NW = T / 64;
   constexpr int NV = PPT <= 32 ? 1 : 2;                 // 56 points per thread: two tuples of 28 (in 32)
   constexpr int PV = PPT / NV;                          // slots per tuple
@@ -233,12 +235,14 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
       ++pos;
     }
   }
+  if (gate && t == 0) __hip_atomic_store(gate, 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // "repaired"
 }
 
 template <int T>
-int launch_threads(const float* xyz, int64_t stride, int n, int m, int start, int32_t* os, int32_t* oo, hipStream_t st) {
+int launch_threads(const float* xyz, int64_t stride, int n, int m, int start, int32_t* os, int32_t* oo, hipStream_t st,
+                   u64* gate = nullptr) {
   const int ppt = occ4d::cdiv(n, T);
-#define OCC4D_FPS(P) fps_kernel<P, T><<<1, T, 0, st>>>(xyz, stride, n, m, start, os, oo)
+#define OCC4D_FPS(P) fps_kernel<P, T><<<1, T, 0, st>>>(xyz, stride, n, m, start, os, oo, gate)
   if (ppt <= 2) OCC4D_FPS(2);
   else if (ppt <= 6) OCC4D_FPS(6);
   else if (ppt <= 10) OCC4D_FPS(10);
@@ -285,4 +289,22 @@ extern "C" int occ4d_fps_start_f32(const float* xyz, int64_t stride, int n, int 
   else rc = launch_threads<1024>(xyz, stride, n, m, start, out_sorted, out_order, st);
   OCC4D_REQUIRE(rc == 0, "occ4d_fps_f32: n=%d does not fit %d threads", n, threads);
   return occ4d::check_launch("occ4d_fps_f32");
+}
+
+// The exhaustive single-workgroup kernel as a CONDITIONAL launch: runs only when *status != 0 (the cooperative kernel's
+// "an inter-workgroup wait timed out"), overwrites out_sorted / out_order with the selection (same arithmetic, same tie
+// rule: the indices the cooperative kernel would have produced) and leaves *status = 2.  Costs one empty launch otherwise.
+extern "C" int occ4d_fps_repair_f32(const float* xyz, int64_t stride, int n, int m, int start, int32_t* out_sorted,
+                                    int32_t* out_order, void* status, void* stream) {
+  OCC4D_REQUIRE(xyz && out_sorted && status, "occ4d_fps_repair_f32: null pointer");
+  OCC4D_REQUIRE(n >= 1 && n <= 32768 && m >= 1 && m <= n && start >= 0 && start < n && stride >= 3,
+                "occ4d_fps_repair_f32: n=%d (1 .. 32768), m=%d, start=%d", n, m, start);
+  hipStream_t st = (hipStream_t)stream;
+  const int threads = n <= 28 * 256 ? 256 : (n <= 56 * 512 ? 512 : 1024);
+  int rc;
+  if (threads == 256) rc = launch_threads<256>(xyz, stride, n, m, start, out_sorted, out_order, st, (u64*)status);
+  else if (threads == 512) rc = launch_threads<512>(xyz, stride, n, m, start, out_sorted, out_order, st, (u64*)status);
+  else rc = launch_threads<1024>(xyz, stride, n, m, start, out_sorted, out_order, st, (u64*)status);
+  OCC4D_REQUIRE(rc == 0, "occ4d_fps_repair_f32: n=%d does not fit %d threads", n, threads);
+  return occ4d::check_launch("occ4d_fps_repair_f32");
 }

@@ -17,9 +17,15 @@
 //              can only ever hold this use's value or the previous use's (opposite tag): a workgroup cannot
 //              publish step j+2 before every workgroup has finished polling step j (it needs all of j+1).
 //              The workspace is reset (tag = 1 everywhere, status = 0) by a small kernel per call.
-//   safety     every spin is bounded; on time-out the status word is set, the kernel finishes quickly with
-//              undefined indices and the host wrapper raises.  Workgroups that are not yet resident only delay
-//              the others (no deadlock as long as other kernels on the device terminate).
+//   safety     every spin is bounded; on time-out the status word is set to 1 and the kernel finishes quickly with
+//              undefined indices.  Workgroups that are not yet resident only delay the others (no deadlock as long
+//              as other kernels on the device terminate).  Round 5: NO consumer ever sees those indices -- for clouds
+//              the single-workgroup kernel can hold (n <= 32768: every training cloud) the entry point enqueues
+//              occ4d_fps_repair_f32 right behind the cooperative kernel: a one-workgroup launch that reads the status
+//              word, returns at once when it is 0 and otherwise recomputes the whole selection (fps.hip: the same
+//              arithmetic and tie rule, identical indices) and sets the status to 2 ("repaired": a warning on the
+//              host, never an error).  In stream order, so it also works inside a captured graph.  Larger clouds
+//              (the dataloader's whole clips) keep status 1; their host wrapper retries the launch.
 //
 // Arithmetic and tie rule identical to fps.hip / oracle/cluster.py: d = ((dx*dx + dy*dy) + dz*dz), running
 // min, first (lowest-index) argmax -- the selected indices are bit-identical for any workgroup count.
@@ -35,6 +41,9 @@ constexpr int SLOT_WORDS = 4 * MAX_WG;          // u64 words per buffer
 constexpr int WS_WORDS = 2 * SLOT_WORDS + 1;    // two buffers + status
 constexpr int FLAG_WORDS = 8192;                // selection bitmask (workgroup 0), n <= 262144
 constexpr unsigned SPIN_LIMIT = 1u << 22;
+// tests: occ4d_fps_coop_debug(spin_limit, fail_round) shortens the bounded spin / declares a time-out in a chosen round
+unsigned g_spin_limit = SPIN_LIMIT;
+int g_fail_round = -1;
 
 template <bool IS_MAX>
 __device__ __forceinline__ unsigned wave_reduce_u32(unsigned v) {
@@ -56,7 +65,8 @@ __device__ __forceinline__ unsigned wave_reduce_u32(unsigned v) {
 template <int PPT, int T>
 __global__ __launch_bounds__(T) void fps_coop_kernel(const float* __restrict__ xyz, int64_t stride, int n, int m,
                                                      int start, int chunk, int32_t* __restrict__ out_sorted,
-                                                     int32_t* __restrict__ out_order, u64* __restrict__ ws) {
+                                                     int32_t* __restrict__ out_order, u64* __restrict__ ws,
+                                                     unsigned spin_limit, int fail_round) {
   static_assert(PPT % 2 == 0, "PPT must be even");
   constexpr int PP = PPT / 2;
   constexpr int NW = T / 64;
@@ -173,13 +183,17 @@ __global__ __launch_bounds__(T) void fps_coop_kernel(const float* __restrict__ x
       // all-to-all: lane L watches word (L & 3) of workgroup (L >> 2)
       const bool watch = lane < 4 * G;
       u64 v = 0ull;
+      if (!dead && r == fail_round) {              // (tests: a declared time-out)
+        dead = true;
+        if (lane == 0) __hip_atomic_store(ws + 2 * SLOT_WORDS, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       if (!dead) {
         unsigned spins = 0;
         for (;;) {
           if (watch) v = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const bool ok = !watch || ((v ^ tag) >> 63) == 0ull;
           if (__ballot(ok) == ~0ull) break;
-          if (++spins > SPIN_LIMIT) {
+          if (++spins > spin_limit) {
             dead = true;
             if (lane == 0) __hip_atomic_store(ws + 2 * SLOT_WORDS, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
@@ -270,7 +284,8 @@ __global__ void fps_coop_reset_kernel(u64* __restrict__ ws) {
 template <int T>
 int launch(int G, int ppt, const float* xyz, int64_t stride, int n, int m, int start, int chunk, int32_t* os,
            int32_t* oo, u64* ws, hipStream_t st) {
-#define OCC4D_FPSC(P) fps_coop_kernel<P, T><<<G, T, 0, st>>>(xyz, stride, n, m, start, chunk, os, oo, ws)
+#define OCC4D_FPSC(P) \
+  fps_coop_kernel<P, T><<<G, T, 0, st>>>(xyz, stride, n, m, start, chunk, os, oo, ws, g_spin_limit, g_fail_round)
   if (ppt <= 2) OCC4D_FPSC(2);
   else if (ppt <= 4) OCC4D_FPSC(4);
   else if (ppt <= 8) OCC4D_FPSC(8);
@@ -310,7 +325,17 @@ int occ4d_fps_coop_f32(const float* xyz, int64_t stride, int n, int m, int start
   int rc = T == 512 ? launch<512>(G, ppt, xyz, stride, n, m, start, chunk, out_sorted, out_order, ws, st)
                     : launch<1024>(G, ppt, xyz, stride, n, m, start, chunk, out_sorted, out_order, ws, st);
   OCC4D_REQUIRE(rc == 0, "occ4d_fps_coop_f32: n=%d does not fit %d workgroups of %d threads", n, G, T);
-  return occ4d::check_launch("occ4d_fps_coop_f32");
+  rc = occ4d::check_launch("occ4d_fps_coop_f32");
+  if (rc) return rc;
+  // no consumer sees a timed-out selection: the single-workgroup kernel, gated on the status word (see the header)
+  if (n <= 32768) return occ4d_fps_repair_f32(xyz, stride, n, m, start, out_sorted, out_order, ws + 2 * SLOT_WORDS, stream);
+  return OCC4D_OK;
+}
+
+int occ4d_fps_coop_debug(unsigned spin_limit, int fail_round) {
+  g_spin_limit = spin_limit ? spin_limit : SPIN_LIMIT;
+  g_fail_round = fail_round;
+  return OCC4D_OK;
 }
 
 }  // extern "C"

@@ -119,6 +119,19 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const float* __restrict_
   }
 }
 
+// distances of caller-supplied neighbour lists, in the search kernel's own expressions
+template <int METRIC>
+__global__ __launch_bounds__(KNN_BLOCK) void knn_dists_kernel(const float* __restrict__ query, int64_t qs, int nq,
+                                                              const float* __restrict__ data, int64_t ds, int nd,
+                                                              const int32_t* __restrict__ idx, int k,
+                                                              float* __restrict__ out_dist) {
+  const int64_t e = (int64_t)blockIdx.x * KNN_BLOCK + threadIdx.x;
+  if (e >= (int64_t)nq * k) return;
+  const float* q = query + (e / k) * qs;
+  const float* p = data + (int64_t)min(max(idx[e], 0), nd - 1) * ds;
+  out_dist[e] = point_dist<METRIC>(q[0], q[1], q[2], p[0], p[1], p[2]);
+}
+
 template <int KT, int METRIC, typename IdxT>
 void launch_t(int tpq, const float* q, int64_t qs, int nq, const float* d, int64_t ds, int nd, int k, IdxT* oi,
               float* od, hipStream_t st) {
@@ -163,4 +176,18 @@ extern "C" int occ4d_knn_f32(const float* query, int64_t q_stride, int n_query, 
   hipStream_t st = (hipStream_t)stream;
   if (k <= 8) return launch_k<8>(query, q_stride, n_query, data, d_stride, n_data, k, metric, out_idx, idx_is_i64, out_dist, st);
   return launch_k<16>(query, q_stride, n_query, data, d_stride, n_data, k, metric, out_idx, idx_is_i64, out_dist, st);
+}
+
+extern "C" int occ4d_knn_dists_f32(const float* query, int64_t q_stride, int n_query, const float* data,
+                                   int64_t d_stride, int n_data, const int32_t* idx, int k, int metric, float* out_dist,
+                                   void* stream) {
+  OCC4D_REQUIRE(k >= 1 && n_data >= 1 && (metric == 0 || metric == 1) && n_query >= 0 && q_stride >= 3 && d_stride >= 3,
+                "occ4d_knn_dists_f32: bad sizes (k = %d, n_data = %d, metric = %d)", k, n_data, metric);
+  OCC4D_REQUIRE(query && data && idx && out_dist, "occ4d_knn_dists_f32: null pointer");
+  if (n_query == 0) return OCC4D_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = (int)occ4d::cdiv((int64_t)n_query * k, KNN_BLOCK);
+  if (metric == 0) knn_dists_kernel<0><<<blocks, KNN_BLOCK, 0, st>>>(query, q_stride, n_query, data, d_stride, n_data, idx, k, out_dist);
+  else knn_dists_kernel<1><<<blocks, KNN_BLOCK, 0, st>>>(query, q_stride, n_query, data, d_stride, n_data, idx, k, out_dist);
+  return occ4d::check_launch("occ4d_knn_dists_f32");
 }

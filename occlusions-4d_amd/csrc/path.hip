@@ -570,9 +570,21 @@ DecoderScene decoder_scene_layout(const occ4d_decoder_weights& w, int m) {
   return s;
 }
 
+// caller-supplied neighbour lists are copied into the workspace with every entry forced into [0, m): the gathers behind
+// them are unchecked
+__global__ void clamp_indices_kernel(const int32_t* __restrict__ src, int64_t n, int m, int32_t* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = min(max(src[i], 0), m - 1);
+}
+int clamp_indices(const int32_t* src, int64_t n, int m, int32_t* dst, hipStream_t st) {
+  clamp_indices_kernel<<<cdiv(n, 256), 256, 0, st>>>(src, n, m, dst);
+  return occ4d::check_launch("occ4d_decoder_query_fwd_f32 (neighbour lists)");
+}
+
 int decoder_forward(const occ4d_decoder_weights& w, const DecoderLayout& L, const float* prep, const float* scene, int m,
-                    const float* queries, int64_t qs, int n, float* out, int64_t ld_out, float* penult, int64_t ld_pen,
-                    Bump& ws, int flags, const Events& E, hipStream_t st, bool dry) {
+                    const float* queries, int64_t qs, int n, const int32_t* knn_local, const int32_t* knn_cross, float* out,
+                    int64_t ld_out, float* penult, int64_t ld_pen, Bump& ws, int flags, const Events& E, hipStream_t st,
+                    bool dry) {
   const int H = L.H;
   const DecoderScene S = decoder_scene_layout(w, m);
   const float* xyz = scene ? scene + S.xyz : nullptr;
@@ -591,10 +603,17 @@ int decoder_forward(const occ4d_decoder_weights& w, const DecoderLayout& L, cons
     float* hbuf = L.resblock ? nullptr : ws.take((int64_t)c * H);
     if (!dry) {
       // D2 + D3 (model/implicit.py:328-342): 8 nearest abstract points by Euclidean norm, inverse-distance weights
-      TRY(occ4d_knn_f32(q, qs, c, xyz, 3, m, w.k_local, 1, idx8, 0, w8, st));
+      // (caller-supplied lists: the reference's own tie order; distances recomputed with the search's expression)
+      if (knn_local) {
+        TRY(clamp_indices(knn_local + (int64_t)lo * w.k_local, (int64_t)c * w.k_local, m, idx8, st));
+        TRY(occ4d_knn_dists_f32(q, qs, c, xyz, 3, m, idx8, w.k_local, 1, w8, st));
+      } else {
+        TRY(occ4d_knn_f32(q, qs, c, xyz, 3, m, w.k_local, 1, idx8, 0, w8, st));
+      }
       TRY(occ4d_interp_weights_f32(w8, c, w.k_local, w8, st));
       // one kNN_torch (model/point_transformer_layer.py:167) serves every cross-attention layer: same xyz, same K
-      if (L.nC) TRY(occ4d_knn_f32(q, qs, c, xyz, 3, m, w.k_cross, 0, idx_att, 0, nullptr, st));
+      if (L.nC && knn_cross) TRY(clamp_indices(knn_cross + (int64_t)lo * w.k_cross, (int64_t)c * w.k_cross, m, idx_att, st));
+      else if (L.nC) TRY(occ4d_knn_f32(q, qs, c, xyz, 3, m, w.k_cross, 0, idx_att, 0, nullptr, st));
       // D5 + lin_in (:405-408)
       const float* emb = q;
       int64_t ld_emb = qs;
@@ -837,13 +856,14 @@ extern "C" int64_t occ4d_decoder_query_workspace_floats(const occ4d_decoder_weig
   if (check_decoder(w, "occ4d_decoder_query_workspace_floats") || n < 0 || m < 0) return -1;
   Bump ws(nullptr);
   Events E{nullptr, nullptr};
-  if (decoder_forward(*w, decoder_layout(*w, flags), nullptr, nullptr, m, nullptr, w->d_in, n, nullptr, w->d_out, nullptr, 0,
-                      ws, flags, E, nullptr, true))
+  if (decoder_forward(*w, decoder_layout(*w, flags), nullptr, nullptr, m, nullptr, w->d_in, n, nullptr, nullptr, nullptr,
+                      w->d_out, nullptr, 0, ws, flags, E, nullptr, true))
     return -1;
   return ws.peak + ALIGN;
 }
 extern "C" int occ4d_decoder_query_fwd_f32(const occ4d_decoder_weights* w, const float* prepared, const float* scene,
-                                           int m, const float* queries, int64_t q_stride, int n, float* out,
+                                           int m, const float* queries, int64_t q_stride, int n,
+                                           const int32_t* knn_local, const int32_t* knn_cross, float* out,
                                            int64_t ld_out, float* penult, int64_t ld_pen, float* workspace, int flags,
                                            occ4d_launch_events* ev, void* stream) {
   const char* who = "occ4d_decoder_query_fwd_f32";
@@ -858,6 +878,6 @@ extern "C" int occ4d_decoder_query_fwd_f32(const occ4d_decoder_weights* w, const
   OCC4D_REQUIRE(m >= w->k_local && (w->n_cross == 0 || m >= w->k_cross), "%s: m = %d abstract points", who, m);
   Bump ws(workspace);
   const Events E{ev, (hipStream_t)stream};
-  return decoder_forward(*w, decoder_layout(*w, flags), prepared, scene, m, queries, q_stride, n, out, ld_out, penult, ld_pen, ws,
-                         flags, E, (hipStream_t)stream, false);
+  return decoder_forward(*w, decoder_layout(*w, flags), prepared, scene, m, queries, q_stride, n, knn_local, knn_cross, out,
+                         ld_out, penult, ld_pen, ws, flags, E, (hipStream_t)stream, false);
 }

@@ -271,7 +271,6 @@ class GuidedImplicitPointSampler(torch.nn.Module):
         air_target (B,A,6), solid_sbs (B,6), air_sbs (B,4))."""
         frame, sizes = pcl_target[time_idx], pcl_target_size[time_idx]
         (B, M, E) = frame.shape
-        assert torch.all(sizes <= M)
         if self.data_kind == 'greater':
             assert E == 9
         elif self.data_kind == 'carla':
@@ -282,6 +281,12 @@ class GuidedImplicitPointSampler(torch.nn.Module):
             if other_time == time_idx:
                 other_time += 1
             other, other_sizes = pcl_target[other_time], pcl_target_size[other_time]
+        # The reference's pipeline moves the clouds to the GPU and leaves meta_data['pcl_target_size'] on the host
+        # (pipeline.py:75-91): the sizes follow their cloud here (a few bytes, no stall), so that the one-transfer
+        # reads below never mix devices.
+        sizes = torch.as_tensor(sizes).to(frame.device)
+        if other_sizes is not None:
+            other_sizes = torch.as_tensor(other_sizes).to(other.device)
         fast = (SAMPLER_FAST and GRID_GAP_FILTER and frame.is_cuda and 'ivalo' not in self.point_sample_bias
                 and self.num_solid > 0 and self.num_air > 0)
         if not fast:

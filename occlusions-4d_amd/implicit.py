@@ -282,14 +282,21 @@ class LocalPclResnetFC(ResnetFC):
         return sc
 
     # -- forward ----------------------------------------------------------------------
-    def forward(self, points_query, points_abstract, features_global, features_abstract):
+    def forward(self, points_query, points_abstract, features_global, features_abstract, knn_local=None, knn_cross=None):
         """points_query (B,N,4) or (N,4); points_abstract (B,M,3) (or (B,M,3+E) with
         features_abstract None); features_global (B,D); features_abstract (B,M,E).
         B must be 1.  Returns (output (B,N,G), penult (B,N,H)) (no batch dim if none came in).
         Inference: ONE library call per mini-batch (occ4d_decoder_query_fwd_f32) on per-scene tables built once per
-        abstract cloud (occ4d_decoder_prepare_scene_f32)."""
+        abstract cloud (occ4d_decoder_prepare_scene_f32).
+        Extension (keyword only in spirit; the reference's four positionals are unchanged): knn_local (N, 8) /
+        knn_cross (N, 14) integer tensors = the caller's own neighbour lists of the abstract cloud -- what
+        geometry.my_knn_torch (model/implicit.py:328) and kNN_torch (model/point_transformer_layer.py:167) returned in
+        the run to be reproduced.  The reference orders equidistant points with an unstable sort; CARLA's two-level
+        abstract cloud holds every coarse point twice (model/model.py:202-228), so there its choice at the k-th rank is
+        implementation-defined and only the run's own lists pin it.  None = searched here, lowest index first."""
         if needs_grad(self, points_abstract, features_global, features_abstract):
-            return self._forward_train(points_query, points_abstract, features_global, features_abstract)
+            return self._forward_train(points_query, points_abstract, features_global, features_abstract,
+                                       knn_local=knn_local, knn_cross=knn_cross)
         if self.num_local_features <= 0:
             return super().do_forward(points_query, features_global)
         if self.local_mode == 'function':
@@ -305,12 +312,18 @@ class LocalPclResnetFC(ResnetFC):
         assert self._library_path_ok(), 'unsupported LocalPclResnetFC configuration for the HIP library'
         sc = self.prepare_scene(points_abstract, features_global, features_abstract)
         w, prepared, flags = self.path_weights()
-        output, penult = ops.decoder_query_fwd(w, prepared, sc['scene'], sc['m'], q, flags)
+        if knn_local is not None and knn_local.dim() == 3:
+            knn_local = knn_local[0]
+        if knn_cross is not None and knn_cross.dim() == 3:
+            knn_cross = knn_cross[0]
+        output, penult = ops.decoder_query_fwd(w, prepared, sc['scene'], sc['m'], q, flags, knn_local=knn_local,
+                                               knn_cross=knn_cross)
         if not no_batch:
             output, penult = output[None], penult[None]
         return (output, penult)
 
-    def forward_output_only(self, points_query, points_abstract, features_global, features_abstract, out):
+    def forward_output_only(self, points_query, points_abstract, features_global, features_abstract, out,
+                            knn_local=None, knn_cross=None):
         """Extension for the device-resident driver (inference.decode_batches): the raw outputs of one mini-batch
         written straight into `out` (a row slice of the caller's result tensor); the penultimate activation, which
         perform_inference discards (eval/inference.py:211), is not materialised for the caller."""
@@ -318,11 +331,13 @@ class LocalPclResnetFC(ResnetFC):
         assert self.num_local_features > 0 and self._library_path_ok() and points_query.dim() == 2
         sc = self.prepare_scene(points_abstract, features_global, features_abstract)
         w, prepared, flags = self.path_weights()
-        ops.decoder_query_fwd(w, prepared, sc['scene'], sc['m'], points_query, flags, out=out, want_penult=False)
+        ops.decoder_query_fwd(w, prepared, sc['scene'], sc['m'], points_query, flags, out=out, want_penult=False,
+                              knn_local=knn_local, knn_cross=knn_cross)
         return out
 
     # -- training path (as-written op order, differentiable kernels) ------------------------
-    def _forward_train(self, points_query, points_abstract, features_global, features_abstract):
+    def _forward_train(self, points_query, points_abstract, features_global, features_abstract, knn_local=None,
+                       knn_cross=None):
         """Same contract as forward(); every op is a occlusions4d_amd.autograd Function, so gradients
         reach this module's parameters and, through features_abstract / features_global, the encoder."""
         assert self.local_mode == 'attention' and self.num_local_features > 0, \
@@ -343,13 +358,19 @@ class LocalPclResnetFC(ResnetFC):
         fa = fa.contiguous()
         n = q.shape[0]
         dg = self.d_latent - self.d_latent_local
-        idx8, dist = ops.knn(q, pa, self.num_local_features, metric=1, return_dist=True)
+        if knn_local is not None:
+            idx8 = (knn_local[0] if knn_local.dim() == 3 else knn_local).to(torch.int32).contiguous()
+            dist = ops.knn_dists(q, pa, idx8, metric=1)
+        else:
+            idx8, dist = ops.knn(q, pa, self.num_local_features, metric=1, return_dist=True)
         w8 = ops.interp_weights(dist)
         f_local = autograd.InterpFn.apply(fa, idx8, w8)                                   # (n, E)
         f_query = torch.cat([autograd.ExpandRowsFn.apply(fg, n), f_local], dim=-1)         # (n, D)
         x = autograd.linear(ops.posenc(q, self.pos_encoding_freqs, 0.1), self.lin_in)
         qxyz = q[:, :3].detach()
         idx_att = None
+        if knn_cross is not None:
+            idx_att = (knn_cross[0] if knn_cross.dim() == 3 else knn_cross).to(torch.int32).contiguous()
         for i in range(self.n_blocks):
             x = autograd.linear(f_query, self.lin_z[i], residual=x)
             x = self.blocks[i]._run_train(x)

@@ -132,13 +132,15 @@ def perform_inference(pcl_input, pcl_input_sem, pcl_target_frame, networks, devi
                       batch_size=1024, predict_segmentation=False, track_mode='none',
                       point_occupancy_radius=0.2, semantic_classes=13,
                       density_threshold=0.5, data_kind='', cube_mode=4, compress_air=False,
-                      encoded=None, return_encoded=False):
+                      encoded=None, return_encoded=False, neighbour_lists=None):
     """One encode of the input point-cloud video + decode of all query points of one output
     frame.  Returns dict(output_solid, output_air, pcl_abstract, features_global,
     implicit_output, points_query) of float32 numpy arrays.
     Extensions (keyword only, default = the reference's behaviour): `encoded` = the (pcl_abstract, features_global)
     device tensors of an earlier call on the same input cloud (the reference's eval loop re-encodes the clip for every
-    output frame, eval/test.py:67-86); `return_encoded` adds them to the result as '_encoded'."""
+    output frame, eval/test.py:67-86); `return_encoded` adds them to the result as '_encoded'; `neighbour_lists` =
+    (knn_local (N_q, 8), knn_cross (N_q, 14)) integer arrays: the decoder's neighbour lists of a particular run of the
+    reference for these queries (LocalPclResnetFC.forward's extension; either entry may be None)."""
     assert task == 'if'
     assert sample_implicit
     output_track_idx = get_track_idx(color_mode)
@@ -175,7 +177,7 @@ def perform_inference(pcl_input, pcl_input_sem, pcl_target_frame, networks, devi
                 pcl_input[..., -1] = (pcl_input_sem[..., input_inst_idx] == inst_id)
             res = infer_device(pcl_input, queries_dev, pcl_net, implicit_net, batch_size, color_mode,
                                predict_segmentation, track_mode, semantic_classes,
-                               encoded=encoded if inst_id < 0 else None)
+                               encoded=encoded if inst_id < 0 else None, neighbour_lists=neighbour_lists)
             output_dev = res['implicit_output']
             all_output.append(copies.fetch(output_dev))
             all_abstract.append(copies.fetch(res['pcl_abstract']))
@@ -249,7 +251,8 @@ def multi_track_merge(track_instance_ids, pcl_abstract, features_global, implici
 
 
 def infer_device(pcl_input, points_query, pcl_net, implicit_net, batch_size, color_mode,
-                 predict_segmentation=False, track_mode='none', semantic_classes=13, encoded=None):
+                 predict_segmentation=False, track_mode='none', semantic_classes=13, encoded=None,
+                 neighbour_lists=None):
     """Device-resident core of perform_inference: encode once, decode every mini-batch, squash.
     All tensors are CUDA; returns CUDA tensors (implicit_output (N,G), pcl_abstract (M,3+E),
     features_global (D))."""
@@ -262,7 +265,11 @@ def infer_device(pcl_input, points_query, pcl_net, implicit_net, batch_size, col
         features_global = features_global.squeeze(0)
     n = points_query.shape[0]
     out = torch.empty((n, implicit_net.d_out), dtype=torch.float32, device=points_query.device)
-    decode_batches(implicit_net, points_query, 0, n, batch_size, pcl_abstract, features_global, out)
+    lists = None
+    if neighbour_lists is not None:
+        lists = tuple(None if a is None else torch.as_tensor(a).to(points_query.device) for a in neighbour_lists)
+        assert len(lists) == 2 and all(a is None or a.shape[0] == n for a in lists)
+    decode_batches(implicit_net, points_query, 0, n, batch_size, pcl_abstract, features_global, out, lists=lists)
     ops.squash(out, squash_codes(implicit_net.d_out, color_mode, predict_segmentation, track_mode,
                                  semantic_classes))
     return dict(implicit_output=out, pcl_abstract=pcl_abstract, features_global=features_global)
@@ -282,19 +289,21 @@ def decode_chunk(batch_size):
     return batch_size
 
 
-def _decode_into(implicit_net, q, pcl_abstract, features_global, out_rows):
+def _decode_into(implicit_net, q, pcl_abstract, features_global, out_rows, lists=None):
     """One mini-batch: the network's raw outputs written into `out_rows`.  The library-backed decoder writes them in
     place and skips the penultimate activation perform_inference discards (eval/inference.py:211); any other module
     with the reference's forward signature is called as the reference calls it."""
     direct = getattr(implicit_net, 'forward_output_only', None)
+    kw = {} if lists is None else dict(knn_local=lists[0], knn_cross=lists[1])
     if direct is not None and getattr(implicit_net, 'num_local_features', 0) > 0 and q.dim() == 2 and q.shape[0] > 0:
-        direct(q, pcl_abstract, features_global, None, out_rows)
+        direct(q, pcl_abstract, features_global, None, out_rows, **kw)
         return
-    (o, _) = implicit_net(q, pcl_abstract, features_global, None)
+    (o, _) = implicit_net(q, pcl_abstract, features_global, None, **kw)
     out_rows.copy_(o)
 
 
-def decode_batches(implicit_net, points_query, lo, hi, batch_size, pcl_abstract, features_global, out, out_offset=0):
+def decode_batches(implicit_net, points_query, lo, hi, batch_size, pcl_abstract, features_global, out, out_offset=0,
+                   lists=None):
     """Runs implicit_net on points_query[lo:hi] in mini-batches of `batch_size` (the reference's
     loop, eval/inference.py:204-246) and writes rows into out[out_offset:].  Mini-batches are
     independent, so consecutive ones alternate between DECODE_STREAMS HIP streams: a 32768-query
@@ -306,17 +315,22 @@ def decode_batches(implicit_net, points_query, lo, hi, batch_size, pcl_abstract,
     batch_size = decode_chunk(batch_size)
     starts = list(range(lo, hi, batch_size))
     side = [torch.cuda.Stream() for _ in range(DECODE_STREAMS)] if DECODE_STREAMS > 1 and len(starts) > 2 else []
+    def rows(b, e):           # the caller's neighbour lists of these queries (rows are indexed like points_query)
+        return None if lists is None else tuple(None if a is None else a[b:e] for a in lists)
+
     for bi, b in enumerate(starts):
         e = min(hi, b + batch_size)
         if bi == 0 or not side:
-            _decode_into(implicit_net, points_query[b:e], pcl_abstract, features_global, out[out_offset + b - lo:out_offset + e - lo])
+            _decode_into(implicit_net, points_query[b:e], pcl_abstract, features_global, out[out_offset + b - lo:out_offset + e - lo],
+                         rows(b, e))
             if bi == 0:
                 for st in side:
                     st.wait_stream(main)
             continue
         st = side[bi % len(side)]
         with torch.cuda.stream(st):
-            _decode_into(implicit_net, points_query[b:e], pcl_abstract, features_global, out[out_offset + b - lo:out_offset + e - lo])
+            _decode_into(implicit_net, points_query[b:e], pcl_abstract, features_global, out[out_offset + b - lo:out_offset + e - lo],
+                         rows(b, e))
     for st in side:
         main.wait_stream(st)
     return out

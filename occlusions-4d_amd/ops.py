@@ -6,6 +6,8 @@ import ctypes as C
 import math
 import os
 
+import warnings
+
 import torch
 
 from . import _lib
@@ -143,6 +145,18 @@ def knn(query, data, k, metric=0, return_dist=False, int64=False):
     return (idx, dist) if return_dist else idx
 
 
+def knn_dists(query, data, idx, metric=0):
+    """Distances (N0, k) of caller-supplied neighbour lists idx (N0, k) in the search kernel's own expressions: what
+    knn(..., return_dist=True) returns beside these indices."""
+    q, qs = _rows(_dev(query, name='query'), 'query')
+    d, ds = _rows(_dev(data, name='data'), 'data')
+    idx = _neighbour_list(idx, q.shape[0], idx.shape[1], 'idx')
+    dist = torch.empty(idx.shape, dtype=torch.float32, device=q.device)
+    _lib.check(_lib.lib().occ4d_knn_dists_f32(_ptr(q), qs, q.shape[0], _ptr(d), ds, d.shape[0], _ptr(idx), idx.shape[1],
+                                              metric, _ptr(dist), _stream()))
+    return dist
+
+
 def fps(xyz, m, return_order=False, start=0):
     """xyz (N,>=3), N <= 32768 -> ascending int32 indices (m) of the farthest-point sample that begins at `start`
     [, the selection order (m)]: one workgroup, the cloud in registers."""
@@ -156,19 +170,33 @@ def fps(xyz, m, return_order=False, start=0):
 
 def fps_coop(xyz, m, start=0, n_workgroups=0, return_order=False, check=True):
     """Farthest-point sample over up to 16 cooperating workgroups (n <= 262144), first sample = `start`.
-    Returns ascending int32 indices (m) [, selection order (m)].  check=True reads the kernel's status word
-    (one 8-byte device->host read) and raises if a bounded inter-workgroup spin timed out."""
+    Returns ascending int32 indices (m) [, selection order (m)].
+    A bounded inter-workgroup spin of the kernel can time out (a scheduling delay under a saturating neighbour).  No
+    consumer ever sees such a selection: for n <= 32768 (every training cloud) the library enqueues, right behind the
+    cooperative kernel, a single-workgroup launch gated on the status word that recomputes the selection (identical
+    indices) -- valid in stream order, also inside a captured graph; the status word then reads 2 and the host only
+    WARNS.  check=True reads the status word (one 8-byte device->host read): larger clouds (status 1, not repaired)
+    are relaunched up to twice before raising.  check=False defers the look to check_pending() without a stall."""
     p, ps = _rows(_dev(xyz, name='xyz'), 'xyz')
     out = torch.empty((m,), dtype=torch.int32, device=p.device)
     order = torch.empty((m,), dtype=torch.int32, device=p.device) if return_order else None
     ws = torch.empty((_lib.lib().occ4d_fps_coop_workspace_bytes() // 8,), dtype=torch.int64, device=p.device)
-    _lib.check(_lib.lib().occ4d_fps_coop_f32(_ptr(p), ps, p.shape[0], m, int(start), int(n_workgroups), _ptr(out),
-                                             _ptr(order), _ptr(ws), _stream()))
-    if check:
-        if int(ws[-1].item()) != 0:
+    for attempt in range(3):
+        _lib.check(_lib.lib().occ4d_fps_coop_f32(_ptr(p), ps, p.shape[0], m, int(start), int(n_workgroups), _ptr(out),
+                                                 _ptr(order), _ptr(ws), _stream()))
+        if not check:
+            break
+        status = int(ws[-1].item())
+        if status == 0:
+            break
+        if status == 2:
+            warnings.warn(_FPS_REPAIRED)
+            break
+        if attempt == 2:
             raise RuntimeError(_FPS_TIMEOUT)
-    elif torch.cuda.is_current_stream_capturing():
-        pass                  # inside a hipGraph capture: no host-side bookkeeping (the spins stay bounded)
+        warnings.warn('occ4d_fps_coop_f32: an inter-workgroup wait timed out on %d points; relaunching' % p.shape[0])
+    if check or torch.cuda.is_current_stream_capturing():
+        pass                  # (inside a hipGraph capture: no host-side bookkeeping; the gated repair launch is captured)
     else:
         # deferred check without a stall: status word -> pinned host memory in stream order + an event
         host = torch.empty(1, dtype=torch.int64, pin_memory=True)
@@ -181,27 +209,39 @@ def fps_coop(xyz, m, start=0, n_workgroups=0, return_order=False, check=True):
     return (out, order) if return_order else out
 
 
-_FPS_TIMEOUT = ('occ4d_fps_coop_f32: an inter-workgroup wait timed out (device oversubscribed?); the sampled '
-                'indices are undefined')
+_FPS_TIMEOUT = ('occ4d_fps_coop_f32: an inter-workgroup wait timed out (device oversubscribed?) on a cloud above the '
+                'single-workgroup kernel\'s 32768 points; the sampled indices are undefined')
+_FPS_REPAIRED = ('occ4d_fps_coop_f32: an inter-workgroup wait timed out (device oversubscribed?); the selection was '
+                 'recomputed by the single-workgroup kernel in stream order -- results are valid, the launch was slow')
 _pending_status = []
 
 
 def check_pending(wait=True):
-    """Verifies the status word of the fps_coop(..., check=False) launches issued since the last call.  wait=True
+    """Looks at the status word of the fps_coop(..., check=False) launches issued since the last call.  wait=True
     blocks on their completion events; wait=False only looks at launches that have already finished (no stall).
-    perform_inference / TrainStep / bench.py call it; raises RuntimeError if any inter-workgroup wait timed out."""
+    perform_inference / TrainStep / bench.py call it.  Status 2 (timed out, repaired in stream order: the results every
+    consumer saw were valid) -> one warning; status 1 (a cloud above 32768 points launched with check=False, not
+    repaired) -> RuntimeError."""
     keep = []
-    bad = False
+    bad = repaired = False
     for host, ev in _pending_status:
         if wait:
             ev.synchronize()
         elif not ev.query():
             keep.append((host, ev))
             continue
-        bad = bad or int(host[0]) != 0
+        bad = bad or int(host[0]) == 1
+        repaired = repaired or int(host[0]) == 2
     _pending_status[:] = keep
+    if repaired:
+        warnings.warn(_FPS_REPAIRED)
     if bad:
         raise RuntimeError(_FPS_TIMEOUT)
+
+
+def fps_coop_debug(spin_limit=0, fail_round=-1):
+    """Tests: shorten the kernel's bounded spin (0 = default) / declare a time-out in round `fail_round` (-1 = never)."""
+    _lib.check(_lib.lib().occ4d_fps_coop_debug(int(spin_limit), int(fail_round)))
 
 
 FPS_COOP_MIN_POINTS = 16385     # above the pruned single-workgroup kernel's range the cooperative kernel: since a round
@@ -765,10 +805,24 @@ def decoder_prepare_scene(w, prepared, xyz, feats, fglobal, flags):
     return scene
 
 
-def decoder_query_fwd(w, prepared, scene, m, queries, flags=0, out=None, penult=None, want_penult=True):
-    """occ4d_decoder_query_fwd_f32 on one mini-batch: queries (n, d_in) -> (out (n, G), penult (n, H) or None)."""
+def _neighbour_list(idx, n, k, name):
+    """Caller-supplied neighbour list -> contiguous (n, k) int32 device tensor (any integer dtype comes in)."""
+    if idx is None:
+        return None
+    assert torch.is_tensor(idx) and idx.is_cuda and not idx.is_floating_point(), name + ' must be an integer CUDA tensor'
+    assert tuple(idx.shape) == (n, k), '%s must have shape (%d, %d), got %s' % (name, n, k, tuple(idx.shape))
+    return idx.to(torch.int32).contiguous()
+
+
+def decoder_query_fwd(w, prepared, scene, m, queries, flags=0, out=None, penult=None, want_penult=True,
+                      knn_local=None, knn_cross=None):
+    """occ4d_decoder_query_fwd_f32 on one mini-batch: queries (n, d_in) -> (out (n, G), penult (n, H) or None).
+    knn_local (n, k_local) / knn_cross (n, k_cross): the caller's own neighbour lists of the abstract cloud (the
+    reference's tie order on clouds with coincident points), or None = searched by the library."""
     q, qs = _rows(_dev(queries, name='points_query'), 'points_query')
     n = q.shape[0]
+    kl = _neighbour_list(knn_local, n, w.k_local, 'knn_local')
+    kc = _neighbour_list(knn_cross, n, w.k_cross, 'knn_cross') if w.n_cross > 0 else None
     if out is None:
         out = torch.empty((n, w.d_out), dtype=torch.float32, device=q.device)
     o, ldo = _rows(_dev(out, name='out'), 'out')
@@ -795,8 +849,8 @@ def decoder_query_fwd(w, prepared, scene, m, queries, flags=0, out=None, penult=
         chunks = path_row_chunks(n)
         ev, finish = _path_timing('resblock', [4.0 * c * d * d for c in chunks for _ in range(w.n_blocks)])
     _lib.check(_lib.lib().occ4d_decoder_query_fwd_f32(
-        C.byref(w), _ptr(prepared), _ptr(scene), m, _ptr(q), qs, n, _ptr(o), ldo, _ptr(penult), ldp, _ptr(ws), flags,
-        C.byref(ev) if ev is not None else None, _stream()))
+        C.byref(w), _ptr(prepared), _ptr(scene), m, _ptr(q), qs, n, _ptr(kl), _ptr(kc), _ptr(o), ldo, _ptr(penult), ldp,
+        _ptr(ws), flags, C.byref(ev) if ev is not None else None, _stream()))
     finish()
     return out, penult
 

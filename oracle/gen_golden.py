@@ -37,6 +37,75 @@ def save(name, **arrays):
     print('%-28s %8.1f KB' % (name, os.path.getsize(path) / 1024))
 
 
+class record_decoder_lists:
+    """with record_decoder_lists(ref) as rec: ...decoder forwards...  ->  rec.lists() = (knn_local (N, 8) int32,
+    knn_local_dists (N, 8) fp32, knn_cross (N, 14) int32): what geometry.my_knn_torch (model/implicit.py:328) and the
+    cross-attention layers' kNN_torch (model/point_transformer_layer.py:167; self-attention calls, where the query cloud IS
+    the data cloud, are not recorded) returned, concatenated over the mini-batches in call order.  Every cross layer
+    of one forward must have taken the same list (same inputs): asserted."""
+
+    def __init__(self, ref):
+        self.ptl, self.geo = ref.point_transformer_layer, ref.geometry
+        self.local, self.dists, self.cross = [], [], []
+
+    def __enter__(self):
+        self._knn, self._my = self.ptl.kNN_torch, self.geo.my_knn_torch
+
+        def knn(query, dataset, k):
+            idx = self._knn(query, dataset, k)
+            if query is not dataset:
+                self.cross.append(idx[0].numpy().astype(np.int32))
+            return idx
+
+        def my_knn(pcl_query, pcl_key, num_neighbors, *a, **kw):
+            res = self._my(pcl_query, pcl_key, num_neighbors, *a, **kw)
+            assert kw.get('return_inds') and kw.get('return_knn') and kw.get('return_dists')
+            self.local.append(res[0].numpy().astype(np.int32))
+            self.dists.append(res[2].numpy())
+            return res
+        self.ptl.kNN_torch, self.geo.my_knn_torch = knn, my_knn
+        return self
+
+    def __exit__(self, *exc):
+        self.ptl.kNN_torch, self.geo.my_knn_torch = self._knn, self._my
+
+    def lists(self):
+        per = len(self.cross) // len(self.local)          # cross layers per forward
+        assert per >= 1 and len(self.cross) == per * len(self.local)
+        cross = []
+        for b in range(len(self.local)):
+            for j in range(1, per):
+                assert np.array_equal(self.cross[b * per], self.cross[b * per + j])
+            cross.append(self.cross[b * per])
+        return dict(knn_local=np.concatenate(self.local), knn_local_dists=np.concatenate(self.dists),
+                    knn_cross=np.concatenate(cross))
+
+
+def run_inference(ref, case):
+    mdl, imp, inf = ref.model, ref.implicit, ref.inference
+    pcl, pa, ia, ia_inf, esd, dsd = gc.infer_inputs(case)
+    enc = mdl.PointCompletionNetV3(**pa)
+    enc.load_state_dict(esd)
+    dec = imp.LocalPclResnetFC(**ia)
+    dec.load_state_dict(dsd)
+    enc.eval()
+    dec.eval()
+    with record_decoder_lists(ref) as rec:
+        res = inf.perform_inference(
+            pcl.clone(), None, None, [enc, dec], torch.device('cpu'), 'if', ia_inf['min_z'],
+            ia_inf['cube_bounds'], ia_inf['color_mode'], case['time_idx'], None,
+            sample_implicit=True, num_sample=case['num_sample'], point_sample_mode='grid',
+            batch_size=case['batch_size'], predict_segmentation=ia_inf['predict_segmentation'],
+            track_mode='none', semantic_classes=13, density_threshold=0.5,
+            data_kind=ia_inf['data_kind'], cube_mode=4, compress_air=True)
+    # CARLA (two-level abstract cloud: coincident points): the run's own neighbour lists pin its tie order
+    extra = rec.lists() if case['kind'] == 'carla' else {}
+    save('g10_infer_' + case['name'], implicit_output=res['implicit_output'],
+         pcl_abstract=res['pcl_abstract'], features_global=res['features_global'],
+         n_solid=np.array([res['output_solid'].shape[0]]), n_air=np.array([res['output_air'].shape[0]]),
+         air_head=res['output_air'][:64], solid_head=res['output_solid'][:64], **extra)
+
+
 @torch.no_grad()
 def main():
     ref = ref_import.load()
@@ -118,24 +187,7 @@ def main():
 
     # G10: perform_inference end to end, config 1 (D8)
     for case in gc.INFER_CASES:
-        pcl, pa, ia, ia_inf, esd, dsd = gc.infer_inputs(case)
-        enc = mdl.PointCompletionNetV3(**pa)
-        enc.load_state_dict(esd)
-        dec = imp.LocalPclResnetFC(**ia)
-        dec.load_state_dict(dsd)
-        enc.eval()
-        dec.eval()
-        res = inf.perform_inference(
-            pcl.clone(), None, None, [enc, dec], torch.device('cpu'), 'if', ia_inf['min_z'],
-            ia_inf['cube_bounds'], ia_inf['color_mode'], case['time_idx'], None,
-            sample_implicit=True, num_sample=case['num_sample'], point_sample_mode='grid',
-            batch_size=case['batch_size'], predict_segmentation=ia_inf['predict_segmentation'],
-            track_mode='none', semantic_classes=13, density_threshold=0.5,
-            data_kind=ia_inf['data_kind'], cube_mode=4, compress_air=True)
-        save('g10_infer_' + case['name'], implicit_output=res['implicit_output'],
-             pcl_abstract=res['pcl_abstract'], features_global=res['features_global'],
-             n_solid=np.array([res['output_solid'].shape[0]]), n_air=np.array([res['output_air'].shape[0]]),
-             air_head=res['output_air'][:64], solid_head=res['output_solid'][:64])
+        run_inference(ref, case)
 
     # G11: perform_inference with track_mode 'all' (one rerun per instance, multi_track_merge) and the
     # ground-truth 1-NN labelling branch (sklearn KDTree in the reference)
@@ -318,24 +370,17 @@ def regimes(ref):
 
     # G10p: perform_inference end to end on zero-padded clouds
     for case in gc.INFER_PAD_CASES:
-        pcl, pa, ia, ia_inf, esd, dsd = gc.infer_inputs(case)
-        enc = mdl.PointCompletionNetV3(**pa)
-        enc.load_state_dict(esd)
-        dec = imp.LocalPclResnetFC(**ia)
-        dec.load_state_dict(dsd)
-        enc.eval()
-        dec.eval()
-        res = inf.perform_inference(
-            pcl.clone(), None, None, [enc, dec], torch.device('cpu'), 'if', ia_inf['min_z'],
-            ia_inf['cube_bounds'], ia_inf['color_mode'], case['time_idx'], None,
-            sample_implicit=True, num_sample=case['num_sample'], point_sample_mode='grid',
-            batch_size=case['batch_size'], predict_segmentation=ia_inf['predict_segmentation'],
-            track_mode='none', semantic_classes=13, density_threshold=0.5,
-            data_kind=ia_inf['data_kind'], cube_mode=4, compress_air=True)
-        save('g10_infer_' + case['name'], implicit_output=res['implicit_output'],
-             pcl_abstract=res['pcl_abstract'], features_global=res['features_global'],
-             n_solid=np.array([res['output_solid'].shape[0]]), n_air=np.array([res['output_air'].shape[0]]),
-             air_head=res['output_air'][:64], solid_head=res['output_solid'][:64])
+        run_inference(ref, case)
+
+    # G8t: decoder on a two-level abstract cloud (coincident coordinates), with the lists the reference took
+    for case in gc.DEC_TWOLEVEL_CASES:
+        q, abstract, fglob, ia, sd = gc.dec_twolevel_inputs(case)
+        net = imp.LocalPclResnetFC(**ia)
+        net.load_state_dict(sd)
+        net.eval()
+        with record_decoder_lists(ref) as rec:
+            out, pen = net(t(q), t(abstract), t(fglob), None)
+        save('g8_dec_' + case['name'], output=out.numpy(), penult=pen.numpy()[:, ::8], **rec.lists())
 
 
 if __name__ == '__main__':

@@ -120,10 +120,13 @@ def gather_rows(points, idx):
 # ----------------------------------------------------------------------------
 # E3: PointTransformerLayer.forward   (model/point_transformer_layer.py:148-183)
 # ----------------------------------------------------------------------------
-def pt_layer(sd, x, pos, x2=None, pos2=None, num_neighbors=16):
+def pt_layer(sd, x, pos, x2=None, pos2=None, num_neighbors=16, idx=None):
+    """idx (B,N,K) int64: the neighbour lists of a particular reference run (its unstable argsort decides the order of
+    equidistant points); None = searched here as the reference does."""
     if x2 is None:
         x2, pos2 = x, pos
-    idx = knn_indices(pos, pos2, num_neighbors)                 # :167
+    if idx is None:
+        idx = knn_indices(pos, pos2, num_neighbors)             # :167
     nb_xyz = gather_rows(pos2, idx)                             # :168
     q = _lin(sd, 'to_q', x)                                     # :170
     k = gather_rows(_lin(sd, 'to_k', x2), idx)                  # :171
@@ -138,12 +141,12 @@ def pt_layer(sd, x, pos, x2=None, pos2=None, num_neighbors=16):
 # ----------------------------------------------------------------------------
 # E2: PointTransformerBlock.forward   (model/modules.py:45-67)
 # ----------------------------------------------------------------------------
-def pt_block(sd, x, p, x2=None, p2=None, num_neighbors=16):
+def pt_block(sd, x, p, x2=None, p2=None, num_neighbors=16, idx=None):
     assert x.shape[:2] == p.shape[:2]
     if x2 is not None:
         assert x2.shape[:2] == p2.shape[:2]
     y = _lin(sd, 'layer1', x)
-    y = pt_layer(_sub(sd, 'layer2.'), y, p, x2, p2, num_neighbors)
+    y = pt_layer(_sub(sd, 'layer2.'), y, p, x2, p2, num_neighbors, idx)
     y = _lin(sd, 'layer3', y)
     return x + y, p
 
@@ -285,11 +288,14 @@ def _act(name, x):
 #                      (model/implicit.py:271-445)
 # ----------------------------------------------------------------------------
 def decoder_forward(sd, cfg, points_query, points_abstract, features_global,
-                    features_abstract=None):
+                    features_abstract=None, knn_local=None, knn_cross=None):
     """points_query (N,4); points_abstract (M,3+E) (or (M,3) with features_abstract
     (M,E)); features_global (D,) -> (output (N,G), penult (N,H)).
     cfg keys: n_blocks, pos_encoding_freqs, activation, num_local_features,
-    cross_attn_neighbors, cross_attn_layers, d_latent, d_latent_local."""
+    cross_attn_neighbors, cross_attn_layers, d_latent, d_latent_local.
+    knn_local (N,8) / knn_cross (N,14) int64: the lists my_knn_torch (:328) / kNN_torch
+    (model/point_transformer_layer.py:167) returned in a particular reference run; the distances of knn_local
+    are recomputed with the same linalg.norm on the gathered differences."""
     if features_abstract is None:                                # :286-290
         features_abstract = points_abstract[..., 3:]
         points_abstract = points_abstract[..., :3]
@@ -301,7 +307,11 @@ def decoder_forward(sd, cfg, points_query, points_abstract, features_global,
 
     # D2 + D3: local feature interpolation (:328-342)
     abstract = torch.cat([points_abstract, features_abstract], dim=-1)
-    inds, dists = knn_with_dists(points_query, abstract, cfg['num_local_features'])
+    if knn_local is None:
+        inds, dists = knn_with_dists(points_query, abstract, cfg['num_local_features'])
+    else:
+        inds = torch.as_tensor(knn_local).long()
+        dists = torch.linalg.norm(points_query[:, None, :3] - points_abstract[inds], axis=-1, ord=2)   # :479-481
     w = 1.0 / (dists + 1e-4)
     w = F.normalize(w, p=1, dim=-1)
     f_local = torch.einsum('ik,ikf->if', w, features_abstract[inds])
@@ -320,7 +330,8 @@ def decoder_forward(sd, cfg, points_query, points_abstract, features_global,
         if i in use_at:                                          # :421-439
             bsd = _sub(sd, 'pt_blocks.%d.' % use_at[i])
             x = pt_block(bsd, x[None], p, features_abstract[None], points_abstract[None],
-                         cfg['cross_attn_neighbors'])[0][0]
+                         cfg['cross_attn_neighbors'],
+                         None if knn_cross is None else torch.as_tensor(knn_cross).long()[None])[0][0]
     penult = x
     out = _lin(sd, 'lin_out', _act(act, x))                      # :441-443
     return out, penult
@@ -466,7 +477,8 @@ def perform_inference(pcl_input, enc_sd, enc_cfg, dec_sd, dec_cfg, min_z, cube_b
                       time_idx, num_sample=16384, point_sample_mode='random', batch_size=1024,
                       predict_segmentation=False, track_mode='none', semantic_classes=13,
                       density_threshold=0.5, data_kind='', cube_mode=4, compress_air=False,
-                      pcl_input_sem=None, pcl_target_frame=None, point_occupancy_radius=0.2):
+                      pcl_input_sem=None, pcl_target_frame=None, point_occupancy_radius=0.2, neighbour_lists=None):
+    """neighbour_lists = (knn_local (N_q,8), knn_cross (N_q,14)): a reference run's own decoder lists (or None)."""
     if isinstance(pcl_input, np.ndarray):
         pcl_input = torch.from_numpy(pcl_input).unsqueeze(0)
     ti = track_channel(color_mode)
@@ -490,7 +502,9 @@ def perform_inference(pcl_input, enc_sd, enc_cfg, dec_sd, dec_cfg, min_z, cube_b
         outs = []
         for lo in range(0, points_query.shape[0], batch_size):                # :204
             q = torch.from_numpy(points_query[lo:lo + batch_size])
-            o, _ = decoder_forward(dec_sd, dec_cfg, q, pcl_abstract, f_global)    # :211
+            kw = {} if neighbour_lists is None else dict(knn_local=neighbour_lists[0][lo:lo + batch_size],
+                                                         knn_cross=neighbour_lists[1][lo:lo + batch_size])
+            o, _ = decoder_forward(dec_sd, dec_cfg, q, pcl_abstract, f_global, **kw)    # :211
             outs.append(squash_outputs(o, color_mode, predict_segmentation, track_mode,
                                        semantic_classes).numpy())
         runs_out.append(np.concatenate(outs, axis=0))

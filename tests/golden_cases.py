@@ -264,6 +264,26 @@ def dec_inputs(case):
     return q, abstract, fglob, ia, sd
 
 
+# Round 5: a decoder case whose abstract cloud has the STRUCTURE of the CARLA encoder's two-level output
+# (model/model.py:202-228: the finer level's points first, level id 1 in the last feature channel, then the coarse level,
+# level id 2 -- and every coarse point is one of the finer points, so its coordinates appear twice).  Equidistant
+# neighbours at the k = 8 / k = 14 rank are systematic here; the fixture stores the lists the reference took.
+DEC_TWOLEVEL_CASES = [
+    dict(name='carla_twolevel_q512', kind='carla', m_fine=1593, m_coarse=531, nq=512, seed=92),
+]
+
+
+def dec_twolevel_inputs(case):
+    q, abstract, fglob, ia, sd = dec_inputs(dict(case, m=case['m_fine'] + case['m_coarse']))
+    rng = _rng(case['seed'] + 5)
+    mf = case['m_fine']
+    chosen = np.sort(rng.choice(mf, size=case['m_coarse'], replace=False))
+    abstract[mf:, :3] = abstract[chosen, :3]
+    abstract[:mf, -1] = 1.0
+    abstract[mf:, -1] = 2.0
+    return q, abstract, fglob, ia, sd
+
+
 # ---------------------------------------------------------------- G9
 GRID_CASES = [
     dict(name='greater_8192', kind='greater', num_sample=8192, min_z=-1.0, cube_bounds=5.0, time_idx=3),

@@ -62,8 +62,9 @@ def lib():
         'occ4d_decoder_scene_floats': (C.c_int64, [DW, C.c_int]),
         'occ4d_decoder_prepare_scene_f32': (C.c_int, [DW, F, F, C.c_int64, F, C.c_int64, F, C.c_int, F, C.c_int, S]),
         'occ4d_decoder_query_workspace_floats': (C.c_int64, [DW, C.c_int, C.c_int, C.c_int]),
-        'occ4d_decoder_query_fwd_f32': (C.c_int, [DW, F, F, C.c_int, F, C.c_int64, C.c_int, F, C.c_int64, F, C.c_int64, F,
-                                                  C.c_int, C.c_void_p, S]),
+        'occ4d_decoder_query_fwd_f32': (C.c_int, [DW, F, F, C.c_int, F, C.c_int64, C.c_int, I, I, F, C.c_int64, F, C.c_int64,
+                                                  F, C.c_int, C.c_void_p, S]),
+        'occ4d_knn_dists_f32': (C.c_int, [F, C.c_int64, C.c_int, F, C.c_int64, C.c_int, I, C.c_int, C.c_int, F, S]),
         'occ4d_pack_trunk_rows_f32': (C.c_int, [F, C.c_int64, C.c_int, F, S]),
         'occ4d_pack_trunk_cols_f32': (C.c_int, [F, C.c_int64, F, S]),
         'occ4d_pack_trunk4_rows_f32': (C.c_int, [F, C.c_int64, C.c_int, F, S]),
@@ -219,7 +220,7 @@ def decoder_struct(sd, ia, keep):
     return w
 
 
-def run_decoder(lib, w, q, abstract, fglob, flags=0, batch=None):
+def run_decoder(lib, w, q, abstract, fglob, flags=0, batch=None, knn_local=None, knn_cross=None):
     m, n = abstract.shape[0], q.shape[0]
     prep = buf(lib.occ4d_decoder_prepared_floats(C.byref(w), flags))
     ok(lib, lib.occ4d_decoder_prepare_f32(C.byref(w), ptr(prep), flags, stream()))
@@ -234,6 +235,8 @@ def run_decoder(lib, w, q, abstract, fglob, flags=0, batch=None):
     for lo in range(0, n, batch):
         c = min(batch, n - lo)
         ok(lib, lib.occ4d_decoder_query_fwd_f32(C.byref(w), ptr(prep), ptr(scene), m, ptr(q[lo:]), q.stride(0), c,
+                                                ptr(None if knn_local is None else knn_local[lo:]),
+                                                ptr(None if knn_cross is None else knn_cross[lo:]),
                                                 ptr(out[lo:]), out.stride(0), ptr(pen[lo:]), pen.stride(0), ptr(ws), flags,
                                                 None, stream()))
     torch.cuda.synchronize()
@@ -250,6 +253,35 @@ def test_g8_decoder_through_the_c_abi(lib, case, flags):
     g = load_golden('g8_dec_' + case['name'])
     assert err(out, g['output']) <= 1e-4
     assert err(pen[:, ::8], g['penult']) <= 1e-4
+
+
+@pytest.mark.parametrize('flags', [0, 1], ids=['default', 'unfused'])
+@pytest.mark.parametrize('case', gc.DEC_TWOLEVEL_CASES, ids=lambda c: c['name'])
+def test_g8t_two_level_cloud_with_the_reference_lists_through_the_c_abi(lib, case, flags):
+    """CARLA-structured abstract cloud (every coarse point twice): the caller hands the library the neighbour lists the
+    reference run took (knn_local / knn_cross of occ4d_decoder_query_fwd_f32) and EVERY row matches the reference."""
+    q, abstract, fglob, ia, sd = gc.dec_twolevel_inputs(case)
+    g = load_golden('g8_dec_' + case['name'])
+    keep = []
+    w = decoder_struct(sd, ia, keep)
+    kl, kc = dev(g['knn_local']), dev(g['knn_cross'])
+    assert kl.dtype == torch.int32 and kc.dtype == torch.int32
+    out, pen = run_decoder(lib, w, dev(q), dev(abstract), dev(fglob), flags, batch=200, knn_local=kl, knn_cross=kc)
+    assert err(out, g['output']) <= 1e-4
+    assert err(pen[:, ::8], g['penult']) <= 1e-4
+    # the distances the library derives from the given indices are the reference's, bit for bit
+    d = torch.empty(kl.shape, dtype=torch.float32, device='cuda')
+    a = dev(abstract)
+    ok(lib, lib.occ4d_knn_dists_f32(ptr(dev(q)), 4, q.shape[0], ptr(a), a.stride(0), a.shape[0], ptr(kl), kl.shape[1], 1,
+                                    ptr(d), stream()))
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy(), g['knn_local_dists'])
+    # out-of-range entries of a caller's list are clamped, never dereferenced
+    bad = kc.clone()
+    bad[::7, 3] = 1 << 30
+    bad[::5, 0] = -5
+    out2, _ = run_decoder(lib, w, dev(q), dev(abstract), dev(fglob), flags, knn_local=kl, knn_cross=bad)
+    assert torch.isfinite(out2).all()
 
 
 @pytest.mark.parametrize('case', gc.DEC_REGIME_CASES, ids=lambda c: c['name'])

@@ -286,6 +286,76 @@ def test_perform_inference(pk, case):
     assert all(v.dtype == np.float32 for k, v in res.items() if k not in ('output_air',))
 
 
+CARLA_INFER = [c for c in gc.INFER_CASES + gc.INFER_PAD_CASES if c['kind'] == 'carla']
+
+
+@pytest.mark.parametrize('case', CARLA_INFER, ids=lambda c: c['name'])
+def test_perform_inference_carla_every_row_with_the_reference_lists(pk, case):
+    """Round 5.  CARLA's two-level abstract cloud holds every coarse point twice; the reference's
+    unstable sort decides which of two equidistant points sits at rank k, so 42 % of these queries used to be masked
+    out of the comparison with the reference.  The fixture now carries the neighbour lists the reference run took;
+    fed to the product (perform_inference(neighbour_lists=...) -> LocalPclResnetFC.forward(knn_local, knn_cross) ->
+    occ4d_decoder_query_fwd_f32), EVERY row is compared with the reference's output at 1e-4: no mask."""
+    pcl, pa, ia, inf, esd, dsd = gc.infer_inputs(case)
+    enc = pk.model.PointCompletionNetV3(**pa).cuda().eval()
+    enc.load_state_dict(esd)
+    dec = pk.implicit.LocalPclResnetFC(**ia).cuda().eval()
+    dec.load_state_dict(dsd)
+    g = load_golden('g10_infer_' + case['name'])
+    res = pk.inference.perform_inference(
+        pcl.clone(), None, None, [enc, dec], torch.device('cuda:0'), 'if', inf['min_z'], inf['cube_bounds'],
+        inf['color_mode'], case['time_idx'], None, sample_implicit=True, num_sample=case['num_sample'],
+        point_sample_mode='grid', batch_size=case['batch_size'],
+        predict_segmentation=inf['predict_segmentation'], track_mode='none', semantic_classes=13,
+        density_threshold=0.5, data_kind=inf['data_kind'], cube_mode=4, compress_air=True,
+        neighbour_lists=(g['knn_local'], g['knn_cross']))
+    close(res['pcl_abstract'], g['pcl_abstract'])
+    close(res['implicit_output'], g['implicit_output'])               # 100 % of the rows
+    dens = g['implicit_output'][:, 0]
+    slack = int((np.abs(dens - 0.5) < TOL).sum())
+    assert abs(res['output_solid'].shape[0] - int(g['n_solid'][0])) <= slack
+    from oracle import path as op
+    amb = op.tie_ambiguous(T(res['points_query']), T(g['pcl_abstract']), ia['num_local_features'],
+                           ia['cross_attn_neighbors']).numpy()
+    assert amb.mean() > 0.2                                            # the rows the mask used to hide are in there
+    print('\n[g10 %s] %d rows, %.1f %% tie-ambiguous, max |hip - ref| %.3g' % (
+        case['name'], amb.size, 100 * amb.mean(), np.abs(res['implicit_output'] - g['implicit_output']).max()))
+
+
+@pytest.mark.parametrize('case', gc.DEC_TWOLEVEL_CASES, ids=lambda c: c['name'])
+def test_decoder_two_level_cloud(pk, case):
+    """G8t: decoder on an abstract cloud with the CARLA encoder's two-level structure (coincident coordinates), (a) with
+    the reference's own lists: every row at 1e-4; (b) searched by the library: the documented lowest-index rule, equal
+    to the oracle under that rule on every row and to the reference wherever the reference is defined; (c) the training
+    (autograd) forward takes the same lists."""
+    from oracle import path as op
+    q, abstract, fglob, ia, sd = gc.dec_twolevel_inputs(case)
+    g = load_golden('g8_dec_' + case['name'])
+    net = pk.implicit.LocalPclResnetFC(**ia).cuda().eval()
+    net.load_state_dict(sd)
+    kl, kc = dev(g['knn_local']), dev(g['knn_cross'])
+    with torch.no_grad():
+        out, pen = net(dev(q), dev(abstract), dev(fglob), None, knn_local=kl, knn_cross=kc)
+        out64, _ = net(dev(q), dev(abstract), dev(fglob), None, knn_local=kl.long(), knn_cross=kc.long()[None])
+        free, _ = net(dev(q), dev(abstract), dev(fglob), None)
+    close(out, g['output'])
+    close(pen[:, ::8], g['penult'])
+    assert torch.equal(out, out64)
+    with op.stable_ties():
+        ref, _ = op.decoder_forward(sd, ia, T(q), T(abstract), T(fglob))
+    close(free, ref)
+    amb = op.tie_ambiguous(T(q), T(abstract), ia['num_local_features'], ia['cross_attn_neighbors']).numpy()
+    close(free[~amb], g['output'][~amb])
+    d = pk.ops.knn_dists(dev(q), dev(abstract), kl, metric=1)
+    assert np.array_equal(d.cpu().numpy(), g['knn_local_dists'])
+    idx, dist = pk.ops.knn(dev(q), dev(abstract), 8, metric=1, return_dist=True)
+    assert torch.equal(pk.ops.knn_dists(dev(q), dev(abstract), idx, metric=1), dist)
+    fa = dev(abstract).clone().requires_grad_(True)
+    out_t, _ = net(dev(q), fa, dev(fglob), None, knn_local=kl, knn_cross=kc)
+    assert out_t.requires_grad
+    close(out_t, g['output'])
+
+
 # ------------------------------------------------------------------ fused vs unfused attention
 @pytest.mark.parametrize('k,n,dim,dim2', [(14, 1003, 416, 288), (13, 100, 416, 288), (12, 9, 416, 288),
                                           (8, 37, 416, 288), (7, 500, 416, 288), (3, 64, 416, 288),

@@ -43,6 +43,22 @@ def test_sampler_replays_reference_draws(pk, case):
     assert all(v.is_cuda for v in res[:4])
 
 
+@pytest.mark.parametrize('case', gc.SAMPLER_CASES[:2], ids=lambda c: c['name'])
+def test_sampler_takes_host_resident_sizes_as_the_reference_pipeline_passes_them(pk, case):
+    """The reference's pipeline moves pcl_target to the GPU and leaves meta_data['pcl_target_size'] (and the valo id
+    tensors) on the host (pipeline.py:75-91); the few-reads path reads sizes and device counts in one transfer, which
+    must not mix devices."""
+    g = load_golden('g13_sampler_' + case['name'])
+    frames, sizes, valo, num_valo = gc.sampler_inputs(case)
+    sampler = pk.geometry.GuidedImplicitPointSampler(_Log(), **gc.sampler_config(case))
+    np.random.seed(case['seed'])
+    torch.manual_seed(case['seed'])
+    res = sampler([torch.from_numpy(f).cuda() for f in frames], [torch.from_numpy(z) for z in sizes],
+                  torch.from_numpy(valo), torch.from_numpy(num_valo), case['time_idx'])
+    for key, val in zip(KEYS, res):
+        assert np.array_equal(val.cpu().numpy(), g[key]), key
+
+
 def test_filter_air_solid_gap_matches_oracle(pk):
     from oracle import sampler as osamp
     rng = np.random.default_rng(4)
