@@ -489,9 +489,8 @@ def main():
         if host_boundary is not None:
             line['host_boundary'] = host_boundary
         # BASELINE configs[2] and configs[4] on the same driver-timed line: each leg is its own
-        # process on this GPU, K timed steps between fences exactly as above, its own `roofline` object.  The CPU
-        # baseline (16 host threads) runs beside them.
-        cpu_child = cpu_baseline_start(args.kind) if world == 1 and not args.no_cpu_baseline else None
+        # process on this GPU, K timed steps between fences exactly as above, its own `roofline` object.  (The CPU
+        # baseline starts after them: beside them its 16 threads cost the host-bound eager training step 1.5 ms.)
         if world == 1 and extra and not args.no_secondary and args.kind == 'greater':
             del out
             torch.cuda.empty_cache()
@@ -502,8 +501,8 @@ def main():
                 'bench_train.py', ['--steps', '10', '--warmup', '3'],
                 ['metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'scaling', 'graph',
                  'attention_backward', 'geometry_prefetch', 'peak_mem_gb', 'roofline', 'config', 'losses'])
-        if cpu_child is not None:
-            line['cpu_baseline'] = cpu_baseline(args.kind, child=cpu_child)
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args.kind)
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -207,6 +207,18 @@ int occ4d_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const f
 int occ4d_maxpool_gather_f32(const float* y, int64_t ldy, const int32_t* idx, int n_out, int k,
                              int d, float* z, int64_t ldz, void* stream);
 
+/* Strided row copy / fill as kernels (never hipMemcpy / hipMemset: kernel nodes in every capture): dst[i, 0:d] =
+ * src[i, 0:d] / value -- the stride-8 xyz view of the input cloud made contiguous (model/model.py:168), the
+ * pos | features concatenation of the encoder's outputs and their level-id channel (model/model.py:202-228). */
+int occ4d_copy_rows_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int n, int d, void* stream);
+int occ4d_fill_rows_f32(float* dst, int64_t ld, int n, int d, float value, void* stream);
+/* Next level of a nested farthest-point chain (replaces the FPS launch of model/modules.py:133-135 for
+ * the levels below the first when every level starts at its point 0): order (>= m) = level 0's selection order (original
+ * indices), orig (n) = ascending original indices of the current cloud's points.  out_pos (m): ascending positions in the
+ * current cloud of the first m picks; out_orig (m) = orig[out_pos] (the next cloud's `orig`).  n <= 32768. */
+int occ4d_nested_fps_level_i32(const int32_t* order, const int32_t* orig, int n, int m, int32_t* out_pos,
+                               int32_t* out_orig, void* stream);
+
 /* gather_rows: out[i,:] = src[idx[i],:]  (index_points, :102-113; p_flat[inds], modules.py:137) */
 int occ4d_gather_rows_f32(const float* src, int64_t lds, const int32_t* idx, int n_out, int d,
                           float* out, int64_t ldo, void* stream);
@@ -495,6 +507,7 @@ int occ4d_broadcast_rows_f32(const float* vec, float scale, int n, int d, float*
 #define OCC4D_PATH_BF16X3 4         /* opt-in: attention-logit GEMMs on split-bf16 MFMAs (implies FIRST_GEN) */
 #define OCC4D_PATH_GENERIC_LINEAR 8 /* generic Linear kernel instead of the row-resident trunk kernels */
 #define OCC4D_PATH_TRUNK4 16        /* half-CU trunk kernels (csrc/trunk4.hip) */
+#define OCC4D_PATH_FUSED_INTERP 32 /* A/B only (slower): lin_z table term of block i + 1 in block i's epilogue */
 
 /* Stage packers as device kernels (layouts: occ4d_resblock_f32 / occ4d_resblock4_f32 / occ4d_pt_cross_attn16p_f32 /
  * occ4d_pt_cross_attn_bf16x3_f32 above).  w: (n_out, 416) row-major with row stride ldw. */

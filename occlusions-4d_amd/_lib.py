@@ -30,7 +30,7 @@ class LinearArgs(C.Structure):
 
 
 # path-level entry points (include/occ4d.h, last section)
-PATH_DEFAULT, PATH_UNFUSED, PATH_FIRST_GEN, PATH_BF16X3, PATH_GENERIC_LINEAR, PATH_TRUNK4 = 0, 1, 2, 4, 8, 16
+PATH_DEFAULT, PATH_UNFUSED, PATH_FIRST_GEN, PATH_BF16X3, PATH_GENERIC_LINEAR, PATH_TRUNK4, PATH_FUSED_INTERP = 0, 1, 2, 4, 8, 16, 32
 PROFILE_CROSS_ATTN, PROFILE_RESBLOCK, PROFILE_ROWLIN = 1, 2, 3
 MAX_BLOCKS, MAX_CROSS = 16, 4
 PROFILE_KINDS = {'cross_attn': PROFILE_CROSS_ATTN, 'resblock': PROFILE_RESBLOCK, 'rowlin': PROFILE_ROWLIN}
@@ -71,6 +71,9 @@ SIGNATURES = {
     'occ4d_fps_start_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, C.c_int, _i, _i, _s]),
     'occ4d_fps_coop_workspace_bytes': (C.c_int64, []),
     'occ4d_fps_coop_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _i, _i, _s, _s]),
+    'occ4d_copy_rows_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, C.c_int, C.c_int, _s]),
+    'occ4d_fill_rows_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, C.c_float, _s]),
+    'occ4d_nested_fps_level_i32': (C.c_int, [_i, _i, C.c_int, C.c_int, _i, _i, _s]),
     'occ4d_fps_repair_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, C.c_int, _i, _i, _s, _s]),
     'occ4d_fps_coop_debug': (C.c_int, [C.c_uint, C.c_int]),
     'occ4d_linear_f32': (C.c_int, [C.POINTER(LinearArgs), _s]),

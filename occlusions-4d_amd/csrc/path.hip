@@ -631,16 +631,27 @@ int decoder_forward(const occ4d_decoder_weights& w, const DecoderLayout& L, cons
     int next_cross = 0;
     for (int i = 0; i < L.nB; ++i) {
       if (!dry) {
-        // x += lin_z[i](features_query) in the exact-in-R form
-        TRY(occ4d_interp_add_f32(x, ldx, scene + S.zconst + (int64_t)i * H, scene + S.ztab + (int64_t)i * H,
-                                 (int64_t)L.nB * H, idx8, w8, c, w.k_local, H, st));
+        // x += lin_z[i](features_query) in the exact-in-R form.  OCC4D_PATH_FUSED_INTERP (A/B only,
+        // measured slower: DESIGN.md 6e): the term of block i + 1 is added in block i's epilogue instead, wherever no
+        // cross-attention layer sits between the two blocks.
+        const bool fuse_ok = (flags & OCC4D_PATH_FUSED_INTERP) && L.resblock && !L.trunk4;
+        const bool cross_behind = next_cross < L.nC && w.cross_after[next_cross] == i;
+        const bool cross_before = i > 0 && next_cross > 0 && w.cross_after[next_cross - 1] == i - 1;
+        const bool had_it = fuse_ok && i > 0 && !cross_before;           // block i - 1's epilogue added this block's term
+        const bool give_next = fuse_ok && i + 1 < L.nB && !cross_behind;
+        if (!had_it)
+          TRY(occ4d_interp_add_f32(x, ldx, scene + S.zconst + (int64_t)i * H, scene + S.ztab + (int64_t)i * H,
+                                   (int64_t)L.nB * H, idx8, w8, c, w.k_local, H, st));
         if (L.resblock) {
           E.before(OCC4D_PROFILE_RESBLOCK);
+          const float* zc = give_next ? scene + S.zconst + (int64_t)(i + 1) * H : nullptr;
+          const float* zt = give_next ? scene + S.ztab + (int64_t)(i + 1) * H : nullptr;
           const int rc = L.trunk4
               ? occ4d_resblock4_f32(x, ldx, x, ldx, prep + L.w0p[i], w.fc0_b[i], prep + L.w1p[i], w.fc1_b[i], nullptr,
                                     nullptr, 0, nullptr, nullptr, 0, c, st)
-              : occ4d_resblock_f32(x, ldx, x, ldx, prep + L.w0p[i], w.fc0_b[i], prep + L.w1p[i], w.fc1_b[i], nullptr,
-                                   nullptr, 0, nullptr, nullptr, 0, c, st);
+              : occ4d_resblock_f32(x, ldx, x, ldx, prep + L.w0p[i], w.fc0_b[i], prep + L.w1p[i], w.fc1_b[i], zc, zt,
+                                   (int64_t)L.nB * H, give_next ? idx8 : nullptr, give_next ? w8 : nullptr,
+                                   give_next ? w.k_local : 0, c, st);
           E.after(OCC4D_PROFILE_RESBLOCK);
           TRY(rc);
         } else {

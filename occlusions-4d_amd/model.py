@@ -83,7 +83,7 @@ class PointCompletionNetV3(torch.nn.Module):
             ev.record(side)
             out[i] = (payload, clouds, ev)
         with torch.cuda.stream(side):
-            cur = [pos[b].contiguous() for b in range(pos.shape[0])]
+            cur = [ops.copy_rows(pos[b]) for b in range(pos.shape[0])]     # (the stride-8 xyz view, packed)
             nested = [modules.NestedFps() for _ in cur]      # (the levels' farthest-point subsets are prefixes of level 0's)
             for c in cur:
                 # allocated on the side stream, read by kernels on the main stream: without this the block could be
@@ -204,18 +204,33 @@ class PointCompletionNetV3(torch.nn.Module):
                         if train:
                             y = ops.stack_batch([autograd.linear(x[b], skip) for b in range(B)])
                             y = torch.cat([y[..., :-1], torch.full_like(y[..., :1], j + 1.0)], dim=-1)
-                        else:
-                            y = ops.stack_batch([ops.linear(x[b], skip.weight, skip.bias) for b in range(B)])
-                            y[..., -1] = j + 1.0
-                        skips.append(torch.cat([pos, y], dim=-1))
-        if self.output_featurized:
+                            skips.append(torch.cat([pos, y], dim=-1))
+                        else:     # (kept as parts: written in place into the output below)
+                            skips.append((pos, [ops.linear(x[b], skip.weight, skip.bias) for b in range(B)], j + 1.0))
+        if self.output_featurized and not train:
+            # pos | features of every level written IN PLACE into one (B, M, 3 + D) tensor by the library's row-copy /
+            # fill kernels (model/model.py:217-228: cat([pos, x]), level id in the last channel, cat of the levels)
+            parts = skips + [(pos, [x[b] for b in range(B)], float(self.abstract_levels))]
+            assert len(parts) == self.abstract_levels
+            total = sum(p.shape[1] for p, _, _ in parts)
+            D = x.shape[-1]
+            pcl_out = torch.empty((B, total, 3 + D), dtype=torch.float32, device=x.device)
+            at = 0
+            for p, feats, level in parts:
+                n = p.shape[1]
+                for b in range(B):
+                    rows = pcl_out[b, at:at + n]
+                    ops.copy_rows(p[b], out=rows[:, :3])
+                    ops.copy_rows(feats[b], out=rows[:, 3:])
+                    if self.abstract_levels > 1:
+                        ops.fill_rows(rows[:, -1:], level)
+                at += n
+        elif self.output_featurized:
             pcl_out = torch.cat([pos, x], dim=-1)
             if self.abstract_levels > 1:
-                if train:    # (no in-place write on a taped tensor)
-                    pcl_out = torch.cat([pcl_out[..., :-1],
-                                         torch.full_like(pcl_out[..., :1], float(self.abstract_levels))], dim=-1)
-                else:
-                    pcl_out[..., -1] = self.abstract_levels
+                # (no in-place write on a taped tensor)
+                pcl_out = torch.cat([pcl_out[..., :-1],
+                                     torch.full_like(pcl_out[..., :1], float(self.abstract_levels))], dim=-1)
                 assert len(skips) == self.abstract_levels - 1
                 pcl_out = torch.cat([torch.cat(skips, dim=1), pcl_out], dim=1)
         else:

@@ -63,21 +63,22 @@ class NestedFps:
     (level-0) index of every point of the current level's cloud."""
 
     def __init__(self):
-        self.order = None          # (m_0) int64 original indices in selection order
-        self.orig = None           # (n_l) int64 ascending original indices of the current cloud's points
+        self.order = None          # (m_0) int32 original indices in selection order
+        self.orig = None           # (n_l) int32 ascending original indices of the current cloud's points
 
     def begin(self, order, inds_sorted):
-        self.order, self.orig = order.long(), inds_sorted.long()
+        self.order, self.orig = order, inds_sorted
 
     def usable(self, n_points, m):
-        return self.order is not None and self.orig.shape[0] == n_points and m <= self.order.shape[0]
+        return (self.order is not None and self.orig.shape[0] == n_points and m <= self.order.shape[0]
+                and n_points <= 32768)
 
     def next_level(self, m):
-        """Ascending int32 positions (in the current cloud) of the next level's subset = the first m picks."""
-        pos = torch.searchsorted(self.orig, self.order[:m])
-        inds = torch.sort(pos)[0]
-        self.orig = self.orig[inds]
-        return inds.to(torch.int32)
+        """Ascending int32 positions (in the current cloud) of the next level's subset = the first m picks: one small
+        library kernel (binary search of every pick in the sorted `orig` + bit-set compaction; round 5 -- the
+        searchsorted / sort / index sequence of round 4 was the last ATen work on the encode path)."""
+        inds, self.orig = ops.nested_fps_level(self.order, self.orig, m)
+        return inds
 
 
 POOL_FROM_SELF_KNN = os.environ.get('OCC4D_POOL_FROM_SELF_KNN', '1') != '0'      # (0: one kNN launch per DownTransition)
@@ -92,8 +93,7 @@ def pool_neighbours_from_self_knn(self_idx, inds, k):
     p's.  self_idx (N, K) int32, inds (n_new) int32 -> (n_new, k) int32: a row gather instead of a kNN launch (the int32
     bit patterns travel through the fp32 gather kernel untouched)."""
     assert self_idx.dtype == torch.int32 and self_idx.is_contiguous() and self_idx.shape[1] >= k
-    rows = ops.gather_rows(self_idx.view(torch.float32), inds).view(torch.int32)
-    return rows[:, :k].contiguous()
+    return ops.gather_rows(self_idx.view(torch.float32), inds, cols=k).view(torch.int32)
 
 
 class DownTransition(torch.nn.Module):
@@ -123,9 +123,7 @@ class DownTransition(torch.nn.Module):
         one long chain on a single CU) back to back on a side stream (model.py).  `nested`: the NestedFps of the chain
         this cloud belongs to; with a deterministic start the subset then comes from the first level's selection order."""
         n_new = int(np.ceil(p.shape[0] / self.factor))
-        # (not while a stream is being captured: the prefix arithmetic sorts with torch, and only kernels of this library
-        # are safe inside a captured region on this runtime -- DESIGN.md 7b)
-        if nested is not None and NESTED_FPS and not self.fps_random_start and not torch.cuda.is_current_stream_capturing():
+        if nested is not None and NESTED_FPS and not self.fps_random_start:
             if nested.usable(p.shape[0], n_new):
                 inds = nested.next_level(n_new)
                 return (inds, ops.gather_rows(p, inds))

@@ -104,7 +104,8 @@ def _aligned_rows(t, name, k_pad=None):
         t = torch.nn.functional.pad(t, (0, k_pad - t.shape[1]))        # contiguous copy, ld = k_pad
         ld = k_pad
     if t.data_ptr() % 16 or ld % 4:
-        t = t.contiguous()
+        # (a library kernel, not .contiguous(): e.g. the abstract cloud's feature columns, a view 12 bytes into its rows)
+        t = copy_rows(t) if (t.is_cuda and t.dtype == torch.float32 and not t.requires_grad) else t.contiguous()
         if t.shape[1] % 4:
             pad = 4 - t.shape[1] % 4
             t = torch.nn.functional.pad(t, (0, pad))
@@ -504,11 +505,46 @@ def maxpool_gather(y, idx):
     return z
 
 
-def gather_rows(src, idx):
+def copy_rows(src, out=None):
+    """Contiguous (or `out`: any row-strided fp32 destination of the same shape) copy of a row-strided 2-D fp32 view, by
+    a library kernel (the stride-8 xyz view of a point cloud; the column blocks of the encoder's output)."""
+    src, lds = _rows(_dev(src, name='src'), 'src')
+    n, d = src.shape
+    if out is None:
+        out = torch.empty((n, d), dtype=torch.float32, device=src.device)
+    o, ldo = _rows(_dev(out, name='out'), 'out')
+    assert o is out and tuple(o.shape) == (n, d)
+    _lib.check(_lib.lib().occ4d_copy_rows_f32(_ptr(o), ldo, _ptr(src), lds, n, d, _stream()))
+    return out
+
+
+def fill_rows(out, value):
+    """out[:, :] = value for a row-strided 2-D fp32 view (the level-id channel of the abstract cloud)."""
+    o, ldo = _rows(_dev(out, name='out'), 'out')
+    assert o is out
+    _lib.check(_lib.lib().occ4d_fill_rows_f32(_ptr(o), ldo, o.shape[0], o.shape[1], float(value), _stream()))
+    return out
+
+
+def nested_fps_level(order, orig, m):
+    """(positions (m) int32 ascending in the current cloud, their original indices (m) int32): the first m picks of the
+    chain's selection order `order` located in the current cloud whose points have ascending original indices `orig`."""
+    assert order.dtype == torch.int32 and orig.dtype == torch.int32 and order.is_cuda and orig.is_cuda
+    assert order.is_contiguous() and orig.is_contiguous() and order.numel() >= m
+    pos = torch.empty((m,), dtype=torch.int32, device=orig.device)
+    nxt = torch.empty((m,), dtype=torch.int32, device=orig.device)
+    _lib.check(_lib.lib().occ4d_nested_fps_level_i32(_ptr(order), _ptr(orig), orig.numel(), int(m), _ptr(pos), _ptr(nxt),
+                                                     _stream()))
+    return pos, nxt
+
+
+def gather_rows(src, idx, cols=None):
+    """out[i, :] = src[idx[i], :cols] (cols None = the whole row)."""
     src, lds = _rows(_dev(src, name='src'), 'src')
     idx = _dev(idx, torch.int32, 'idx').contiguous()
     n_out = idx.numel()
-    d = src.shape[1]
+    d = src.shape[1] if cols is None else int(cols)
+    assert 0 < d <= src.shape[1]
     out = torch.empty((n_out, d), dtype=torch.float32, device=src.device)
     _lib.check(_lib.lib().occ4d_gather_rows_f32(_ptr(src), lds, _ptr(idx), n_out, d, _ptr(out), d, _stream()))
     return out

@@ -33,6 +33,8 @@ USE_TRUNK4 = os.environ.get('OCC4D_TRUNK4', '0') != '0'
 # 'f32' (default): every GEMM exact fp32.  'bf16x3': the attention-logit GEMM of the fused kernel on split-bf16 MFMAs
 # (occ4d_pt_cross_attn_bf16x3_f32); everything else unchanged.  Opt-in.
 LOGIT_PRECISION = os.environ.get('OCC4D_LOGIT_PRECISION', 'f32')
+# A/B only (measured slower): the lin_z table term of block i + 1 added in block i's epilogue
+FUSED_INTERP = os.environ.get('OCC4D_FUSED_INTERP', '0') != '0'
 
 
 def path_flags():
@@ -50,6 +52,8 @@ def path_flags():
         f |= L.PATH_GENERIC_LINEAR
     if USE_TRUNK4:
         f |= L.PATH_TRUNK4
+    if FUSED_INTERP:
+        f |= L.PATH_FUSED_INTERP
     return f
 
 

@@ -192,3 +192,82 @@ def test_fps_coop_several_samples_per_exchange_on_tie_storms(pk, kind, n, m, wgs
     assert torch.equal(order, ref_order)
     if int(torch.unique(order).numel()) == m:          # (once every distinct point is taken the rule re-picks: the sorted
         assert torch.equal(idx, ref_idx)               # list then has fewer than m entries and an unspecified tail)
+
+
+# ------------------------------------------------------------------ time-out handling (round 5: no poisoned step)
+@pytest.mark.parametrize('n,m,start,fail_round', [(28672, 7168, 0, 5), (28672, 9558, 123, 0), (16385, 5462, 0, 700),
+                                                  (2048, 683, 7, 2)])
+def test_fps_coop_forced_timeout_is_repaired_in_stream_order(pk, n, m, start, fail_round):
+    """A bounded inter-workgroup spin that times out (declared here in a chosen round through occ4d_fps_coop_debug)
+    must never hand undefined indices to a consumer: the gated single-workgroup launch behind the cooperative kernel
+    recomputes the selection -- same indices, status word 2 -- and the host only warns.  The consumer here is queued on
+    the stream right behind the launch, without any host look at the status (what a training step does)."""
+    p = torch.from_numpy(_cloud(n, 5 * n + m, dup=True)).cuda()
+    want_idx, want_order = pk.ops.fps(p, m, start=start, return_order=True)
+    pk.ops.fps_coop_debug(fail_round=fail_round)
+    try:
+        pk.ops.check_pending()
+        idx, order = pk.ops.fps_coop(p, m, start=start, n_workgroups=16, return_order=True, check=False)
+        gathered = p[idx.long()]                                   # a consumer in stream order
+        with pytest.warns(UserWarning, match='recomputed by the single-workgroup kernel'):
+            pk.ops.check_pending()                                 # ...and the deferred look only warns
+        assert torch.equal(idx, want_idx) and torch.equal(order, want_order)
+        assert torch.equal(gathered, p[want_idx.long()])
+        with pytest.warns(UserWarning, match='recomputed by the single-workgroup kernel'):
+            idx2 = pk.ops.fps_coop(p, m, start=start, n_workgroups=16, check=True)
+        assert torch.equal(idx2, want_idx)
+        if n >= pk.ops.FPS_COOP_MIN_POINTS:                        # the route a training step takes
+            idx3 = pk.ops.fps_auto(p, m, start=start)
+            assert torch.equal(idx3, want_idx)
+            with pytest.warns(UserWarning):
+                pk.ops.check_pending()
+    finally:
+        pk.ops.fps_coop_debug()
+        pk.ops.check_pending()
+    # with the default settings the status is 0 again: no warning
+    import warnings as _w
+    with _w.catch_warnings():
+        _w.simplefilter('error')
+        idx4 = pk.ops.fps_coop(p, m, start=start, n_workgroups=16, check=True)
+    assert torch.equal(idx4, want_idx)
+
+
+def test_fps_coop_timeout_above_the_repair_range_retries_then_raises(pk):
+    """Clouds above the single-workgroup kernel's 32768 points (the dataloader's whole clips, host-checked): a timed-out
+    launch is relaunched; a time-out that persists (forced here) raises instead of returning undefined indices."""
+    p = torch.from_numpy(_cloud(40000, 3)).cuda()
+    pk.ops.fps_coop_debug(fail_round=1)
+    try:
+        with pytest.warns(UserWarning, match='relaunching'):
+            with pytest.raises(RuntimeError, match='timed out'):
+                pk.ops.fps_coop(p, 2000, check=True)
+    finally:
+        pk.ops.fps_coop_debug()
+    assert pk.ops.fps_coop(p, 2000, check=True).shape == (2000,)
+
+
+def test_captured_fps_coop_replays_the_repair(pk):
+    """Inside a hipGraph the host never looks at the status word; the gated repair launch is captured with the
+    cooperative kernel, so a replay that times out still leaves valid indices."""
+    p = torch.from_numpy(_cloud(28672, 77)).cuda()
+    want = pk.ops.fps(p, 7168)
+    out = torch.zeros(7168, dtype=torch.int32, device='cuda')
+    pk.ops.fps_coop_debug(fail_round=3)
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            pk.ops.fps_coop(p, 7168, n_workgroups=16, check=False)           # warm-up outside the capture
+        torch.cuda.current_stream().wait_stream(side)
+        with pytest.warns(UserWarning):
+            pk.ops.check_pending()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out.copy_(pk.ops.fps_coop(p, 7168, n_workgroups=16, check=False))
+        for _ in range(2):
+            out.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, want)
+    finally:
+        pk.ops.fps_coop_debug()

@@ -247,3 +247,65 @@ def test_encoder_with_and_without_the_derived_geometry_is_bit_identical():
         (pk.modules.NESTED_FPS, pk.modules.POOL_FROM_SELF_KNN) = old
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert all(torch.equal(x, y) for x, y in zip(outs[0][2], outs[1][2]))
+
+
+# ------------------------------------------------------------------ round 5: the nested levels as ONE library kernel
+@pytest.mark.parametrize('n,m_levels', [(14336, (4779, 1593, 531)), (28672, (9558, 3186, 1062)), (2048, (683, 228, 76)),
+                                        (100, (34, 12, 4)), (3, (1, 1, 1))])
+def test_nested_level_kernel_equals_searchsorted_sort(pk, n, m_levels):
+    """occ4d_nested_fps_level_i32 (binary search of every pick in the sorted original indices + bit-set compaction)
+    against the torch expression it replaces (searchsorted + sort + index), level by level down a chain."""
+    rng = np.random.default_rng(n)
+    p = torch.from_numpy(rng.uniform(-5, 5, size=(n, 3)).astype(np.float32)).cuda()
+    inds, order = pk.ops.fps_auto(p, m_levels[0], start=0, return_order=True)
+    orig_t = inds.long()
+    orig_k = inds
+    for m in m_levels[1:]:
+        pos_t = torch.sort(torch.searchsorted(orig_t, order[:m].long()))[0]
+        pos_k, nxt_k = pk.ops.nested_fps_level(order, orig_k, m)
+        assert pos_k.dtype == torch.int32 and torch.equal(pos_k.long(), pos_t)
+        orig_t = orig_t[pos_t]
+        assert torch.equal(nxt_k.long(), orig_t)
+        orig_k = nxt_k
+
+
+def test_nested_level_kernel_with_repeated_picks(pk):
+    """A constant cloud (fewer distinct points than samples): the selection order repeats index 0 and so does the sorted
+    subset; the kernel returns what the torch expression returned (repeated positions), nothing uninitialised."""
+    p = torch.zeros((64, 3), device='cuda')
+    inds, order = pk.ops.fps(p, 22, return_order=True)
+    assert set(order.tolist()) == {0} and set(inds.tolist()) == {0}
+    pos = torch.full((8,), -7, dtype=torch.int32, device='cuda')
+    pos, nxt = pk.ops.nested_fps_level(order, inds, 8)
+    want = torch.sort(torch.searchsorted(inds.long(), order[:8].long()))[0]
+    assert torch.equal(pos.long(), want) and torch.equal(nxt, inds[pos.long()])
+
+
+@pytest.mark.parametrize('kind', ['greater', 'carla'])
+def test_inference_step_launches_library_kernels_only(pk, kind):
+    """Round 5: one encode + decode (model.forward, the decoder's mini-batches, the squash) issues no
+    ATen kernel -- the nested-FPS prefix, the pooling-list slices, the xyz packing and the pos | features | level-id
+    layout of the abstract cloud are library kernels now."""
+    from torch.profiler import ProfilerActivity, profile
+    pa, ia, inf = pk.configs.model_args(kind, 2048)
+    esd, dsd = pk.configs.synthetic_weights(pa, ia, 5)
+    enc = pk.model.PointCompletionNetV3(**pa).cuda().eval()
+    dec = pk.implicit.LocalPclResnetFC(**ia).cuda().eval()
+    enc.load_state_dict(esd)
+    dec.load_state_dict(dsd)
+    pcl = pk.configs.synthetic_pcl(kind, 2048, 4, 5).cuda()
+    q = pk.geometry.sample_implicit_points_blind_device(4096, inf['min_z'], inf['cube_bounds'], 1, inf['data_kind'],
+                                                        inf['cube_mode'], 'grid', pcl.device)
+
+    def step():
+        with torch.no_grad():
+            return pk.inference.infer_device(pcl, q, enc, dec, 2048, inf['color_mode'], inf['predict_segmentation'],
+                                             'none', 13)
+    step()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        step()
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages() if e.device_type == torch.autograd.DeviceType.CUDA or 'kernel' in e.key.lower()]
+    foreign = [k for k in names if 'at::native' in k or 'rocclr' in k or 'emcpy' in k or 'emset' in k]
+    assert names and not foreign, foreign

@@ -194,7 +194,7 @@ def test_decoder(pk, case):
     assert out_b.shape == (1,) + tuple(out.shape) and torch.equal(out_b[0], out)
 
 
-@pytest.mark.parametrize('variant', ['trunk4', 'generic_trunk', 'first_gen', 'unfused'])
+@pytest.mark.parametrize('variant', ['trunk4', 'generic_trunk', 'first_gen', 'unfused', 'fused_interp'])
 @pytest.mark.parametrize('case', gc.DEC_CASES, ids=lambda c: c['name'])
 def test_decoder_kernel_variants(pk, case, variant):
     """The opt-in / fallback kernel selections of the decoder (OCC4D_PATH_* flags of the library's path-level entry
@@ -203,6 +203,7 @@ def test_decoder_kernel_variants(pk, case, variant):
     chain.  The library's launch-event hook tells which kernels really ran."""
     ptl = pk.point_transformer_layer
     old = (ptl.USE_TRUNK4, ptl.USE_TRUNK_KERNELS, ptl.USE_ATTN16, ptl.USE_FUSED_ATTENTION)
+    old_fi, ptl.FUSED_INTERP = ptl.FUSED_INTERP, variant == 'fused_interp'
     ptl.USE_TRUNK4 = variant == 'trunk4'
     ptl.USE_TRUNK_KERNELS = variant != 'generic_trunk'
     ptl.USE_ATTN16 = variant != 'first_gen'
@@ -222,6 +223,7 @@ def test_decoder_kernel_variants(pk, case, variant):
     finally:
         pk.ops.set_kernel_timer(None)
         (ptl.USE_TRUNK4, ptl.USE_TRUNK_KERNELS, ptl.USE_ATTN16, ptl.USE_FUSED_ATTENTION) = old
+        ptl.FUSED_INTERP = old_fi
     g = load_golden('g8_dec_' + case['name'])
     close(out, g['output'])
     close(pen[:, ::8], g['penult'])
