@@ -507,6 +507,7 @@ int occ4d_broadcast_rows_f32(const float* vec, float scale, int n, int d, float*
 #define OCC4D_PATH_BF16X3 4         /* opt-in: attention-logit GEMMs on split-bf16 MFMAs (implies FIRST_GEN) */
 #define OCC4D_PATH_GENERIC_LINEAR 8 /* generic Linear kernel instead of the row-resident trunk kernels */
 #define OCC4D_PATH_TRUNK4 16        /* half-CU trunk kernels (csrc/trunk4.hip) */
+#define OCC4D_PATH_BF16X6 64        /* opt-in, fp32-class: d = 416 attention GEMMs on 3-way split bf16 MFMAs, 6 partial products */
 #define OCC4D_PATH_FUSED_INTERP 32 /* A/B only (slower): lin_z table term of block i + 1 in block i's epilogue */
 
 /* Stage packers as device kernels (layouts: occ4d_resblock_f32 / occ4d_resblock4_f32 / occ4d_pt_cross_attn16p_f32 /
@@ -547,6 +548,19 @@ typedef struct occ4d_pt_layer_weights {
   const float *attn0_w, *attn0_b, *attn2_w, *attn2_b;
   const float *pre_w, *pre_b, *post_w, *post_b;
 } occ4d_pt_layer_weights;
+
+/* d = 416, K <= 14 vector attention with every GEMM on v_mfma_f32_16x16x32_bf16, both operands split into three bf16
+ * truncation pieces (x = x1 + x2 + x3 exactly), six partial products accumulated in fp32 (csrc/crossattn_bf16x6.hip):
+ * the contract of occ4d_pt_cross_attn16p_f32 (vtc = Wv f + c2; attn_mlp[2].bias cancels in the softmax), fp32-class
+ * results.  wstream: occ4d_pack_attn_bf16x6_stream_f32(attn_mlp[2].weight (416, 832), merged W1 P2 (832, 32),
+ * pos_mlp[2].weight (416, 32)) -> occ4d_pt_cross_attn_bf16x6_stream_floats() floats. */
+int64_t occ4d_pt_cross_attn_bf16x6_stream_floats(void);
+int occ4d_pack_attn_bf16x6_stream_f32(const float* w2, const float* wp, const float* p2, float* wstream, void* stream);
+int occ4d_debug_x6_stamps(unsigned long long* out, int n_words);   /* debug: phase time stamps (OCC4D_X6_STAMPS=1) */
+int occ4d_pt_cross_attn_bf16x6_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t q_stride, const float* apos,
+                                   int64_t a_stride, const int32_t* idx, const float* kt, int64_t ld_kt, const float* vtc,
+                                   int64_t ld_vt, const float* pos0_w, const float* pos0_b, const float* wstream, float* agg,
+                                   int64_t ld_agg, int n, int m, int k, int d, float divisor, void* stream);
 
 int64_t occ4d_pt_layer_prepared_floats(const occ4d_pt_layer_weights* w, int flags);
 int occ4d_pt_layer_prepare_f32(const occ4d_pt_layer_weights* w, float* prepared, int flags, void* stream);

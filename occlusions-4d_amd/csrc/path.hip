@@ -218,8 +218,8 @@ bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 // ----------------------------------------------------------------------------------------------------------------
 struct LayerLayout {
   int D, D2, h, Kq;                 // Kq: input width of the merged query projection (d_in when layer1 is folded in)
-  bool fold_pre, fused16p, fused_first, fused_self16, bf16x3, wq_rows, w3_rows, trunk4;
-  int64_t wq, bq, wk, wp, wq_packed, stream, w2_bf, wp_bf, w3_packed, scratch, total;
+  bool fold_pre, fused16p, fused_first, fused_self16, bf16x3, bf16x6, wq_rows, w3_rows, trunk4;
+  int64_t wq, bq, wk, wp, wq_packed, stream, stream6, w2_bf, wp_bf, w3_packed, scratch, total;
   int64_t s_A, s_B, s_C, s_C2, s_v, s_bq;      // doubles, inside the scratch region
 };
 
@@ -248,9 +248,10 @@ LayerLayout layer_layout(const occ4d_pt_layer_weights& w, int flags) {
   L.fold_pre = w.cross && w.pre_w;
   L.Kq = L.fold_pre ? w.d_in : L.D;
   const bool fusable = (L.D == 288 || L.D == 416) && L.h == 32 && !(flags & OCC4D_PATH_UNFUSED);
+  L.bf16x6 = fusable && L.D == 416 && (flags & OCC4D_PATH_BF16X6) && !(flags & (OCC4D_PATH_FIRST_GEN | OCC4D_PATH_BF16X3));
   L.bf16x3 = fusable && (flags & OCC4D_PATH_BF16X3);
-  L.fused16p = fusable && L.D == 416 && !(flags & (OCC4D_PATH_FIRST_GEN | OCC4D_PATH_BF16X3));
-  L.fused_first = fusable && !L.fused16p;
+  L.fused16p = fusable && L.D == 416 && !L.bf16x6 && !(flags & (OCC4D_PATH_FIRST_GEN | OCC4D_PATH_BF16X3));
+  L.fused_first = fusable && !L.fused16p && !L.bf16x6;
   L.fused_self16 = L.h == 32 && L.D % 4 == 0 && L.D <= 288 && !(flags & OCC4D_PATH_UNFUSED);   // (used when k == 16)
   L.trunk4 = flags & OCC4D_PATH_TRUNK4;
   const bool trunk = !(flags & OCC4D_PATH_GENERIC_LINEAR);
@@ -267,6 +268,7 @@ LayerLayout layer_layout(const occ4d_pt_layer_weights& w, int flags) {
   };
   L.wq_packed = L.wq_rows ? take(packed(2 * L.D)) : -1;
   L.stream = L.fused16p ? take(occ4d_pt_cross_attn16p_stream_floats()) : -1;
+  L.stream6 = L.bf16x6 ? take(occ4d_pt_cross_attn_bf16x6_stream_floats()) : -1;
   L.w2_bf = L.bf16x3 ? take((int64_t)L.D * 2 * L.D) : -1;
   L.wp_bf = L.bf16x3 ? take((int64_t)2 * L.D * L.h) : -1;
   L.w3_packed = L.w3_rows ? take(packed(w.d_out)) : -1;
@@ -318,6 +320,7 @@ int layer_prepare(const occ4d_pt_layer_weights& w, const LayerLayout& L, float* 
     else TRY(occ4d_pack_trunk_rows_f32(prep + L.wq, L.Kq, 2 * D, prep + L.wq_packed, st));
   }
   if (L.fused16p) TRY(occ4d_pack_attn16p_stream_f32(w.attn2_w, prep + L.wp, w.pos2_w, prep + L.stream, st));
+  if (L.bf16x6) TRY(occ4d_pack_attn_bf16x6_stream_f32(w.attn2_w, prep + L.wp, w.pos2_w, prep + L.stream6, st));
   if (L.bf16x3) {
     TRY(occ4d_pack_bf16x3_f32(w.attn2_w, D, 2 * D, prep + L.w2_bf, st));
     TRY(occ4d_pack_bf16x3_f32(prep + L.wp, 2 * D, h, prep + L.wp_bf, st));
@@ -377,7 +380,7 @@ int layer_forward(const occ4d_pt_layer_weights& w, const LayerLayout& L, const f
     }
     float* ktb = ws.take((int64_t)n * 2 * D);
     float* vtb = ws.take((int64_t)n * D);
-    float* vcb = L.fused16p ? ws.take((int64_t)n * D) : nullptr;
+    float* vcb = (L.fused16p || L.bf16x6) ? ws.take((int64_t)n * D) : nullptr;
     float* aqb = ws.take((int64_t)n * 2 * D);
     if (!dry) {
       TRY(lin(yfeat, ld_y, prep + L.wk, D, nullptr, ktb, 2 * D, n, D, 2 * D, 0, 0, nullptr, 0, st));
@@ -399,7 +402,7 @@ int layer_forward(const occ4d_pt_layer_weights& w, const LayerLayout& L, const f
   float* agg = out;
   int64_t ld_agg = ldo;
   if (w.post_w) { agg = ws.take((int64_t)n * D); ld_agg = D; }
-  const bool fused = (L.fused16p || L.fused_first) && k <= 14;
+  const bool fused = (L.fused16p || L.fused_first || L.bf16x6) && k <= 14;
   const float divisor = sqrtf((float)D);          // fp32(sqrt(d)), as torch.tensor(math.sqrt(d), float32)
   const int step = row_step(n);
   for (int lo = 0; lo < n; lo += step) {
@@ -437,7 +440,10 @@ int layer_forward(const occ4d_pt_layer_weights& w, const LayerLayout& L, const f
       if (!dry) {
         E.before(OCC4D_PROFILE_CROSS_ATTN);
         int rc;
-        if (L.fused16p)
+        if (L.bf16x6)
+          rc = occ4d_pt_cross_attn_bf16x6_f32(aq, 2 * D, qp, ps, pos2, p2s, idx, kt, 2 * D, vtc, D, w.pos0_w, w.pos0_b,
+                                              prep + L.stream6, agg_c, ld_agg, c, m, k, D, divisor, st);
+        else if (L.fused16p)
           rc = occ4d_pt_cross_attn16p_f32(aq, 2 * D, qp, ps, pos2, p2s, idx, kt, 2 * D, vtc, D, w.pos0_w, w.pos0_b,
                                           prep + L.stream, agg_c, ld_agg, c, m, k, D, divisor, occ4d::attn16p_skew(), st);
         else if (L.bf16x3)

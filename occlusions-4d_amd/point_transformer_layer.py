@@ -31,7 +31,8 @@ USE_TRUNK_KERNELS = True     # row-resident fused trunk kernels (csrc/trunk*.hip
 # 6c): half-CU re-cut of the trunk kernels (csrc/trunk4.hip: 4-wave workgroups, two per CU)
 USE_TRUNK4 = os.environ.get('OCC4D_TRUNK4', '0') != '0'
 # 'f32' (default): every GEMM exact fp32.  'bf16x3': the attention-logit GEMM of the fused kernel on split-bf16 MFMAs
-# (occ4d_pt_cross_attn_bf16x3_f32); everything else unchanged.  Opt-in.
+# (occ4d_pt_cross_attn_bf16x3_f32); everything else unchanged.  Opt-in.  'bf16x6' (round 5, opt-in): the d = 416 attention
+# GEMMs on three-way split bf16 MFMAs, six partial products, fp32 accumulate (csrc/crossattn_bf16x6.hip): fp32-class.
 LOGIT_PRECISION = os.environ.get('OCC4D_LOGIT_PRECISION', 'f32')
 # A/B only (measured slower): the lin_z table term of block i + 1 added in block i's epilogue
 FUSED_INTERP = os.environ.get('OCC4D_FUSED_INTERP', '0') != '0'
@@ -39,7 +40,7 @@ FUSED_INTERP = os.environ.get('OCC4D_FUSED_INTERP', '0') != '0'
 
 def path_flags():
     """The OCC4D_PATH_* flags (include/occ4d.h) the switches above select for the library's path-level entry points."""
-    assert LOGIT_PRECISION in ('f32', 'bf16x3'), LOGIT_PRECISION
+    assert LOGIT_PRECISION in ('f32', 'bf16x3', 'bf16x6'), LOGIT_PRECISION
     L = ops._lib
     f = L.PATH_DEFAULT
     if not USE_FUSED_ATTENTION:
@@ -48,6 +49,8 @@ def path_flags():
         f |= L.PATH_FIRST_GEN
     if LOGIT_PRECISION == 'bf16x3':
         f |= L.PATH_BF16X3
+    if LOGIT_PRECISION == 'bf16x6':
+        f |= L.PATH_BF16X6
     if not USE_TRUNK_KERNELS:
         f |= L.PATH_GENERIC_LINEAR
     if USE_TRUNK4:

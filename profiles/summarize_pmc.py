@@ -13,7 +13,7 @@ import os
 import sys
 from collections import defaultdict
 
-WANT = ('cross_attn16p_kernel', 'cross_attn16_kernel', 'cross_attn_kernel', 'resblock_kernel', 'rowlin_kernel', 'linear_kernel<13', 'interp_add', 'knn_kernel')
+WANT = ('cross_attn_bf16x6_kernel', 'cross_attn16p_kernel', 'cross_attn16_kernel', 'cross_attn_kernel', 'resblock_kernel', 'rowlin_kernel', 'linear_kernel<13', 'interp_add', 'knn_kernel')
 
 
 def short(name):

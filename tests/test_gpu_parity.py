@@ -364,13 +364,13 @@ def test_decoder_two_level_cloud(pk, case):
                                           (1, 10, 416, 288), (14, 531, 288, 288), (5, 1, 416, 288),
                                           (14, 8, 416, 288), (14, 10, 416, 288), (14, 17, 416, 288), (14, 18, 416, 288),
                                           (14, 19, 416, 288), (11, 2, 416, 288), (2, 4000, 416, 288)])
-@pytest.mark.parametrize('generation', ['attn16p', 'first'])
+@pytest.mark.parametrize('generation', ['attn16p', 'first', 'bf16x6'])
 def test_fused_attention_matches_unfused_chain(pk, k, n, dim, dim2, generation):
     """The fused kernels (9 queries x 14 rows packed per workgroup, masked slots for k < 14, ragged
     tail for n % 9 != 0) against the unfused kernel chain on the same inputs: the paired-workgroup 16 x 16
     MFMA kernel (crossattn16p.hip, d = 416) and the first-generation 32 x 32 kernel (crossattn.hip, d = 288 / 416)."""
     if generation != 'first' and dim != 416:
-        pytest.skip('crossattn16p.hip is built for d = 416')
+        pytest.skip('crossattn16p.hip / crossattn_bf16x6.hip are built for d = 416')
     rng = np.random.default_rng(1000 * k + n)
     m = 76
     x = rng.normal(size=(n, dim)).astype(np.float32)
@@ -384,13 +384,16 @@ def test_fused_attention_matches_unfused_chain(pk, k, n, dim, dim2, generation):
     args = (dev(x)[None], dev(pos)[None], dev(x2)[None], dev(pos2)[None])
     with torch.no_grad():
         ptl.USE_ATTN16 = generation != 'first'
+        old_prec, ptl.LOGIT_PRECISION = ptl.LOGIT_PRECISION, 'bf16x6' if generation == 'bf16x6' else 'f32'
         try:
             fused = layer(*args)[0]
             ptl.USE_FUSED_ATTENTION = False
+            ptl.LOGIT_PRECISION = 'f32'
             chain = layer(*args)[0]
         finally:
             ptl.USE_FUSED_ATTENTION = True
             ptl.USE_ATTN16 = True
+            ptl.LOGIT_PRECISION = old_prec
     assert torch.isfinite(fused).all()
     close(fused, chain, 2e-5)
 
@@ -461,6 +464,39 @@ def bf16x3_logits(pk):
     ptl.LOGIT_PRECISION = 'bf16x3'
     yield
     ptl.LOGIT_PRECISION = old
+
+
+@pytest.fixture
+def bf16x6_attention(pk):
+    ptl = pk.point_transformer_layer
+    old = ptl.LOGIT_PRECISION
+    ptl.LOGIT_PRECISION = 'bf16x6'
+    yield
+    ptl.LOGIT_PRECISION = old
+
+
+@pytest.mark.parametrize('case', gc.DEC_CASES + gc.DEC_TWOLEVEL_CASES, ids=lambda c: c['name'])
+def test_decoder_with_three_way_split_bf16_attention(pk, bf16x6_attention, case):
+    """Round 5 opt-in mode (csrc/crossattn_bf16x6.hip): every GEMM of the two cross-attention layers on bf16 MFMAs with
+    both operands split three ways (exact) and six partial products: the golden vectors at the fp32 path's own bar, and
+    the library must really have taken that kernel (its launches are counted)."""
+    two = case in gc.DEC_TWOLEVEL_CASES
+    q, abstract, fglob, ia, sd = (gc.dec_twolevel_inputs if two else gc.dec_inputs)(case)
+    net = pk.implicit.LocalPclResnetFC(**ia).cuda().eval()
+    net.load_state_dict(sd)
+    g = load_golden('g8_dec_' + case['name'])
+    kw = dict(knn_local=dev(g['knn_local']), knn_cross=dev(g['knn_cross'])) if two else {}
+    with torch.no_grad():
+        out, pen = net(dev(q), dev(abstract), dev(fglob), None, **kw)
+        pk.point_transformer_layer.LOGIT_PRECISION = 'f32'
+        out32, pen32 = net(dev(q), dev(abstract), dev(fglob), None, **kw)
+    close(out, g['output'], 2e-5)
+    close(pen[:, ::8], g['penult'], 4e-5 if two else 2e-5)
+    d = float((out - out32).abs().max())
+    print('\n[bf16x6 %s] |x6 - f32 path| %.3g, |x6 - ref| %.3g, |f32 path - ref| %.3g' % (
+        case['name'], d, float(np.abs(out.cpu().numpy() - g['output']).max()),
+        float(np.abs(out32.cpu().numpy() - g['output']).max())))
+    assert 0.0 < d < 2e-5                 # a different kernel ran, and it agrees
 
 
 def test_pack_w2_bf16x3_roundtrip(pk):

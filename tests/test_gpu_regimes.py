@@ -51,18 +51,20 @@ def bf16x3_bound(fp32_bound, ref64):
     return max(fp32_bound, 2.0 ** -13 * float(np.abs(ref64).max()))
 
 
-ATTN_PATHS = ['attn16p', 'first', 'chain', 'bf16x3']
+ATTN_PATHS = ['attn16p', 'first', 'chain', 'bf16x3', 'bf16x6']
 
 
 @contextlib.contextmanager
 def attention_path(pk, which):
     """Selects the kernel generation the inference layer takes: 'attn16p' (default, csrc/crossattn16p.hip), 'first'
-    (crossattn.hip), 'chain' (unfused kernels), 'bf16x3' (split-bf16 logits, crossattn.hip)."""
+    (crossattn.hip), 'chain' (unfused kernels), 'bf16x3' (split-bf16 logits, crossattn.hip), 'bf16x6' (round 5: every
+    attention GEMM on three-way split bf16 MFMAs, six partial products, csrc/crossattn_bf16x6.hip -- held to the fp32
+    paths' own bound, no relaxation: that is its claim)."""
     ptl = pk.point_transformer_layer
     old = (ptl.USE_ATTN16, ptl.USE_FUSED_ATTENTION, ptl.LOGIT_PRECISION)
-    ptl.USE_ATTN16 = which == 'attn16p'
+    ptl.USE_ATTN16 = which in ('attn16p', 'bf16x6')
     ptl.USE_FUSED_ATTENTION = which != 'chain'
-    ptl.LOGIT_PRECISION = 'bf16x3' if which == 'bf16x3' else 'f32'
+    ptl.LOGIT_PRECISION = which if which in ('bf16x3', 'bf16x6') else 'f32'
     try:
         yield
     finally:
@@ -75,8 +77,8 @@ def attention_path(pk, which):
 def test_pt_layer_regimes(pk, case, path):
     if case['dim'] not in pk.ops.FUSED_ATTN_DIMS and path != 'chain':
         pytest.skip('encoder widths run the unfused chain only')
-    if case['dim'] != 416 and path == 'attn16p':
-        pytest.skip('crossattn16p.hip is built for d = 416')
+    if case['dim'] != 416 and path in ('attn16p', 'bf16x6'):
+        pytest.skip('crossattn16p.hip / crossattn_bf16x6.hip are built for d = 416')
     x, pos, x2, pos2, sd = gc.ptl_inputs(case)
     layer = pk.point_transformer_layer.PointTransformerLayer(case['dim'], num_neighbors=case['k'],
                                                              dim2=case.get('dim2')).cuda()
@@ -132,7 +134,7 @@ def test_geometry_of_zero_padded_clouds_is_the_restated_torch_cluster(pk, case):
 
 
 # ------------------------------------------------------------------ G8r: decoder
-DEC_VARIANTS = ['default', 'trunk4', 'generic_trunk', 'first', 'chain', 'bf16x3']
+DEC_VARIANTS = ['default', 'trunk4', 'generic_trunk', 'first', 'chain', 'bf16x3', 'bf16x6']
 
 
 @contextlib.contextmanager
@@ -141,7 +143,7 @@ def decoder_variant(pk, variant):
     old = (ptl.USE_TRUNK4, ptl.USE_TRUNK_KERNELS)
     ptl.USE_TRUNK4 = variant == 'trunk4'
     ptl.USE_TRUNK_KERNELS = variant != 'generic_trunk'
-    path = variant if variant in ('first', 'chain', 'bf16x3') else 'attn16p'
+    path = variant if variant in ('first', 'chain', 'bf16x3', 'bf16x6') else 'attn16p'
     try:
         with attention_path(pk, path):
             yield
