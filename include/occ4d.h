@@ -508,6 +508,7 @@ int occ4d_broadcast_rows_f32(const float* vec, float scale, int n, int d, float*
 #define OCC4D_PATH_GENERIC_LINEAR 8 /* generic Linear kernel instead of the row-resident trunk kernels */
 #define OCC4D_PATH_TRUNK4 16        /* half-CU trunk kernels (csrc/trunk4.hip) */
 #define OCC4D_PATH_BF16X6 64        /* opt-in, fp32-class: d = 416 attention GEMMs on 3-way split bf16 MFMAs, 6 partial products */
+#define OCC4D_PATH_BF16X6_TRUNK 128 /* opt-in, fp32-class: the decoder's 416-input Linear layers on the same split (csrc/trunk_bf16x6.hip) */
 #define OCC4D_PATH_FUSED_INTERP 32 /* A/B only (slower): lin_z table term of block i + 1 in block i's epilogue */
 
 /* Stage packers as device kernels (layouts: occ4d_resblock_f32 / occ4d_resblock4_f32 / occ4d_pt_cross_attn16p_f32 /
@@ -556,6 +557,14 @@ typedef struct occ4d_pt_layer_weights {
  * pos_mlp[2].weight (416, 32)) -> occ4d_pt_cross_attn_bf16x6_stream_floats() floats. */
 int64_t occ4d_pt_cross_attn_bf16x6_stream_floats(void);
 int occ4d_pack_attn_bf16x6_stream_f32(const float* w2, const float* wp, const float* p2, float* wstream, void* stream);
+/* y[:, 0 .. n_out) = [res +] W [relu](x) + b, K = 416, on v_mfma_f32_16x16x32_bf16 with both operands split into three
+ * bf16 pieces and six partial products (csrc/trunk_bf16x6.hip): occ4d_rowlin_f32's contract (no interpolation term),
+ * fp32-class results.  n_out in {208, 416, 832, 1664}; y may alias res, never x.  w_packed: occ4d_pack_rowlin_bf16x6_f32
+ * of the (n_out, 416) weight (row stride ldw) -> occ4d_rowlin_bf16x6_packed_floats(n_out) floats. */
+int64_t occ4d_rowlin_bf16x6_packed_floats(int n_out);
+int occ4d_pack_rowlin_bf16x6_f32(const float* w, int64_t ldw, int n_out, float* packed, void* stream);
+int occ4d_rowlin_bf16x6_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed, const float* b,
+                            int n_out, int relu_in, const float* res, int64_t ldr, int n, void* stream);
 int occ4d_debug_x6_stamps(unsigned long long* out, int n_words);   /* debug: phase time stamps (OCC4D_X6_STAMPS=1) */
 int occ4d_pt_cross_attn_bf16x6_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t q_stride, const float* apos,
                                    int64_t a_stride, const int32_t* idx, const float* kt, int64_t ld_kt, const float* vtc,

@@ -218,8 +218,8 @@ bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 // ----------------------------------------------------------------------------------------------------------------
 struct LayerLayout {
   int D, D2, h, Kq;                 // Kq: input width of the merged query projection (d_in when layer1 is folded in)
-  bool fold_pre, fused16p, fused_first, fused_self16, bf16x3, bf16x6, wq_rows, w3_rows, trunk4;
-  int64_t wq, bq, wk, wp, wq_packed, stream, stream6, w2_bf, wp_bf, w3_packed, scratch, total;
+  bool fold_pre, fused16p, fused_first, fused_self16, bf16x3, bf16x6, wq_rows, w3_rows, trunk4, x6rows;
+  int64_t wq, bq, wk, wp, wq_packed, stream, stream6, w2_bf, wp_bf, w3_packed, wq_x6, w3_x6, scratch, total;
   int64_t s_A, s_B, s_C, s_C2, s_v, s_bq;      // doubles, inside the scratch region
 };
 
@@ -266,7 +266,11 @@ LayerLayout layer_layout(const occ4d_pt_layer_weights& w, int flags) {
   const auto packed = [&](int n_out) {
     return L.trunk4 ? occ4d_trunk4_packed_floats(n_out) : occ4d_trunk_packed_floats(n_out);
   };
+  // split-precision trunk rows (csrc/trunk_bf16x6.hip): the merged query projection and layer3 of a d = 416 cross layer
+  L.x6rows = (flags & OCC4D_PATH_BF16X6_TRUNK) && L.wq_rows && L.w3_rows && !L.trunk4;
   L.wq_packed = L.wq_rows ? take(packed(2 * L.D)) : -1;
+  L.wq_x6 = L.x6rows ? take(occ4d_rowlin_bf16x6_packed_floats(2 * L.D)) : -1;
+  L.w3_x6 = L.x6rows ? take(occ4d_rowlin_bf16x6_packed_floats(w.d_out)) : -1;
   L.stream = L.fused16p ? take(occ4d_pt_cross_attn16p_stream_floats()) : -1;
   L.stream6 = L.bf16x6 ? take(occ4d_pt_cross_attn_bf16x6_stream_floats()) : -1;
   L.w2_bf = L.bf16x3 ? take((int64_t)L.D * 2 * L.D) : -1;
@@ -319,6 +323,10 @@ int layer_prepare(const occ4d_pt_layer_weights& w, const LayerLayout& L, float* 
     if (L.trunk4) TRY(occ4d_pack_trunk4_rows_f32(prep + L.wq, L.Kq, 2 * D, prep + L.wq_packed, st));
     else TRY(occ4d_pack_trunk_rows_f32(prep + L.wq, L.Kq, 2 * D, prep + L.wq_packed, st));
   }
+  if (L.x6rows) {
+    TRY(occ4d_pack_rowlin_bf16x6_f32(prep + L.wq, L.Kq, 2 * D, prep + L.wq_x6, st));
+    TRY(occ4d_pack_rowlin_bf16x6_f32(w.post_w, D, w.d_out, prep + L.w3_x6, st));
+  }
   if (L.fused16p) TRY(occ4d_pack_attn16p_stream_f32(w.attn2_w, prep + L.wp, w.pos2_w, prep + L.stream, st));
   if (L.bf16x6) TRY(occ4d_pack_attn_bf16x6_stream_f32(w.attn2_w, prep + L.wp, w.pos2_w, prep + L.stream6, st));
   if (L.bf16x3) {
@@ -358,6 +366,14 @@ int rowlin_any(bool trunk4, const float* x, int64_t ldx, float* y, int64_t ldy, 
   const int rc = trunk4
       ? occ4d_rowlin4_f32(x, ldx, y, ldy, wpk, b, n_out, relu_in, res, ldr, nullptr, nullptr, 0, nullptr, nullptr, 0, n, st)
       : occ4d_rowlin_f32(x, ldx, y, ldy, wpk, b, n_out, relu_in, res, ldr, nullptr, nullptr, 0, nullptr, nullptr, 0, n, st);
+  E.after(OCC4D_PROFILE_ROWLIN);
+  return rc;
+}
+
+int rowlin_x6(const float* x, int64_t ldx, float* y, int64_t ldy, const float* wpk, const float* b, int n_out, int relu_in,
+              const float* res, int64_t ldr, int n, const Events& E, hipStream_t st) {
+  E.before(OCC4D_PROFILE_ROWLIN);
+  const int rc = occ4d_rowlin_bf16x6_f32(x, ldx, y, ldy, wpk, b, n_out, relu_in, res, ldr, n, st);
   E.after(OCC4D_PROFILE_ROWLIN);
   return rc;
 }
@@ -426,7 +442,9 @@ int layer_forward(const occ4d_pt_layer_weights& w, const LayerLayout& L, const f
     } else {
       float* ab = ws.take((int64_t)c * 2 * D);
       if (!dry) {
-        if (L.wq_rows)
+        if (L.x6rows)
+          TRY(rowlin_x6(x + (int64_t)lo * ldx, ldx, ab, 2 * D, prep + L.wq_x6, prep + L.bq, 2 * D, 0, nullptr, 0, c, E, st));
+        else if (L.wq_rows)
           TRY(rowlin_any(L.trunk4, x + (int64_t)lo * ldx, ldx, ab, 2 * D, prep + L.wq_packed, prep + L.bq, 2 * D, 0, nullptr, 0,
                          c, E, st));
         else
@@ -483,7 +501,9 @@ int layer_forward(const occ4d_pt_layer_weights& w, const LayerLayout& L, const f
     ws.release(cmark);
   }
   if (w.post_w && !dry) {
-    if (L.w3_rows)
+    if (L.x6rows)
+      TRY(rowlin_x6(agg, D, out, ldo, prep + L.w3_x6, w.post_b, w.d_out, 0, x, ldx, n, E, st));
+    else if (L.w3_rows)
       TRY(rowlin_any(L.trunk4, agg, D, out, ldo, prep + L.w3_packed, w.post_b, w.d_out, 0, x, ldx, n, E, st));
     else
       TRY(lin(agg, D, w.post_w, D, w.post_b, out, ldo, n, D, w.d_out, 0, 0, x, ldx, st));
@@ -498,7 +518,9 @@ int layer_forward(const occ4d_pt_layer_weights& w, const LayerLayout& L, const f
 struct DecoderLayout {
   int H, P, P4, dg, E, nB, nC;
   bool trunk, trunk4, resblock;              // row-resident Linear kernels usable / half-CU variant / fused residual block
+  bool x6trunk;                              // residual blocks as two split-precision launches (csrc/trunk_bf16x6.hip)
   int64_t w0p[OCC4D_MAX_BLOCKS], w1p[OCC4D_MAX_BLOCKS];
+  int64_t w0x[OCC4D_MAX_BLOCKS], w1x[OCC4D_MAX_BLOCKS];
   int64_t cross[OCC4D_MAX_CROSS];
   LayerLayout cl[OCC4D_MAX_CROSS];
   int64_t total;
@@ -548,12 +570,15 @@ DecoderLayout decoder_layout(const occ4d_decoder_weights& w, int flags) {
   L.trunk = L.H == TRUNK && !(flags & OCC4D_PATH_GENERIC_LINEAR);
   L.trunk4 = flags & OCC4D_PATH_TRUNK4;
   L.resblock = L.trunk && w.activation == 0;
+  L.x6trunk = L.resblock && !L.trunk4 && (flags & OCC4D_PATH_BF16X6_TRUNK);
   int64_t o = 0;
   auto take = [&](int64_t n) { const int64_t at = o; o += up(n); return at; };
   const int64_t pk = L.trunk4 ? occ4d_trunk4_packed_floats(TRUNK) : occ4d_trunk_packed_floats(TRUNK);
   for (int i = 0; i < L.nB; ++i) {
     L.w0p[i] = L.resblock ? take(pk) : -1;
     L.w1p[i] = L.resblock ? take(pk) : -1;
+    L.w0x[i] = L.x6trunk ? take(occ4d_rowlin_bf16x6_packed_floats(TRUNK)) : -1;
+    L.w1x[i] = L.x6trunk ? take(occ4d_rowlin_bf16x6_packed_floats(TRUNK)) : -1;
   }
   for (int j = 0; j < L.nC; ++j) {
     L.cl[j] = layer_layout(w.cross[j], flags);
@@ -606,7 +631,7 @@ int decoder_forward(const occ4d_decoder_weights& w, const DecoderLayout& L, cons
     float* w8 = ws.take((int64_t)c * w.k_local);
     int32_t* idx_att = L.nC ? reinterpret_cast<int32_t*>(ws.take((int64_t)c * w.k_cross)) : nullptr;
     float* pe = ws.take((int64_t)c * L.P4);
-    float* hbuf = L.resblock ? nullptr : ws.take((int64_t)c * H);
+    float* hbuf = (L.resblock && !L.x6trunk) ? nullptr : ws.take((int64_t)c * H);
     if (!dry) {
       // D2 + D3 (model/implicit.py:328-342): 8 nearest abstract points by Euclidean norm, inverse-distance weights
       // (caller-supplied lists: the reference's own tie order; distances recomputed with the search's expression)
@@ -648,7 +673,14 @@ int decoder_forward(const occ4d_decoder_weights& w, const DecoderLayout& L, cons
         if (!had_it)
           TRY(occ4d_interp_add_f32(x, ldx, scene + S.zconst + (int64_t)i * H, scene + S.ztab + (int64_t)i * H,
                                    (int64_t)L.nB * H, idx8, w8, c, w.k_local, H, st));
-        if (L.resblock) {
+        if (L.x6trunk) {
+          // h = fc_0(relu(x)); x = x + fc_1(relu(h)): two split-precision launches, h through the workspace
+          E.before(OCC4D_PROFILE_RESBLOCK);
+          int rc = occ4d_rowlin_bf16x6_f32(x, ldx, hbuf, H, prep + L.w0x[i], w.fc0_b[i], H, 1, nullptr, 0, c, st);
+          if (!rc) rc = occ4d_rowlin_bf16x6_f32(hbuf, H, x, ldx, prep + L.w1x[i], w.fc1_b[i], H, 1, x, ldx, c, st);
+          E.after(OCC4D_PROFILE_RESBLOCK);
+          TRY(rc);
+        } else if (L.resblock) {
           E.before(OCC4D_PROFILE_RESBLOCK);
           const float* zc = give_next ? scene + S.zconst + (int64_t)(i + 1) * H : nullptr;
           const float* zt = give_next ? scene + S.ztab + (int64_t)(i + 1) * H : nullptr;
@@ -831,6 +863,10 @@ extern "C" int occ4d_decoder_prepare_f32(const occ4d_decoder_weights* w, float* 
       TRY(occ4d_pack_trunk_rows_f32(w->fc0_w[i], TRUNK, TRUNK, prepared + L.w0p[i], st));
       TRY(occ4d_pack_trunk_cols_f32(w->fc1_w[i], TRUNK, prepared + L.w1p[i], st));
     }
+  }
+  for (int i = 0; i < L.nB && L.x6trunk; ++i) {
+    TRY(occ4d_pack_rowlin_bf16x6_f32(w->fc0_w[i], TRUNK, TRUNK, prepared + L.w0x[i], st));
+    TRY(occ4d_pack_rowlin_bf16x6_f32(w->fc1_w[i], TRUNK, TRUNK, prepared + L.w1x[i], st));
   }
   for (int j = 0; j < L.nC; ++j) TRY(layer_prepare(w->cross[j], L.cl[j], prepared + L.cross[j], st));
   return OCC4D_OK;

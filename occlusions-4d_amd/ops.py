@@ -367,6 +367,27 @@ FUSED_ATTN_DIMS = (288, 416)
 FUSED_ATTN_MAX_K = 14
 
 
+def rowlin_bf16x6(x, w, b=None, relu_in=False, res=None, out=None):
+    """y = [res +] w [relu](x) + b for a (n_out, 416) weight on the split-precision trunk kernel
+    (occ4d_rowlin_bf16x6_f32; n_out in {208, 416, 832, 1664}).  The weight is packed per call: tests and probes."""
+    x, ldx = _aligned_rows(_dev(x, name='x'), 'x')
+    w, ldw = _rows(_dev(w, name='w'), 'w')
+    n, n_out = x.shape[0], w.shape[0]
+    assert x.shape[1] == 416 and w.shape[1] == 416
+    L = _lib.lib()
+    packed = torch.empty((int(L.occ4d_rowlin_bf16x6_packed_floats(n_out)),), dtype=torch.float32, device=x.device)
+    _lib.check(L.occ4d_pack_rowlin_bf16x6_f32(_ptr(w), ldw, n_out, _ptr(packed), _stream()))
+    if out is None:
+        out = torch.empty((n, n_out), dtype=torch.float32, device=x.device)
+    ldr = 0
+    if res is not None:
+        res, ldr = _rows(_dev(res, name='res'), 'res')
+    bb = _cont(b, 'bias') if b is not None else None
+    _lib.check(L.occ4d_rowlin_bf16x6_f32(_ptr(x), ldx, _ptr(out), out.stride(0), _ptr(packed), _ptr(bb), n_out, int(relu_in),
+                                         _ptr(res), ldr, n, _stream()))
+    return out
+
+
 def pack_w2_bf16x3(w2):
     """(d, 2d) fp32 attn_mlp[2] weight -> same-shaped fp32 container holding, per 32-wide hidden block and channel,
     [32 hi | 32 lo] bf16 (hi = bf16(w), lo = bf16(w - hi)) in MFMA fragment order (occ4d_pack_bf16x3_f32)."""

@@ -34,6 +34,9 @@ USE_TRUNK4 = os.environ.get('OCC4D_TRUNK4', '0') != '0'
 # (occ4d_pt_cross_attn_bf16x3_f32); everything else unchanged.  Opt-in.  'bf16x6' (round 5, opt-in): the d = 416 attention
 # GEMMs on three-way split bf16 MFMAs, six partial products, fp32 accumulate (csrc/crossattn_bf16x6.hip): fp32-class.
 LOGIT_PRECISION = os.environ.get('OCC4D_LOGIT_PRECISION', 'f32')
+# Opt-in (round 5): the decoder's 416-input Linear layers (residual blocks, merged query projection, layer3) on the same
+# three-way split bf16 MFMAs (csrc/trunk_bf16x6.hip); 'bf16x6' here + LOGIT_PRECISION 'bf16x6' = the whole decoder GEMM work
+TRUNK_PRECISION = os.environ.get('OCC4D_TRUNK_PRECISION', 'f32')
 # A/B only (measured slower): the lin_z table term of block i + 1 added in block i's epilogue
 FUSED_INTERP = os.environ.get('OCC4D_FUSED_INTERP', '0') != '0'
 
@@ -51,6 +54,9 @@ def path_flags():
         f |= L.PATH_BF16X3
     if LOGIT_PRECISION == 'bf16x6':
         f |= L.PATH_BF16X6
+    assert TRUNK_PRECISION in ('f32', 'bf16x6'), TRUNK_PRECISION
+    if TRUNK_PRECISION == 'bf16x6':
+        f |= L.PATH_BF16X6_TRUNK
     if not USE_TRUNK_KERNELS:
         f |= L.PATH_GENERIC_LINEAR
     if USE_TRUNK4:

@@ -475,6 +475,52 @@ def bf16x6_attention(pk):
     ptl.LOGIT_PRECISION = old
 
 
+@pytest.mark.parametrize('n,n_out,relu_in,with_res', [(1000, 416, True, True), (257, 416, True, False), (32, 832, False, False),
+                                                      (5, 208, False, True), (3000, 832, False, False), (256, 1664, True, True)])
+def test_split_precision_rowlin_against_fp64(pk, n, n_out, relu_in, with_res):
+    """csrc/trunk_bf16x6.hip alone: y = [res +] W [relu](x) + b, K = 416, three-way split bf16 operands, six partial
+    products, against fp64 -- at the accuracy of an fp32 GEMM (a few 2^-24 of sum |w||x|), ragged row counts included."""
+    rng = np.random.default_rng(n + n_out)
+    x = (3.0 * rng.normal(size=(n, 416))).astype(np.float32)
+    w = (rng.normal(size=(n_out, 416)) / np.sqrt(416)).astype(np.float32)
+    b = rng.normal(size=(n_out,)).astype(np.float32)
+    r = rng.normal(size=(n, n_out)).astype(np.float32) if with_res else None
+    xin = np.maximum(x, 0) if relu_in else x
+    ref = xin.astype(np.float64) @ w.astype(np.float64).T + b + (r if with_res else 0.0)
+    got = pk.ops.rowlin_bf16x6(dev(x), dev(w), dev(b), relu_in=relu_in, res=None if r is None else dev(r))
+    f32 = (T(xin) @ T(w).T + T(b) + (T(r) if with_res else 0.0)).numpy()
+    e6, e32 = np.abs(got.cpu().numpy() - ref).max(), np.abs(f32 - ref).max()
+    scale = (np.abs(xin).astype(np.float64) @ np.abs(w).astype(np.float64).T).max()
+    print('\n[rowlin x6 %d x %d] |x6 - f64| %.3g, |torch f32 - f64| %.3g, sum|w||x| %.3g' % (n, n_out, e6, e32, scale))
+    assert e6 <= 8 * 2.0 ** -24 * scale
+    # in place over the residual rows (how the decoder calls it)
+    if with_res:
+        rr = dev(r).clone()
+        pk.ops.rowlin_bf16x6(dev(x), dev(w), dev(b), relu_in=relu_in, res=rr, out=rr)
+        assert torch.equal(rr, got)
+
+
+@pytest.mark.parametrize('case', gc.DEC_CASES + gc.DEC_TWOLEVEL_CASES, ids=lambda c: c['name'])
+def test_decoder_entirely_on_three_way_split_bf16(pk, bf16x6_attention, case):
+    """Attention AND trunk on the split-precision kernels (every GEMM of the decoder except lin_in / lin_out and the
+    per-scene tables): the golden vectors at the fp32 path's own bar."""
+    two = case in gc.DEC_TWOLEVEL_CASES
+    q, abstract, fglob, ia, sd = (gc.dec_twolevel_inputs if two else gc.dec_inputs)(case)
+    net = pk.implicit.LocalPclResnetFC(**ia).cuda().eval()
+    net.load_state_dict(sd)
+    g = load_golden('g8_dec_' + case['name'])
+    kw = dict(knn_local=dev(g['knn_local']), knn_cross=dev(g['knn_cross'])) if two else {}
+    ptl = pk.point_transformer_layer
+    old, ptl.TRUNK_PRECISION = ptl.TRUNK_PRECISION, 'bf16x6'
+    try:
+        with torch.no_grad():
+            out, pen = net(dev(q), dev(abstract), dev(fglob), None, **kw)
+    finally:
+        ptl.TRUNK_PRECISION = old
+    close(out, g['output'], 2e-5)
+    close(pen[:, ::8], g['penult'], 4e-5 if two else 2e-5)
+
+
 @pytest.mark.parametrize('case', gc.DEC_CASES + gc.DEC_TWOLEVEL_CASES, ids=lambda c: c['name'])
 def test_decoder_with_three_way_split_bf16_attention(pk, bf16x6_attention, case):
     """Round 5 opt-in mode (csrc/crossattn_bf16x6.hip): every GEMM of the two cross-attention layers on bf16 MFMAs with

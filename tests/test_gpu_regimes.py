@@ -134,21 +134,24 @@ def test_geometry_of_zero_padded_clouds_is_the_restated_torch_cluster(pk, case):
 
 
 # ------------------------------------------------------------------ G8r: decoder
-DEC_VARIANTS = ['default', 'trunk4', 'generic_trunk', 'first', 'chain', 'bf16x3', 'bf16x6']
+DEC_VARIANTS = ['default', 'trunk4', 'generic_trunk', 'first', 'chain', 'bf16x3', 'bf16x6', 'bf16x6_trunk', 'bf16x6_all']
 
 
 @contextlib.contextmanager
 def decoder_variant(pk, variant):
     ptl = pk.point_transformer_layer
-    old = (ptl.USE_TRUNK4, ptl.USE_TRUNK_KERNELS)
+    old = (ptl.USE_TRUNK4, ptl.USE_TRUNK_KERNELS, ptl.TRUNK_PRECISION)
     ptl.USE_TRUNK4 = variant == 'trunk4'
     ptl.USE_TRUNK_KERNELS = variant != 'generic_trunk'
-    path = variant if variant in ('first', 'chain', 'bf16x3', 'bf16x6') else 'attn16p'
+    # round 5: the trunk's Linear layers (bf16x6_trunk) / the whole decoder (bf16x6_all) on three-way split bf16 MFMAs,
+    # held to the fp32 paths' own bound
+    ptl.TRUNK_PRECISION = 'bf16x6' if variant in ('bf16x6_trunk', 'bf16x6_all') else 'f32'
+    path = variant if variant in ('first', 'chain', 'bf16x3', 'bf16x6') else ('bf16x6' if variant == 'bf16x6_all' else 'attn16p')
     try:
         with attention_path(pk, path):
             yield
     finally:
-        (ptl.USE_TRUNK4, ptl.USE_TRUNK_KERNELS) = old
+        (ptl.USE_TRUNK4, ptl.USE_TRUNK_KERNELS, ptl.TRUNK_PRECISION) = old
 
 
 @pytest.mark.parametrize('variant', DEC_VARIANTS)
