@@ -343,16 +343,19 @@ def main():
                                                                ' (%d per GPU)' % (hi2 - lo2) if world > 1 else ''),
                          steps=k2, ms_per_step=1e3 * e2 / k2, value=q2.shape[0] * k2 / e2, n_gpus=world)
             del q2
-        # Opt-in split-precision modes, reported next to the official fp32 number (never as `value`).
-        #   bf16x6 (round 5, csrc/crossattn_bf16x6.hip): EVERY GEMM of the two cross-attention layers on
-        #     v_mfma_f32_16x16x32_bf16, both operands split three ways into bf16 pieces (exact), six partial products,
-        #     fp32 accumulate: fp32-class -- held by tests/test_gpu_regimes.py to the fp32 paths' own bound in every
-        #     saturated regime.  Its own roofline object: executed bf16 MFMA FLOP / kernel time / dense bf16 peak.
-        #   bf16x3 (round 1): only the logit GEMM, two pieces, three products: NOT fp32-class (its bound is on the line).
-        alt = alt3 = None
+        # Opt-in split-precision mode, reported next to the official fp32 number (never as `value`): bf16x6 (round 5) --
+        # EVERY GEMM of the two cross-attention layers (csrc/crossattn_bf16x6.hip) and the trunk's 416-input Linear
+        # layers (csrc/trunk_bf16x6.hip: residual blocks, merged query projection, layer3) on v_mfma_f32_16x16x32_bf16
+        # with both operands split three ways into bf16 pieces (exact), six partial products, fp32 accumulate:
+        # fp32-class -- held by tests/test_gpu_regimes.py to the fp32 paths' own bound in every saturated regime.  Its
+        # own roofline object: executed bf16 MFMA FLOP of the attention kernel / its HIP-event time / dense bf16 peak.
+        # (The round-1 bf16x3 logit mode -- two pieces, NOT fp32-class -- is slower than this and no longer reported.)
+        alt = None
         if not args.no_alt and extra and world == 1:
             ptl = pk.point_transformer_layer
             ptl.LOGIT_PRECISION = 'bf16x6'
+            attn_elapsed, _, _ = timed(step, max(2, args.steps // 2), 1)
+            ptl.TRUNK_PRECISION = 'bf16x6'
             alt_elapsed, _, (out_alt, _) = timed(step, args.steps, 1)
             timer6 = pk.ops.KernelTimer(lambda name, **sh: name == 'cross_attn' and sh.get('d') == 416)
             pk.inference.DECODE_STREAMS = 1
@@ -361,24 +364,25 @@ def main():
             pk.ops.set_kernel_timer(None)
             pk.inference.DECODE_STREAMS = streams_saved
             ps6 = timer6.summary().get('cross_attn', dict(launches=0, total_ms=0.0, total_flops=0.0))
-            ptl.LOGIT_PRECISION = 'bf16x3'
-            alt3_elapsed, _, (out_alt3, _) = timed(step, max(2, args.steps // 2), 1)
-            ptl.LOGIT_PRECISION = 'f32'
-            # MFMAs the kernel executes per launch: workgroups (18 queries x 2 channel halves) x 8 waves x
+            ptl.LOGIT_PRECISION = ptl.TRUNK_PRECISION = 'f32'
+            # MFMAs the attention kernel executes per launch: workgroups (18 queries x 2 channel halves) x 8 waves x
             # (26 stages x 180 + 14 epilogue pairs x 12) v_mfma_f32_16x16x32_bf16 of 2 * 16 * 16 * 32 FLOP
             t6 = ps6['total_ms'] * 1e-3
             bs6 = pk.inference.decode_chunk(BATCH)
             batches6 = [min(bs6, hi - b) for b in range(lo, hi, bs6)]
             wgs6 = sum(2 * (-(-c // 18)) for b in batches6 for c in pk.ops.path_row_chunks(b)) * ia['cross_attn_layers']
             mfma6 = wgs6 * 8 * (26 * 180 + 14 * 12) * (2.0 * 16 * 16 * 32)
-            alt = dict(mode='bf16x6: every GEMM of the cross-attention layers (87 % of the decode FLOP) on 3-way split bf16 '
-                            'MFMAs, 6 partial products, fp32 accumulate (csrc/crossattn_bf16x6.hip); trunk and encoder fp32',
+            k_attn = max(2, args.steps // 2)
+            alt = dict(mode='bf16x6: the GEMMs of the cross-attention layers and of the trunk (residual blocks, query '
+                            'projection, layer3: 99 % of the decode FLOP) on 3-way split bf16 MFMAs, 6 partial products, fp32 '
+                            'accumulate (csrc/crossattn_bf16x6.hip, csrc/trunk_bf16x6.hip); encoder, lin_in / lin_out, tables fp32',
                        dtype='bf16 x 3 pieces per operand, 6 of 9 products, f32 accumulate (fp32-class)',
                        ms_per_step=1e3 * alt_elapsed / args.steps, value=n_total * args.steps / alt_elapsed,
+                       attention_only=dict(ms_per_step=1e3 * attn_elapsed / k_attn, value=n_total * k_attn / attn_elapsed),
                        max_abs_diff_vs_f32=float((out_alt - out).abs().max()),
                        regime_bound='every gate of the fp32 path: golden vectors at 1e-4 (measured <= 5e-6) and, with weights '
                                     'x 4 / x 8, equal / dominant logits, far queries, |hip - ref64| <= max(1e-4, 2 |ref32 - '
-                                    'ref64|) (tests/test_gpu_regimes.py, variants "bf16x6")',
+                                    'ref64|) (tests/test_gpu_regimes.py, variants "bf16x6", "bf16x6_trunk", "bf16x6_all")',
                        roofline=dict(bound='mfma', unit='TFLOP/s', peak=2500.0,
                                      achieved=mfma6 / t6 / 1e12 if t6 > 0 else None,
                                      frac=mfma6 / t6 / 2.5e15 if t6 > 0 else None,
@@ -387,12 +391,6 @@ def main():
                                      kernel='cross_attn_bf16x6_kernel; achieved = executed v_mfma_f32_16x16x32_bf16 FLOP '
                                             '(6 products, duplicated GEMM1 and dead rows included) / HIP-event time; '
                                             'fp32_equivalent = the fp32 kernel\'s executed FLOP count / the same time'))
-            k3 = max(2, args.steps // 2)
-            alt3 = dict(mode='bf16x3: attention-logit GEMM only, 2 pieces, 3 products (round 1, csrc/crossattn.hip)',
-                        ms_per_step=1e3 * alt3_elapsed / k3, value=n_total * k3 / alt3_elapsed,
-                        max_abs_diff_vs_f32=float((out_alt3 - out).abs().max()),
-                        regime_bound='NOT fp32-class once the softmax saturates: 2^-13 of the largest output (11-19 x the '
-                                     'reference\'s own fp32 error at weights x 8); init-scale agreement only')
         # Throughput mode (informational, never `value`): clips pipelined across steps -- the encode of step i + 1 is
         # issued on a side stream while step i decodes (distributed.ClipPipeline).  Every step still encodes and
         # decodes in full; K steps contain K encode launches and K decodes.
@@ -523,7 +521,6 @@ def main():
             line['config4_single_gpu' if world == 1 else 'strong_config2'] = other
         if alt is not None:
             line['alt_precision'] = alt
-            line['alt_precision_bf16x3'] = alt3
         if pipelined is not None:
             line['pipelined'] = pipelined
         if host_boundary is not None:
