@@ -421,6 +421,20 @@ int occ4d_linear_wgrad_bias_f32(const float* g, int64_t ldg, const float* x, int
 /* out (d) (+)= column sums of x (n,d)  (bias gradients); workspace: chunks*d floats */
 int occ4d_colsum_f32(const float* x, int64_t ldx, int n, int d, float* out, int accumulate,
                      float* workspace, int chunks, void* stream);
+/* BatchNorm1d in TRAINING mode + ReLU of DownTransition(norm_type='batch') (model/modules.py:98-102,152; csrc/batchnorm.hip):
+ * fwd: mean / var (biased) = the batch statistics of the n rows of y (written out: the caller updates the running
+ * statistics from them, var * n / (n - 1) as torch does), out = relu(gamma (y - mean) / sqrt(var + eps) + beta);
+ * bwd: g = dL/d out -> dx = dL/dy, dgamma, dbeta.  workspace: occ4d_bn_workspace_doubles(n, d) doubles. */
+int64_t occ4d_bn_workspace_doubles(int n, int d);
+int occ4d_bn_train_fwd_f32(const float* y, int64_t ldy, int n, int d, const float* gamma, const float* beta, float eps,
+                           float* mean, float* var, float* out, int64_t ldo, double* workspace, void* stream);
+int occ4d_bn_train_bwd_f32(const float* y, int64_t ldy, const float* g, int64_t ldg, const float* out, int64_t ldo, int n,
+                           int d, const float* mean, const float* var, const float* gamma, float eps, float* dx, int64_t ldx,
+                           float* dgamma, float* dbeta, double* workspace, void* stream);
+/* swish (model/implicit.py:46-64) for the training path: y = x sigmoid(x); out = g d/dx [x sigmoid(x)] */
+int occ4d_swish_f32(const float* x, int64_t ldx, int n, int d, float* y, int64_t ldy, void* stream);
+int occ4d_swish_bwd_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int n, int d, float* out, int64_t ldo,
+                        void* stream);
 /* out = ref > 0 ? g : 0   (ReLU backward) */
 int occ4d_relu_mask_f32(const float* g, int64_t ldg, const float* ref, int64_t ldr, int n, int d,
                         float* out, int64_t ldo, void* stream);

@@ -141,6 +141,12 @@ SIGNATURES = {
     'occ4d_linear_wgrad_bias_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _f, _f,
                                               C.c_int, _f, C.c_int, _s]),
     'occ4d_colsum_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, _f, C.c_int, _f, C.c_int, _s]),
+    'occ4d_bn_workspace_doubles': (C.c_int64, [C.c_int, C.c_int]),
+    'occ4d_bn_train_fwd_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, _f, _f, C.c_float, _f, _f, _f, C.c_int64, _f, _s]),
+    'occ4d_bn_train_bwd_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, C.c_int64, C.c_int, C.c_int, _f, _f, _f, C.c_float, _f,
+                                         C.c_int64, _f, _f, _f, _s]),
+    'occ4d_swish_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, _f, C.c_int64, _s]),
+    'occ4d_swish_bwd_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, C.c_int, C.c_int, _f, C.c_int64, _s]),
     'occ4d_relu_mask_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, C.c_int, C.c_int, _f, C.c_int64, _s]),
     'occ4d_scatter_add_rows_f32': (C.c_int, [_f, C.c_int64, _i, C.c_int, C.c_int, C.c_float, _f, C.c_int64, _s]),
     'occ4d_segment_sum_f32': (C.c_int, [_f, C.c_int, C.c_int, C.c_int, _f, C.c_int64, _s]),

@@ -330,6 +330,49 @@ class LayerNormReluFn(Function):
         return dx, dgamma, dbeta, None
 
 
+class BatchNormReluFn(Function):
+    """BatchNorm1d in training mode + ReLU (model/modules.py:98-102,152).  Returns (out, batch mean, biased batch
+    variance); the statistics are outputs without gradient (the module updates its running statistics from them)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, eps):
+        out, mean, var = ops.bn_train_fwd(y, gamma, beta, eps)
+        ctx.eps = eps
+        ctx.save_for_backward(y, gamma, out, mean, var)
+        ctx.mark_non_differentiable(mean, var)
+        return out, mean, var
+
+    @staticmethod
+    def backward(ctx, g, _gm, _gv):
+        y, gamma, out, mean, var = ctx.saved_tensors
+        dx, dgamma, dbeta = ops.bn_train_bwd(y, g.contiguous(), out, mean, var, gamma, ctx.eps)
+        return dx, dgamma, dbeta, None
+
+
+class SwishFn(Function):
+    """x sigmoid(x) (model/implicit.py:46-64, the reference's other activation) with its analytic backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.swish(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.swish_bwd(g.contiguous(), x)
+
+
+def act_linear(x, lin, activation, residual=None):
+    """lin(activation(x)) [+ residual] for the training path: 'relu' folds into the Linear kernels (relu_in), 'swish' is an
+    element-wise pass in front of a plain Linear."""
+    if activation == 'relu':
+        return linear(x, lin, relu_in=True, residual=residual)
+    if activation == 'swish':
+        return linear(SwishFn.apply(x), lin, residual=residual)
+    raise ValueError('Unknown activation: ' + str(activation))
+
+
 class MeanRowsFn(Function):
     @staticmethod
     def forward(ctx, x):

@@ -229,6 +229,28 @@ __global__ __launch_bounds__(TPB) void relu_mask_kernel(const float* __restrict_
   out[i * ldo + c] = ref[i * ldr + c] > 0.f ? g[i * ldg + c] : 0.f;
 }
 
+// swish (model/implicit.py:46-64): y = x * sigmoid(x); dx = g * (s + x s (1 - s)), s = sigmoid(x) -- the linear kernel's
+// own expression (csrc/linear.hip swish1), so that the training forward equals the inference forward
+__device__ __forceinline__ float sigmoid1(float v) { return 1.0f / (1.0f + __expf(-v)); }
+__global__ __launch_bounds__(TPB) void swish_kernel(const float* __restrict__ x, int64_t ldx, int64_t total, int d,
+                                                    float* __restrict__ y, int64_t ldy) {
+  const int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)(e % d);
+  const int64_t i = e / d;
+  const float v = x[i * ldx + c];
+  y[i * ldy + c] = v * sigmoid1(v);
+}
+__global__ __launch_bounds__(TPB) void swish_bwd_kernel(const float* __restrict__ g, int64_t ldg, const float* __restrict__ x,
+                                                        int64_t ldx, int64_t total, int d, float* __restrict__ out, int64_t ldo) {
+  const int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)(e % d);
+  const int64_t i = e / d;
+  const float v = x[i * ldx + c], sg = sigmoid1(v);
+  out[i * ldo + c] = g[i * ldg + c] * (sg + v * sg * (1.0f - sg));
+}
+
 // out[idx[i]][c] += scale * src[i][c]
 __global__ __launch_bounds__(TPB) void scatter_add_rows_kernel(const float* __restrict__ src, int64_t lds,
                                                                const int32_t* __restrict__ idx, int64_t total, int d,
@@ -829,6 +851,23 @@ int occ4d_relu_mask_f32(const float* g, int64_t ldg, const float* ref, int64_t l
   if (!total) return OCC4D_OK;
   relu_mask_kernel<<<grid1d(total), TPB, 0, (hipStream_t)stream>>>(g, ldg, ref, ldr, total, d, out, ldo);
   return occ4d::check_launch("occ4d_relu_mask_f32");
+}
+
+int occ4d_swish_f32(const float* x, int64_t ldx, int n, int d, float* y, int64_t ldy, void* stream) {
+  OCC4D_REQUIRE(x && y && n >= 0 && d >= 1, "occ4d_swish_f32: bad arguments");
+  const int64_t total = (int64_t)n * d;
+  if (!total) return OCC4D_OK;
+  swish_kernel<<<grid1d(total), TPB, 0, (hipStream_t)stream>>>(x, ldx, total, d, y, ldy);
+  return occ4d::check_launch("occ4d_swish_f32");
+}
+
+int occ4d_swish_bwd_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int n, int d, float* out, int64_t ldo,
+                        void* stream) {
+  OCC4D_REQUIRE(g && x && out && n >= 0 && d >= 1, "occ4d_swish_bwd_f32: bad arguments");
+  const int64_t total = (int64_t)n * d;
+  if (!total) return OCC4D_OK;
+  swish_bwd_kernel<<<grid1d(total), TPB, 0, (hipStream_t)stream>>>(g, ldg, x, ldx, total, d, out, ldo);
+  return occ4d::check_launch("occ4d_swish_bwd_f32");
 }
 
 int occ4d_scatter_add_rows_f32(const float* src, int64_t lds, const int32_t* idx, int n, int d, float scale,

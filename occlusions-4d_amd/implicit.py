@@ -75,11 +75,9 @@ class ResnetBlockFC(torch.nn.Module):
         return self._run(flat).reshape(*x.shape[:-1], self.d_out)
 
     def _run_train(self, x):
-        if self.activation != 'relu':
-            raise NotImplementedError("training is implemented for activation 'relu' (every published configuration)")
-        h = autograd.linear(x, self.fc_0, relu_in=True)
+        h = autograd.act_linear(x, self.fc_0, self.activation)
         xs = x if self.shortcut is None else autograd.linear(x, self.shortcut)
-        return autograd.linear(h, self.fc_1, relu_in=True, residual=xs)
+        return autograd.act_linear(h, self.fc_1, self.activation, residual=xs)
 
     def _run(self, x, inplace=False):
         act = ACTIVATIONS[self.activation]
@@ -342,8 +340,6 @@ class LocalPclResnetFC(ResnetFC):
         reach this module's parameters and, through features_abstract / features_global, the encoder."""
         assert self.local_mode == 'attention' and self.num_local_features > 0, \
             "training is implemented for the published configuration (local_mode='attention')"
-        if self.activation != 'relu':
-            raise NotImplementedError("training is implemented for activation 'relu' (every published configuration)")
         no_batch = points_query.dim() == 2
         q = points_query if no_batch else points_query[0]
         pa, fa, fg = points_abstract, features_abstract, features_global
@@ -382,7 +378,7 @@ class LocalPclResnetFC(ResnetFC):
                 agg = blk.layer2._forward(y[None], qxyz[None], fa[None], pa[None], pre=None,
                                           knn_idx=idx_att[None])[0]
                 x = autograd.linear(agg, blk.layer3, residual=x)
-        output = autograd.linear(x, self.lin_out, relu_in=True)
+        output = autograd.act_linear(x, self.lin_out, self.activation)
         penult = x
         if not no_batch:
             output, penult = output[None], penult[None]

@@ -110,8 +110,8 @@ class DownTransition(torch.nn.Module):
             self.mlp = torch.nn.Sequential(torch.nn.Linear(d_in, d_out), torch.nn.LayerNorm(d_out),
                                            torch.nn.ReLU())
         elif norm_type == 'batch':
-            # (model/modules.py:98-102: eps 1e-3, default momentum)  Inference uses the running statistics (eval mode);
-            # batch statistics (training mode) are not implemented -- no published configuration trains with it
+            # (model/modules.py:98-102: eps 1e-3, default momentum)  eval mode: running statistics; training mode (round 5):
+            # batch statistics over the B N rows of the level + running-statistics update (csrc/batchnorm.hip)
             self.mlp = torch.nn.Sequential(torch.nn.Linear(d_in, d_out), torch.nn.BatchNorm1d(d_out, eps=1e-3),
                                            torch.nn.ReLU())
         else:
@@ -152,12 +152,14 @@ class DownTransition(torch.nn.Module):
         (B, N, d_in) = x.shape
         lin = self.mlp[0]
         train = needs_grad(self, x)
+        if self.norm_type == 'batch' and self.mlp[1].training:
+            return self._forward_batchnorm_training(x, p, geometry, train)
+        if self.norm_type == 'batch' and train:
+            raise NotImplementedError("DownTransition(norm_type='batch'): gradients through an eval-mode BatchNorm (frozen "
+                                      "running statistics) are not implemented; train with .train() or run without grad")
         zs, ps = [], []
         for b in range(B):
             (inds, p_sub, nn_idx) = geometry[b] if geometry is not None else self.geometry(p[b].detach())
-            if self.norm_type == 'batch' and (train or self.mlp[1].training):
-                raise NotImplementedError("DownTransition(norm_type='batch') runs in eval mode only (running statistics); "
-                                          "call .eval() -- batch statistics are not implemented")
             if train:
                 if self.norm_type == 'layer':
                     ln = self.mlp[1]
@@ -177,5 +179,33 @@ class DownTransition(torch.nn.Module):
             else:
                 z = ops.down_pool_fwd(x[b], lin.weight, lin.bias, nn_idx, norm=0)
             zs.append(z)
+            ps.append(p_sub)
+        return (ops.stack_batch(zs), ops.stack_batch(ps))
+
+    def _forward_batchnorm_training(self, x, p, geometry, train):
+        """BatchNorm1d in training mode (model/modules.py:98-102, 152: the MLP runs on the flat (B N, d_in) rows, so the
+        statistics are those of ALL rows of the level): y = Linear(x); batch mean / biased variance; ReLU(BN(y)); the
+        running statistics move by `momentum` towards the batch mean and the UNBIASED batch variance, as torch does."""
+        (B, N, _) = x.shape
+        lin, bn = self.mlp[0], self.mlp[1]
+        geom = [geometry[b] if geometry is not None else self.geometry(p[b].detach()) for b in range(B)]
+        ys = [autograd.linear(x[b], lin) if train else ops.linear(x[b], lin.weight, lin.bias) for b in range(B)]
+        y_all = ys[0] if B == 1 else torch.cat(ys, dim=0)
+        if train:
+            out, mean, var = autograd.BatchNormReluFn.apply(y_all, bn.weight, bn.bias, bn.eps)
+        else:
+            out, mean, var = ops.bn_train_fwd(y_all, bn.weight, bn.bias, bn.eps)
+        if bn.track_running_stats:
+            with torch.no_grad():
+                rows = y_all.shape[0]
+                bn.num_batches_tracked += 1
+                m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                bn.running_mean.mul_(1.0 - m).add_(mean, alpha=m)
+                bn.running_var.mul_(1.0 - m).add_(var, alpha=m * rows / max(rows - 1, 1))
+        zs, ps = [], []
+        for b in range(B):
+            (inds, p_sub, nn_idx) = geom[b]
+            y_b = out[b * N:(b + 1) * N]
+            zs.append(autograd.MaxPoolGatherFn.apply(y_b, nn_idx) if train else ops.maxpool_gather(y_b, nn_idx))
             ps.append(p_sub)
         return (ops.stack_batch(zs), ops.stack_batch(ps))

@@ -1096,6 +1096,53 @@ def colsum(x):
     return out
 
 
+def bn_train_fwd(y, gamma, beta, eps):
+    """BatchNorm1d (training mode) + ReLU over the rows of y (n, d): (out, batch mean, biased batch variance)."""
+    y, ldy = _rows(_dev(y, name='y'), 'y')
+    n, d = y.shape
+    mean = torch.empty((d,), dtype=torch.float32, device=y.device)
+    var = torch.empty((d,), dtype=torch.float32, device=y.device)
+    out = torch.empty((n, d), dtype=torch.float32, device=y.device)
+    ws = torch.empty((int(_lib.lib().occ4d_bn_workspace_doubles(n, d)),), dtype=torch.float64, device=y.device)
+    _lib.check(_lib.lib().occ4d_bn_train_fwd_f32(_ptr(y), ldy, n, d, _ptr(_cont(gamma.detach(), 'gamma')),
+                                                 _ptr(_cont(beta.detach(), 'beta')), float(eps), _ptr(mean), _ptr(var),
+                                                 _ptr(out), d, _ptr(ws), _stream()))
+    return out, mean, var
+
+
+def bn_train_bwd(y, g, out, mean, var, gamma, eps):
+    """(dx, dgamma, dbeta) of bn_train_fwd."""
+    y, ldy = _rows(_dev(y, name='y'), 'y')
+    g, ldg = _rows(_dev(g, name='g'), 'g')
+    out, ldo = _rows(_dev(out, name='out'), 'out')
+    n, d = y.shape
+    dx = torch.empty((n, d), dtype=torch.float32, device=y.device)
+    dgamma = torch.empty((d,), dtype=torch.float32, device=y.device)
+    dbeta = torch.empty((d,), dtype=torch.float32, device=y.device)
+    ws = torch.empty((int(_lib.lib().occ4d_bn_workspace_doubles(n, d)),), dtype=torch.float64, device=y.device)
+    _lib.check(_lib.lib().occ4d_bn_train_bwd_f32(_ptr(y), ldy, _ptr(g), ldg, _ptr(out), ldo, n, d, _ptr(mean), _ptr(var),
+                                                 _ptr(_cont(gamma.detach(), 'gamma')), float(eps), _ptr(dx), d, _ptr(dgamma),
+                                                 _ptr(dbeta), _ptr(ws), _stream()))
+    return dx, dgamma, dbeta
+
+
+def swish(x):
+    x, ldx = _rows(_dev(x, name='x'), 'x')
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().occ4d_swish_f32(_ptr(x), ldx, x.shape[0], x.shape[1], _ptr(out), x.shape[1], _stream()))
+    return out
+
+
+def swish_bwd(g, x):
+    g, ldg = _rows(_dev(g, name='g'), 'g')
+    x, ldx = _rows(_dev(x, name='x'), 'x')
+    assert g.shape == x.shape
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().occ4d_swish_bwd_f32(_ptr(g), ldg, _ptr(x), ldx, x.shape[0], x.shape[1], _ptr(out), x.shape[1],
+                                              _stream()))
+    return out
+
+
 def relu_mask(g, ref):
     g, ldg = _rows(_dev(g, name='g'), 'g')
     ref, ldr = _rows(_dev(ref, name='ref'), 'ref')

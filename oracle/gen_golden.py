@@ -372,6 +372,38 @@ def regimes(ref):
     for case in gc.INFER_PAD_CASES:
         run_inference(ref, case)
 
+    # G15: gradients of the decoder with the swish activation, by the reference's own autograd
+    for case in gc.TRAIN_OPTION_CASES:
+        q, abstract, fglob, ia, sd, go, gp = gc.train_option_inputs(case)
+        with torch.enable_grad():
+            net = imp.LocalPclResnetFC(**ia)
+            net.load_state_dict(sd)
+            net.train()
+            ab = t(abstract).clone().requires_grad_(True)
+            fg = t(fglob).clone().requires_grad_(True)
+            out, pen = net(t(q), ab, fg, None)
+            ((out * t(go)).sum() + (pen * t(gp)).sum()).backward()
+        params = dict(net.named_parameters())
+        save('g15_train_' + case['name'], output=out.detach().numpy(), penult=pen.detach().numpy()[:, ::8],
+             grad_abstract=ab.grad.numpy()[:, ::3], grad_fglob=fg.grad.numpy(),
+             **{'grad__' + k: gc.grad_sample(params[k].grad.numpy()) for k in gc.TRAIN_OPTION_PARAMS})
+
+    # G16: DownTransition with BatchNorm in training mode: outputs, updated running statistics, gradients
+    for case in gc.DOWN_BN_TRAIN_CASES:
+        x, pos, sd, gz = gc.down_bn_train_inputs(case)
+        with torch.enable_grad():
+            dt = mods.DownTransition(case['d_in'], case['d_out'], factor=3, knn_k=case['k'], norm_type='batch',
+                                     fps_random_start=False)
+            dt.load_state_dict(sd)
+            dt.train()
+            xin = t(x).clone().requires_grad_(True)
+            z, p_sub = dt(xin, t(pos))
+            (z * t(gz)).sum().backward()
+        save('g16_down_' + case['name'], z=z.detach().numpy(), p_sub=p_sub.numpy(),
+             running_mean=dt.mlp[1].running_mean.numpy(), running_var=dt.mlp[1].running_var.numpy(),
+             num_batches=np.array([int(dt.mlp[1].num_batches_tracked)]), grad_x=xin.grad.numpy(),
+             **{'grad__' + k: v.grad.numpy() for k, v in dt.named_parameters()})
+
     # G8t: decoder on a two-level abstract cloud (coincident coordinates), with the lists the reference took
     for case in gc.DEC_TWOLEVEL_CASES:
         q, abstract, fglob, ia, sd = gc.dec_twolevel_inputs(case)

@@ -154,7 +154,7 @@ def pt_block(sd, x, p, x2=None, p2=None, num_neighbors=16, idx=None):
 # ----------------------------------------------------------------------------
 # E6 (+E7): DownTransition.forward   (model/modules.py:113-163)
 # ----------------------------------------------------------------------------
-def down_transition(sd, x, p, factor, knn_k, norm_type='none', return_inds=False):
+def down_transition(sd, x, p, factor, knn_k, norm_type='none', return_inds=False, training=False):
     assert x.shape[:2] == p.shape[:2]
     B, N, d_in = x.shape
     n_new = int(np.ceil(N / factor))                            # :126
@@ -168,9 +168,11 @@ def down_transition(sd, x, p, factor, knn_k, norm_type='none', return_inds=False
     y = _lin(sd, 'mlp.0', x.reshape(B * N, d_in))               # :152
     if norm_type == 'layer':
         y = F.layer_norm(y, (y.shape[-1],), sd['mlp.1.weight'], sd['mlp.1.bias'], 1e-5)
-    elif norm_type == 'batch':                                  # :98-102, eval mode (running statistics), eps 1e-3
+    elif norm_type == 'batch':                                  # :98-102: BatchNorm1d(eps 1e-3, momentum 0.1)
+        # eval mode: running statistics; training mode: the statistics of the B N rows, and the running statistics in
+        # `sd` move towards them in place (unbiased variance), as the module does
         y = F.batch_norm(y, sd['mlp.1.running_mean'], sd['mlp.1.running_var'], sd['mlp.1.weight'], sd['mlp.1.bias'],
-                         False, 0.0, 1e-3)
+                         training, 0.1 if training else 0.0, 1e-3)
     elif norm_type != 'none':
         raise ValueError(norm_type)
     y = _relu(y)

@@ -227,6 +227,56 @@ DEC_SWISH_CASES = [
     dict(name='carla_m2124_q256_swish', kind='carla', m=2124, nq=256, seed=91, activation='swish'),
 ]
 
+# Round 5: gradients of the training path for the reference's options no published configuration trains with -- the
+# swish activation (model/implicit.py:46-64) -- taken from the reference's own autograd on CPU (G15)
+TRAIN_OPTION_CASES = [
+    dict(name='greater_m76_swish', base=dict(name='greater_m76_q256_swish_t', kind='greater', m=76, nq=256, seed=93,
+                                             activation='swish'), nq=96, seed=94),
+    dict(name='carla_m300_swish', base=dict(name='carla_m300_q256_swish_t', kind='carla', m=300, nq=256, seed=95,
+                                            activation='swish'), nq=64, seed=96),
+]
+TRAIN_OPTION_PARAMS = ['lin_out.weight', 'lin_in.bias', 'blocks.0.fc_0.weight', 'blocks.5.fc_1.bias', 'lin_z.3.weight',
+                       'pt_blocks.1.layer2.to_q.weight', 'pt_blocks.0.layer2.attn_mlp.0.weight', 'pt_blocks.0.layer3.bias']
+
+
+def grad_sample(a):
+    """What the G15 fixtures keep of a parameter gradient: every 5th row and 3rd column of a matrix, a vector whole."""
+    return a[::5, ::3] if a.ndim == 2 else a
+
+
+def train_option_inputs(case):
+    """(q, abstract, fglob, ia, sd, go, gp): decoder inputs + the cotangents of (output, penult) that define the scalar
+    loss = sum(output * go) + sum(penult * gp)."""
+    q, abstract, fglob, ia, sd = dec_inputs(case['base'])
+    q = q[:case['nq']]
+    rng = _rng(case['seed'])
+    go = rng.normal(size=(q.shape[0], ia['d_out'])).astype(np.float32)
+    gp = (0.1 * rng.normal(size=(q.shape[0], ia['d_hidden']))).astype(np.float32)
+    return q, abstract, fglob, ia, sd, go, gp
+
+
+# Round 5: DownTransition(norm_type='batch') in TRAINING mode (model/modules.py:98-102): batch statistics, running-stat
+# update, gradients -- from the reference's own module and autograd on CPU (G16); B = 2 clouds share the statistics
+DOWN_BN_TRAIN_CASES = [
+    dict(name='batch_train_n200_72to144_k12', n=200, d_in=72, d_out=144, k=12, norm='batch', seed=44, batch=2),
+    dict(name='batch_train_n301_36to72_k12', n=301, d_in=36, d_out=72, k=12, norm='batch', seed=45, batch=1),
+]
+
+
+def down_bn_train_inputs(case):
+    """(x (B,n,d_in), pos (B,n,3), state_dict, cotangent of z)."""
+    xs, ps = [], []
+    for b in range(case['batch']):
+        x, pos, sd = down_inputs(dict(case, seed=case['seed'] + 100 * b))
+        xs.append(x)
+        ps.append(pos)
+    _, _, sd = down_inputs(case)
+    rng = _rng(case['seed'] + 7)
+    n_new = int(np.ceil(case['n'] / 3))
+    gz = rng.normal(size=(case['batch'], n_new, case['d_out'])).astype(np.float32)
+    return np.stack(xs), np.stack(ps), sd, gz
+
+
 DEC_REGIME_CASES = [
     dict(name='greater_m531_q256_w4', kind='greater', m=531, nq=256, seed=85, attn_wscale=4.0, fscale=4.0),
     dict(name='greater_m531_q256_w8', kind='greater', m=531, nq=256, seed=86, attn_wscale=8.0, fscale=4.0),

@@ -249,6 +249,44 @@ def test_g8t_decoder_on_two_level_cloud_with_reference_lists(case):
     assert np.abs(free.numpy()[amb] - g['output'][amb]).max() > 1e-4  # and the lists matter where it is not
 
 
+@pytest.mark.parametrize('case', gc.DOWN_BN_TRAIN_CASES, ids=lambda c: c['name'])
+def test_g16_down_transition_batchnorm_training(case):
+    """DownTransition(norm_type='batch') in training mode: outputs, the running statistics after one step and the
+    gradients (input, Linear, BatchNorm affine) of the restatement against the reference's module + autograd."""
+    x, pos, sd, gz = gc.down_bn_train_inputs(case)
+    g = load_golden('g16_down_' + case['name'])
+    rsd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v.clone())
+           for k, v in sd.items()}
+    xin = T(x).clone().requires_grad_(True)
+    z, p_sub = op.down_transition(rsd, xin, T(pos), 3, case['k'], 'batch', training=True)
+    (z * T(gz)).sum().backward()
+    close(z.detach(), g['z'])
+    assert np.array_equal(p_sub.numpy(), g['p_sub'])
+    close(rsd['mlp.1.running_mean'], g['running_mean'], 1e-6)
+    close(rsd['mlp.1.running_var'], g['running_var'], 1e-6)
+    rel = lambda a, b: float(np.abs(np.asarray(a) - b).max()) / (float(np.abs(b).max()) + 1e-12)
+    assert rel(xin.grad, g['grad_x']) < 1e-4
+    for k in ('mlp.0.weight', 'mlp.0.bias', 'mlp.1.weight', 'mlp.1.bias'):
+        assert rel(rsd[k].grad, g['grad__' + k]) < 1e-4, k
+
+
+@pytest.mark.parametrize('case', gc.TRAIN_OPTION_CASES, ids=lambda c: c['name'])
+def test_g15_swish_training_gradients(case):
+    """The restatement's autograd through the swish decoder against the reference's own (CPU): values and the gradients
+    w.r.t. the abstract cloud, the global embedding and a sample of the parameters."""
+    q, abstract, fglob, ia, sd, go, gp = gc.train_option_inputs(case)
+    g = load_golden('g15_train_' + case['name'])
+    rsd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ab, fg = T(abstract).clone().requires_grad_(True), T(fglob).clone().requires_grad_(True)
+    out, pen = op.decoder_forward(rsd, ia, T(q), ab, fg)
+    ((out * T(go)).sum() + (pen * T(gp)).sum()).backward()
+    close(out.detach(), g['output'])
+    rel = lambda a, b: float(np.abs(np.asarray(a) - b).max()) / (float(np.abs(b).max()) + 1e-12)
+    assert rel(ab.grad[:, ::3][:, 1:], g['grad_abstract'][:, 1:]) < 1e-4 and rel(fg.grad, g['grad_fglob']) < 1e-4
+    for k in gc.TRAIN_OPTION_PARAMS:
+        assert rel(gc.grad_sample(rsd[k].grad.numpy()), g['grad__' + k]) < 1e-4, k
+
+
 @pytest.mark.parametrize('case', gc.TRACK_CASES, ids=lambda c: c['name'])
 def test_g11_tracks_and_gt_labels(case):
     """track_mode 'all' (one rerun per instance id with >= 16 points, multi_track_merge) and the 1-NN
