@@ -113,6 +113,14 @@ def cpu_baseline_worker(kind):
         op.encoder_forward(esd, pa, pcl)
         t_enc = time.time() - t0
     print(json.dumps(dict(stage='encode', t_enc=t_enc)), flush=True)
+    # the same decode with EVERY host core (SURVEY 8(d)'s wording), on one full mini-batch: reported beside the 16-thread
+    # figure, which stays the baseline (many-core hosts thrash on the oracle's small ops)
+    with torch.no_grad():
+        torch.set_num_threads(os.cpu_count() or 1)
+        t0 = time.time()
+        op.decoder_forward(dsd, ia, torch.from_numpy(q[:BATCH]), ab, fg)
+        print(json.dumps(dict(stage='all_cores', t_all=time.time() - t0, all_sample=BATCH, all_cores=torch.get_num_threads())),
+              flush=True)
 
 
 def cpu_baseline_start(kind):
@@ -177,7 +185,13 @@ def cpu_baseline(kind, budget_s=240.0, child=None):
         note = ('oracle/path.py on host CPU: %d-query decode %.2f s extrapolated linearly to %d queries; the encode '
                 'did not finish within the %.0f s budget and is NOT included (decode-only upper bound)'
                 % (sample, rec['t_dec'], n, budget_s))
+    all_cores = None
+    if 't_all' in rec:       # (did not finish within the budget on a thrashing host: then absent)
+        all_cores = dict(cores=rec['all_cores'], decode_value=rec['all_sample'] / rec['t_all'], unit='query-points/s (decode only)',
+                         sample='%d-query decode with torch.set_num_threads(%d): %.1f s' % (rec['all_sample'], rec['all_cores'],
+                                                                                           rec['t_all']))
     return dict(value=n / total, unit='query-points/s', cores=rec['cores'], host_cores=os.cpu_count(), kind='port',
+                all_cores=all_cores,
                 sample=note + ' (torch threads capped at %d of the host\'s %d logical cores: the oracle\'s small ops thrash '
                 'beyond that)' % (rec['cores'], os.cpu_count() or 0))
 
@@ -196,8 +210,44 @@ def self_launch(n_gpus):
         port = sk.getsockname()[1]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % n_gpus,
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: this image's host driver only supports dmabuf IPC; without it RCCL's device-memory
+    # sharing across processes fails with `hipIpcGetMemHandle: invalid argument` (the build environment's own note; the
+    # driver's launcher exports it as well -- kept here so that a bare `python bench.py --gpus N` behaves the same)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     return subprocess.call(cmd, env=env)
+
+
+def rccl_log_setup(rank):
+    """N > 1 runs record RCCL's own initialisation log (NCCL_DEBUG=INFO into a per-process file) so that the bench line can
+    carry which transport / ring RCCL really built: the first 8-GPU run is then diagnosable from its JSON tail."""
+    path = '/tmp/occ4d_rccl_rank%d_%d.log' % (rank, os.getpid())
+    os.environ.setdefault('NCCL_DEBUG', 'INFO')
+    os.environ.setdefault('NCCL_DEBUG_SUBSYS', 'INIT,GRAPH')
+    os.environ['NCCL_DEBUG_FILE'] = path
+    return path
+
+
+def rccl_log_excerpt(path, limit=14):
+    """The lines of RCCL's log that name the version, the topology search result, rings / trees and transports."""
+    keep = []
+    try:
+        with open(path, errors='replace') as f:
+            for ln in f:
+                if 'NCCL INFO' not in ln:
+                    continue
+                msg = ln.split('NCCL INFO', 1)[1].strip()
+                if any(k in msg for k in ('version', 'RCCL', 'Ring ', 'Trees', 'Channel 00', 'via ', 'Connected all', 'comm 0x',
+                                          'nChannels', 'Pattern', 'XGMI', 'P2P')):
+                    keep.append(msg[:160])
+    except OSError as e:
+        return ['(no RCCL log: %s)' % e]
+    seen, out = set(), []
+    for m in keep:
+        key = m[:40]
+        if key not in seen:
+            seen.add(key)
+            out.append(m)
+    return out[:limit]
 
 
 def pmc_traffic(kind):
@@ -254,7 +304,10 @@ def main():
     device = torch.device('cuda', dev_index)
     use_dist = world > 1 or os.environ.get('OCC4D_FORCE_DIST') == '1'   # (1-rank RCCL: smoke test of the N > 1 path)
     rccl_ranks = 1
+    rccl_log = None
     if use_dist:
+        if backend == 'nccl':
+            rccl_log = rccl_log_setup(rank)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', str(rank))
@@ -493,6 +546,7 @@ def main():
                                        'N = 1 point.',
                        'encode_ms_per_rank': [e[0] for e in exchange], 'broadcast_ms_per_rank': [e[1] for e in exchange],
                        'rccl_ranks': rccl_ranks, 'backend': ('rccl' if backend == 'nccl' else backend) if use_dist else None,
+                       'rccl_info': rccl_log_excerpt(rccl_log) if rccl_log else None,
                        'ranks_share_one_gpu': share_gpu or None,
                        'per_rank_ms_per_step': [1e3 * t / args.steps for t in per_rank_s],
                        'decode_streams': pk.inference.DECODE_STREAMS, 'decode_chunk': chunk},

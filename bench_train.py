@@ -46,6 +46,7 @@ def self_launch(n_gpus):
         port = sk.getsockname()[1]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % n_gpus,
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # (HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver only supports dmabuf IPC; see bench.py:self_launch)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     return subprocess.call(cmd, env=env)
 

@@ -429,9 +429,6 @@ __global__ __launch_bounds__(256, 2) void cross_attn16p_kernel(const Attn16pArgs
       }
     };
     asm volatile("; OCC4D_MARK epilogue");
-#ifdef OCC4D_CA16P_EPI_PRIO
-    __builtin_amdgcn_s_setprio(OCC4D_CA16P_EPI_PRIO);
-#endif
     // buf0 holds the first P2 stage (it followed the last hidden stage in the stream); the second lands in buf1 under it
     dma_stage_p(a.wstream + (int64_t)(PHS + 1) * PSTAGE, buf1, wave, lane16);
     using I0 = std::integral_constant<int, 0>;
@@ -449,9 +446,6 @@ __global__ __launch_bounds__(256, 2) void cross_attn16p_kernel(const Attn16pArgs
     chunk(IA{}, I4{}, IA{}, buf1);
     chunk(std::integral_constant<int, PTA + 4>{}, I4{}, IA{}, buf1);
     chunk(std::integral_constant<int, PTA + 8>{}, I4{}, IA{}, buf1);
-#ifdef OCC4D_CA16P_EPI_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
 #ifdef OCC4D_CA16P_STAMP
     ts[3 + 3 * ps] = __builtin_amdgcn_s_memtime();
 #endif

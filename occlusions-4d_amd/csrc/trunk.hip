@@ -145,9 +145,6 @@ __global__ __launch_bounds__(512, 2) void resblock_kernel(const TrunkArgs a) {
 
   dma_stage(a.w0p, bufA, wave, lane);
   if (tid < TH) s_b0[tid] = a.b0[tid];
-#ifdef OCC4D_TR_PRIO
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses every arbitration otherwise
-#endif
   f32x4 xr[TKG], yacc[TKG];
   {
     const float* xp = a.x + (int64_t)rowc * a.ldx + 4 * g;

@@ -166,6 +166,8 @@ class Participation:
         self.used = None
 
     def clear(self):
+        """Forget the agreement: the next eager step of EVERY rank agrees again (call it on all ranks at the same point
+        of the program -- an epoch boundary, after freezing / unfreezing parameters)."""
         self.used = None
 
 
@@ -184,14 +186,23 @@ def allreduce_gradients(params, world=None, participation=None):
     # reduces the same flat layout -- but one that NO rank used keeps grad = None, so that the optimiser skips it
     # (no weight decay, no moment update), exactly as in a single-process run and as under the reference's
     # nn.DataParallel (train.py:305).
-    # The agreement needs one host read, which a stream capture forbids: a captured step (GraphedTrainStep) reuses the
-    # agreement of the eager warm-up steps that precede every capture -- all ranks are capturing (or not) at the same
-    # point of the program, so they take the same branch.
-    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
-        assert participation is not None and participation.used is not None and \
-            len(participation.used) == len(params), \
-            'a captured step needs the participation mask of a preceding eager step (GraphedTrainStep.capture warmup >= 1)'
+    # The agreement needs one host read (a stall of the launching thread, and forbidden inside a stream capture), so it is
+    # made ONCE per Participation record -- the first eager step -- and reused by every later step, eager or captured,
+    # until the caller clears it (round 5; round 4 agreed again in every eager step).  All ranks run the same program, so
+    # they agree / reuse at the same steps.  The set of parameters that receive gradients is a property of the model
+    # graph (which heads and losses are switched on), not of the data; a parameter that turns up with a gradient after
+    # the agreement excluded it is a program error and raises instead of silently skipping its reduction.
+    capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+    if participation is not None and participation.used is not None and len(participation.used) == len(params):
         used = participation.used
+        late = [i for i, (p, u) in enumerate(zip(params, used)) if p.grad is not None and not u]
+        if late:
+            raise RuntimeError('allreduce_gradients: %d parameter(s) received a gradient after the ranks agreed that nobody '
+                               'uses them; call Participation.clear() on every rank when the set of trained parameters '
+                               'changes' % len(late))
+    elif capturing:
+        raise AssertionError('a captured step needs the participation mask of a preceding eager step '
+                             '(GraphedTrainStep.capture warmup >= 1)')
     else:
         has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], device=params[0].device)
         dist.all_reduce(has, op=dist.ReduceOp.MAX)

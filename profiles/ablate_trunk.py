@@ -14,7 +14,6 @@ import occlusions4d_amd as pk  # noqa: E402
 CSRC = os.path.join(ROOT, 'occlusions-4d_amd', 'csrc')
 VARIANTS = {
     'base': [],
-    'prio': ['-DOCC4D_TR_PRIO'],
     'nodma': ['-DOCC4D_TR_NODMA'],
     'nobar': ['-DOCC4D_TR_NOBAR'],
     'nodma-nobar': ['-DOCC4D_TR_NODMA', '-DOCC4D_TR_NOBAR'],

@@ -146,6 +146,32 @@ def _grad_worker(rank, world, port, ret):
         pk.training.allreduce_gradients(params, participation=part)
         assert part.used == [True, True, True, False]       # the mask a captured step would reuse lives on the caller
         ret[rank] = [None if p.grad is None else p.grad.clone() for p in params]
+        # round 5: a second step REUSES the agreement (no mask all-reduce, no host read): rank 0 comes without a gradient
+        # for params[2] again and still reduces it as zeros; the unused parameter stays untouched
+        agreed = part.used
+        params[0].grad = torch.full((5, 3), 10.0 * (rank + 1))
+        if rank == 0:
+            params[2].grad = None
+        else:
+            params[2].grad = torch.full((2, 2), 8.0)
+        calls = []
+        orig = dist.all_reduce
+        dist.all_reduce = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            pk.training.allreduce_gradients(params, participation=part)
+        finally:
+            dist.all_reduce = orig
+        assert len(calls) == 1 and part.used is agreed       # the flat bucket only
+        assert torch.allclose(params[0].grad, torch.full((5, 3), 15.0)) and torch.allclose(params[2].grad, torch.full((2, 2), 4.0))
+        assert params[3].grad is None
+        # a gradient that turns up for a parameter the ranks agreed nobody uses is an error, not a silent skip
+        params[3].grad = torch.ones(3)
+        try:
+            pk.training.allreduce_gradients(params, participation=part)
+            raise SystemExit('expected a RuntimeError')
+        except RuntimeError as e:
+            assert 'Participation.clear()' in str(e)
+        params[3].grad = None
     finally:
         dist.destroy_process_group()
 
