@@ -209,6 +209,16 @@ __global__ __launch_bounds__(256) void grid_far_kernel(const float* __restrict__
 // The same search with ONE thread per query, for searches with so many queries that the machine is full without
 // splitting them (the decoder's 68812 queries of a training step): exact termination (the thread knows its own k-th
 // distance), no merge.  profiles/r04_time_knn_grid.txt has both on every shape.
+// Rounding slack of the face distances `ox + c h - q` (and of the cell a point was binned into): 8 ulp of the largest
+// magnitude involved.  1 % of a cell (the fixed margin) covers it for normalised clouds; for coordinates that are large
+// against their extent (|origin| / h >~ 1e5: un-normalised world coordinates) ulp(origin) approaches the cell
+// edge, so the slack scales with the coordinates.  A larger margin can only cost a ring, never an error.
+__device__ __forceinline__ float coord_slack(const GridPlan& g, float h, float qx, float qy, float qz) {
+  const float big = fmaxf(fmaxf(fabsf(qx), fabsf(qy)), fabsf(qz)) +
+                    fmaxf(fmaxf(fabsf(g.ox) + h * (float)g.nx, fabsf(g.oy) + h * (float)g.ny), fabsf(g.oz) + h * (float)g.nz);
+  return 1e-6f * big;
+}
+
 template <int KT, int METRIC>
 __global__ __launch_bounds__(64) void knn_grid1_kernel(const float* __restrict__ query, int64_t qs, int nq,
                                                       const GridPlan* __restrict__ plan, const int* __restrict__ starts,
@@ -270,7 +280,7 @@ __global__ __launch_bounds__(64) void knn_grid1_kernel(const float* __restrict__
     if (cz - rho > 0) lb = fminf(lb, qz - (g.oz + (float)(cz - rho) * h));
     if (cz + rho < g.nz - 1) lb = fminf(lb, (g.oz + (float)(cz + rho + 1) * h) - qz);
     if (lb == __builtin_inff()) break;                                // the block covers the grid
-    lb = fmaxf(0.f, lb - 1e-2f * h);
+    lb = fmaxf(0.f, lb - (1e-2f * h + coord_slack(g, h, qx, qy, qz)));
     const float kth = bd[k - 1];
     if (METRIC == 0 ? kth < lb * lb : kth < lb) break;
   }
@@ -365,7 +375,7 @@ __global__ __launch_bounds__(KG_BLOCK) void knn_grid_kernel(const float* __restr
     if (cz - rho > 0) lb = fminf(lb, qz - (g.oz + (float)(cz - rho) * h));
     if (cz + rho < g.nz - 1) lb = fminf(lb, (g.oz + (float)(cz + rho + 1) * h) - qz);
     if (lb == __builtin_inff()) break;                                // the block covers the grid
-    lb = fmaxf(0.f, lb - 1e-2f * h);
+    lb = fmaxf(0.f, lb - (1e-2f * h + coord_slack(g, h, qx, qy, qz)));
     float lo = bd[k - 1], hi = bd[0];                                 // upper bounds of the union's k-th distance
 #pragma unroll
     for (int o = KG_TPQ / 2; o > 0; o >>= 1) {

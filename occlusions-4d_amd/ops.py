@@ -1179,6 +1179,11 @@ class deterministic:
 _SEGMENTS = []       # a few recent (key, base tensor, order, offsets): one neighbour list serves several scatters
 
 
+def forget_segments():
+    """Drops the cached segmentations (see _segments: needed only by callers that refill an index buffer in place)."""
+    del _SEGMENTS[:]
+
+
 def _segments(idx_flat, n_out, stable=True):
     """Pair indices sorted stably by target row (int32) and the (n_out + 1) segment bounds (stable=False: grouped by target
     row in unspecified order inside a group, built by the library's counting sort -- kernels only, so it can be captured;
@@ -1188,7 +1193,12 @@ def _segments(idx_flat, n_out, stable=True):
     While a stream is being captured the cache is neither read nor written: a hit would bake tensors of an EARLIER
     (eager) call into the graph -- constants of the normal memory pool that the cache frees on its next eviction while
     every replay still reads them -- and an entry made during the capture would hand graph-pool tensors to later eager
-    calls."""
+    calls.
+    INVARIANT the cache relies on: an index buffer is never refilled IN PLACE by a library kernel between two
+    uses -- the library writes through raw pointers and does not bump `_version`.  Every producer of neighbour lists in
+    this package (ops.knn, ops.fps*, gather / nested-level helpers) allocates a fresh output, so it holds; a caller that
+    reuses one index buffer for different lists (`out=` style static buffers) must call forget_segments() after
+    refilling it."""
     capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
     stable = bool(stable) or n_out > 16384
     assert not (capturing and stable), 'the stable (deterministic) segmentation sorts with torch: eager steps only'

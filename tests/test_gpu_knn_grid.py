@@ -63,6 +63,19 @@ def test_grid_knn_equals_brute_force_self(kind, n, k, metric):
     assert torch.equal(gd, bd)
 
 
+@pytest.mark.parametrize('offset', [1e3, 1e5, 3e6])
+@pytest.mark.parametrize('k,metric', [(16, 0), (8, 1)])
+def test_grid_knn_on_unnormalised_world_coordinates(offset, k, metric):
+    """clouds whose coordinates are large against their extent (|origin| / cell edge up to ~1e7: one ulp of the
+    origin is then a sizeable fraction of a cell).  The ring-termination margin scales with the coordinates' ulp, so the
+    grid lists stay those of the brute-force kernel bit for bit (fp32 coordinates are what they are: both see the same)."""
+    import occlusions4d_amd as pk
+    rng = np.random.default_rng(int(offset) + k)
+    d = (rng.uniform(-5, 5, size=(6000, 3)) + np.array([offset, -0.7 * offset, 0.3 * offset])).astype(np.float32)
+    (bi, bd), (gi, gd) = _both(pk, d, d, k, metric)
+    assert torch.equal(gi, bi) and torch.equal(gd, bd)
+
+
 @pytest.mark.parametrize('kind,nd,nq', [('scene', 4248, 20000), ('uniform', 531, 3000), ('clusters', 3000, 4000),
                                         ('lattice', 1000, 2000), ('flat', 2000, 1500)])
 @pytest.mark.parametrize('k,metric', [(14, 0), (8, 1)])
