@@ -9,9 +9,18 @@ def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     n_enc = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
-    # one encode ends with the torch.cat of its outputs (CatArrayBatchedCopy): the last encode = the kernels behind the
-    # second-to-last of them (encodes are issued back to back, so gaps do not delimit them)
-    ends = [i for i, r in enumerate(rows) if 'CatArrayBatchedCopy' in r['Kernel_Name']]
+    # one encode ends with the row copies / level-id fills that lay out its abstract cloud (round 5: library kernels; up to
+    # round 4 a torch.cat), the last of a run of them behind the global mean-pool: the last encode = the kernels behind
+    # the second-to-last such end (encodes are issued back to back, so gaps do not delimit them)
+    ends, seen_mean = [], False
+    for i, r in enumerate(rows):
+        name = r['Kernel_Name']
+        seen_mean = seen_mean or 'mean_rows_kernel' in name
+        tail = 'copy_rows_kernel' in name or 'fill_rows_kernel' in name
+        nxt = rows[i + 1]['Kernel_Name'] if i + 1 < len(rows) else ''
+        if seen_mean and tail and not ('copy_rows_kernel' in nxt or 'fill_rows_kernel' in nxt):
+            ends.append(i)
+            seen_mean = False
     assert len(ends) >= 2, 'need at least two encodes in the trace'
     seg = rows[ends[-2] + 1:ends[-1] + 1]
     t0 = int(seg[0]['Start_Timestamp'])

@@ -30,10 +30,15 @@ def main():
     lg = torch.empty((n * k, d), device='cuda')
     pe = torch.empty((n * k, d), device='cuda')
     so = '/tmp/pair_mlp_var.so'
-    subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
+    # the variant = this file rebuilt with the extra flags, linked against the library's other objects (build/*.o):
+    # crossattn16p.hip calls into path.hip / memops.hip (phase skew, CU count), so it cannot be linked alone
+    objs = [os.path.join(ROOT, 'occlusions-4d_amd', 'build', f) for f in sorted(os.listdir(os.path.join(ROOT, 'occlusions-4d_amd', 'build')))
+            if f.endswith('.o') and f != 'crossattn16p.o']
+    obj = '/tmp/pair_mlp_var.o'
+    subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC',
                     '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC, '-fno-honor-nans'] + sys.argv[1:] +
-                   [os.path.join(CSRC, 'crossattn16p.hip'), os.path.join(CSRC, 'error.hip'), '-o', so], check=True,
-                   stderr=subprocess.DEVNULL)
+                   ['-c', os.path.join(CSRC, 'crossattn16p.hip'), '-o', obj], check=True)
+    subprocess.run(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', so, obj] + objs, check=True)
     lib = C.CDLL(so)
     fn = lib.occ4d_pt_pair_mlp_f32
     fn.restype = C.c_int
