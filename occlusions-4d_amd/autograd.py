@@ -6,6 +6,7 @@ supplies the tape, tensor glue (cat / slicing) and the optimiser only.  The trai
 uses the as-written op order of model/*.py (no weight merging), built from the unfused kernels;
 kNN / FPS carry no gradient (they depend on coordinates only).
 """
+import contextlib
 import os
 
 import torch
@@ -26,6 +27,152 @@ ROWLIN_HALF_CU = os.environ.get('OCC4D_TRAIN_ROWLIN_HALF_CU', '1') == '1'
 _PACKS = {}           # stage-packed copies of nn.Parameters only (small LRU); transient leaves are packed uncached
 _PACKS_MAX = 64
 _ZEROS = {}           # zero bias vectors, kept apart from the packs and created eagerly (never inside a capture)
+
+
+# ---- parameter gradients beside the data-gradient chain ---------------------------------------------------------------
+# A backward pass is one dependency chain of DATA gradients (each layer's dx feeds the layer below) with a PARAMETER
+# gradient hanging off every link (dW = g^T x, db, the scatter onto the key / value tables, ...) that nothing reads until
+# the optimiser.  Issued on one stream they serialise: every partial dispatch round of a GEMM, every split-M partial sum
+# and every 5 us reduction is waited for.  Inside `gradient_overlap()` (training.TrainStep wraps loss.backward() in it)
+# the parameter-gradient launches go to a second stream that is ordered behind the producer of their operands (an event
+# per submission) and joined at the end of the pass: they fill the tails and small-kernel gaps of the chain
+# (88.7 -> 83.7 ms per config-5 step when first measured; same kernels, same operands, same sums).
+#   * results are never handed to the autograd engine from the side stream (its accumulation would run on the main
+#     stream, unordered): gradients of nn.Parameters collect in private buffers that `gradient_overlap()` adds to .grad
+#     on exit, after the join; gradients of the transient leaves of a recompute pass collect in `gradient_sinks()`;
+#   * every operand a side-stream kernel reads is HELD (a reference, released once an event behind that kernel has
+#     completed): the allocator cannot recycle it underneath, and -- the hazard a record_stream would not cover -- the
+#     autograd engine cannot accumulate into it in place (it adds a later gradient contribution INTO a buffer it holds
+#     the only reference to: `dy` handed on as the residual's gradient is such a buffer while the side stream still
+#     reads it as the `g` of a weight gradient);
+#   * while a stream is being captured (GraphedTrainStep) nothing is moved: one stream, the order of round 4.
+#   * the side stream may fall behind (the chain's kernels are submitted first and fill the machine); the operands held
+#     for it are bounded: beyond GRADIENT_OVERLAP_BYTES the main stream waits for the oldest submission before it goes on.
+GRADIENT_OVERLAP = os.environ.get('OCC4D_GRADIENT_OVERLAP', '1') == '1'
+GRADIENT_OVERLAP_BYTES = int(float(os.environ.get('OCC4D_GRADIENT_OVERLAP_GB', '6')) * 2 ** 30)
+
+
+class _Overlap:
+    stream = None
+    depth = 0
+    params = {}          # id(parameter) -> [parameter, sum]      (filled on the side stream)
+    sinks = {}           # id(leaf) -> [leaf, sum or None]        (gradient_sinks)
+    held = []            # (event behind a side-stream submission, the operands it reads, their bytes), oldest first
+    held_bytes = 0
+
+
+def _release_held(everything=False, room_for=None):
+    held = _Overlap.held
+    while held and (everything or held[0][0].query()):
+        _Overlap.held_bytes -= held.pop(0)[2]
+    if room_for is not None:
+        # over the budget: the current stream waits for the oldest submissions (a stream-side wait, the host goes on);
+        # what is queued here afterwards is ordered behind their reads
+        while held and _Overlap.held_bytes + room_for > GRADIENT_OVERLAP_BYTES:
+            torch.cuda.current_stream().wait_event(held[0][0])
+            _Overlap.held_bytes -= held.pop(0)[2]
+
+
+def _overlap_on():
+    return (_Overlap.depth > 0 and GRADIENT_OVERLAP and torch.cuda.is_available()
+            and not torch.cuda.is_current_stream_capturing())
+
+
+def join_gradients():
+    """The current stream waits for every parameter-gradient launch submitted so far."""
+    if _Overlap.stream is not None and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.current_stream().wait_stream(_Overlap.stream)
+        # (operands still held are read by kernels the current stream now waits for: anything queued here from now on is
+        # ordered behind those reads, so the references can go)
+        _release_held(everything=True)
+
+
+@contextlib.contextmanager
+def gradient_overlap():
+    """Scope of one backward pass whose parameter gradients may run beside the data-gradient chain (see above).  On exit
+    the current stream waits for them and the collected sums are added to the parameters' .grad."""
+    _Overlap.depth += 1
+    try:
+        yield
+    finally:
+        _Overlap.depth -= 1
+        if _Overlap.depth == 0:
+            join_gradients()
+            collected, _Overlap.params = _Overlap.params, {}
+            for p, g in collected.values():
+                p.grad = g if p.grad is None else p.grad + g
+
+
+class gradient_sinks:
+    """`with gradient_sinks(leaves) as sink:` -- inside, the Functions of this module do not return the gradients of these
+    leaf tensors to autograd (they return None: ask autograd.grad with allow_unused=True) but add them up here, on the
+    stream the parameter gradients run on; `sink.sums()` joins that stream and returns one tensor per leaf (zeros for a leaf
+    nothing reached)."""
+
+    def __init__(self, leaves):
+        self.leaves = list(leaves)
+
+    def __enter__(self):
+        for t in self.leaves:
+            assert id(t) not in _Overlap.sinks
+            _Overlap.sinks[id(t)] = [t, None]
+        return self
+
+    def sums(self):
+        join_gradients()
+        return [torch.zeros_like(t) if _Overlap.sinks[id(t)][1] is None else _Overlap.sinks[id(t)][1] for t in self.leaves]
+
+    def __exit__(self, *exc):
+        for t in self.leaves:
+            _Overlap.sinks.pop(id(t), None)
+        return False
+
+
+def _deposit(targets, compute, *operands):
+    """`compute()` returns one gradient per entry of `targets` (the tensors they are gradients OF; None = not wanted).
+    Gradients of sink leaves and -- inside gradient_overlap() -- of nn.Parameters are added to their private sums on the
+    side stream and reported to autograd as None; everything else is computed on the current stream and returned."""
+    modes = []
+    for t in targets:
+        if t is None:
+            modes.append(None)
+        elif id(t) in _Overlap.sinks:
+            modes.append('sink')
+        elif _overlap_on() and isinstance(t, torch.nn.Parameter):
+            modes.append('param')
+        else:
+            modes.append('plain')
+    if not any(m in ('sink', 'param') for m in modes):
+        return compute()
+    side = _overlap_on() and 'plain' not in modes
+
+    def run():
+        out = []
+        for t, m, g in zip(targets, modes, compute()):
+            if m in ('sink', 'param') and g is not None:
+                slot = _Overlap.sinks[id(t)] if m == 'sink' else _Overlap.params.setdefault(id(t), [t, None])
+                slot[1] = g if slot[1] is None else slot[1].add_(g)
+                g = None
+            out.append(g)
+        return tuple(out)
+
+    if not side:
+        join_gradients()                       # (earlier deposits into the same sums ran on the side stream)
+        return run()
+    if _Overlap.stream is None:
+        _Overlap.stream = torch.cuda.Stream()
+    ready = torch.cuda.Event()
+    ready.record()
+    _Overlap.stream.wait_event(ready)
+    with torch.cuda.stream(_Overlap.stream):
+        res = run()
+        done = torch.cuda.Event()
+        done.record()
+    nbytes = sum(t.numel() * t.element_size() for t in operands if torch.is_tensor(t))
+    _release_held(room_for=nbytes)
+    _Overlap.held.append((done, operands, nbytes))
+    _Overlap.held_bytes += nbytes
+    return res
 
 
 def _packed(w, transposed):
@@ -118,7 +265,8 @@ class LinearFn(Function):
         y = _linear_fwd(x, w, b, relu_in=relu_in, relu_out=relu_out, residual=residual)
         ctx.flags = (relu_in, relu_out, b is not None, residual is not None)
         ctx.save_for_backward(x, w, y if relu_out else None)
-        return y
+        ctx.params = (w, b)        # (the objects themselves: saved_tensors hands back new tensor objects, and the
+        return y                   #  gradient sums of _deposit are keyed on the parameter / leaf object)
 
     @staticmethod
     def backward(ctx, dy):
@@ -132,10 +280,12 @@ class LinearFn(Function):
         want_db = has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             # one kernel: dW = g^T [relu](x) on the MFMA, db = column sums of the g tiles it stages
-            res = ops.linear_wgrad(g, x, bias=want_db, relu_x=relu_in)
-            (dw, db) = res if want_db else (res, None)
+            def wgrad():
+                res = ops.linear_wgrad(g, x, bias=want_db, relu_x=relu_in)
+                return res if want_db else (res, None)
+            dw, db = _deposit((ctx.params[0], ctx.params[1] if want_db else None), wgrad, g, x)
         elif want_db:
-            db = ops.colsum(g)
+            (db,) = _deposit((ctx.params[1],), lambda: (ops.colsum(g),), g)
         if has_res and ctx.needs_input_grad[5]:
             dres = dy
         return dx, dw, db, None, None, dres
@@ -153,12 +303,14 @@ class PosHiddenFn(Function):
     def forward(ctx, pos, pos2, idx, P1, c1):
         r = ops.pt_pos_hidden(pos, pos2, idx, P1, c1)
         ctx.save_for_backward(pos, pos2, idx, r)
+        ctx.params = (P1, c1)
         return r
 
     @staticmethod
     def backward(ctx, gr):
         pos, pos2, idx, r = ctx.saved_tensors
-        dP1, dc1 = ops.pt_pos_hidden_bwd(pos, pos2, idx, r, gr.contiguous())
+        gr = gr.contiguous()
+        dP1, dc1 = _deposit(ctx.params, lambda: ops.pt_pos_hidden_bwd(pos, pos2, idx, r, gr), pos, pos2, idx, r, gr)
         return None, None, None, dP1, dc1
 
 
@@ -190,17 +342,21 @@ class AttnInLinearFn(Function):
         a = ops.linear(r, wp, add_rows=q, add_div=k, sub_rows=kf, sub_idx=idx.reshape(-1))
         ctx.save_for_backward(r, wp, idx)
         ctx.m = kf.shape[0]
+        ctx.params = (kf, wp)
         return a
 
     @staticmethod
     def backward(ctx, da):
         r, wp, idx = ctx.saved_tensors
         da = da.contiguous()
-        k = idx.shape[1]
+        k, m = idx.shape[1], ctx.m
         dq = ops.segment_sum(da, k) if ctx.needs_input_grad[0] else None
-        dkf = ops.scatter_add_rows(da, idx, ctx.m, scale=-1.0) if ctx.needs_input_grad[1] else None
+        dkf = dwp = None
+        if ctx.needs_input_grad[1]:
+            (dkf,) = _deposit(ctx.params[:1], lambda: (ops.scatter_add_rows(da, idx, m, scale=-1.0),), da, idx)
         dr = _linear_fwd(da, wp, None, transposed=True) if ctx.needs_input_grad[2] else None
-        dwp = ops.linear_wgrad(da, r) if ctx.needs_input_grad[3] else None
+        if ctx.needs_input_grad[3]:
+            (dwp,) = _deposit(ctx.params[1:], lambda: (ops.linear_wgrad(da, r),), da, r)
         return dq, dkf, dr, dwp, None
 
 
@@ -240,6 +396,7 @@ class PairMlpFn(Function):
         a, logits, pe = ops.pt_pair_mlp(aq, kt, r, idx, c2, stream)
         ctx.save_for_backward(a, r, wp, W2, P2, idx)
         ctx.m = kt.shape[0]
+        ctx.params = (kt, wp, W2, b2, P2, c2)
         return logits, pe
 
     @staticmethod
@@ -249,25 +406,27 @@ class PairMlpFn(Function):
         k = idx.shape[1]
         dlogits, dpe = dlogits.contiguous(), dpe.contiguous()
         dW2 = db2 = dP2 = dc2 = dwp = daq = dkt = dr = None
+        (t_kt, t_wp, t_W2, t_b2, t_P2, t_c2), m = ctx.params, ctx.m
+
+        def wgrad_bias(g, x, want_w, want_b, relu_x):
+            if not want_w:
+                return (None, ops.colsum(g))
+            res = ops.linear_wgrad(g, x, bias=bool(want_b), relu_x=relu_x)
+            return res if want_b else (res, None)
+
         if need[4] or need[5]:
-            if need[4]:
-                res = ops.linear_wgrad(dlogits, a, bias=bool(need[5]), relu_x=True)
-                (dW2, db2) = res if need[5] else (res, None)
-            else:
-                db2 = ops.colsum(dlogits)
+            dW2, db2 = _deposit((t_W2 if need[4] else None, t_b2 if need[5] else None),
+                                lambda: wgrad_bias(dlogits, a, need[4], need[5], True), dlogits, a)
         da = _linear_fwd(dlogits, W2, None, transposed=True, mask=a)          # (x > 0) . (g W2)
         if need[0]:
             daq = ops.segment_sum(da, k)
         if need[1]:
-            dkt = ops.scatter_add_rows(da, idx, ctx.m, scale=-1.0)
+            (dkt,) = _deposit((t_kt,), lambda: (ops.scatter_add_rows(da, idx, m, scale=-1.0),), da, idx)
         if need[3]:
-            dwp = ops.linear_wgrad(da, r)
+            (dwp,) = _deposit((t_wp,), lambda: (ops.linear_wgrad(da, r),), da, r)
         if need[6] or need[7]:
-            if need[6]:
-                res = ops.linear_wgrad(dpe, r, bias=bool(need[7]))
-                (dP2, dc2) = res if need[7] else (res, None)
-            else:
-                dc2 = ops.colsum(dpe)
+            dP2, dc2 = _deposit((t_P2 if need[6] else None, t_c2 if need[7] else None),
+                                lambda: wgrad_bias(dpe, r, need[6], need[7], False), dpe, r)
         if need[2]:
             dr = _linear_fwd(da, wp, None, transposed=True)
             dr += _linear_fwd(dpe, P2, None, transposed=True)
@@ -280,12 +439,21 @@ class SoftmaxAggFn(Function):
     @staticmethod
     def forward(ctx, logits, v, pe, idx):
         ctx.save_for_backward(logits, v, pe, idx)
+        ctx.params = (v,)
         return ops.pt_softmax_agg(logits, v, pe, idx)
 
     @staticmethod
     def backward(ctx, dagg):
         logits, v, pe, idx = ctx.saved_tensors
-        dlogits, dpe, dv = ops.pt_softmax_agg_bwd(logits, v, pe, idx, dagg.contiguous())
+        dlogits, dpe, dv = ops.pt_softmax_agg_bwd(logits, v, pe, idx, dagg.contiguous(), reduce_dv=False)
+        if not torch.is_tensor(dv):
+            # the kernel left the per-pair value gradients (dv = (dval, idx32, m)): their sum per abstract point is a
+            # parameter-side reduction nothing below reads
+            dval, idx32, m = dv
+            (dv,) = _deposit(ctx.params, lambda: (ops.scatter_add_rows(dval, idx32, m),), dval, idx32)
+        else:
+            done = dv
+            (dv,) = _deposit(ctx.params, lambda: (done,), done)
         return dlogits, dv, dpe, None
 
 
@@ -297,6 +465,7 @@ class SoftmaxAggGradOnlyFn(Function):
     @staticmethod
     def forward(ctx, logits, v, pe, idx):
         ctx.save_for_backward(logits, v, pe, idx)
+        ctx.params = (v,)
         return logits.new_empty((idx.shape[0], v.shape[1]))
 
     backward = SoftmaxAggFn.backward

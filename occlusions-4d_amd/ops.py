@@ -1205,8 +1205,10 @@ def _segments(idx_flat, n_out, stable=True):
     key = (idx_flat.untyped_storage().data_ptr(), idx_flat.storage_offset(), idx_flat._version, idx_flat.numel(),
            idx_flat.stride(0) if idx_flat.numel() > 1 else 1, n_out, stable)
     if not capturing:
-        for k, keep, order, off in _SEGMENTS:
+        for k, keep, order, off, built in _SEGMENTS:
             if k == key:
+                if built is not None:
+                    torch.cuda.current_stream().wait_event(built)     # (a hit from another stream than the builder's)
                 return order, off
     if stable:
         keys, order = torch.sort(idx_flat.long(), stable=True)
@@ -1220,7 +1222,11 @@ def _segments(idx_flat, n_out, stable=True):
         _lib.check(_lib.lib().occ4d_segments_build_i32(_ptr(idx_c), idx_c.numel(), n_out, _ptr(order), _ptr(off), _ptr(ws),
                                                       _stream()))
     if not capturing:
-        _SEGMENTS.append((key, idx_flat, order, off))
+        built = None
+        if idx_flat.is_cuda:
+            built = torch.cuda.Event()
+            built.record()
+        _SEGMENTS.append((key, idx_flat, order, off, built))
         del _SEGMENTS[:-4]
     return order, off
 
@@ -1317,7 +1323,9 @@ def layernorm_bwd(x, gamma, g, eps):
 SOFTMAX_BWD_SPLIT = os.environ.get('OCC4D_SOFTMAX_BWD4', '1') != '0'
 
 
-def pt_softmax_agg_bwd(logits, v, pe, idx, dagg):
+def pt_softmax_agg_bwd(logits, v, pe, idx, dagg, reduce_dv=True):
+    """(dlogits, dpe, dv).  reduce_dv=False: where the kernel leaves per-pair value gradients, dv comes back as the
+    triple (dval, idx32, m) for the caller to reduce (`scatter_add_rows(dval, idx32, m)`), e.g. on another stream."""
     logits = _cont(logits, 'logits')
     v, ldv = _rows(_dev(v, name='v'), 'v')
     dagg, ldda = _rows(_dev(dagg, name='dagg'), 'dagg')
@@ -1344,7 +1352,7 @@ def pt_softmax_agg_bwd(logits, v, pe, idx, dagg):
         _lib.check(_lib.lib().occ4d_pt_softmax_agg_bwd_f32(_ptr(logits), _ptr(v), ldv, _ptr(pe), _ptr(idx32), n, k, d,
                                                            divisor, _ptr(dagg), ldda, _ptr(dlogits), _ptr(dval), None, d,
                                                            _stream()))
-        dv = scatter_add_rows(dval, idx32, v.shape[0])
+        dv = scatter_add_rows(dval, idx32, v.shape[0]) if reduce_dv else (dval, idx32, v.shape[0])
         return dlogits, (dval if pe is not None else None), dv
     dpe = torch.empty_like(logits) if pe is not None else None
     dv = torch.zeros((v.shape[0], d), dtype=torch.float32, device=logits.device)

@@ -152,7 +152,6 @@ class _CheckpointedAttention(torch.autograd.Function):
             # (detached leaf copies, so that frozen parameters do not break the per-chunk autograd.grad)
             P1, c1, P2l, c2l, W2, b2 = (t.detach().requires_grad_(True) for t in (P1, c1, P2, c2, W2, b2))
             leaves = [kt_l, vt_l, wp_l, P1, c1, P2l, c2l, W2, b2]
-            sums = [torch.zeros_like(t) for t in leaves]
             # the query projection for ALL queries at once, outside the chunk loop (it holds no pair tensor: (n, 2D)): one
             # Linear, one data gradient and one weight gradient over 68812 rows instead of three of each over 22976 rows,
             # which fill two thirds of a dispatch round (83 -> 105 TFLOP/s on these launches)
@@ -164,28 +163,32 @@ class _CheckpointedAttention(torch.autograd.Function):
             # kernel of the backward at a fraction of its rate (94.8 -> 94.0 ms per step, 9.5 -> 7.7 GB peak)
             n_chunks = max(1, -(-x.shape[0] // _CHECKPOINT_CHUNK))
             step = -(-x.shape[0] // (64 * n_chunks)) * 64
-            for lo in range(0, x.shape[0], step):
-                hi = min(x.shape[0], lo + step)
-                ic = idx[lo:hi].contiguous()
-                aq = aq_all[lo:hi].detach().requires_grad_(True)                                # (c, 2D)
-                r = autograd.PosHiddenFn.apply(pos[lo:hi].contiguous(), pos2, ic, P1, c1)      # (c*K, 32)
-                if autograd.pair_mlp_fused_ok(aq, r, ic):
-                    # a = aq_i - kt_j + Wp r, logits = W2 relu(a), pe = P2 r + c2 from one kernel
-                    logits, pe = autograd.PairMlpFn.apply(aq, kt_l, r, wp_l, W2, b2, P2l, c2l, ic)
-                else:
-                    a = autograd.AttnInLinearFn.apply(aq, kt_l, r, wp_l, ic)                     # aq_i - kt_j + Wp r
-                    logits = L(a, W2, b2, True, False, None)                                    # W2 relu(.) + b2
-                    pe = L(r, P2l, c2l, False, False, None)
-                out = autograd.SoftmaxAggGradOnlyFn.apply(logits, vt_l, pe, ic)      # (value unused: no launch)
-                grads = torch.autograd.grad(out, [aq] + leaves, g[lo:hi])
-                g_aq[lo:hi] = grads[0]
-                for acc, gr in zip(sums, grads[1:]):
-                    acc += gr
-            (g_kt, g_vt, g_wp, g_P1, g_c1, g_P2, g_c2, g_W2, g_b2) = sums
-            (gx, g_wq, g_bq) = torch.autograd.grad(aq_all, [x_all, wq_l, bq_l], g_aq)
-            # key / value tables -> abstract features, Wk' and Wv
-            (gx2a, g_wk) = torch.autograd.grad(kt, [x2d, wk_l], g_kt)
-            (gx2b, g_Wv) = _grad_or_none(vt, [x2d, Wv], g_vt)
+            # The gradients of the leaves (merged matrices, tables, pos-MLP) are sums over the chunks that nothing reads
+            # before the loop ends: they collect in sinks (autograd.gradient_sinks: added up on the parameter-gradient
+            # stream beside the chunks' data-gradient chain; autograd.grad hands back None for them)
+            with autograd.gradient_sinks(leaves + [wq_l, bq_l, wk_l]) as sink:
+                for lo in range(0, x.shape[0], step):
+                    hi = min(x.shape[0], lo + step)
+                    ic = idx[lo:hi].contiguous()
+                    aq = aq_all[lo:hi].detach().requires_grad_(True)                                # (c, 2D)
+                    r = autograd.PosHiddenFn.apply(pos[lo:hi].contiguous(), pos2, ic, P1, c1)      # (c*K, 32)
+                    if autograd.pair_mlp_fused_ok(aq, r, ic):
+                        # a = aq_i - kt_j + Wp r, logits = W2 relu(a), pe = P2 r + c2 from one kernel
+                        logits, pe = autograd.PairMlpFn.apply(aq, kt_l, r, wp_l, W2, b2, P2l, c2l, ic)
+                    else:
+                        a = autograd.AttnInLinearFn.apply(aq, kt_l, r, wp_l, ic)                     # aq_i - kt_j + Wp r
+                        logits = L(a, W2, b2, True, False, None)                                    # W2 relu(.) + b2
+                        pe = L(r, P2l, c2l, False, False, None)
+                    out = autograd.SoftmaxAggGradOnlyFn.apply(logits, vt_l, pe, ic)      # (value unused: no launch)
+                    grads = torch.autograd.grad(out, [aq] + leaves, g[lo:hi], allow_unused=True)
+                    assert all(gr is None for gr in grads[1:]), 'a leaf gradient bypassed its sink'
+                    g_aq[lo:hi] = grads[0]
+                (gx, _, _) = torch.autograd.grad(aq_all, [x_all, wq_l, bq_l], g_aq, allow_unused=True)
+                # key / value tables -> abstract features, Wk' and Wv  (the table gradients are complete: sums() joins)
+                (g_kt, g_vt) = sink.sums()[:2]
+                (gx2a, _) = torch.autograd.grad(kt, [x2d, wk_l], g_kt, allow_unused=True)
+                (gx2b, g_Wv) = _grad_or_none(vt, [x2d, Wv], g_vt)
+                (g_kt, g_vt, g_wp, g_P1, g_c1, g_P2, g_c2, g_W2, g_b2, g_wq, g_bq, g_wk) = sink.sums()
             # merged matrices -> original parameters (frozen ones are skipped: autograd.grad rejects them)
             (d_W1, d_b1, d_Wq, d_Wk, d_P2, d_c2) = _grad_or_none(merged, [W1, b1, Wq, Wk, P2, c2], [g_wq, g_bq, g_wk, g_wp])
         add = lambda u, v: u if v is None else (v if u is None else u + v)   # noqa: E731

@@ -16,7 +16,7 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
-from . import ops
+from . import autograd, ops
 from .point_transformer_layer import invalidate_weight_caches
 
 
@@ -318,7 +318,8 @@ class TrainStep:
         loss = self.forward_loss(pcl_input, points_query, implicit_target)
         if next_pcl_input is not None:
             self.pcl_net.prefetch_geometry(next_pcl_input)
-        loss.backward()
+        with autograd.gradient_overlap():      # parameter gradients beside the data-gradient chain, joined on exit
+            loss.backward()
         allreduce_gradients(self.params, participation=self.participation)
         if self.grad_clip:
             torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)

@@ -31,9 +31,30 @@ step.batch_frames = True
 for _ in range(2):
     step(pcl, q, target, next_pcl_input=pcl)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     step(pcl, q, target, next_pcl_input=pcl)
     torch.cuda.synchronize()
+import collections  # noqa: E402
+by_site = collections.defaultdict(lambda: [0, 0.0])
+for e in prof.events():
+    if not e.name.startswith('aten::') or not e.kernels:
+        continue
+    site = '?'
+    for fr in (e.stack or []):
+        if ('occlusions' in fr or 'bench_train' in fr or 'torch/optim' in fr or 'clip_grad' in fr) and 'profiles/' not in fr:
+            site = fr.strip()[-90:]
+            break
+    else:
+        site = 'autograd engine (gradient accumulation / tape glue)' if not e.stack else (e.stack[0].strip()[-90:])
+    o = by_site[(e.name, site)]
+    o[0] += len(e.kernels)
+    o[1] += sum(k.duration for k in e.kernels)
+print('kernels launched by ATen operators, by operator and the nearest frame of this package:')
+print('%6s %9s  %-24s %s' % ('n', 'us', 'op', 'site'))
+for (name, site), (n, us) in sorted(by_site.items(), key=lambda kv: -kv[1][0]):
+    print('%6d %9.1f  %-24s %s' % (n, us, name, site))
+print('total: %d kernels, %.1f us' % (sum(v[0] for v in by_site.values()), sum(v[1] for v in by_site.values())))
+print()
 rows = []
 for e in prof.key_averages(group_by_input_shape=True):
     dt = getattr(e, 'self_device_time_total', None)

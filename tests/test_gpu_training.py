@@ -426,6 +426,60 @@ def test_deterministic_reductions_match_the_atomic_ones_and_repeat_bit_for_bit()
     assert all(torch.equal(a, b) for a, b in zip(g1, g2))
 
 
+def test_parameter_gradients_beside_the_chain_change_nothing(monkeypatch):
+    """autograd.gradient_overlap(): weight / bias / table gradients are launched on a second stream and collected in
+    private sums (never handed to the autograd engine from there).  Same kernels on the same operands: in deterministic
+    mode the gradients of a whole step are bit-identical to the one-stream pass, with the recompute path cut into several
+    chunks (sinks across chunks) and with a frozen parameter; a poisoned allocator (every freed block overwritten at once
+    on the main stream) would expose an operand recycled under the side stream."""
+    rng = np.random.default_rng(77)
+    Tc = lambda a, dt=np.float32: torch.from_numpy(np.asarray(a, dtype=dt)).cuda()   # noqa: E731
+    kind, npts = 'carla', 512
+    pa, ia, inf = pk.configs.model_args(kind, npts)
+    pcl = pk.configs.synthetic_pcl(kind, npts, 4, 31).cuda()
+    esd, dsd = pk.configs.synthetic_weights(pa, ia, 32)
+    q = Tc(np.concatenate([rng.uniform(-3, 3, size=(2, 200, 3)), np.zeros((2, 200, 1))], -1))
+    tgt = Tc(np.concatenate([rng.integers(0, 2, size=(2, 200, 1)), rng.uniform(size=(2, 200, 3)), np.zeros((2, 200, 1)),
+                             rng.integers(-1, 13, size=(2, 200, 1))], -1))
+    monkeypatch.setattr(pk.point_transformer_layer, '_CHECKPOINT_CHUNK', 128)      # 400 queries -> 4 chunks
+
+    def grads(overlap):
+        enc = pk.model.PointCompletionNetV3(**pa).cuda().train()
+        dec = pk.implicit.LocalPclResnetFC(**ia).cuda().train()
+        enc.load_state_dict(esd)
+        dec.load_state_dict(dsd)
+        dec.pt_blocks[0].layer2.to_v.weight.requires_grad_(False)
+        step = pk.training.TrainStep(enc, dec, loss_kwargs=dict(density_lw=1.0, segmentation_lw=0.6))
+        loss = step.forward_loss(pcl, q, tgt)
+        submitted = []
+        if overlap:
+            real = pk.autograd._deposit
+
+            def spy(targets, compute, *operands):
+                before = torch.cuda.current_stream()
+                res = real(targets, lambda: (submitted.append(torch.cuda.current_stream() != before), compute())[1],
+                           *operands)
+                return res
+            monkeypatch.setattr(pk.autograd, '_deposit', spy)
+            with pk.autograd.gradient_overlap():
+                loss.backward()
+                # work queued behind the pass on the main stream while the side stream may still be running: every
+                # block the pass has freed is handed out again and overwritten
+                junk = [torch.full((1 << 20,), float('nan'), device='cuda') for _ in range(64)]
+                del junk
+            monkeypatch.setattr(pk.autograd, '_deposit', real)
+            assert sum(submitted) > 20 and pk.autograd._Overlap.params == {} and pk.autograd._Overlap.sinks == {}
+        else:
+            loss.backward()
+        return [None if p.grad is None else p.grad.clone() for p in step.params]
+    with pk.ops.deterministic():
+        g_one, g_two = grads(False), grads(True)
+    assert sum(g is None for g in g_one) == 1
+    for a, b in zip(g_one, g_two):
+        assert (a is None) == (b is None)
+        assert a is None or torch.equal(a, b)
+
+
 def test_chained_blocks_gradients_strict():
     case = gc.PTB_CASES[1]
     x, pos, x2, pos2, sd = gc.ptb_inputs(case)
