@@ -275,7 +275,9 @@ def main():
     if not args.graph:
         counter = StepCounter()
         pk.ops.set_kernel_timer(counter)
-        run_step()
+        overlap, pk.autograd.GRADIENT_OVERLAP = pk.autograd.GRADIENT_OVERLAP, False   # (one stream: a launch's events
+        run_step()                                                                     #  bracket that kernel alone)
+        pk.autograd.GRADIENT_OVERLAP = overlap
         pk.ops.set_kernel_timer(None)
         summ = counter.summary()
         fence()
@@ -289,7 +291,9 @@ def main():
                     achieved_as_written=written / sec / 1e12, frac_as_written=written / sec / 1e12 / PEAK_F32_MFMA,
                     executed_tflop_per_step=executed / 1e12, as_written_tflop_per_step=written / 1e12,
                     note='executed = sum of the FLOP of every GEMM / fused-kernel launch of one step (forward, data and '
-                         'weight gradients, recompute); as written = 3 x the reference forward count (SURVEY.md 8(d))',
+                         'weight gradients, recompute); as written = 3 x the reference forward count (SURVEY.md 8(d)); the per-kernel '
+                         'table is taken on ONE extra step with the parameter-gradient stream switched off, so that a '
+                         'launch\'s HIP events bracket that kernel alone',
                     kernels={k: dict(launches=v['launches'], total_ms=v['total_ms'],
                                      avg_launch_ms=v['total_ms'] / max(1, v['launches']),
                                      tflops=v['total_flops'] / max(v['total_ms'], 1e-9) / 1e9)
@@ -300,7 +304,7 @@ def main():
             'metric': 'training step (BASELINE config 5: CARLA-4D, batch 1/GPU, n_points=28672, 4 x 17203 queries)',
             'value': world * args.steps / elapsed, 'unit': 'examples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'dtype': 'f32', 'data': 'synthetic', 'losses': losses, 'sampler_ms_per_step': sampler_ms, 'sampler': (None if not args.sampler else 'in front of the step (serial)' if args.sampler_serial else "next step's points drawn on a side stream beside this step (host time per step in sampler_ms_per_step)"), 'graph': bool(args.graph), 'loss_read': 'per step (static tensor of the replay)' if args.graph else 'after the timed region', 'geometry_prefetch': bool(nxt), 'frames_batched': bool(step.batch_frames), 'attention_backward': ('stored pair tensors (%s form)' % pk.point_transformer_layer.STORED_ATTENTION_FORM) if args.no_checkpoint else 'recompute in backward (equal chunks of at most %d queries)' % pk.point_transformer_layer._CHECKPOINT_CHUNK,
+            'scaling': 'weak', 'dtype': 'f32', 'data': 'synthetic', 'losses': losses, 'sampler_ms_per_step': sampler_ms, 'sampler': (None if not args.sampler else 'in front of the step (serial)' if args.sampler_serial else "next step's points drawn on a side stream beside this step (host time per step in sampler_ms_per_step)"), 'graph': bool(args.graph), 'loss_read': 'per step (static tensor of the replay)' if args.graph else 'after the timed region', 'geometry_prefetch': bool(nxt), 'gradient_overlap': (None if args.graph else ('parameter gradients on a second stream beside the data-gradient chain, at most %.0f GB of operands held for it' % (pk.autograd.GRADIENT_OVERLAP_BYTES / 2 ** 30)) if pk.autograd.GRADIENT_OVERLAP else False), 'frames_batched': bool(step.batch_frames), 'attention_backward': ('stored pair tensors (%s form)' % pk.point_transformer_layer.STORED_ATTENTION_FORM) if args.no_checkpoint else 'recompute in backward (equal chunks of at most %d queries)' % pk.point_transformer_layer._CHECKPOINT_CHUNK,
             'peak_mem_gb': torch.cuda.max_memory_allocated() / 2 ** 30,
             'roofline': roof,
             'config': {'workload': 'CARLA-4D training step (BASELINE configs[4]): batch 1 per GPU, n_points=%d, %d x %d '

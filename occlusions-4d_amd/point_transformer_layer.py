@@ -105,6 +105,29 @@ def _grad_or_none(outputs, inputs, grad_outputs):
     return tuple(next(got) if t.requires_grad else None for t in inputs)
 
 
+def _merged_to_parameters(W1, b1, Wq, Wk, P2, c2, g_wq, g_bq, g_wk, g_wp):
+    """Gradients of the parameters behind the merged matrices of DESIGN.md 4 (i)
+        wq = W1 Wq,  bq = W1 c2 + b1,  wk = W1 Wk,  wp = W1 P2        (fp64 products, rounded once)
+    from the gradients of the merged matrices: what autograd computes for those products (matmul64 / the casts), written
+    out -- plain launches on the CURRENT stream (an autograd pass would run each node on the stream of its forward), fp64
+    sums rounded once.  None for a frozen parameter.  Order: (W1, b1, Wq, Wk, P2, c2)."""
+    f64 = torch.float64
+    mm = ops.matmul_f64
+    gq, gb, gk, gp = (t.to(f64) for t in (g_wq, g_bq, g_wk, g_wp))
+    W1d = W1.detach().to(f64)
+    d_W1 = None
+    if W1.requires_grad:
+        d_W1 = (mm(gq, Wq.detach().to(f64).t()) + gb[:, None] * c2.detach().to(f64)[None, :]
+                + mm(gk, Wk.detach().to(f64).t()) + mm(gp, P2.detach().to(f64).t())).float()
+    d_b1 = g_bq if b1.requires_grad else None
+    W1t = W1d.t()
+    d_Wq = mm(W1t, gq).float() if Wq.requires_grad else None
+    d_Wk = mm(W1t, gk).float() if Wk.requires_grad else None
+    d_P2 = mm(W1t, gp).float() if P2.requires_grad else None
+    d_c2 = mm(W1t, gb[:, None])[:, 0].float() if c2.requires_grad else None
+    return (d_W1, d_b1, d_Wq, d_Wk, d_P2, d_c2)
+
+
 class _CheckpointedAttention(torch.autograd.Function):
     """Training-time vector attention without stored pair tensors ("recompute-in-backward to
     avoid storing (N_q, K, 832)").  forward = the fused inference kernel: nothing of size (N*K, .) is written.
@@ -138,6 +161,7 @@ class _CheckpointedAttention(torch.autograd.Function):
         W1, b1 = layer.attn_mlp[0].weight, layer.attn_mlp[0].bias
         W2, b2 = layer.attn_mlp[2].weight, layer.attn_mlp[2].bias
         Wq, Wk, Wv = layer.to_q.weight, layer.to_k.weight, layer.to_v.weight
+        lp0, la2 = layer.pos_mlp[0], layer.attn_mlp[2]
         with torch.enable_grad():
             # merged matrices as differentiable functions of the parameters (fp64 products, rounded once)
             W1d = W1.to(f64)
@@ -189,13 +213,22 @@ class _CheckpointedAttention(torch.autograd.Function):
                 (gx2a, _) = torch.autograd.grad(kt, [x2d, wk_l], g_kt, allow_unused=True)
                 (gx2b, g_Wv) = _grad_or_none(vt, [x2d, Wv], g_vt)
                 (g_kt, g_vt, g_wp, g_P1, g_c1, g_P2, g_c2, g_W2, g_b2, g_wq, g_bq, g_wk) = sink.sums()
-            # merged matrices -> original parameters (frozen ones are skipped: autograd.grad rejects them)
-            (d_W1, d_b1, d_Wq, d_Wk, d_P2, d_c2) = _grad_or_none(merged, [W1, b1, Wq, Wk, P2, c2], [g_wq, g_bq, g_wk, g_wp])
+            # merged matrices -> original parameters (frozen ones are skipped: autograd.grad rejects them).  Every input of
+            # this small fp64 pass is a sum the parameter-gradient stream produced and every output a parameter gradient:
+            # the whole pass is deposited there (autograd._deposit: inside gradient_overlap() it leaves the data-gradient
+            # chain; the gradients then reach .grad through the overlap's sums, and this Function reports None for them)
+            targets = (W1, b1, Wq, Wk, P2, c2, P2, c2, lp0.weight, lp0.bias, la2.weight, la2.bias)
+
+            def to_parameters():
+                return _merged_to_parameters(W1, b1, Wq, Wk, P2, c2, g_wq, g_bq, g_wk, g_wp) + \
+                    (g_P2, g_c2, g_P1, g_c1, g_W2, g_b2)
+            res = autograd._deposit(tuple(t if t.requires_grad else None for t in targets), to_parameters,
+                                    g_wq, g_bq, g_wk, g_wp, g_P2, g_c2, g_P1, g_c1, g_W2, g_b2)
+            (d_W1, d_b1, d_Wq, d_Wk, d_P2, d_c2, g_P2, g_c2, g_P1, g_c1, g_W2, g_b2) = res
         add = lambda u, v: u if v is None else (v if u is None else u + v)   # noqa: E731
-        lp, la = layer.pos_mlp, layer.attn_mlp
-        by_param = {id(Wq): d_Wq, id(Wk): d_Wk, id(Wv): g_Wv, id(lp[0].weight): g_P1, id(lp[0].bias): g_c1,
+        by_param = {id(Wq): d_Wq, id(Wk): d_Wk, id(Wv): g_Wv, id(lp0.weight): g_P1, id(lp0.bias): g_c1,
                     id(P2): add(g_P2, d_P2), id(c2): add(g_c2, d_c2), id(W1): d_W1, id(b1): d_b1,
-                    id(la[2].weight): g_W2, id(la[2].bias): g_b2}
+                    id(la2.weight): g_W2, id(la2.bias): g_b2}
         return (None, gx, None, gx2a + gx2b, None, None) + tuple(by_param[id(p)] for p in layer.parameters())
 
 
