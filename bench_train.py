@@ -111,7 +111,6 @@ def main():
     ap.add_argument('--no-checkpoint', action='store_true', help='store the attention pair tensors (merged form; OCC4D_STORED_ATTENTION_FORM=as_written for the round-1 path) instead of recomputing them in backward')
     ap.add_argument('--per-frame', action='store_true', help='decode the target frames one after the other (the reference\'s loop) instead of in one batched decoder call')
     ap.add_argument('--no-prefetch', action='store_true', help='do not prefetch the next step\'s FPS chain / kNNs under this step\'s backward')
-    ap.add_argument('--graph', action='store_true', help='replay the step as one captured hipGraph (GraphedTrainStep)')
     ap.add_argument('--sampler', action='store_true',
                     help='draw the supervision points of every step with GuidedImplicitPointSampler (57344-point target '
                          'frames, bias low_moving_vehped_sembal) instead of fixed synthetic queries: the NEXT step\'s points '
@@ -170,17 +169,10 @@ def main():
     q = torch.from_numpy(q.astype(np.float32)).to(device)
     target = torch.from_numpy(target.astype(np.float32)).to(device)
     # static_shapes: the loss's masked means by weighting instead of boolean indexing (training.implicit_loss) -- the
-    # form GraphedTrainStep always uses; in the eager step it removes the 12 device->host reads (one per boolean index) that
+    # form without data-dependent shapes; it removes the 12 device->host reads (one per boolean index) that
     # stall the host between forward and backward.  OCC4D_BENCH_INDEXED_LOSS=1: the reference's indexing form.
     lkw = dict(density_lw=1.0, segmentation_lw=0.6, static_shapes=os.environ.get('OCC4D_BENCH_INDEXED_LOSS') != '1')
-    if args.graph:
-        # (the guided sampler draws on the host: it is not part of the captured step -- it runs beside the replay)
-        step = pk.training.GraphedTrainStep(enc, dec, lr=1e-3, grad_clip=0.2, loss_kwargs=lkw,
-                                            external_geometry=not args.no_prefetch)
-        step.batch_frames = not args.per_frame
-        step.capture(pcl, q, target)
-    else:
-        step = pk.training.TrainStep(enc, dec, lr=1e-3, grad_clip=0.2, loss_kwargs=lkw)
+    step = pk.training.TrainStep(enc, dec, lr=1e-3, grad_clip=0.2, loss_kwargs=lkw)
 
     def fence():
         torch.cuda.synchronize()
@@ -228,18 +220,16 @@ def main():
                 draw()
                 primed[0] = True
             qq, tt = side.take()
-            loss = step(pcl, qq, tt, **nxt)        # queued (eager launches or one graph replay), not waited for
+            loss = step(pcl, qq, tt, **nxt)        # queued, not waited for
             draw()                                 # the next step's points, beside it
             return loss
     else:
         def run_step():
             return step(pcl, q, target, **nxt)
 
-    # The loss of an eager step is a device scalar: it is read after the timed region (a loop that logs every step's loss
-    # with .item() stalls the host once per step; the usual loop logs every N-th).  A replayed step leaves its loss in a
-    # static tensor that the next replay overwrites; it is read per step (measured: cloning it instead and issuing the
-    # replays back to back is SLOWER, 95.5 vs 94.8 ms per step).
-    read = (lambda t: float(t)) if args.graph else (lambda t: t)
+    # The loss of a step is a device scalar: it is read after the timed region (a loop that logs every step's loss with
+    # .item() stalls the host once per step; the usual loop logs every N-th).
+    read = lambda t: t                                                           # noqa: E731
     losses = []
     for _ in range(args.warmup):
         losses.append(read(run_step()))
@@ -263,7 +253,7 @@ def main():
         elapsed = max(per_rank)
     # the gradient all-reduce alone (one flat 28.8 MB bucket): the gradients of the last step are still there
     allreduce_ms = None
-    if use_dist and not args.graph:
+    if use_dist:
         fence()
         t1 = time.perf_counter()
         for _ in range(3):
@@ -272,7 +262,7 @@ def main():
         allreduce_ms = 1e3 * (time.perf_counter() - t1) / 3
     # roofline leg: one more (untimed) step with HIP events around every reported launch
     roof = None
-    if not args.graph:
+    if True:
         counter = StepCounter()
         pk.ops.set_kernel_timer(counter)
         overlap, pk.autograd.GRADIENT_OVERLAP = pk.autograd.GRADIENT_OVERLAP, False   # (one stream: a launch's events
@@ -304,7 +294,7 @@ def main():
             'metric': 'training step (BASELINE config 5: CARLA-4D, batch 1/GPU, n_points=28672, 4 x 17203 queries)',
             'value': world * args.steps / elapsed, 'unit': 'examples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'dtype': 'f32', 'data': 'synthetic', 'losses': losses, 'sampler_ms_per_step': sampler_ms, 'sampler': (None if not args.sampler else 'in front of the step (serial)' if args.sampler_serial else "next step's points drawn on a side stream beside this step (host time per step in sampler_ms_per_step)"), 'graph': bool(args.graph), 'loss_read': 'per step (static tensor of the replay)' if args.graph else 'after the timed region', 'geometry_prefetch': bool(nxt), 'gradient_overlap': (None if args.graph else ('parameter gradients on a second stream beside the data-gradient chain, at most %.0f GB of operands held for it' % (pk.autograd.GRADIENT_OVERLAP_BYTES / 2 ** 30)) if pk.autograd.GRADIENT_OVERLAP else False), 'frames_batched': bool(step.batch_frames), 'attention_backward': ('stored pair tensors (%s form)' % pk.point_transformer_layer.STORED_ATTENTION_FORM) if args.no_checkpoint else 'recompute in backward (equal chunks of at most %d queries)' % pk.point_transformer_layer._CHECKPOINT_CHUNK,
+            'scaling': 'weak', 'dtype': 'f32', 'data': 'synthetic', 'losses': losses, 'sampler_ms_per_step': sampler_ms, 'sampler': (None if not args.sampler else 'in front of the step (serial)' if args.sampler_serial else "next step's points drawn on a side stream beside this step (host time per step in sampler_ms_per_step)"), 'graph': False, 'loss_read': 'after the timed region', 'geometry_prefetch': bool(nxt), 'gradient_overlap': (('parameter gradients on a second stream beside the data-gradient chain, at most %.0f GB of operands held for it' % (pk.autograd.GRADIENT_OVERLAP_BYTES / 2 ** 30)) if pk.autograd.GRADIENT_OVERLAP else False), 'frames_batched': bool(step.batch_frames), 'attention_backward': ('stored pair tensors (%s form)' % pk.point_transformer_layer.STORED_ATTENTION_FORM) if args.no_checkpoint else 'recompute in backward (equal chunks of at most %d queries)' % pk.point_transformer_layer._CHECKPOINT_CHUNK,
             'peak_mem_gb': torch.cuda.max_memory_allocated() / 2 ** 30,
             'roofline': roof,
             'config': {'workload': 'CARLA-4D training step (BASELINE configs[4]): batch 1 per GPU, n_points=%d, %d x %d '

@@ -45,7 +45,8 @@ _ZEROS = {}           # zero bias vectors, kept apart from the packs and created
 #     autograd engine cannot accumulate into it in place (it adds a later gradient contribution INTO a buffer it holds
 #     the only reference to: `dy` handed on as the residual's gradient is such a buffer while the side stream still
 #     reads it as the `g` of a weight gradient);
-#   * while a stream is being captured (GraphedTrainStep) nothing is moved: one stream, the order of round 4.
+#   * while a stream is being captured nothing is moved (one stream).  A captured step with the same two branches was
+#     measured in round 5 and is gone with the captured step itself (profiles/r05_train_graph_vs_eager.txt).
 #   * the side stream may fall behind (the chain's kernels are submitted first and fill the machine); the operands held
 #     for it are bounded: beyond GRADIENT_OVERLAP_BYTES the main stream waits for the oldest submission before it goes on.
 GRADIENT_OVERLAP = os.environ.get('OCC4D_GRADIENT_OVERLAP', '1') == '1'
@@ -61,6 +62,10 @@ class _Overlap:
     held_bytes = 0
 
 
+def _capturing():
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 def _release_held(everything=False, room_for=None):
     held = _Overlap.held
     while held and (everything or held[0][0].query()):
@@ -74,13 +79,12 @@ def _release_held(everything=False, room_for=None):
 
 
 def _overlap_on():
-    return (_Overlap.depth > 0 and GRADIENT_OVERLAP and torch.cuda.is_available()
-            and not torch.cuda.is_current_stream_capturing())
+    return _Overlap.depth > 0 and GRADIENT_OVERLAP and torch.cuda.is_available() and not _capturing()
 
 
 def join_gradients():
     """The current stream waits for every parameter-gradient launch submitted so far."""
-    if _Overlap.stream is not None and not torch.cuda.is_current_stream_capturing():
+    if _Overlap.stream is not None and not _capturing():
         torch.cuda.current_stream().wait_stream(_Overlap.stream)
         # (operands still held are read by kernels the current stream now waits for: anything queued here from now on is
         # ordered behind those reads, so the references can go)

@@ -68,8 +68,8 @@ def path_flags():
 
 # Derived-weight caches (merged matrices, per-scene tables, bf16 packs) are keyed on (data_ptr, _version) of the
 # parameters PLUS this epoch.  A parameter's _version does not move when it is updated outside Python's view: a
-# captured hipGraph replay (training.GraphedTrainStep), `p.data.add_()`, a raw-pointer write.  Whoever updates
-# parameters that way calls invalidate_weight_caches(); TrainStep / GraphedTrainStep do after every step.
+# captured hipGraph replay, `p.data.add_()`, a raw-pointer write.  Whoever updates parameters that way calls
+# invalidate_weight_caches(); TrainStep does after every step.
 _WEIGHTS_EPOCH = [0]
 
 

@@ -116,7 +116,7 @@ def implicit_loss(implicit_output, implicit_target, density_lw=1.0, color_lw=0.0
     where density >= 0.1 AND mark_track >= 0 (:175-194) -- the per-(example, frame) values are averaged
     (:243-250) and summed with their weights (:276-277).
     static_shapes=True computes the masked means by weighting instead of boolean indexing (no host sync, no
-    data-dependent shapes): the form GraphedTrainStep captures."""
+    data-dependent shapes): the form a captured step needs, and the one the eager step uses to avoid its host reads."""
     if implicit_output.dim() == 3:
         implicit_output, implicit_target = implicit_output[:, None], implicit_target[:, None]
     if not squashed and color_lw > 0.0:
@@ -202,7 +202,7 @@ def allreduce_gradients(params, world=None, participation=None):
                                'changes' % len(late))
     elif capturing:
         raise AssertionError('a captured step needs the participation mask of a preceding eager step '
-                             '(GraphedTrainStep.capture warmup >= 1)')
+                             '(run one eager step before capturing)')
     else:
         has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], device=params[0].device)
         dist.all_reduce(has, op=dist.ReduceOp.MAX)
@@ -326,109 +326,3 @@ class TrainStep:
         self.optimizer.step()
         invalidate_weight_caches()             # merged inference matrices / per-scene tables are stale now
         return loss.detach()
-
-
-class GraphedTrainStep(TrainStep):
-    """TrainStep replayed as ONE captured hipGraph: forward, losses, backward, gradient all-reduce, clip and the
-    AdamW update of a step are ~2200 kernel launches issued from Python; captured once (static shapes, static input
-    buffers, capturable optimiser, masked-mean losses), a step is a single graph launch.  Restrictions: fixed
-    shapes, no guided sampler inside.
-
-    external_geometry (default): the encoder's FPS chain and kNNs -- coordinates only, no weights -- are NOT part of
-    the graph.  They run eagerly on the encoder's geometry stream into static index buffers the graph reads; given
-    `next_pcl_input`, the next step's run concurrently with this step's replay (PointCompletionNetV3.prefetch_geometry),
-    which takes the 23 ms FPS chain of a 28672-point cloud off the step's critical path and lets fps_random_start draw
-    a new start every step.  external_geometry=False captures them inside the graph (start index frozen: requires
-    fps_random_start=False)."""
-
-    def __init__(self, pcl_net, implicit_net, lr=1e-3, weight_decay=1e-2, grad_clip=0.2, loss_kwargs=None,
-                 external_geometry=True):
-        super().__init__(pcl_net, implicit_net, lr, weight_decay, grad_clip, dict(loss_kwargs or {}, static_shapes=True))
-        self.optimizer = torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay, capturable=True)
-        self.graph = None
-        self.external_geometry = external_geometry
-        self._geom_static = None          # {block index: (tensors, None, None)} read by the captured graph
-        self._geom_next = None            # (key of the next cloud, its geometry on the geometry stream)
-
-    @staticmethod
-    def _geom_tensors(entry):
-        g = entry[0]
-        return [t for item in g for t in (item if isinstance(item, tuple) else (item,))]
-
-    def _load_geometry(self, pcl_input):
-        """Brings the geometry of `pcl_input` into the static buffers: the prefetched one if it is this cloud's,
-        otherwise computed now."""
-        key = self.pcl_net.geometry_key(pcl_input)
-        nxt, self._geom_next = self._geom_next, None
-        geom = nxt[1] if (nxt is not None and nxt[2] is pcl_input and nxt[0] == key) else \
-            self.pcl_net._geometry_chain(pcl_input[..., :3].detach(), full=True)
-        self.pcl_net._prefetched = None
-        cur = torch.cuda.current_stream()
-        for i, entry in geom.items():
-            cur.wait_event(entry[2])
-            for dst, src in zip(self._geom_tensors(self._geom_static[i]), self._geom_tensors(entry)):
-                dst.copy_(src)
-
-    def _eager(self, pcl_input, points_query, implicit_target):
-        loss = self.forward_loss(pcl_input, points_query, implicit_target)
-        loss.backward()
-        allreduce_gradients(self.params, participation=self.participation)
-        if self.grad_clip:
-            torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
-        self.optimizer.step()
-        return loss.detach()
-
-    def capture(self, pcl_input, points_query, implicit_target, warmup=2):
-        """Warm-up steps on a side stream (they DO update the parameters), then the capture."""
-        self.static = (pcl_input.clone(), points_query.clone(), implicit_target.clone())
-        self.participation.clear()          # the mask the graph freezes comes from THIS capture's warm-up steps
-        if dist.is_available() and dist.is_initialized():
-            assert warmup >= 1, 'a distributed capture needs at least one eager warm-up step (gradient participation mask)'
-        cur = torch.cuda.current_stream()
-        side = torch.cuda.Stream()
-        side.wait_stream(cur)
-        losses = []
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self.optimizer.zero_grad(set_to_none=True)
-                losses.append(self._eager(*self.static))
-        cur.wait_stream(side)
-        ops.check_pending()
-        if self.external_geometry:
-            geom = self.pcl_net._geometry_chain(self.static[0][..., :3].detach(), full=True)
-            torch.cuda.synchronize()
-            ops.check_pending()
-            self._geom_static = {i: (g, None, None) for i, (g, _, _) in geom.items()}
-            self.pcl_net._prefetched = None
-        self.optimizer.zero_grad(set_to_none=True)
-        invalidate_weight_caches()      # derived weights must be recomputed INSIDE the capture (as graph nodes), not
-        self.graph = torch.cuda.CUDAGraph()                                       # taken from the warm-up's cache
-        with torch.cuda.graph(self.graph):
-            if self.external_geometry:      # the captured forward reads the static index buffers (no events: same stream)
-                self.pcl_net._prefetched = (self.pcl_net.geometry_key(self.static[0]), self._geom_static, self.static[0])
-            self.static_loss = self._eager(*self.static)
-        invalidate_weight_caches()
-        return losses
-
-    def __call__(self, pcl_input, points_query, implicit_target, next_pcl_input=None):
-        assert self.graph is not None, 'call capture(...) first'
-        ready = None
-        if self.external_geometry:
-            ops.check_pending(wait=False)
-            self._load_geometry(pcl_input)
-            if next_pcl_input is not None:
-                ready = torch.cuda.Event()
-                ready.record()              # next_pcl_input is complete here; the replay queued below is not waited for
-        for dst, src in zip(self.static, (pcl_input, points_query, implicit_target)):
-            if dst is not src:
-                dst.copy_(src)
-        self.graph.replay()
-        if ready is not None:
-            # (key, geometry, the tensor object: held alive so that its address cannot be recycled by another cloud)
-            self._geom_next = (self.pcl_net.geometry_key(next_pcl_input),
-                               self.pcl_net.prefetch_geometry(next_pcl_input, ready=ready), next_pcl_input)
-            self.pcl_net._prefetched = None     # (kept here, not for an eager forward)
-        # the replay updates the parameters in place without touching their _version counters: the derived-weight
-        # caches of the inference path (keyed on _version + this epoch) must not survive it
-        invalidate_weight_caches()
-        return self.static_loss

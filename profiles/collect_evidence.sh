@@ -27,17 +27,18 @@ step bench_kernel_stats_streams1.csv 'OCC4D_DECODE_STREAMS=1 rocprofv3 --kernel-
 step bench_kernel_stats.csv 'rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof2" -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra > /dev/null 2>&1; cp "$(find "$OUT/prof2" -name "*kernel_stats.csv" | head -1)" "$OUT/bench_kernel_stats.csv"'
 step bench_kernel_stats_bf16x6_streams1.csv 'OCC4D_LOGIT_PRECISION=bf16x6 OCC4D_TRUNK_PRECISION=bf16x6 OCC4D_DECODE_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof6" -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra 2>/dev/null | tail -1 > "$OUT/bench_bf16x6_streams1_under_rocprof.json"; cp "$(find "$OUT/prof6" -name "*kernel_stats.csv" | head -1)" "$OUT/bench_kernel_stats_bf16x6_streams1.csv"'
 : > "$OUT/bench_train.jsonl"
-for flags in "" "--graph" "--no-checkpoint" "--graph --no-checkpoint"; do
+for flags in "" "--no-checkpoint"; do
   step - "python bench_train.py --steps 20 --warmup 3 $flags 2>/dev/null | tail -1 >> \"$OUT/bench_train.jsonl\""
 done
 : > "$OUT/bench_train_sampler.jsonl"
-for flags in "--graph" "--sampler --graph" "--sampler" "--sampler --sampler-serial"; do
+for flags in "" "--sampler" "--sampler --sampler-serial"; do
   step - "python bench_train.py --steps 20 --warmup 3 $flags 2>/dev/null | tail -1 >> \"$OUT/bench_train_sampler.jsonl\""
 done
 step time_pair_mlp.txt 'python profiles/time_pair_mlp.py 2>/dev/null | grep -v amdgpu.ids > "$OUT/time_pair_mlp.txt"'
 step time_wgrad.txt 'python profiles/time_wgrad.py 2>/dev/null | grep -v amdgpu.ids > "$OUT/time_wgrad.txt"'
 step profile_sampler.txt 'python profiles/profile_sampler.py 2>/dev/null | head -3 > "$OUT/profile_sampler.txt"'
-step train_kernel_stats.csv 'rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof3" -- python bench_train.py --steps 4 --warmup 2 > /dev/null 2>&1; cp "$(find "$OUT/prof3" -name "*kernel_stats.csv" | head -1)" "$OUT/train_kernel_stats.csv"'
+step train_kernel_stats.csv 'rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof3" -- python bench_train.py --steps 4 --warmup 2 > /dev/null 2>&1; cp "$(find "$OUT/prof3" -name "*kernel_stats.csv" | head -1)" "$OUT/train_kernel_stats.csv"; python profiles/train_timeline.py "$(find "$OUT/prof3" -name "*kernel_trace.csv" | head -1)" 30 > "$OUT/train_timeline.txt"'
+step train_phases.txt 'python profiles/train_phases.py 10 2>/dev/null | grep -v amdgpu.ids > "$OUT/train_phases.txt"'
 step train_shapes.txt 'python profiles/train_shapes.py 2>/dev/null > "$OUT/train_shapes.txt"'
 step time_rowlin_tail.txt 'python profiles/time_rowlin_tail.py 2>/dev/null > "$OUT/time_rowlin_tail.txt"'
 step time_fps.txt 'python profiles/time_fps.py 2>/dev/null > "$OUT/time_fps.txt"; OCC4D_FPS_PRUNE=0 python profiles/time_fps.py 2>/dev/null >> "$OUT/time_fps.txt"'

@@ -80,7 +80,7 @@ def test_merged_weights_of_the_library_are_exact_in_fp64():
 
 def test_merged_weight_caches_follow_untracked_parameter_updates():
     """`p.data.mul_()` does not move p._version: the caches keyed on it alone would serve stale merged
-    matrices.  invalidate_weight_caches() (what TrainStep / GraphedTrainStep call) must rebuild them."""
+    matrices.  invalidate_weight_caches() (what TrainStep calls) must rebuild them."""
     pa, ia, inf, enc, dec = _small_nets()
     pcl = pk.configs.synthetic_pcl('greater', 512, 4, 6).cuda()
     np.random.seed(6)
@@ -98,9 +98,9 @@ def test_merged_weight_caches_follow_untracked_parameter_updates():
     assert torch.equal(out1, want)
 
 
-def test_inference_after_graph_replays_uses_current_weights():
-    """validate, N hipGraph replays (parameters updated inside the graph, no Python), validate again: the second
-    validation must see the new weights (the (data_ptr, _version) key alone missed this)."""
+def test_inference_after_training_steps_uses_current_weights():
+    """validate, N training steps, validate again: the second validation must see the new weights (the
+    (data_ptr, _version) key alone missed an update that does not move _version; TrainStep invalidates the caches)."""
     kind, n = 'carla', 512
     pa, ia, inf, enc, dec = _small_nets(kind, n, 52, train=True)
     pcl = pk.configs.synthetic_pcl(kind, n, 4, 51).cuda()
@@ -118,10 +118,9 @@ def test_inference_after_graph_replays_uses_current_weights():
             ab, fg, _ = enc(pcl, False)
             return dec(qe, ab[0], fg[0], None)[0].clone(), ab[0].clone(), fg[0].clone()
     v0, _, _ = validate()
-    step = pk.training.GraphedTrainStep(enc, dec, lr=5e-3, grad_clip=0.2,
-                                        loss_kwargs=dict(density_lw=1.0, segmentation_lw=0.6))
-    step.capture(pcl, q, target, warmup=1)
-    validate()                                                              # fills the caches between replays
+    step = pk.training.TrainStep(enc, dec, lr=5e-3, grad_clip=0.2,
+                                 loss_kwargs=dict(density_lw=1.0, segmentation_lw=0.6))
+    validate()                                                              # fills the caches between steps
     for _ in range(3):
         step(pcl, q, target)
     v1, ab1, fg1 = validate()

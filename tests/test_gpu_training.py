@@ -801,113 +801,3 @@ def test_batched_frames_equal_the_per_frame_loop():
     assert abs(res[0][0] - res[1][0]) <= 2e-6 * abs(res[0][0])
     for k, g in res[0][1].items():
         assert rel_err(res[1][1][k], g) <= 1e-4 or float(g.abs().max()) < 1e-7, k
-
-
-@pytest.mark.parametrize('mode', ['external', 'external_prefetch', 'new_cloud_each_step', 'captured', 'stored'])
-def test_graphed_train_step_matches_eager(mode):
-    """GraphedTrainStep (one captured hipGraph per step, masked-mean losses, capturable AdamW) follows the same
-    loss trajectory as the eager TrainStep from the same initial state on the same batch -- with the encoder's FPS /
-    kNN geometry outside the graph (computed per step, or prefetched under the previous replay, also when every step
-    brings another cloud) and captured inside it; the attention pair tensors recomputed in backward inside the graph
-    (default) or stored ('stored')."""
-    if pk.ops.DETERMINISTIC:
-        pytest.skip('OCC4D_DETERMINISTIC=1 orders its reductions with torch.sort: eager steps only (INTEGRATION.md G)')
-    kind, n = 'carla', 512
-    pa, ia, inf = pk.configs.model_args(kind, n)
-    pcl = pk.configs.synthetic_pcl(kind, n, 4, 51).cuda()
-    esd, dsd = pk.configs.synthetic_weights(dict(pa), ia, 52)
-    rng = np.random.default_rng(53)
-    np.random.seed(1268)          # (the oracle sampler draws from numpy's global generator)
-    q = torch.stack([T(op.sample_query_points(128, inf['min_z'], inf['cube_bounds'], t, kind, 4, 'random'))
-                     for t in range(2)]).cuda()
-    target = torch.from_numpy(np.concatenate(
-        [rng.integers(0, 2, size=(2, 128, 1)), rng.uniform(size=(2, 128, 3)), np.zeros((2, 128, 1)),
-         rng.integers(-1, 13, size=(2, 128, 1))], -1).astype(np.float32)).cuda()
-    lkw = dict(density_lw=1.0, segmentation_lw=0.6)
-
-    def nets():
-        enc = pk.model.PointCompletionNetV3(**pa).cuda().train()
-        dec = pk.implicit.LocalPclResnetFC(**ia).cuda().train()
-        enc.load_state_dict(esd)
-        dec.load_state_dict(dsd)
-        return enc, dec
-    clouds = [pcl] * 6
-    saved_ckpt = pk.point_transformer_layer.CHECKPOINT_ATTENTION
-    pk.point_transformer_layer.CHECKPOINT_ATTENTION = mode != 'stored'
-    calls0 = pk.point_transformer_layer._CheckpointedAttention.calls
-    if mode == 'new_cloud_each_step':      # steps 3 .. 6 see other clouds: the graph must read THEIR geometry
-        clouds = [pcl, pcl] + [pk.configs.synthetic_pcl(kind, n, 4, 54 + i).cuda() for i in range(4)]
-    enc_e, dec_e = nets()
-    eager = pk.training.TrainStep(enc_e, dec_e, lr=2e-4, grad_clip=0.2, loss_kwargs=lkw)
-    ref = [float(eager(c, q, target)) for c in clouds]
-    enc_g, dec_g = nets()
-    graphed = pk.training.GraphedTrainStep(enc_g, dec_g, lr=2e-4, grad_clip=0.2, loss_kwargs=lkw,
-                                           external_geometry=mode != 'captured')
-    got = [float(v) for v in graphed.capture(pcl, q, target, warmup=2)]      # steps 1, 2 (eager, on a side stream)
-    for i in range(2, 6):                                                     # steps 3 .. 6 (graph replays)
-        nxt = clouds[i + 1] if (mode in ('external_prefetch', 'new_cloud_each_step') and i + 1 < 6) else None
-        got.append(float(graphed(clouds[i], q, target, next_pcl_input=nxt) if mode != 'captured'
-                         else graphed(clouds[i], q, target)))
-    pk.point_transformer_layer.CHECKPOINT_ATTENTION = saved_ckpt
-    assert (pk.point_transformer_layer._CheckpointedAttention.calls > calls0) == (mode != 'stored')
-    if mode == 'new_cloud_each_step':
-        assert len(set(round(v, 4) for v in ref[2:])) > 1                     # (the clouds do differ)
-    assert np.allclose(got, ref, rtol=2e-3, atol=2e-4), (got, ref)
-    w_e = torch.cat([p.detach().reshape(-1) for p in eager.params])
-    w_g = torch.cat([p.detach().reshape(-1) for p in graphed.params])
-    assert float((w_e - w_g).abs().max()) < 5e-3
-
-
-def test_captured_step_has_no_memset_nodes_and_ignores_eager_kernels_between_replays():
-    """Round-4 finding (profiles/r04_graph_replay_probe.txt): on this HIP runtime a MEMSET NODE of a captured graph is not
-    ordered reliably against the kernel nodes around it.  torch's backward of `expand` (the global embedding broadcast
-    to every query) is a multi-block reduction whose completion counters are cleared by cudaMemsetAsync: captured, it
-    gave the global embedding a wrong gradient whenever an eager kernel had run since the last device-wide
-    synchronisation.  The broadcast is now autograd.ExpandRowsFn (library kernels both ways).  Checked here at a query
-    count where torch's reduction needs its counters (70 K rows): (1) the step issues no memset at all, (2) an eager
-    reduction kernel between two replays leaves the trajectory on the eager step's."""
-    from torch.profiler import ProfilerActivity, profile
-    if pk.ops.DETERMINISTIC:
-        pytest.skip('OCC4D_DETERMINISTIC=1 orders its reductions with torch.sort: eager steps only (INTEGRATION.md G)')
-    kind, n, nq = 'carla', 512, 17500
-    pa, ia, inf = pk.configs.model_args(kind, n)
-    pcl = pk.configs.synthetic_pcl(kind, n, 4, 61).cuda()
-    esd, dsd = pk.configs.synthetic_weights(dict(pa), ia, 62)
-    rng = np.random.default_rng(63)
-    (x0, x1), (y0, y1), (z0, z1) = (0.0, 40.0), (-16.0, 16.0), (-1.0, 6.4)
-    q = np.concatenate([rng.uniform([x0, y0, z0], [x1, y1, z1], size=(4, nq, 3)),
-                        np.broadcast_to(np.arange(4, dtype=np.float64)[:, None, None], (4, nq, 1))], -1)
-    target = np.concatenate([rng.integers(0, 2, size=(4, nq, 1)), rng.uniform(size=(4, nq, 3)), np.zeros((4, nq, 1)),
-                             rng.integers(-1, 13, size=(4, nq, 1))], -1)
-    q, target = T(q.astype(np.float32)).cuda(), T(target.astype(np.float32)).cuda()
-    lkw = dict(density_lw=1.0, segmentation_lw=0.6)
-
-    def nets():
-        enc = pk.model.PointCompletionNetV3(**pa).cuda().train()
-        dec = pk.implicit.LocalPclResnetFC(**ia).cuda().train()
-        enc.load_state_dict(esd)
-        dec.load_state_dict(dsd)
-        return enc, dec
-    # torch's own expand backward at this size does use a memset (otherwise this test would prove nothing)
-    v = torch.randn(128, device='cuda', requires_grad=True)
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-        v[None, :].expand(4 * nq, 128).mul(2.0).sum().backward()
-        torch.cuda.synchronize()
-    assert any('emset' in e.key for e in prof.key_averages()), 'torch reduction without a memset: raise the query count'
-    e_e, d_e = nets()
-    eager = pk.training.TrainStep(e_e, d_e, lr=2e-4, grad_clip=0.2, loss_kwargs=dict(lkw, static_shapes=True))
-    ref = [float(eager(pcl, q, target)) for _ in range(5)]
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:      # (1): the step the graph captures
-        ref.append(float(eager(pcl, q, target)))
-        torch.cuda.synchronize()
-    memsets = [e.key for e in prof.key_averages() if 'emset' in e.key]
-    assert not memsets, memsets
-    e_g, d_g = nets()
-    graphed = pk.training.GraphedTrainStep(e_g, d_g, lr=2e-4, grad_clip=0.2, loss_kwargs=lkw)
-    got = [float(x) for x in graphed.capture(pcl, q, target, warmup=2)]
-    z = torch.ones(1000, device='cuda')
-    for i in range(2, 6):
-        got.append(float(graphed(pcl, q, target, next_pcl_input=pcl)))
-        torch.cuda.synchronize()
-        keep = z.abs().max()            # an eager kernel, not followed by a synchronisation
-    assert np.allclose(got, ref, rtol=2e-3, atol=2e-4), (got, ref)
