@@ -180,20 +180,9 @@ int occ4d_pt_cross_attn_f32(const float* aq, int64_t ld_aq, const float* qpos, i
                             float* agg, int64_t ld_agg, int n, int m, int k, int d,
                             float divisor, void* stream);
 
-/* Same kernel with the attention-logit GEMM (w2) on the bf16 MFMA with split operands
- * (h = h_hi + h_lo, w = w_hi + w_lo; three bf16 products, fp32 accumulate), 5.3x the fp32 MFMA rate
- * for that GEMM; the small K = 32 GEMM (wp @ r) that feeds the same logit branch is split the same
- * way.  Everything on the value path (P2, V, softmax, accumulation) stays fp32.  w2_packed / wp_packed:
- * per 32-wide block and row [32 hi | 32 lo] bf16 in fragment order, same bytes/shape as w2 / wp
- * (built by the host: occlusions-4d_amd/ops.py:pack_w2_bf16x3).  Opt-in; measured output change
- * <= 1e-6 (the logits are divided by sqrt(d) and soft-maxed). */
-int occ4d_pt_cross_attn_bf16x3_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t qs,
-                                   const float* apos, int64_t as, const int32_t* idx,
-                                   const float* kt, int64_t ld_kt, const float* vt, int64_t ld_vt,
-                                   const float* P1, const float* c1, const float* wp_packed,
-                                   const float* w2_packed, const float* b2, const float* p2, const float* c2,
-                                   float* agg, int64_t ld_agg, int n, int m, int k, int d,
-                                   float divisor, void* stream);
+/* (Rounds 1-4 also exported occ4d_pt_cross_attn_bf16x3_f32 / occ4d_pack_bf16x3_f32: the logit branch on TWO-piece split
+ * bf16 MFMAs.  Not fp32-class; superseded by the three-piece kernels (occ4d_pt_cross_attn_bf16x6_f32,
+ * occ4d_rowlin_bf16x6_f32) and removed in round 5 together with flag value 4 of the path entry points.) */
 
 /* ------------------------------------------------------------------------
  * E6 pieces (model/modules.py:152-158), K7 / K12.
@@ -518,25 +507,21 @@ int occ4d_broadcast_rows_f32(const float* vec, float scale, int n, int d, float*
 #define OCC4D_PATH_DEFAULT 0
 #define OCC4D_PATH_UNFUSED 1        /* vector attention as the unfused kernel chain (pos_hidden .. softmax_agg) */
 #define OCC4D_PATH_FIRST_GEN 2      /* d = 416: csrc/crossattn.hip instead of crossattn16p.hip */
-#define OCC4D_PATH_BF16X3 4         /* opt-in: attention-logit GEMMs on split-bf16 MFMAs (implies FIRST_GEN) */
+/*      4 was OCC4D_PATH_BF16X3 (rounds 1-4): retired, the value is not reused */
 #define OCC4D_PATH_GENERIC_LINEAR 8 /* generic Linear kernel instead of the row-resident trunk kernels */
 #define OCC4D_PATH_TRUNK4 16        /* half-CU trunk kernels (csrc/trunk4.hip) */
 #define OCC4D_PATH_BF16X6 64        /* opt-in, fp32-class: d = 416 attention GEMMs on 3-way split bf16 MFMAs, 6 partial products */
 #define OCC4D_PATH_BF16X6_TRUNK 128 /* opt-in, fp32-class: the decoder's 416-input Linear layers on the same split (csrc/trunk_bf16x6.hip) */
 #define OCC4D_PATH_FUSED_INTERP 32 /* A/B only (slower): lin_z table term of block i + 1 in block i's epilogue */
 
-/* Stage packers as device kernels (layouts: occ4d_resblock_f32 / occ4d_resblock4_f32 / occ4d_pt_cross_attn16p_f32 /
- * occ4d_pt_cross_attn_bf16x3_f32 above).  w: (n_out, 416) row-major with row stride ldw. */
+/* Stage packers as device kernels (layouts: occ4d_resblock_f32 / occ4d_resblock4_f32 / occ4d_pt_cross_attn16p_f32).
+ * w: (n_out, 416) row-major with row stride ldw. */
 int occ4d_pack_trunk_rows_f32(const float* w, int64_t ldw, int n_out, float* packed, void* stream);
 int occ4d_pack_trunk_cols_f32(const float* w, int64_t ldw, float* packed, void* stream);
 int occ4d_pack_trunk4_rows_f32(const float* w, int64_t ldw, int n_out, float* packed, void* stream);
 int occ4d_pack_trunk4_cols_f32(const float* w, int64_t ldw, float* packed, void* stream);
 /* w2 (416, 832) = attn_mlp[2].weight, wp (832, 32) = W1 P2 (merged), p2 (416, 32) = pos_mlp[2].weight */
 int occ4d_pack_attn16p_stream_f32(const float* w2, const float* wp, const float* p2, float* wstream, void* stream);
-/* w (rows, cols) contiguous, cols % 32 == 0 -> same shape: per row and 32-column block [32 hi | 32 lo] bf16 (hi =
- * bf16(w), lo = bf16(w - hi), round to nearest even) in MFMA fragment order (position 16 t + 8 half + j holds column
- * 16 t + 8 (j >> 2) + 4 half + (j & 3)) */
-int occ4d_pack_bf16x3_f32(const float* w, int rows, int cols, float* packed, void* stream);
 
 /* Optional profiling hook of the path-level forwards: the library records events[2 i] / events[2 i + 1] (hipEvent_t,
  * created by the caller with timing enabled) on `stream` right before / after the i-th launch of the chosen kernel

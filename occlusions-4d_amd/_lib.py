@@ -30,7 +30,7 @@ class LinearArgs(C.Structure):
 
 
 # path-level entry points (include/occ4d.h, last section)
-PATH_DEFAULT, PATH_UNFUSED, PATH_FIRST_GEN, PATH_BF16X3, PATH_GENERIC_LINEAR, PATH_TRUNK4, PATH_FUSED_INTERP, PATH_BF16X6, PATH_BF16X6_TRUNK = 0, 1, 2, 4, 8, 16, 32, 64, 128
+PATH_DEFAULT, PATH_UNFUSED, PATH_FIRST_GEN, PATH_GENERIC_LINEAR, PATH_TRUNK4, PATH_FUSED_INTERP, PATH_BF16X6, PATH_BF16X6_TRUNK = 0, 1, 2, 8, 16, 32, 64, 128
 PROFILE_CROSS_ATTN, PROFILE_RESBLOCK, PROFILE_ROWLIN = 1, 2, 3
 MAX_BLOCKS, MAX_CROSS = 16, 4
 PROFILE_KINDS = {'cross_attn': PROFILE_CROSS_ATTN, 'resblock': PROFILE_RESBLOCK, 'rowlin': PROFILE_ROWLIN}
@@ -88,9 +88,6 @@ SIGNATURES = {
     'occ4d_pt_self_attn16_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, C.c_int64, _i, _f, C.c_int64, _f,
                                            C.c_int64, _f, _f, _f, _f, _f, _f, _f, C.c_int64, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_float, _s]),
-    'occ4d_pt_cross_attn_bf16x3_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, C.c_int64, _i, _f, C.c_int64, _f,
-                                                 C.c_int64, _f, _f, _f, _f, _f, _f, _f, _f, C.c_int64, C.c_int,
-                                                 C.c_int, C.c_int, C.c_int, C.c_float, _s]),
     'occ4d_matmul_f64': (C.c_int, [_f, C.c_int64, C.c_int64, _f, C.c_int64, C.c_int64, _f, C.c_int, C.c_int, C.c_int, _s]),
     'occ4d_pt_cross_attn16p_stream_floats': (C.c_int64, []),
     'occ4d_pt_cross_attn16p_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, C.c_int64, _i, _f, C.c_int64, _f,
@@ -177,7 +174,6 @@ SIGNATURES = {
     'occ4d_pack_trunk4_rows_f32': (C.c_int, [_f, C.c_int64, C.c_int, _f, _s]),
     'occ4d_pack_trunk4_cols_f32': (C.c_int, [_f, C.c_int64, _f, _s]),
     'occ4d_pack_attn16p_stream_f32': (C.c_int, [_f, _f, _f, _f, _s]),
-    'occ4d_pack_bf16x3_f32': (C.c_int, [_f, C.c_int, C.c_int, _f, _s]),
     'occ4d_pt_cross_attn_bf16x6_stream_floats': (C.c_int64, []),
     'occ4d_debug_x6_stamps': (C.c_int, [C.c_void_p, C.c_int]),
     'occ4d_rowlin_bf16x6_packed_floats': (C.c_int64, [C.c_int]),

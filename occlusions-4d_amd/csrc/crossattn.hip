@@ -37,8 +37,6 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int HB = 32;        // hidden block (k-tile of GEMM2)
 constexpr int LDW = 36;       // padded LDS row (floats): stride 9 x 16 B -> conflict-free ds_read_b128
@@ -63,15 +61,6 @@ struct CrossAttnArgs {
 
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
 
-// round-to-nearest-even bf16 of f (bits in the low half) and the bf16 of the remainder
-__device__ __forceinline__ void bf16_split(float f, unsigned& hi, unsigned& lo) {
-  unsigned u = __float_as_uint(f);
-  hi = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-  const float r = f - __uint_as_float(hi << 16);
-  u = __float_as_uint(r);
-  lo = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-
 // (local query, neighbour slot) carried by C/D register `reg` of half-wave `half` in row tile `w`
 __device__ __forceinline__ void pair_of(int w, int half, int reg, int& ql, int& slot) {
   if (reg < 7) { ql = 2 * w; slot = 7 * half + reg; }
@@ -81,7 +70,7 @@ __device__ __forceinline__ void pair_of(int w, int half, int reg, int& ql, int& 
 
 // Body for one channel group: tiles [CBEG, CBEG + NTW) of the NT channel tiles (compile-time, so
 // the MFMA / ds_read stream of a hidden block is one straight-line basic block).
-template <int NT, int CBEG, int NTW, bool SPLIT>
+template <int NT, int CBEG, int NTW>
 __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* smem, int* s_idx) {
   constexpr int D = 32 * NT;
   constexpr int H2 = 2 * D;
@@ -129,20 +118,6 @@ __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* s
       const float v = fmaf(dz, w[2], fmaf(dy, w[1], dx * w[0])) + a.c1[m];
       r[s] = my_valid ? fmaxf(v, 0.f) : 0.f;
     }
-  }
-  // split-bf16 pieces of r for GEMM1 (k-step t uses r[8t .. 8t+7]: the same k permutation as GEMM2)
-  u32x4 rs_hi[2], rs_lo[2];
-  if (SPLIT) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        unsigned h0, l0, h1, l1;
-        bf16_split(r[8 * t + 2 * jj], h0, l0);
-        bf16_split(r[8 * t + 2 * jj + 1], h1, l1);
-        rs_hi[t][jj] = h0 | (h1 << 16);
-        rs_lo[t][jj] = l0 | (l1 << 16);
-      }
   }
   const float* aq_row = a.aq + (int64_t)my_q * a.ld_aq + 4 * half;
   const float* kt_row = a.kt + (int64_t)my_j * a.ld_kt + 4 * half;
@@ -217,77 +192,28 @@ __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* s
 #ifndef OCC4D_ABLATE_NOLOAD
     gload(nb);
 #endif
-    if (SPLIT) {
-      // GEMM1 on split-bf16 MFMAs as well (it feeds only the logit branch): Wp rows are packed
-      // [32 hi | 32 lo] bf16 in fragment order like W2; r was split once (rs_hi / rs_lo).
-      const float* Wps = W + D * LDW + prow * LDW;
+    const float* Wp = W + D * LDW + frag_off;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const u32x4 wh = *reinterpret_cast<const u32x4*>(Wps + 4 * (2 * t + half));
-        const u32x4 wl = *reinterpret_cast<const u32x4*>(Wps + 16 + 4 * (2 * t + half));
-        const bf16x8 w_hi = __builtin_bit_cast(bf16x8, wh), w_lo = __builtin_bit_cast(bf16x8, wl);
-        const bf16x8 r_hi = __builtin_bit_cast(bf16x8, rs_hi[t]), r_lo = __builtin_bit_cast(bf16x8, rs_lo[t]);
-        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_lo, r_hi, hacc, 0, 0, 0);
-        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi, r_lo, hacc, 0, 0, 0);
-        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi, r_hi, hacc, 0, 0, 0);
-      }
-    } else {
-      const float* Wp = W + D * LDW + frag_off;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(Wp + 8 * g);
-        hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, r[4 * g + 0], hacc, 0, 0, 0);
-        hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, r[4 * g + 1], hacc, 0, 0, 0);
-        hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, r[4 * g + 2], hacc, 0, 0, 0);
-        hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, r[4 * g + 3], hacc, 0, 0, 0);
-      }
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(Wp + 8 * g);
+      hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, r[4 * g + 0], hacc, 0, 0, 0);
+      hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, r[4 * g + 1], hacc, 0, 0, 0);
+      hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, r[4 * g + 2], hacc, 0, 0, 0);
+      hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, r[4 * g + 3], hacc, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) hacc[i] = fmaxf(hacc[i], 0.f);
     // GEMM2 over this wave's channel tiles
     const float* W2 = W + CBEG * 32 * LDW + frag_off;
-    if (SPLIT) {
-      // Attention logits on the bf16 MFMA with split operands (fp32 accumulate):
-      //   h = h_hi + h_lo, w = w_hi + w_lo (bf16 each);  h w ~ h_hi w_hi + h_hi w_lo + h_lo w_hi
-      // 3 x v_mfma_f32_32x32x16_bf16 (32 cycles each, 16 hidden per step) instead of 8 fp32 MFMAs
-      // (64 cycles each).  The dropped h_lo w_lo term is 2^-16 relative; the logits are divided by
-      // sqrt(D) and soft-maxed, and the measured effect on the outputs is <= 1e-6 (tests).
-      // The LDS row of a channel holds this hidden block as [32 hi | 32 lo] bf16 in fragment order
-      // (ops.pack_w2_bf16x3), i.e. the same 128 bytes as the fp32 layout.
-      const float* W2s = W + CBEG * 32 * LDW + prow * LDW;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        u32x4 ah, al;
+    for (int g = 0; g < 4; ++g) {
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          unsigned h0, l0, h1, l1;
-          bf16_split(hacc[8 * t + 2 * jj], h0, l0);
-          bf16_split(hacc[8 * t + 2 * jj + 1], h1, l1);
-          ah[jj] = h0 | (h1 << 16);
-          al[jj] = l0 | (l1 << 16);
-        }
-        const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ah), a_lo = __builtin_bit_cast(bf16x8, al);
-#pragma unroll
-        for (int c = 0; c < NTW; ++c) {
-          const u32x4 bh = *reinterpret_cast<const u32x4*>(W2s + c * 32 * LDW + 4 * (2 * t + half));
-          const u32x4 bl = *reinterpret_cast<const u32x4*>(W2s + c * 32 * LDW + 16 + 4 * (2 * t + half));
-          const bf16x8 b_hi = __builtin_bit_cast(bf16x8, bh), b_lo = __builtin_bit_cast(bf16x8, bl);
-          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[c], 0, 0, 0);
-          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[c], 0, 0, 0);
-          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[c], 0, 0, 0);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-#pragma unroll
-        for (int c = 0; c < NTW; ++c) {
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(W2 + c * 32 * LDW + 8 * g);
-          acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(hacc[4 * g + 0], bv.x, acc[c], 0, 0, 0);
-          acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(hacc[4 * g + 1], bv.y, acc[c], 0, 0, 0);
-          acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(hacc[4 * g + 2], bv.z, acc[c], 0, 0, 0);
-          acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(hacc[4 * g + 3], bv.w, acc[c], 0, 0, 0);
-        }
+      for (int c = 0; c < NTW; ++c) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(W2 + c * 32 * LDW + 8 * g);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(hacc[4 * g + 0], bv.x, acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(hacc[4 * g + 1], bv.y, acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(hacc[4 * g + 2], bv.z, acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(hacc[4 * g + 3], bv.w, acc[c], 0, 0, 0);
       }
     }
 #ifndef OCC4D_ABLATE_NOLOAD
@@ -300,7 +226,7 @@ __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* s
     // (Pinned at the top / bottom of the block instead, every wave of the workgroup did its memory phase at the
     // same time right after the barrier and the MFMA pipes idled: 13 % of the kernel.)
     {
-      constexpr int NMFMA = SPLIT ? 6 + 6 * NTW : 16 + 16 * NTW;
+      constexpr int NMFMA = 16 + 16 * NTW;
       constexpr int NVM = 8 + W2_LOADS;
 #ifndef OCC4D_CA_P1
 #define OCC4D_CA_P1 2
@@ -308,11 +234,11 @@ __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* s
 #ifndef OCC4D_CA_P2
 #define OCC4D_CA_P2 3
 #endif
-      constexpr int P1 = SPLIT ? 1 : OCC4D_CA_P1, P2 = SPLIT ? 2 : OCC4D_CA_P2;
+      constexpr int P1 = OCC4D_CA_P1, P2 = OCC4D_CA_P2;
 #ifndef OCC4D_CA_TAIL
 #define OCC4D_CA_TAIL 0
 #endif
-      constexpr int TAIL = SPLIT ? 0 : OCC4D_CA_TAIL;          // MFMAs after the last ds_write (covers its latency before the barrier)
+      constexpr int TAIL = OCC4D_CA_TAIL;          // MFMAs after the last ds_write (covers its latency before the barrier)
       static_assert(NVM * P1 + W2_LOADS * P2 + TAIL <= NMFMA, "pipeline needs enough MFMAs");
 #pragma unroll
       for (int i = 0; i < NVM; ++i) {
@@ -492,18 +418,18 @@ __device__ __forceinline__ void cross_attn_body(const CrossAttnArgs& a, float* s
   }
 }
 
-template <int NT, bool SPLIT>
+template <int NT>
 __global__ __launch_bounds__(512, 2) void cross_attn_kernel(const CrossAttnArgs a) {
   constexpr int BUF = (32 * NT + HB) * LDW;
   static_assert(2 * BUF >= 12 * 32 * NT, "partial-softmax scratch must fit the weight buffers");
   __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
   __shared__ int s_idx[QPB * 16];
   constexpr int NTW0 = (NT + 1) / 2;               // channel group 0: tiles [0, NTW0), group 1: the rest
-  if (threadIdx.x < 256) cross_attn_body<NT, 0, NTW0, SPLIT>(a, smem, s_idx);
-  else cross_attn_body<NT, NTW0, NT - NTW0, SPLIT>(a, smem, s_idx);
+  if (threadIdx.x < 256) cross_attn_body<NT, 0, NTW0>(a, smem, s_idx);
+  else cross_attn_body<NT, NTW0, NT - NTW0>(a, smem, s_idx);
 }
 
-static int cross_attn_launch(bool split, const float* aq, int64_t ld_aq, const float* qpos, int64_t qs,
+static int cross_attn_launch(const float* aq, int64_t ld_aq, const float* qpos, int64_t qs,
                              const float* apos, int64_t as, const int32_t* idx, const float* kt, int64_t ld_kt,
                              const float* vt, int64_t ld_vt, const float* P1, const float* c1, const float* wp,
                              const float* w2, const float* b2, const float* p2, const float* c2, float* agg,
@@ -524,13 +450,8 @@ static int cross_attn_launch(bool split, const float* aq, int64_t ld_aq, const f
                   agg, ld_agg, n, m, k, divisor};
   dim3 grid(occ4d::cdiv(n, QPB)), block(512);
   hipStream_t st = (hipStream_t)stream;
-  if (d == 416) {
-    if (split) cross_attn_kernel<13, true><<<grid, block, 0, st>>>(a);
-    else cross_attn_kernel<13, false><<<grid, block, 0, st>>>(a);
-  } else {
-    if (split) cross_attn_kernel<9, true><<<grid, block, 0, st>>>(a);
-    else cross_attn_kernel<9, false><<<grid, block, 0, st>>>(a);
-  }
+  if (d == 416) cross_attn_kernel<13><<<grid, block, 0, st>>>(a);
+  else cross_attn_kernel<9><<<grid, block, 0, st>>>(a);
   return occ4d::check_launch("occ4d_pt_cross_attn");
 }
 
@@ -542,16 +463,6 @@ extern "C" int occ4d_pt_cross_attn_f32(const float* aq, int64_t ld_aq, const flo
                                        const float* c1, const float* wp, const float* w2, const float* b2,
                                        const float* p2, const float* c2, float* agg, int64_t ld_agg, int n, int m,
                                        int k, int d, float divisor, void* stream) {
-  return cross_attn_launch(false, aq, ld_aq, qpos, qs, apos, as, idx, kt, ld_kt, vt, ld_vt, P1, c1, wp, w2, b2, p2, c2,
+  return cross_attn_launch(aq, ld_aq, qpos, qs, apos, as, idx, kt, ld_kt, vt, ld_vt, P1, c1, wp, w2, b2, p2, c2,
                            agg, ld_agg, n, m, k, d, divisor, stream);
-}
-
-extern "C" int occ4d_pt_cross_attn_bf16x3_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t qs,
-                                              const float* apos, int64_t as, const int32_t* idx, const float* kt,
-                                              int64_t ld_kt, const float* vt, int64_t ld_vt, const float* P1,
-                                              const float* c1, const float* wp, const float* w2_packed,
-                                              const float* b2, const float* p2, const float* c2, float* agg,
-                                              int64_t ld_agg, int n, int m, int k, int d, float divisor, void* stream) {
-  return cross_attn_launch(true, aq, ld_aq, qpos, qs, apos, as, idx, kt, ld_kt, vt, ld_vt, P1, c1, wp, w2_packed, b2, p2,
-                           c2, agg, ld_agg, n, m, k, d, divisor, stream);
 }

@@ -127,32 +127,6 @@ __global__ void pack_attn16p_kernel(const float* __restrict__ w2, const float* _
   out[i] = v;
 }
 
-__device__ inline uint32_t bf16_rne(float f) {
-  uint32_t u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return u >> 16;
-}
-
-// one thread per output dword = two bf16 (positions 2 q, 2 q + 1 of a [32 hi | 32 lo] block)
-__global__ void pack_bf16x3_kernel(const float* __restrict__ w, int rows, int cols, uint32_t* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)rows * cols) return;
-  const int row = (int)(i / cols), cw = (int)(i % cols);
-  const int blk = cw >> 5, q = cw & 31;                 // dword q of the block: bf16 positions 2 q, 2 q + 1
-  uint32_t half[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int pos64 = 2 * q + h;                        // 0..31 hi plane, 32..63 lo plane
-    const int pos = pos64 & 31;
-    const int t = pos >> 4, hf = (pos >> 3) & 1, j = pos & 7;
-    const int col = 32 * blk + 16 * t + 8 * (j >> 2) + 4 * hf + (j & 3);
-    const float v = w[(int64_t)row * cols + col];
-    const uint32_t hi = bf16_rne(v);
-    half[h] = pos64 < 32 ? hi : bf16_rne(v - __uint_as_float(hi << 16));
-  }
-  out[i] = half[0] | (half[1] << 16);
-}
-
 // ----------------------------------------------------------------------------------------------------------------
 // fp64 helpers of the merged-weight algebra
 // ----------------------------------------------------------------------------------------------------------------
@@ -218,8 +192,8 @@ bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 // ----------------------------------------------------------------------------------------------------------------
 struct LayerLayout {
   int D, D2, h, Kq;                 // Kq: input width of the merged query projection (d_in when layer1 is folded in)
-  bool fold_pre, fused16p, fused_first, fused_self16, bf16x3, bf16x6, wq_rows, w3_rows, trunk4, x6rows;
-  int64_t wq, bq, wk, wp, wq_packed, stream, stream6, w2_bf, wp_bf, w3_packed, wq_x6, w3_x6, scratch, total;
+  bool fold_pre, fused16p, fused_first, fused_self16, bf16x6, wq_rows, w3_rows, trunk4, x6rows;
+  int64_t wq, bq, wk, wp, wq_packed, stream, stream6, w3_packed, wq_x6, w3_x6, scratch, total;
   int64_t s_A, s_B, s_C, s_C2, s_v, s_bq;      // doubles, inside the scratch region
 };
 
@@ -248,9 +222,8 @@ LayerLayout layer_layout(const occ4d_pt_layer_weights& w, int flags) {
   L.fold_pre = w.cross && w.pre_w;
   L.Kq = L.fold_pre ? w.d_in : L.D;
   const bool fusable = (L.D == 288 || L.D == 416) && L.h == 32 && !(flags & OCC4D_PATH_UNFUSED);
-  L.bf16x6 = fusable && L.D == 416 && (flags & OCC4D_PATH_BF16X6) && !(flags & (OCC4D_PATH_FIRST_GEN | OCC4D_PATH_BF16X3));
-  L.bf16x3 = fusable && (flags & OCC4D_PATH_BF16X3);
-  L.fused16p = fusable && L.D == 416 && !L.bf16x6 && !(flags & (OCC4D_PATH_FIRST_GEN | OCC4D_PATH_BF16X3));
+  L.bf16x6 = fusable && L.D == 416 && (flags & OCC4D_PATH_BF16X6) && !(flags & OCC4D_PATH_FIRST_GEN);
+  L.fused16p = fusable && L.D == 416 && !L.bf16x6 && !(flags & OCC4D_PATH_FIRST_GEN);
   L.fused_first = fusable && !L.fused16p && !L.bf16x6;
   L.fused_self16 = L.h == 32 && L.D % 4 == 0 && L.D <= 288 && !(flags & OCC4D_PATH_UNFUSED);   // (used when k == 16)
   L.trunk4 = flags & OCC4D_PATH_TRUNK4;
@@ -273,8 +246,6 @@ LayerLayout layer_layout(const occ4d_pt_layer_weights& w, int flags) {
   L.w3_x6 = L.x6rows ? take(occ4d_rowlin_bf16x6_packed_floats(w.d_out)) : -1;
   L.stream = L.fused16p ? take(occ4d_pt_cross_attn16p_stream_floats()) : -1;
   L.stream6 = L.bf16x6 ? take(occ4d_pt_cross_attn_bf16x6_stream_floats()) : -1;
-  L.w2_bf = L.bf16x3 ? take((int64_t)L.D * 2 * L.D) : -1;
-  L.wp_bf = L.bf16x3 ? take((int64_t)2 * L.D * L.h) : -1;
   L.w3_packed = L.w3_rows ? take(packed(w.d_out)) : -1;
   // fp64 scratch (doubles): A = W1, B = right factor, C = W1 Wq, C2 = C L1, v / bq vectors
   int64_t d = 0;
@@ -329,10 +300,6 @@ int layer_prepare(const occ4d_pt_layer_weights& w, const LayerLayout& L, float* 
   }
   if (L.fused16p) TRY(occ4d_pack_attn16p_stream_f32(w.attn2_w, prep + L.wp, w.pos2_w, prep + L.stream, st));
   if (L.bf16x6) TRY(occ4d_pack_attn_bf16x6_stream_f32(w.attn2_w, prep + L.wp, w.pos2_w, prep + L.stream6, st));
-  if (L.bf16x3) {
-    TRY(occ4d_pack_bf16x3_f32(w.attn2_w, D, 2 * D, prep + L.w2_bf, st));
-    TRY(occ4d_pack_bf16x3_f32(prep + L.wp, 2 * D, h, prep + L.wp_bf, st));
-  }
   if (L.w3_rows) {
     if (L.trunk4) TRY(occ4d_pack_trunk4_rows_f32(w.post_w, D, w.d_out, prep + L.w3_packed, st));
     else TRY(occ4d_pack_trunk_rows_f32(w.post_w, D, w.d_out, prep + L.w3_packed, st));
@@ -464,10 +431,6 @@ int layer_forward(const occ4d_pt_layer_weights& w, const LayerLayout& L, const f
         else if (L.fused16p)
           rc = occ4d_pt_cross_attn16p_f32(aq, 2 * D, qp, ps, pos2, p2s, idx, kt, 2 * D, vtc, D, w.pos0_w, w.pos0_b,
                                           prep + L.stream, agg_c, ld_agg, c, m, k, D, divisor, occ4d::attn16p_skew(), st);
-        else if (L.bf16x3)
-          rc = occ4d_pt_cross_attn_bf16x3_f32(aq, 2 * D, qp, ps, pos2, p2s, idx, kt, 2 * D, vt, D, w.pos0_w, w.pos0_b,
-                                              prep + L.wp_bf, prep + L.w2_bf, w.attn2_b, w.pos2_w, w.pos2_b, agg_c, ld_agg, c,
-                                              m, k, D, divisor, st);
         else
           rc = occ4d_pt_cross_attn_f32(aq, 2 * D, qp, ps, pos2, p2s, idx, kt, 2 * D, vt, D, w.pos0_w, w.pos0_b, prep + L.wp,
                                        w.attn2_w, w.attn2_b, w.pos2_w, w.pos2_b, agg_c, ld_agg, c, m, k, D, divisor, st);
@@ -756,13 +719,6 @@ extern "C" int occ4d_pack_attn16p_stream_f32(const float* w2, const float* wp, c
   OCC4D_REQUIRE(w2 && wp && p2 && wstream, "occ4d_pack_attn16p_stream_f32: null pointer");
   pack_attn16p_kernel<<<cdiv(54 * 28 * 256, 256), 256, 0, (hipStream_t)stream>>>(w2, wp, p2, wstream);
   return occ4d::check_launch("occ4d_pack_attn16p_stream_f32");
-}
-extern "C" int occ4d_pack_bf16x3_f32(const float* w, int rows, int cols, float* packed, void* stream) {
-  OCC4D_REQUIRE(w && packed && rows >= 1 && cols >= 32 && cols % 32 == 0,
-                "occ4d_pack_bf16x3_f32: (%d, %d): cols must be a multiple of 32", rows, cols);
-  pack_bf16x3_kernel<<<cdiv((int64_t)rows * cols, 256), 256, 0, (hipStream_t)stream>>>(w, rows, cols,
-                                                                                      reinterpret_cast<uint32_t*>(packed));
-  return occ4d::check_launch("occ4d_pack_bf16x3_f32");
 }
 
 extern "C" int64_t occ4d_pt_layer_prepared_floats(const occ4d_pt_layer_weights* w, int flags) {

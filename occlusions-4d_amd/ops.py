@@ -388,21 +388,8 @@ def rowlin_bf16x6(x, w, b=None, relu_in=False, res=None, out=None):
     return out
 
 
-def pack_w2_bf16x3(w2):
-    """(d, 2d) fp32 attn_mlp[2] weight -> same-shaped fp32 container holding, per 32-wide hidden block and channel,
-    [32 hi | 32 lo] bf16 (hi = bf16(w), lo = bf16(w - hi)) in MFMA fragment order (occ4d_pack_bf16x3_f32)."""
-    w2 = _cont(w2.detach().float(), 'w2')
-    d, h2 = w2.shape
-    assert h2 % 32 == 0
-    out = torch.empty_like(w2)
-    _lib.check(_lib.lib().occ4d_pack_bf16x3_f32(_ptr(w2), d, h2, _ptr(out), _stream()))
-    return out
-
-
-def pt_cross_attn(aq, qpos, apos, idx, kt, vt, P1, c1, wp, w2, b2, p2, c2, out=None, w2_packed=None,
-                  wp_packed=None):
-    """Fused vector attention (occ4d_pt_cross_attn_f32): agg (n,d).  With w2_packed (pack_w2_bf16x3) the
-    attention-logit GEMM runs on the split-bf16 MFMA path (occ4d_pt_cross_attn_bf16x3_f32)."""
+def pt_cross_attn(aq, qpos, apos, idx, kt, vt, P1, c1, wp, w2, b2, p2, c2, out=None):
+    """Fused vector attention (occ4d_pt_cross_attn_f32): agg (n,d)."""
     aq, ld_aq = _aligned_rows(_dev(aq, name='aq'), 'aq')
     kt, ld_kt = _aligned_rows(_dev(kt, name='kt'), 'kt')
     vt, ld_vt = _rows(_dev(vt, name='vt'), 'vt')
@@ -423,10 +410,6 @@ def pt_cross_attn(aq, qpos, apos, idx, kt, vt, P1, c1, wp, w2, b2, p2, c2, out=N
     flops = 2.0 * n * k * (32 * 2 * d + 2 * d * d + 32 * d)
     fn = _lib.lib().occ4d_pt_cross_attn_f32
     w2_arg, wp_arg = ws[3], ws[2]
-    if w2_packed is not None:
-        assert w2_packed.shape == ws[3].shape and w2_packed.dtype == torch.float32 and w2_packed.is_contiguous()
-        assert wp_packed is not None and wp_packed.shape == ws[2].shape and wp_packed.is_contiguous()
-        fn, w2_arg, wp_arg = _lib.lib().occ4d_pt_cross_attn_bf16x3_f32, w2_packed, wp_packed
     _lib.check(_launch('cross_attn', dict(n=n, k=k, d=d), flops, lambda: fn(
         _ptr(aq), ld_aq, _ptr(qp), qs, _ptr(ap), as_, _ptr(idx), _ptr(kt), ld_kt, _ptr(vt), ld_vt,
         _ptr(ws[0]), _ptr(ws[1]), _ptr(wp_arg), _ptr(w2_arg), _ptr(ws[4]), _ptr(ws[5]), _ptr(ws[6]),

@@ -30,9 +30,9 @@ USE_TRUNK_KERNELS = True     # row-resident fused trunk kernels (csrc/trunk*.hip
 # tested alternative (bench.py, 20 steps, 2 decode streams: default 122.5-122.8 ms / step; OCC4D_TRUNK4=1 123.7; DESIGN.md
 # 6c): half-CU re-cut of the trunk kernels (csrc/trunk4.hip: 4-wave workgroups, two per CU)
 USE_TRUNK4 = os.environ.get('OCC4D_TRUNK4', '0') != '0'
-# 'f32' (default): every GEMM exact fp32.  'bf16x3': the attention-logit GEMM of the fused kernel on split-bf16 MFMAs
-# (occ4d_pt_cross_attn_bf16x3_f32); everything else unchanged.  Opt-in.  'bf16x6' (round 5, opt-in): the d = 416 attention
-# GEMMs on three-way split bf16 MFMAs, six partial products, fp32 accumulate (csrc/crossattn_bf16x6.hip): fp32-class.
+# 'f32' (default): every GEMM exact fp32.  'bf16x6' (round 5, opt-in): the d = 416 attention GEMMs on three-way split bf16
+# MFMAs, six partial products, fp32 accumulate (csrc/crossattn_bf16x6.hip): fp32-class.  (The two-piece 'bf16x3' logit mode
+# of rounds 1-4 -- not fp32-class, and slower than this one -- is gone.)
 LOGIT_PRECISION = os.environ.get('OCC4D_LOGIT_PRECISION', 'f32')
 # Opt-in (round 5): the decoder's 416-input Linear layers (residual blocks, merged query projection, layer3) on the same
 # three-way split bf16 MFMAs (csrc/trunk_bf16x6.hip); 'bf16x6' here + LOGIT_PRECISION 'bf16x6' = the whole decoder GEMM work
@@ -43,15 +43,13 @@ FUSED_INTERP = os.environ.get('OCC4D_FUSED_INTERP', '0') != '0'
 
 def path_flags():
     """The OCC4D_PATH_* flags (include/occ4d.h) the switches above select for the library's path-level entry points."""
-    assert LOGIT_PRECISION in ('f32', 'bf16x3', 'bf16x6'), LOGIT_PRECISION
+    assert LOGIT_PRECISION in ('f32', 'bf16x6'), LOGIT_PRECISION
     L = ops._lib
     f = L.PATH_DEFAULT
     if not USE_FUSED_ATTENTION:
         f |= L.PATH_UNFUSED
     if not USE_ATTN16:
         f |= L.PATH_FIRST_GEN
-    if LOGIT_PRECISION == 'bf16x3':
-        f |= L.PATH_BF16X3
     if LOGIT_PRECISION == 'bf16x6':
         f |= L.PATH_BF16X6
     assert TRUNK_PRECISION in ('f32', 'bf16x6'), TRUNK_PRECISION

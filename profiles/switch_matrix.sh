@@ -11,7 +11,7 @@ run "OCC4D_PAIR_MLP=0 OCC4D_TRAIN_ROWLIN_HALF_CU=0" "tests/test_gpu_training.py"
 run "OCC4D_DETERMINISTIC=1" "tests/test_gpu_training.py"
 run "OCC4D_FPS_PRUNE=0" "tests/test_gpu_parity.py tests/test_gpu_fps_pruned.py"
 run "OCC4D_DECODE_STREAMS=1 OCC4D_PINNED_HOST_IO=0" "tests/test_gpu_parity.py tests/test_gpu_postops.py"
-run "OCC4D_LOGIT_PRECISION=bf16x3" "tests/test_gpu_fullsize.py"
+run "OCC4D_LOGIT_PRECISION=bf16x6 OCC4D_TRUNK_PRECISION=bf16x6" "tests/test_gpu_fullsize.py"
 run "OCC4D_KNN_GRID=0" "tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_contracts.py"
 run "OCC4D_KNN_GRID_MIN_PAIRS=1 OCC4D_KNN_GRID_MIN_DATA=1" "tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_training.py tests/test_gpu_sampler.py"
 run "OCC4D_KNN_GRID_MIN_PAIRS=1 OCC4D_KNN_GRID_MIN_DATA=1 OCC4D_KNN_GRID_ONE_THREAD_FROM=1" "tests/test_gpu_parity.py tests/test_gpu_fullsize.py"

@@ -70,7 +70,6 @@ def lib():
         'occ4d_pack_trunk4_rows_f32': (C.c_int, [F, C.c_int64, C.c_int, F, S]),
         'occ4d_pack_trunk4_cols_f32': (C.c_int, [F, C.c_int64, F, S]),
         'occ4d_pack_attn16p_stream_f32': (C.c_int, [F, F, F, F, S]),
-        'occ4d_pack_bf16x3_f32': (C.c_int, [F, C.c_int, C.c_int, F, S]),
         'occ4d_trunk_packed_floats': (C.c_int64, [C.c_int]),
         'occ4d_trunk4_packed_floats': (C.c_int64, [C.c_int]),
         'occ4d_pt_cross_attn16p_stream_floats': (C.c_int64, []),
@@ -354,15 +353,6 @@ def test_packers_match_the_layouts_of_the_header(lib):
     want = torch.cat([torch.cat([a, b], 1), c[:14].reshape(1, -1),
                       torch.cat([c[14:].reshape(1, -1), torch.zeros((1, 1024), device='cuda')], 1)], 0)
     assert torch.equal(got, want.reshape(-1))
-    # split-bf16 planes: [32 hi | 32 lo] per 32-column block, fragment order, round to nearest even
-    m = dev(rng.normal(size=(64, 128)).astype(np.float32))
-    got = call(lib.occ4d_pack_bf16x3_f32, 64 * 128, ptr(m), 64, 128).view(64, 128)
-    hi = m.bfloat16()
-    lo = (m - hi.float()).bfloat16()
-    i = torch.arange(32, device='cuda')
-    perm = 16 * (i // 16) + 8 * ((i % 8) // 4) + 4 * ((i // 8) % 2) + (i % 4)
-    want = torch.cat([hi.view(64, 4, 32)[:, :, perm], lo.view(64, 4, 32)[:, :, perm]], dim=2).contiguous()
-    assert torch.equal(got.view(torch.bfloat16).view(64, 4, 64), want)
 
 
 def test_the_binding_printed_in_integration_md_runs_as_printed():

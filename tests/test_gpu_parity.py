@@ -456,16 +456,7 @@ def test_perform_inference_tracks_and_gt_labels(pk, case):
         assert res['gt_air'].shape[1] == 2
 
 
-# ------------------------------------------------------------------ opt-in split-bf16 attention logits
-@pytest.fixture
-def bf16x3_logits(pk):
-    ptl = pk.point_transformer_layer
-    old = ptl.LOGIT_PRECISION
-    ptl.LOGIT_PRECISION = 'bf16x3'
-    yield
-    ptl.LOGIT_PRECISION = old
-
-
+# ------------------------------------------------------------------ opt-in split-precision (bf16 x 3 pieces) kernels
 @pytest.fixture
 def bf16x6_attention(pk):
     ptl = pk.point_transformer_layer
@@ -543,49 +534,6 @@ def test_decoder_with_three_way_split_bf16_attention(pk, bf16x6_attention, case)
         case['name'], d, float(np.abs(out.cpu().numpy() - g['output']).max()),
         float(np.abs(out32.cpu().numpy() - g['output']).max())))
     assert 0.0 < d < 2e-5                 # a different kernel ran, and it agrees
-
-
-def test_pack_w2_bf16x3_roundtrip(pk):
-    """hi + lo reproduces w to 2^-16 relative and the fragment permutation is a bijection per block."""
-    rng = np.random.default_rng(0)
-    w = torch.from_numpy(rng.normal(size=(64, 128)).astype(np.float32)).cuda()
-    packed = pk.ops.pack_w2_bf16x3(w)
-    assert packed.shape == w.shape and packed.dtype == torch.float32
-    planes = packed.view(torch.bfloat16).view(64, 4, 64).float()
-    perm = torch.tensor([16 * t + 8 * (j >> 2) + 4 * h + (j & 3) for t in range(2) for h in range(2) for j in range(8)])
-    rec = torch.empty(64, 4, 32, device='cuda')
-    rec[:, :, perm.cuda()] = planes[:, :, :32] + planes[:, :, 32:]
-    assert (rec.view(64, 128) - w).abs().max() <= 2.0 ** -16 * w.abs().max()
-    assert sorted(perm.tolist()) == list(range(32))
-
-
-@pytest.mark.parametrize('case', gc.DEC_CASES, ids=lambda c: c['name'])
-def test_decoder_with_split_bf16_logits(pk, bf16x3_logits, case):
-    """Opt-in mode: attention-logit GEMM on split-bf16 MFMAs.  Same golden vectors, same 1e-4 bar;
-    the measured deviation from the fp32 path is of the order of 1e-6."""
-    q, abstract, fglob, ia, sd = gc.dec_inputs(case)
-    net = pk.implicit.LocalPclResnetFC(**ia).cuda().eval()
-    net.load_state_dict(sd)
-    with torch.no_grad():
-        out, pen = net(dev(q), dev(abstract), dev(fglob), None)
-    g = load_golden('g8_dec_' + case['name'])
-    close(out, g['output'], 2e-5)
-    close(pen[:, ::8], g['penult'], 2e-5)
-
-
-def test_perform_inference_with_split_bf16_logits(pk, bf16x3_logits):
-    case = gc.INFER_CASES[0]
-    pcl, pa, ia, inf, esd, dsd = gc.infer_inputs(case)
-    enc = pk.model.PointCompletionNetV3(**pa).cuda().eval()
-    enc.load_state_dict(esd)
-    dec = pk.implicit.LocalPclResnetFC(**ia).cuda().eval()
-    dec.load_state_dict(dsd)
-    res = pk.inference.perform_inference(
-        pcl.clone(), None, None, [enc, dec], torch.device('cuda:0'), 'if', inf['min_z'], inf['cube_bounds'],
-        inf['color_mode'], case['time_idx'], None, sample_implicit=True, num_sample=case['num_sample'],
-        point_sample_mode='grid', batch_size=case['batch_size'], predict_segmentation=False, track_mode='none',
-        semantic_classes=13, density_threshold=0.5, data_kind='greater', cube_mode=4, compress_air=True)
-    close(res['implicit_output'], load_golden('g10_infer_' + case['name'])['implicit_output'], 2e-5)
 
 
 # ------------------------------------------------------------------ edge cases
