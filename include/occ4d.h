@@ -337,6 +337,12 @@ int occ4d_rowlin4_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const 
 int occ4d_rowlin4_masked_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed, const float* b,
                              int n_out, int relu_in, const float* res, int64_t ldr, const float* mask, int64_t ldm,
                              int n, void* stream);
+/* y = [mask > 0] ([relu](x) W^T + b) + skip: the data gradient of a residual block's first layer with the gradient of the
+ * skip connection added AFTER the mask (model/implicit.py:66-85 backward: dx = dy + relu'(x) (dh W0)) -- the masked
+ * kernel and the element-wise add of the autograd engine in one launch. */
+int occ4d_rowlin4_masked_skip_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed,
+                                  const float* b, int n_out, int relu_in, const float* skip, int64_t lds,
+                                  const float* mask, int64_t ldm, int n, void* stream);
 
 /* K13 post-ops (eval/inference.py:218-243): per channel op code in `ops` (G ints):
  * 0 = identity, 1 = sigmoid, 2 = clamp to [0,1].  In place. */

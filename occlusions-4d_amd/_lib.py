@@ -113,6 +113,8 @@ SIGNATURES = {
                                           C.c_int64, C.c_int, _s]),
     'occ4d_rowlin4_masked_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, _f, C.c_int, C.c_int, _f, C.c_int64, _f,
                                           C.c_int64, C.c_int, _s]),
+    'occ4d_rowlin4_masked_skip_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, _f, C.c_int, C.c_int, _f, C.c_int64, _f,
+                                               C.c_int64, C.c_int, _s]),
     'occ4d_trunk4_packed_floats': (C.c_int64, [C.c_int]),
     'occ4d_resblock4_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, _f, _f, _f, _f, _f, C.c_int64, _i, _f, C.c_int,
                                       C.c_int, _s]),

@@ -213,19 +213,23 @@ def _zeros(n, device):
     return z
 
 
-def _linear_fwd(x, w, b, relu_in=False, relu_out=False, residual=None, transposed=False, mask=None):
+def _linear_fwd(x, w, b, relu_in=False, relu_out=False, residual=None, transposed=False, mask=None, skip=None):
     """[relu]([relu](x) W'^T + b) + residual with W' = w (or w^T when `transposed`: the data gradient); `mask`: the
-    result is zeroed where mask <= 0 (the ReLU of a relu_in layer applied to its data gradient)."""
+    result is zeroed where mask <= 0 (the ReLU of a relu_in layer applied to its data gradient); `skip` is added AFTER the
+    mask (the gradient of a skip connection around the layer: one launch on the half-CU row kernel)."""
     n_out, k = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
     if (ROWLIN_IN_TRAINING and k == ops.TRUNK_WIDTH and n_out % 32 == 0 and not relu_out and x.shape[0] >= 1024
             and x.is_contiguous() and (residual is None or residual.is_contiguous())):
         bias = b if b is not None else _zeros(n_out, x.device)
         if mask is not None and not mask.is_contiguous():
             mask = mask.contiguous()
-        return ops.rowlin(x, _packed(w, transposed), bias, n_out, relu_in=relu_in, residual=residual, mask=mask)
+        if skip is not None and not (ROWLIN_HALF_CU and mask is not None and residual is None and skip.is_contiguous()):
+            return ops.rowlin(x, _packed(w, transposed), bias, n_out, relu_in=relu_in, residual=residual, mask=mask) + skip
+        return ops.rowlin(x, _packed(w, transposed), bias, n_out, relu_in=relu_in, residual=residual, mask=mask, skip=skip)
     y = ops.linear(x, w.t().contiguous() if transposed else w, b, relu_in=relu_in, relu_out=relu_out,
                    residual=residual)
-    return y if mask is None else ops.relu_mask(y, mask)
+    y = y if mask is None else ops.relu_mask(y, mask)
+    return y if skip is None else y + skip
 
 
 class MatmulF64Fn(Function):
@@ -260,13 +264,24 @@ def matmul64(a, b):
     return MatmulF64Fn.apply(a, b)
 
 
+class FanOut:
+    """Shared by the `uses` LinearFn calls that consume the SAME input tensor (the decoder's per-query latent feeds one
+    lin_z layer per block): each call's data gradient is a GEMM whose epilogue adds the running sum of the calls before it,
+    and only the last one reports the total to autograd (the others report None) -- instead of `uses` separate gradients
+    that the engine adds up in `uses - 1` element-wise passes over an (n, K) tensor."""
+
+    def __init__(self, uses):
+        self.left, self.total = uses, None
+
+
 class LinearFn(Function):
     """y = [relu]( [relu](x) W^T + b ) + residual   (never relu_out together with residual)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu_in, relu_out, residual):
+    def forward(ctx, x, w, b, relu_in, relu_out, residual, fan=None):
         assert not (relu_out and residual is not None)
         y = _linear_fwd(x, w, b, relu_in=relu_in, relu_out=relu_out, residual=residual)
+        ctx.fan = fan
         ctx.flags = (relu_in, relu_out, b is not None, residual is not None)
         ctx.save_for_backward(x, w, y if relu_out else None)
         ctx.params = (w, b)        # (the objects themselves: saved_tensors hands back new tensor objects, and the
@@ -280,7 +295,15 @@ class LinearFn(Function):
         g = ops.relu_mask(dy, y) if relu_out else dy
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
-            dx = _linear_fwd(g, w, None, transposed=True, mask=x if relu_in else None)
+            fan = ctx.fan
+            if fan is not None and not relu_in:
+                dx = _linear_fwd(g, w, None, transposed=True, residual=fan.total)
+                fan.left -= 1
+                fan.total = dx if fan.left > 0 else None
+                if fan.left > 0:
+                    dx = None                      # (reported by the last of the calls that share the input)
+            else:
+                dx = _linear_fwd(g, w, None, transposed=True, mask=x if relu_in else None)
         want_db = has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             # one kernel: dW = g^T [relu](x) on the MFMA, db = column sums of the g tiles it stages
@@ -292,12 +315,57 @@ class LinearFn(Function):
             (db,) = _deposit((ctx.params[1],), lambda: (ops.colsum(g),), g)
         if has_res and ctx.needs_input_grad[5]:
             dres = dy
-        return dx, dw, db, None, None, dres
+        return (dx, dw, db, None, None, dres, None)[:len(ctx.needs_input_grad)]     # (`fan` may be left out)
 
 
-def linear(x, lin, relu_in=False, relu_out=False, residual=None):
-    """x (n,K) through an nn.Linear's parameters."""
-    return LinearFn.apply(x, lin.weight, lin.bias, relu_in, relu_out, residual)
+def linear(x, lin, relu_in=False, relu_out=False, residual=None, fan=None):
+    """x (n,K) through an nn.Linear's parameters.  `fan`: a FanOut shared by every call that consumes this same x."""
+    return LinearFn.apply(x, lin.weight, lin.bias, relu_in, relu_out, residual, fan)
+
+
+class ResBlockFn(Function):
+    """y = x + W1 relu(W0 relu(x) + b0) + b1  (model/implicit.py:66-85 without shortcut, ReLU): the two Linear layers of a
+    residual block as ONE autograd node, so that the skip connection's gradient is added in the epilogue of the last
+    data-gradient GEMM (dx = dy + relu'(x) (dh W0)) instead of by the engine in a separate pass over (n, d)."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1):
+        h = _linear_fwd(x, w0, b0, relu_in=True)
+        y = _linear_fwd(h, w1, b1, relu_in=True, residual=x)
+        ctx.save_for_backward(x, h, w0, w1)
+        ctx.params = (w0, b0, w1, b1)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, h, w0, w1 = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        g = dy.contiguous()
+        dx = dw0 = db0 = dw1 = db1 = None
+
+        def wgrad(gg, xx, want_w, want_b):
+            if not want_w:
+                return (None, ops.colsum(gg))
+            res = ops.linear_wgrad(gg, xx, bias=bool(want_b), relu_x=True)
+            return res if want_b else (res, None)
+
+        (t0, tb0, t1, tb1) = ctx.params
+        if need[3] or need[4]:
+            dw1, db1 = _deposit((t1 if need[3] else None, tb1 if need[4] else None),
+                                lambda: wgrad(g, h, need[3], need[4]), g, h)
+        if need[0] or need[1] or need[2]:
+            dh = _linear_fwd(g, w1, None, transposed=True, mask=h)
+            if need[1] or need[2]:
+                dw0, db0 = _deposit((t0 if need[1] else None, tb0 if need[2] else None),
+                                    lambda: wgrad(dh, x, need[1], need[2]), dh, x)
+            if need[0]:
+                dx = _linear_fwd(dh, w0, None, transposed=True, mask=x, skip=g)
+        return dx, dw0, db0, dw1, db1
+
+
+def resblock(x, fc_0, fc_1):
+    """The residual block above through two nn.Linear modules' parameters (both with bias)."""
+    return ResBlockFn.apply(x, fc_0.weight, fc_0.bias, fc_1.weight, fc_1.bias)
 
 
 class PosHiddenFn(Function):

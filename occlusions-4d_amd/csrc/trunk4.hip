@@ -42,6 +42,7 @@ struct Trunk4Args {
   // rowlin: the row tiles behind the last FULL dispatch round (full_tiles = a multiple of 2 x CUs) are each split over
   // `tail_parts` workgroups by output stage range, so that a nearly empty last round is a fraction of a round long
   int full_tiles, tail_parts;
+  int res_post;                              // rowlin with mask: res is added AFTER the mask (skip gradient of a residual block)
 };
 
 __device__ __forceinline__ unsigned lds_addr_q(const float* p) {
@@ -261,6 +262,8 @@ __device__ __forceinline__ void rowlin4_stage(const Trunk4Args& a, int s, const 
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  f32x4 post = {0.f, 0.f, 0.f, 0.f};
+  if (a.res_post) { post = rs; rs = f32x4{0.f, 0.f, 0.f, 0.f}; }           // (kernel-uniform)
   o0.x += o1.x + (bz.x + rs.x); o0.y += o1.y + (bz.y + rs.y); o0.z += o1.z + (bz.z + rs.z); o0.w += o1.w + (bz.w + rs.w);
   if (a.ztab) {
     const f32x4 ca = *reinterpret_cast<const f32x4*>(a.zconst + c0);
@@ -275,6 +278,7 @@ __device__ __forceinline__ void rowlin4_stage(const Trunk4Args& a, int s, const 
     o0.x = mk.x > 0.f ? o0.x : 0.f; o0.y = mk.y > 0.f ? o0.y : 0.f;
     o0.z = mk.z > 0.f ? o0.z : 0.f; o0.w = mk.w > 0.f ? o0.w : 0.f;
   }
+  if (a.res_post) { o0.x += post.x; o0.y += post.y; o0.z += post.z; o0.w += post.w; }
   if (row < a.n) *reinterpret_cast<f32x4*>(a.y + (int64_t)row * a.ldy + c0) = o0;
 }
 
@@ -400,4 +404,26 @@ extern "C" int occ4d_rowlin4_masked_f32(const float* x, int64_t ldx, float* y, i
   const int grid = rowlin4_grid(a);
   rowlin4_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
   return occ4d::check_launch("occ4d_rowlin4_masked_f32");
+}
+
+// Data gradient of a residual block's first layer with the skip gradient folded in:
+//   y = [mask > 0] (x W^T + b) + skip        (skip added AFTER the mask; b may be a zero vector)
+// -- what occ4d_rowlin4_masked_f32 computes followed by an element-wise add of `skip`, in one launch.
+extern "C" int occ4d_rowlin4_masked_skip_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed,
+                                             const float* b, int n_out, int relu_in, const float* skip, int64_t lds,
+                                             const float* mask, int64_t ldm, int n, void* stream) {
+  Trunk4Args a{x, ldx, y, ldy, w_packed, b, nullptr, nullptr, skip, lds, nullptr, nullptr, 0, nullptr, nullptr, 0, n,
+               n_out / 16, relu_in, mask, ldm};
+  a.res_post = 1;
+  if (n == 0) return OCC4D_OK;
+  if (int rc = check_common4(a, "occ4d_rowlin4_masked_skip_f32")) return rc;
+  OCC4D_REQUIRE(n_out >= 16 && n_out % 16 == 0 && ldy >= n_out,
+                "occ4d_rowlin4_masked_skip_f32: n_out = %d must be a multiple of 16 <= ldy", n_out);
+  OCC4D_REQUIRE(skip && lds % 4 == 0 && ((uintptr_t)skip % 16) == 0 && lds >= n_out,
+                "occ4d_rowlin4_masked_skip_f32: skip rows must be 16-byte aligned with lds %% 4 == 0 and lds >= n_out");
+  OCC4D_REQUIRE(mask && ldm % 4 == 0 && ((uintptr_t)mask % 16) == 0 && ldm >= n_out,
+                "occ4d_rowlin4_masked_skip_f32: mask rows must be 16-byte aligned with ldm %% 4 == 0 and ldm >= n_out");
+  const int grid = rowlin4_grid(a);
+  rowlin4_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  return occ4d::check_launch("occ4d_rowlin4_masked_skip_f32");
 }

@@ -75,6 +75,9 @@ class ResnetBlockFC(torch.nn.Module):
         return self._run(flat).reshape(*x.shape[:-1], self.d_out)
 
     def _run_train(self, x):
+        if (self.shortcut is None and self.activation == 'relu' and self.fc_0.bias is not None
+                and self.fc_1.bias is not None):
+            return autograd.resblock(x, self.fc_0, self.fc_1)          # one autograd node: skip gradient in the GEMM epilogue
         h = autograd.act_linear(x, self.fc_0, self.activation)
         xs = x if self.shortcut is None else autograd.linear(x, self.shortcut)
         return autograd.act_linear(h, self.fc_1, self.activation, residual=xs)
@@ -367,8 +370,9 @@ class LocalPclResnetFC(ResnetFC):
         idx_att = None
         if knn_cross is not None:
             idx_att = (knn_cross[0] if knn_cross.dim() == 3 else knn_cross).to(torch.int32).contiguous()
+        fan = autograd.FanOut(self.n_blocks)       # f_query feeds one lin_z layer per block: one running gradient sum
         for i in range(self.n_blocks):
-            x = autograd.linear(f_query, self.lin_z[i], residual=x)
+            x = autograd.linear(f_query, self.lin_z[i], residual=x, fan=fan)
             x = self.blocks[i]._run_train(x)
             if i in self.use_pt_inds:
                 blk = self.pt_blocks[self.use_pt_inds[i]]

@@ -676,9 +676,10 @@ def resblock(x, w0_packed, b0, w1_packed, b1, out=None, interp=None):
     return out
 
 
-def rowlin(x, w_packed, b, n_out, relu_in=False, residual=None, out=None, interp=None, mask=None):
+def rowlin(x, w_packed, b, n_out, relu_in=False, residual=None, out=None, interp=None, mask=None, skip=None):
     """out (n, n_out) = [residual +] W [relu](x) + b [+ interpolation term], K = 416 (occ4d_rowlin_f32); with `mask`
-    (n, n_out): rows zeroed where mask <= 0 (occ4d_rowlin_masked_f32: the ReLU mask of a data gradient)."""
+    (n, n_out): rows zeroed where mask <= 0 (occ4d_rowlin_masked_f32: the ReLU mask of a data gradient); with `skip`
+    (needs mask, half-CU packing): + skip AFTER the mask (occ4d_rowlin4_masked_skip_f32)."""
     xx, ldx = _rows(_dev(x, name='x'), 'x')
     n, d = xx.shape
     half_cu = n_out % 16 == 0 and w_packed.numel() == (n_out // 16 + 1) * 6656      # csrc/trunk4.hip packing
@@ -695,10 +696,16 @@ def rowlin(x, w_packed, b, n_out, relu_in=False, residual=None, out=None, interp
     assert interp is None or n_out == TRUNK_WIDTH
     bc = _dev(b).contiguous()
     assert bc.numel() == n_out
+    if skip is not None:
+        assert mask is not None and half_cu and residual is None, 'rowlin: skip needs a mask and the half-CU packing'
+        rr, ldr = _rows(_dev(skip, name='skip'), 'skip')
+        assert rr.shape == (n, n_out)
     if mask is not None:
         mm, ldm = _rows(_dev(mask, name='mask'), 'mask')
         assert mm.shape == (n, n_out) and interp is None
         mfn = _lib.lib().occ4d_rowlin4_masked_f32 if half_cu else _lib.lib().occ4d_rowlin_masked_f32
+        if skip is not None:
+            mfn = _lib.lib().occ4d_rowlin4_masked_skip_f32
         _lib.check(_launch('rowlin', dict(n=n, n_out=n_out), 2.0 * n * d * n_out,
                            lambda: mfn(_ptr(xx), ldx, _ptr(o), ldo, _ptr(w_packed), _ptr(bc),
                                                                       n_out, int(relu_in), _ptr(rr), ldr, _ptr(mm), ldm, n,

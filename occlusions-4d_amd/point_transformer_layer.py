@@ -168,8 +168,8 @@ class _CheckpointedAttention(torch.autograd.Function):
                       mm(W1d, Wk.to(f64)).float(), mm(W1d, P2.to(f64)).float()]
             wq_l, bq_l, wk_l, wp_l = (m.detach().requires_grad_(True) for m in merged)
             x2d = x2.detach().requires_grad_(True)
-            kt = L(x2d, wk_l, None, False, False, None)                    # (M, 2D), once per backward
-            vt = L(x2d, Wv, None, False, False, None)                      # (M, D)
+            kt = L(x2d, wk_l, None, False, False, None, None)                    # (M, 2D), once per backward
+            vt = L(x2d, Wv, None, False, False, None, None)                      # (M, D)
             kt_l, vt_l = kt.detach().requires_grad_(True), vt.detach().requires_grad_(True)
             # (detached leaf copies, so that frozen parameters do not break the per-chunk autograd.grad)
             P1, c1, P2l, c2l, W2, b2 = (t.detach().requires_grad_(True) for t in (P1, c1, P2, c2, W2, b2))
@@ -178,7 +178,7 @@ class _CheckpointedAttention(torch.autograd.Function):
             # Linear, one data gradient and one weight gradient over 68812 rows instead of three of each over 22976 rows,
             # which fill two thirds of a dispatch round (83 -> 105 TFLOP/s on these launches)
             x_all = x.detach().requires_grad_(True)
-            aq_all = L(x_all, wq_l, bq_l, False, False, None)                                   # (n, 2D)
+            aq_all = L(x_all, wq_l, bq_l, False, False, None, None)                                   # (n, 2D)
             g_aq = torch.empty_like(aq_all)
             # chunks of EQUAL size, at most _CHECKPOINT_CHUNK queries each (a multiple of 64: whole 128-pair-row workgroups
             # of the fused pair kernel): 68812 queries = 3 x 22976 instead of 2 x 32768 + 3276 -- the short chunk ran every
@@ -199,8 +199,8 @@ class _CheckpointedAttention(torch.autograd.Function):
                         logits, pe = autograd.PairMlpFn.apply(aq, kt_l, r, wp_l, W2, b2, P2l, c2l, ic)
                     else:
                         a = autograd.AttnInLinearFn.apply(aq, kt_l, r, wp_l, ic)                     # aq_i - kt_j + Wp r
-                        logits = L(a, W2, b2, True, False, None)                                    # W2 relu(.) + b2
-                        pe = L(r, P2l, c2l, False, False, None)
+                        logits = L(a, W2, b2, True, False, None, None)                                    # W2 relu(.) + b2
+                        pe = L(r, P2l, c2l, False, False, None, None)
                     out = autograd.SoftmaxAggGradOnlyFn.apply(logits, vt_l, pe, ic)      # (value unused: no launch)
                     grads = torch.autograd.grad(out, [aq] + leaves, g[lo:hi], allow_unused=True)
                     assert all(gr is None for gr in grads[1:]), 'a leaf gradient bypassed its sink'
@@ -402,16 +402,16 @@ class PointTransformerLayer(nn.Module):
         bq = (mm(W1d, c2.to(f64)) + b1.to(f64)).float()
         wk = mm(W1d, self.to_k.weight.to(f64)).float()
         wp = mm(W1d, P2.to(f64)).float()
-        kt = L(x2, wk, None, False, False, None)                       # (M, 2D)
-        vt = L(x2, self.to_v.weight, None, False, False, None)         # (M, D)
-        aq = L(x, wq, bq, False, False, None)                          # (N, 2D)
+        kt = L(x2, wk, None, False, False, None, None)                       # (M, 2D)
+        vt = L(x2, self.to_v.weight, None, False, False, None, None)         # (M, D)
+        aq = L(x, wq, bq, False, False, None, None)                          # (N, 2D)
         r = autograd.PosHiddenFn.apply(pos, pos2, idx, P1, c1)         # (N*K, 32)
         if autograd.pair_mlp_fused_ok(aq, r, idx):
             logits, pe = autograd.PairMlpFn.apply(aq, kt, r, wp, W2, b2, P2, c2, idx)
         else:
             a = autograd.AttnInLinearFn.apply(aq, kt, r, wp, idx)                       # aq_i - kt_j + Wp r
-            logits = L(a, W2, b2, True, False, None)                   # W2 relu(.) + b2
-            pe = L(r, P2, c2, False, False, None)
+            logits = L(a, W2, b2, True, False, None, None)                   # W2 relu(.) + b2
+            pe = L(r, P2, c2, False, False, None, None)
         return autograd.SoftmaxAggFn.apply(logits, vt, pe, idx)
 
     def forward_train(self, x, pos, x2=None, pos2=None, idx=None):

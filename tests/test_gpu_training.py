@@ -480,6 +480,62 @@ def test_parameter_gradients_beside_the_chain_change_nothing(monkeypatch):
         assert a is None or torch.equal(a, b)
 
 
+def test_residual_block_node_and_shared_input_sum_match_the_separate_nodes():
+    """autograd.ResBlockFn (skip gradient added in the epilogue of the last data-gradient GEMM,
+    occ4d_rowlin4_masked_skip_f32) against the two LinearFn nodes + the engine's add, and autograd.FanOut (one running
+    data-gradient sum for an input shared by several Linear layers) against separate gradients: same forward values bit
+    for bit, gradients to rounding (the adds associate differently), and against an fp64 reference."""
+    rng = np.random.default_rng(5)
+    Tc = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32)).cuda()   # noqa: E731
+    n, d = 3000, 416
+    ag = pk.autograd
+    x0 = Tc(rng.normal(size=(n, d)))
+    ws = [Tc(rng.normal(size=(d, d)) / 20) for _ in range(2)]
+    bs = [Tc(rng.normal(size=(d,)) / 10) for _ in range(2)]
+    gy = Tc(rng.normal(size=(n, d)))
+
+    def run(fused):
+        x = x0.clone().requires_grad_(True)
+        w = [t.clone().requires_grad_(True) for t in ws]
+        b = [t.clone().requires_grad_(True) for t in bs]
+        if fused:
+            y = ag.ResBlockFn.apply(x * 1.0, w[0], b[0], w[1], b[1])
+        else:
+            xx = x * 1.0
+            h = ag.LinearFn.apply(xx, w[0], b[0], True, False, None)
+            y = ag.LinearFn.apply(h, w[1], b[1], True, False, xx)
+        y.backward(gy)
+        return [y.detach()] + [t.grad for t in [x] + w + b]
+    a, b_ = run(True), run(False)
+    assert torch.equal(a[0], b_[0])
+    for u, v in zip(a[1:], b_[1:]):
+        assert rel_err(u, v) < 2e-6
+    xd = x0.double().requires_grad_(True)
+    wd = [t.double().requires_grad_(True) for t in ws]
+    yd = xd + torch.relu(torch.relu(xd) @ wd[0].t() + bs[0].double()) @ wd[1].t() + bs[1].double()
+    yd.backward(gy.double())
+    assert rel_err(a[1], xd.grad.float()) < 2e-5 and rel_err(a[2], wd[0].grad.float()) < 2e-5
+    # shared input: three 704 -> 416 layers on the same (n, 704) tensor
+    k = 704
+    f0 = Tc(rng.normal(size=(n, k)))
+    wz = [Tc(rng.normal(size=(d, k)) / 20) for _ in range(3)]
+    gz = [Tc(rng.normal(size=(n, d))) for _ in range(3)]
+
+    def run2(shared):
+        f = f0.clone().requires_grad_(True)
+        ff = f * 1.0
+        fan = ag.FanOut(3) if shared else None
+        w = [t.clone().requires_grad_(True) for t in wz]
+        outs = [ag.LinearFn.apply(ff, w[i], None, False, False, None, fan) for i in range(3)]
+        torch.autograd.backward(outs, gz)
+        return [f.grad] + [t.grad for t in w]
+    a, b_ = run2(True), run2(False)
+    for u, v in zip(a, b_):
+        assert rel_err(u, v) < 2e-6
+    ref = sum(g.double() @ w.double() for g, w in zip(gz, wz))
+    assert rel_err(a[0], ref.float()) < 2e-5
+
+
 def test_chained_blocks_gradients_strict():
     case = gc.PTB_CASES[1]
     x, pos, x2, pos2, sd = gc.ptb_inputs(case)
