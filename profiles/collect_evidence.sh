@@ -37,7 +37,7 @@ done
 step time_pair_mlp.txt 'python profiles/time_pair_mlp.py 2>/dev/null | grep -v amdgpu.ids > "$OUT/time_pair_mlp.txt"'
 step time_wgrad.txt 'python profiles/time_wgrad.py 2>/dev/null | grep -v amdgpu.ids > "$OUT/time_wgrad.txt"'
 step profile_sampler.txt 'python profiles/profile_sampler.py 2>/dev/null | head -3 > "$OUT/profile_sampler.txt"'
-step train_kernel_stats.csv 'rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof3" -- python bench_train.py --steps 4 --warmup 2 > /dev/null 2>&1; cp "$(find "$OUT/prof3" -name "*kernel_stats.csv" | head -1)" "$OUT/train_kernel_stats.csv"; python profiles/train_timeline.py "$(find "$OUT/prof3" -name "*kernel_trace.csv" | head -1)" 30 > "$OUT/train_timeline.txt"'
+step train_kernel_stats.csv 'rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof3" -- python bench_train.py --steps 4 --warmup 2 > /dev/null 2>&1; cp "$(find "$OUT/prof3" -name "*kernel_stats.csv" | head -1)" "$OUT/train_kernel_stats.csv"; python profiles/train_timeline.py "$(find "$OUT/prof3" -name "*kernel_trace.csv" | head -1)" 30 - 1 > "$OUT/train_timeline.txt"'
 step train_phases.txt 'python profiles/train_phases.py 10 2>/dev/null | grep -v amdgpu.ids > "$OUT/train_phases.txt"'
 step train_shapes.txt 'python profiles/train_shapes.py 2>/dev/null > "$OUT/train_shapes.txt"'
 step time_rowlin_tail.txt 'python profiles/time_rowlin_tail.py 2>/dev/null > "$OUT/time_rowlin_tail.txt"'

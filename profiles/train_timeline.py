@@ -2,7 +2,8 @@
 at the optimizer's kernels (the multi-tensor AdamW launches end a step), then per queue: kernel time, idle time between
 consecutive kernels, and per kernel name its own time plus the idle time that follows it (what removing it would give
 back when the stream is serial).
-Usage: python profiles/train_timeline.py <kernel_trace.csv> [top] [sequence.txt: the step's launches in order]"""
+Usage: python profiles/train_timeline.py <kernel_trace.csv> [top] [sequence.txt | -: the step's launches in order] [back]
+(back = 1: the step before the last -- bench_train.py ends with one extra step on ONE stream for its per-kernel table)"""
 import collections
 import csv
 import sys
@@ -22,11 +23,13 @@ def main():
     # runs of optimizer kernels: a step ends with the last kernel of a run
     ends = [i for k, i in enumerate(opt) if k + 1 == len(opt) or opt[k + 1] - i > 50]
     assert len(ends) >= 2, 'need two steps in the trace'
-    seg = rows[ends[-2] + 1:ends[-1] + 1]
+    back = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    assert len(ends) >= 2 + back, 'not enough steps in the trace'
+    seg = rows[ends[-2 - back] + 1:ends[-1 - back] + 1]
     t0 = int(seg[0]['Start_Timestamp'])
     t1 = max(int(r['End_Timestamp']) for r in seg)
-    print('last step: %d kernels, %.2f ms first start to last end' % (len(seg), (t1 - t0) / 1e6))
-    if len(sys.argv) > 3:
+    print('step %d from the end: %d kernels, %.2f ms first start to last end' % (back, len(seg), (t1 - t0) / 1e6))
+    if len(sys.argv) > 3 and sys.argv[3] != '-':
         with open(sys.argv[3], 'w') as f:
             prev = {}
             for r in seg:
