@@ -15,3 +15,4 @@ run "OCC4D_LOGIT_PRECISION=bf16x6 OCC4D_TRUNK_PRECISION=bf16x6" "tests/test_gpu_
 run "OCC4D_KNN_GRID=0" "tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_contracts.py"
 run "OCC4D_KNN_GRID_MIN_PAIRS=1 OCC4D_KNN_GRID_MIN_DATA=1" "tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_training.py tests/test_gpu_sampler.py"
 run "OCC4D_KNN_GRID_MIN_PAIRS=1 OCC4D_KNN_GRID_MIN_DATA=1 OCC4D_KNN_GRID_ONE_THREAD_FROM=1" "tests/test_gpu_parity.py tests/test_gpu_fullsize.py"
+run "OCC4D_GRADIENT_OVERLAP=0" "tests/test_gpu_training.py tests/test_gpu_contracts.py"
