@@ -92,11 +92,13 @@ __global__ __launch_bounds__(512, 2) void rowlin_bf16x6_kernel(const RowlinX6Arg
     for (int rt = 0; rt < 2; ++rt)
       xs[rt] = RELU_IN ? split8(relu4x(xa[rt][0]), relu4x(xa[rt][1])) : split8(xa[rt][0], xa[rt][1]);
     const int sn = s + 1 < YKS ? s + 1 : s;           // next stage's inputs (consumed at its top)
+#ifndef OCC4D_X6T_ABL_NOX                              // (timing-only ablations: profiles/time_rowlin_x6.py)
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       xa[rt][0] = *reinterpret_cast<const f32x4*>(xrow[rt] + 32 * sn);
       xa[rt][1] = *reinterpret_cast<const f32x4*>(xrow[rt] + 32 * sn + 4);
     }
+#endif
     u32x4 bh = *reinterpret_cast<const u32x4*>(f);
     u32x4 bm = *reinterpret_cast<const u32x4*>(f + YFW);
     u32x4 bl = *reinterpret_cast<const u32x4*>(f + 2 * YFW);
@@ -142,7 +144,11 @@ __global__ __launch_bounds__(512, 2) void rowlin_bf16x6_kernel(const RowlinX6Arg
     const int row = row0 + 16 * rt + c;
     const int rowc = min(row, a.n - 1);
     f32x4 r[YT];
+#ifdef OCC4D_X6T_ABL_NORES
+    if (a.res && a.n < 0) {
+#else
     if (a.res) {
+#endif
 #pragma unroll
       for (int t = 0; t < YT; ++t) r[t] = *reinterpret_cast<const f32x4*>(a.res + (int64_t)rowc * a.ldr + ch0 + 16 * t);
     }
@@ -150,7 +156,12 @@ __global__ __launch_bounds__(512, 2) void rowlin_bf16x6_kernel(const RowlinX6Arg
     for (int t = 0; t < YT; ++t) {
       f32x4 v = acc[rt][t];
       if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + ch0 + 16 * t);
+#ifndef OCC4D_X6T_ABL_NORES
       if (a.res) v += r[t];
+#endif
+#ifdef OCC4D_X6T_ABL_NOSTORE
+      if (v.x == 123.456f)                           // (ablation: accumulators stay live, nothing is stored)
+#endif
       if (row < a.n) *reinterpret_cast<f32x4*>(a.y + (int64_t)row * a.ldy + ch0 + 16 * t) = v;
     }
   }
