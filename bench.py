@@ -592,7 +592,14 @@ def main():
             line['train_config5'] = secondary_leg(
                 'bench_train.py', ['--steps', '10', '--warmup', '3'],
                 ['metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'scaling', 'graph',
-                 'attention_backward', 'geometry_prefetch', 'peak_mem_gb', 'roofline', 'config', 'losses'])
+                 'attention_backward', 'geometry_prefetch', 'gradient_overlap', 'peak_mem_gb', 'roofline', 'config',
+                 'losses'])
+            if 'error' not in line['train_config5']:
+                # the same step with its 416-input Linear layers, their data gradients and the forward attention kernel on
+                # the split-precision kernels (fp32-class, opt-in): informational, `train_config5.value` stays fp32
+                line['train_config5']['alt_precision'] = secondary_leg(
+                    'bench_train.py', ['--steps', '10', '--warmup', '3', '--precision', 'bf16x6'],
+                    ['value', 'ms_per_step', 'dtype', 'precision', 'peak_mem_gb', 'losses'])
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.kind)
         print(json.dumps(line), flush=True)

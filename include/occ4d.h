@@ -570,6 +570,12 @@ int64_t occ4d_rowlin_bf16x6_packed_floats(int n_out);
 int occ4d_pack_rowlin_bf16x6_f32(const float* w, int64_t ldw, int n_out, float* packed, void* stream);
 int occ4d_rowlin_bf16x6_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed, const float* b,
                             int n_out, int relu_in, const float* res, int64_t ldr, int n, void* stream);
+/* The same kernel with the epilogue of a training data gradient: y = [mask > 0] ([relu](x) W^T + b [+ res]) [+ res];
+ * res_after_mask = 0: res before the mask (occ4d_rowlin4_masked_f32's contract), != 0: after it (the skip gradient of a
+ * residual block, occ4d_rowlin4_masked_skip_f32's contract).  b and res may be NULL. */
+int occ4d_rowlin_bf16x6_masked_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed,
+                                   const float* b, int n_out, int relu_in, const float* res, int64_t ldr,
+                                   int res_after_mask, const float* mask, int64_t ldm, int n, void* stream);
 int occ4d_debug_x6_stamps(unsigned long long* out, int n_words);   /* debug: phase time stamps (OCC4D_X6_STAMPS=1) */
 int occ4d_pt_cross_attn_bf16x6_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t q_stride, const float* apos,
                                    int64_t a_stride, const int32_t* idx, const float* kt, int64_t ld_kt, const float* vtc,

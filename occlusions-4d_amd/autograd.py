@@ -24,8 +24,12 @@ ROWLIN_IN_TRAINING = True
 # workgroups); a half-CU workgroup that has its CU to itself in the last round runs faster, and at whole rounds the two
 # are level: 232 vs 301 us at 68812 rows, 276 vs 302 us at 98304 (profiles/time_rowlin_tail.py).
 ROWLIN_HALF_CU = os.environ.get('OCC4D_TRAIN_ROWLIN_HALF_CU', '1') == '1'
+# Opt-in (round 5), fp32-class: the 416-input Linear layers of the training path -- forward, and the data gradients whose
+# reduction side is 416 wide -- on the split-precision row kernel (csrc/trunk_bf16x6.hip: bf16 x 3 pieces, 6 partial
+# products, fp32 accumulate).  Weight gradients stay on the fp32 MFMA kernels.  Same strict gradient tests.
+TRAIN_PRECISION = os.environ.get('OCC4D_TRAIN_PRECISION', 'f32')
 _PACKS = {}           # stage-packed copies of nn.Parameters only (small LRU); transient leaves are packed uncached
-_PACKS_MAX = 64
+_PACKS_MAX = 128
 _ZEROS = {}           # zero bias vectors, kept apart from the packs and created eagerly (never inside a capture)
 
 
@@ -179,20 +183,21 @@ def _deposit(targets, compute, *operands):
     return res
 
 
-def _packed(w, transposed):
+def _packed(w, transposed, x6=False):
     from . import point_transformer_layer as ptl
     src = w.detach().t().contiguous() if transposed else w.detach()
+    pack = ops.pack_rowlin_bf16x6 if x6 else (ops.pack_trunk4_rows if ROWLIN_HALF_CU else ops.pack_trunk_rows)
     if not isinstance(w, torch.nn.Parameter):
         # a transient leaf (the merged matrices rebuilt by every _CheckpointedAttention.backward): caching it would only
         # pin the leaf and its packed copy (a few MB each) until the table is cleared -- it can never hit again
-        return ops.pack_trunk4_rows(src) if ROWLIN_HALF_CU else ops.pack_trunk_rows(src)
-    key = (id(w), bool(transposed))
+        return pack(src)
+    key = (id(w), bool(transposed), bool(x6))
     tag = (w.data_ptr(), w._version, tuple(w.shape), ptl.weights_epoch(), ROWLIN_HALF_CU)
     hit = _PACKS.get(key)
     if hit is not None and hit[0] is w and hit[1] == tag:
         _PACKS[key] = _PACKS.pop(key)              # most recently used last
         return hit[2]
-    packed = ops.pack_trunk4_rows(src) if ROWLIN_HALF_CU else ops.pack_trunk_rows(src)
+    packed = pack(src)
     _PACKS.pop(key, None)
     while len(_PACKS) >= _PACKS_MAX:
         _PACKS.pop(next(iter(_PACKS)))             # least recently used first
@@ -218,6 +223,11 @@ def _linear_fwd(x, w, b, relu_in=False, relu_out=False, residual=None, transpose
     result is zeroed where mask <= 0 (the ReLU of a relu_in layer applied to its data gradient); `skip` is added AFTER the
     mask (the gradient of a skip connection around the layer: one launch on the half-CU row kernel)."""
     n_out, k = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
+    if (TRAIN_PRECISION == 'bf16x6' and k == ops.TRUNK_WIDTH and n_out in ops.X6_ROWLIN_WIDTHS and not relu_out
+            and x.shape[0] >= 1024 and x.is_contiguous() and not (residual is not None and skip is not None)):
+        res = residual if residual is not None else skip
+        return ops.rowlin_bf16x6(x, None, b, relu_in=relu_in, res=res, packed=_packed(w, transposed, x6=True), mask=mask,
+                                 res_after_mask=skip is not None, n_out=n_out)
     if (ROWLIN_IN_TRAINING and k == ops.TRUNK_WIDTH and n_out % 32 == 0 and not relu_out and x.shape[0] >= 1024
             and x.is_contiguous() and (residual is None or residual.is_contiguous())):
         bias = b if b is not None else _zeros(n_out, x.device)

@@ -35,6 +35,8 @@ struct RowlinX6Args {
   const float* res; int64_t ldr;
   int n, nblk;                            // rows; channel blocks (N / 208)
   int rowgroups, per;                     // groups of 256 rows; groups per XCD share
+  const float* mask; int64_t ldm;         // training data gradients: output zeroed where mask <= 0 (or null)
+  int res_post;                           // with a mask: res is added AFTER the mask (a skip connection's gradient)
 };
 
 template <bool RELU_IN>
@@ -152,6 +154,22 @@ __global__ __launch_bounds__(512, 2) void rowlin_bf16x6_kernel(const RowlinX6Arg
 #pragma unroll
       for (int t = 0; t < YT; ++t) r[t] = *reinterpret_cast<const f32x4*>(a.res + (int64_t)rowc * a.ldr + ch0 + 16 * t);
     }
+    if (a.mask) {                         // (kernel-uniform; the masked epilogue is its own pass over the tiles)
+      f32x4 mk[YT];
+#pragma unroll
+      for (int t = 0; t < YT; ++t) mk[t] = *reinterpret_cast<const f32x4*>(a.mask + (int64_t)rowc * a.ldm + ch0 + 16 * t);
+#pragma unroll
+      for (int t = 0; t < YT; ++t) {
+        f32x4 v = acc[rt][t];
+        if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + ch0 + 16 * t);
+        if (a.res && !a.res_post) v += r[t];
+        v.x = mk[t].x > 0.f ? v.x : 0.f; v.y = mk[t].y > 0.f ? v.y : 0.f;
+        v.z = mk[t].z > 0.f ? v.z : 0.f; v.w = mk[t].w > 0.f ? v.w : 0.f;
+        if (a.res && a.res_post) v += r[t];
+        if (row < a.n) *reinterpret_cast<f32x4*>(a.y + (int64_t)row * a.ldy + ch0 + 16 * t) = v;
+      }
+      continue;
+    }
 #pragma unroll
     for (int t = 0; t < YT; ++t) {
       f32x4 v = acc[rt][t];
@@ -191,21 +209,40 @@ extern "C" int occ4d_pack_rowlin_bf16x6_f32(const float* w, int64_t ldw, int n_o
   return occ4d::check_launch("occ4d_pack_rowlin_bf16x6_f32");
 }
 
-extern "C" int occ4d_rowlin_bf16x6_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed,
-                                       const float* b, int n_out, int relu_in, const float* res, int64_t ldr, int n,
-                                       void* stream) {
-  const char* who = "occ4d_rowlin_bf16x6_f32";
+static int rowlin_x6_launch(const char* who, const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed,
+                            const float* b, int n_out, int relu_in, const float* res, int64_t ldr, int res_post,
+                            const float* mask, int64_t ldm, int n, void* stream) {
   if (n == 0) return OCC4D_OK;
   OCC4D_REQUIRE(x && y && w_packed && n > 0, "%s: null pointer", who);
   OCC4D_REQUIRE(n_out >= YCB && n_out % YCB == 0 && 8 % (n_out / YCB) == 0 && ldy >= n_out && ldx >= YK && ldx % 4 == 0 &&
                     ((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)y % 16) == 0 && ldy % 4 == 0 &&
                     (!b || ((uintptr_t)b % 16) == 0) && (!res || (ldr >= n_out && ldr % 4 == 0 && ((uintptr_t)res % 16) == 0)),
                 "%s: n_out = %d (208, 416, 832 or 1664), rows 16-byte aligned with ldx %% 4 == 0", who, n_out);
-  RowlinX6Args a{x, ldx, y, ldy, reinterpret_cast<const unsigned*>(w_packed), b, res, ldr, n, n_out / YCB, 0, 0};
+  OCC4D_REQUIRE(!mask || (ldm >= n_out && ldm % 4 == 0 && ((uintptr_t)mask % 16) == 0),
+                "%s: mask rows must be 16-byte aligned with ldm %% 4 == 0 and ldm >= n_out", who);
+  RowlinX6Args a{x, ldx, y, ldy, reinterpret_cast<const unsigned*>(w_packed), b, res, ldr, n, n_out / YCB, 0, 0,
+                 mask, ldm, res_post};
   a.rowgroups = (int)occ4d::cdiv(n, YROWS);
   a.per = (int)occ4d::cdiv(a.rowgroups, 8 / a.nblk);
   hipStream_t st = (hipStream_t)stream;
   if (relu_in) rowlin_bf16x6_kernel<true><<<8 * a.per, 512, 0, st>>>(a);
   else rowlin_bf16x6_kernel<false><<<8 * a.per, 512, 0, st>>>(a);
   return occ4d::check_launch(who);
+}
+
+extern "C" int occ4d_rowlin_bf16x6_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed,
+                                       const float* b, int n_out, int relu_in, const float* res, int64_t ldr, int n,
+                                       void* stream) {
+  return rowlin_x6_launch("occ4d_rowlin_bf16x6_f32", x, ldx, y, ldy, w_packed, b, n_out, relu_in, res, ldr, 0, nullptr, 0, n,
+                          stream);
+}
+
+// The same with the epilogue of a training data gradient: y = [mask > 0] ([relu](x) W^T + b [+ res]) [+ res], `res`
+// before (res_after_mask = 0) or after the mask (the contracts of occ4d_rowlin4_masked_f32 / _masked_skip_f32).
+extern "C" int occ4d_rowlin_bf16x6_masked_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed,
+                                              const float* b, int n_out, int relu_in, const float* res, int64_t ldr,
+                                              int res_after_mask, const float* mask, int64_t ldm, int n, void* stream) {
+  OCC4D_REQUIRE(mask, "occ4d_rowlin_bf16x6_masked_f32: null mask");
+  return rowlin_x6_launch("occ4d_rowlin_bf16x6_masked_f32", x, ldx, y, ldy, w_packed, b, n_out, relu_in, res, ldr,
+                          res_after_mask != 0, mask, ldm, n, stream);
 }

@@ -367,24 +367,47 @@ FUSED_ATTN_DIMS = (288, 416)
 FUSED_ATTN_MAX_K = 14
 
 
-def rowlin_bf16x6(x, w, b=None, relu_in=False, res=None, out=None):
-    """y = [res +] w [relu](x) + b for a (n_out, 416) weight on the split-precision trunk kernel
-    (occ4d_rowlin_bf16x6_f32; n_out in {208, 416, 832, 1664}).  The weight is packed per call: tests and probes."""
-    x, ldx = _aligned_rows(_dev(x, name='x'), 'x')
+X6_ROWLIN_WIDTHS = (208, 416, 832, 1664)
+
+
+def pack_rowlin_bf16x6(w):
+    """(n_out, 416) weight -> the stage-packed three-piece stream of occ4d_rowlin_bf16x6_f32."""
     w, ldw = _rows(_dev(w, name='w'), 'w')
-    n, n_out = x.shape[0], w.shape[0]
-    assert x.shape[1] == 416 and w.shape[1] == 416
+    n_out = w.shape[0]
+    assert w.shape[1] == 416 and n_out in X6_ROWLIN_WIDTHS
     L = _lib.lib()
-    packed = torch.empty((int(L.occ4d_rowlin_bf16x6_packed_floats(n_out)),), dtype=torch.float32, device=x.device)
+    packed = torch.empty((int(L.occ4d_rowlin_bf16x6_packed_floats(n_out)),), dtype=torch.float32, device=w.device)
     _lib.check(L.occ4d_pack_rowlin_bf16x6_f32(_ptr(w), ldw, n_out, _ptr(packed), _stream()))
+    return packed
+
+
+def rowlin_bf16x6(x, w, b=None, relu_in=False, res=None, out=None, packed=None, mask=None, res_after_mask=False, n_out=None):
+    """y = [res +] w [relu](x) + b for a (n_out, 416) weight on the split-precision trunk kernel
+    (occ4d_rowlin_bf16x6_f32; n_out in {208, 416, 832, 1664}).  `packed` (pack_rowlin_bf16x6) instead of `w` skips the
+    per-call packing.  `mask` (n, n_out): the training data-gradient epilogue (occ4d_rowlin_bf16x6_masked_f32): zero where
+    mask <= 0, `res` added before (default) or after the mask."""
+    x, ldx = _aligned_rows(_dev(x, name='x'), 'x')
+    n = x.shape[0]
+    if packed is None:
+        packed, n_out = pack_rowlin_bf16x6(w), w.shape[0]
+    assert x.shape[1] == 416 and n_out in X6_ROWLIN_WIDTHS
+    L = _lib.lib()
     if out is None:
         out = torch.empty((n, n_out), dtype=torch.float32, device=x.device)
     ldr = 0
     if res is not None:
         res, ldr = _rows(_dev(res, name='res'), 'res')
     bb = _cont(b, 'bias') if b is not None else None
-    _lib.check(L.occ4d_rowlin_bf16x6_f32(_ptr(x), ldx, _ptr(out), out.stride(0), _ptr(packed), _ptr(bb), n_out, int(relu_in),
-                                         _ptr(res), ldr, n, _stream()))
+    flops = 2.0 * n * 416 * n_out
+    if mask is not None:
+        mm, ldm = _rows(_dev(mask, name='mask'), 'mask')
+        assert mm.shape == (n, n_out)
+        _lib.check(_launch('rowlin', dict(n=n, n_out=n_out), flops, lambda: L.occ4d_rowlin_bf16x6_masked_f32(
+            _ptr(x), ldx, _ptr(out), out.stride(0), _ptr(packed), _ptr(bb), n_out, int(relu_in), _ptr(res), ldr,
+            int(res_after_mask), _ptr(mm), ldm, n, _stream())))
+        return out
+    _lib.check(_launch('rowlin', dict(n=n, n_out=n_out), flops, lambda: L.occ4d_rowlin_bf16x6_f32(
+        _ptr(x), ldx, _ptr(out), out.stride(0), _ptr(packed), _ptr(bb), n_out, int(relu_in), _ptr(res), ldr, n, _stream())))
     return out
 
 

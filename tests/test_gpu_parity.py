@@ -491,6 +491,27 @@ def test_split_precision_rowlin_against_fp64(pk, n, n_out, relu_in, with_res):
         assert torch.equal(rr, got)
 
 
+@pytest.mark.parametrize('n,n_out,after', [(1500, 416, False), (1500, 416, True), (700, 832, False), (257, 208, True)])
+def test_split_precision_rowlin_masked_epilogue(pk, n, n_out, after):
+    """occ4d_rowlin_bf16x6_masked_f32 (training data gradients): y = [mask > 0] (x W^T [+ res]) [+ res] -- the residual
+    before or after the mask -- against fp64 at the accuracy of an fp32 GEMM, and the masked zeros exactly zero."""
+    rng = np.random.default_rng(3 * n + n_out)
+    x = rng.normal(size=(n, 416)).astype(np.float32)
+    w = (rng.normal(size=(n_out, 416)) / np.sqrt(416)).astype(np.float32)
+    r = rng.normal(size=(n, n_out)).astype(np.float32)
+    m = rng.normal(size=(n, n_out)).astype(np.float32)
+    m[::7, ::5] = 0.0                                               # (mask == 0 counts as masked)
+    lin = x.astype(np.float64) @ w.astype(np.float64).T
+    ref = np.where(m > 0, lin, 0.0) + r if after else np.where(m > 0, lin + r, 0.0)
+    got = pk.ops.rowlin_bf16x6(dev(x), dev(w), None, res=dev(r), mask=dev(m), res_after_mask=after).cpu().numpy()
+    scale = (np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64).T).max()
+    assert np.abs(got - ref).max() <= 8 * 2.0 ** -24 * scale
+    if not after:
+        assert (got[m <= 0] == 0).all()
+    else:
+        assert (got[m <= 0] == r[m <= 0]).all()
+
+
 @pytest.mark.parametrize('case', gc.DEC_CASES + gc.DEC_TWOLEVEL_CASES, ids=lambda c: c['name'])
 def test_decoder_entirely_on_three_way_split_bf16(pk, bf16x6_attention, case):
     """Attention AND trunk on the split-precision kernels (every GEMM of the decoder except lin_in / lin_out and the

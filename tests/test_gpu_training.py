@@ -536,6 +536,26 @@ def test_residual_block_node_and_shared_input_sum_match_the_separate_nodes():
     assert rel_err(a[0], ref.float()) < 2e-5
 
 
+def test_training_gemms_on_the_split_precision_kernels(monkeypatch):
+    """OCC4D_TRAIN_PRECISION=bf16x6 (opt-in, fp32-class): forward Linears and data gradients with a 416-wide reduction on
+    csrc/trunk_bf16x6.hip.  The same strict tests as the fp32 path -- residual-block node / shared-input sum, recompute
+    attention layer, whole decoder -- must hold unchanged, and the kernel must actually have run."""
+    calls = []
+    real = pk.ops.rowlin_bf16x6
+
+    def spy(*a, **k):
+        calls.append(k.get('mask') is not None)
+        return real(*a, **k)
+    monkeypatch.setattr(pk.ops, 'rowlin_bf16x6', spy)
+    monkeypatch.setattr(pk.autograd, 'TRAIN_PRECISION', 'bf16x6')
+    test_residual_block_node_and_shared_input_sum_match_the_separate_nodes()
+    n_block = len(calls)
+    assert n_block >= 8 and any(calls)                       # forward, masked data gradients, the shared-input chain
+    test_checkpointed_attention_gradients_strict(4096)
+    test_decoder_gradients(gc.DEC_CASES[2])
+    assert len(calls) > n_block
+
+
 def test_chained_blocks_gradients_strict():
     case = gc.PTB_CASES[1]
     x, pos, x2, pos2, sd = gc.ptb_inputs(case)
