@@ -27,7 +27,7 @@ step bench_kernel_stats_streams1.csv 'OCC4D_DECODE_STREAMS=1 rocprofv3 --kernel-
 step bench_kernel_stats.csv 'rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof2" -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra > /dev/null 2>&1; cp "$(find "$OUT/prof2" -name "*kernel_stats.csv" | head -1)" "$OUT/bench_kernel_stats.csv"'
 step bench_kernel_stats_bf16x6_streams1.csv 'OCC4D_LOGIT_PRECISION=bf16x6 OCC4D_TRUNK_PRECISION=bf16x6 OCC4D_DECODE_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof6" -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra 2>/dev/null | tail -1 > "$OUT/bench_bf16x6_streams1_under_rocprof.json"; cp "$(find "$OUT/prof6" -name "*kernel_stats.csv" | head -1)" "$OUT/bench_kernel_stats_bf16x6_streams1.csv"'
 : > "$OUT/bench_train.jsonl"
-for flags in "" "--no-checkpoint"; do
+for flags in "" "--no-checkpoint" "--precision bf16x6" "--precision bf16x6 --no-checkpoint"; do
   step - "python bench_train.py --steps 20 --warmup 3 $flags 2>/dev/null | tail -1 >> \"$OUT/bench_train.jsonl\""
 done
 : > "$OUT/bench_train_sampler.jsonl"
