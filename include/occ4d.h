@@ -570,6 +570,13 @@ int64_t occ4d_rowlin_bf16x6_packed_floats(int n_out);
 int occ4d_pack_rowlin_bf16x6_f32(const float* w, int64_t ldw, int n_out, float* packed, void* stream);
 int occ4d_rowlin_bf16x6_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed, const float* b,
                             int n_out, int relu_in, const float* res, int64_t ldr, int n, void* stream);
+/* Training, opt-in, fp32-class: occ4d_pt_pair_mlp_f32 (the recompute's pair tensors a / logits / pe) on the three-way split
+ * bf16 MFMAs.  wstream: occ4d_pack_attn_bf16x6_stream_f32(W2, Wp, P2).  a (n k, 832), logits (n k, 416), pe (n k, 416)
+ * contiguous; aq (n, >= 832) / kt (m, >= 832) rows 16-byte aligned with ld % 4 == 0; n k < 2^31, n ld_aq and m ld_kt
+ * below 2^29 floats (32-bit row offsets). */
+int occ4d_pt_pair_mlp_bf16x6_f32(const float* aq, int64_t ld_aq, const float* kt, int64_t ld_kt, const float* r,
+                                 const int32_t* idx, const float* c2, const float* wstream, float* a_out, float* logits,
+                                 float* pe, int n, int m, int k, int d, void* stream);
 /* The same kernel with the epilogue of a training data gradient: y = [mask > 0] ([relu](x) W^T + b [+ res]) [+ res];
  * res_after_mask = 0: res before the mask (occ4d_rowlin4_masked_f32's contract), != 0: after it (the skip gradient of a
  * residual block, occ4d_rowlin4_masked_skip_f32's contract).  b and res may be NULL. */

@@ -181,6 +181,8 @@ SIGNATURES = {
     'occ4d_rowlin_bf16x6_packed_floats': (C.c_int64, [C.c_int]),
     'occ4d_pack_rowlin_bf16x6_f32': (C.c_int, [_f, C.c_int64, C.c_int, _f, _s]),
     'occ4d_rowlin_bf16x6_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, _f, C.c_int, C.c_int, _f, C.c_int64, C.c_int, _s]),
+    'occ4d_pt_pair_mlp_bf16x6_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, _i, _f, _f, _f, _f, _f, C.c_int, C.c_int, C.c_int,
+                                              C.c_int, _s]),
     'occ4d_rowlin_bf16x6_masked_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, _f, C.c_int, C.c_int, _f, C.c_int64, C.c_int,
                                                 _f, C.c_int64, C.c_int, _s]),
     'occ4d_pack_attn_bf16x6_stream_f32': (C.c_int, [_f, _f, _f, _f, _s]),

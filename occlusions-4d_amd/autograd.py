@@ -464,18 +464,22 @@ class PairMlpFn(Function):
 
     @staticmethod
     def _packed_stream(W2, b2, wp, P2, c2):
+        x6 = TRAIN_PRECISION == 'bf16x6'
         hit = PairMlpFn._stream
         if (hit is not None and hit[0] is W2 and hit[1] is wp and hit[2] is P2
-                and hit[3] == (W2._version, wp._version, P2._version)):
+                and hit[3] == (W2._version, wp._version, P2._version, x6)):
             return hit[4]
-        stream = ops.pack_attn16p_stream(W2, b2, wp, P2, c2)
-        PairMlpFn._stream = (W2, wp, P2, (W2._version, wp._version, P2._version), stream)
+        stream = ops.pack_attn_bf16x6_stream(W2, wp, P2) if x6 else ops.pack_attn16p_stream(W2, b2, wp, P2, c2)
+        PairMlpFn._stream = (W2, wp, P2, (W2._version, wp._version, P2._version, x6), stream)
         return stream
 
     @staticmethod
     def forward(ctx, aq, kt, r, wp, W2, b2, P2, c2, idx):
         stream = PairMlpFn._packed_stream(W2, b2, wp, P2, c2)
-        a, logits, pe = ops.pt_pair_mlp(aq, kt, r, idx, c2, stream)
+        if TRAIN_PRECISION == 'bf16x6':
+            a, logits, pe = ops.pt_pair_mlp_bf16x6(aq, kt, r, idx, c2, stream)
+        else:
+            a, logits, pe = ops.pt_pair_mlp(aq, kt, r, idx, c2, stream)
         ctx.save_for_backward(a, r, wp, W2, P2, idx)
         ctx.m = kt.shape[0]
         ctx.params = (kt, wp, W2, b2, P2, c2)

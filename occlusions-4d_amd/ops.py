@@ -507,6 +507,39 @@ def pt_pair_mlp(aq, kt, r, idx, c2, wstream, skew=None):
     return a, logits, pe
 
 
+def pack_attn_bf16x6_stream(w2, wp, p2):
+    """Fragment stream of the split-precision attention kernels (occ4d_pack_attn_bf16x6_stream_f32): w2 (416, 832) =
+    attn_mlp[2].weight, wp (832, 32) = W1 P2 (merged), p2 (416, 32) = pos_mlp[2].weight."""
+    w2, wp, p2 = (_cont(t.detach(), 'w') for t in (w2, wp, p2))
+    assert w2.shape == (TRUNK_WIDTH, 2 * TRUNK_WIDTH) and wp.shape == (2 * TRUNK_WIDTH, 32) and p2.shape == (TRUNK_WIDTH, 32)
+    L = _lib.lib()
+    out = torch.empty((int(L.occ4d_pt_cross_attn_bf16x6_stream_floats()),), dtype=torch.float32, device=w2.device)
+    _lib.check(L.occ4d_pack_attn_bf16x6_stream_f32(_ptr(w2), _ptr(wp), _ptr(p2), _ptr(out), _stream()))
+    return out
+
+
+def pt_pair_mlp_bf16x6(aq, kt, r, idx, c2, wstream6):
+    """pt_pair_mlp on the three-way split bf16 MFMAs (occ4d_pt_pair_mlp_bf16x6_f32; opt-in, fp32-class).
+    wstream6 = pack_attn_bf16x6_stream(W2, Wp, P2)."""
+    aq, ld_aq = _aligned_rows(_dev(aq, name='aq'), 'aq')
+    kt, ld_kt = _aligned_rows(_dev(kt, name='kt'), 'kt')
+    idx = _dev(idx, torch.int32, 'idx')
+    n, k = idx.shape
+    d = TRUNK_WIDTH
+    r = _dev(r, name='r')
+    c2 = _dev(c2).contiguous()
+    assert idx.is_contiguous() and r.is_contiguous() and r.shape == (n * k, 32) and aq.shape == (n, 2 * d)
+    assert kt.shape[1] == 2 * d and c2.shape == (d,) and wstream6.is_contiguous()
+    a = torch.empty((n * k, 2 * d), dtype=torch.float32, device=aq.device)
+    logits = torch.empty((n * k, d), dtype=torch.float32, device=aq.device)
+    pe = torch.empty((n * k, d), dtype=torch.float32, device=aq.device)
+    flops = 2.0 * n * k * (32 * 2 * d + 2 * d * d + 32 * d)
+    _lib.check(_launch('pair_mlp', dict(n=n, k=k, d=d), flops, lambda: _lib.lib().occ4d_pt_pair_mlp_bf16x6_f32(
+        _ptr(aq), ld_aq, _ptr(kt), ld_kt, _ptr(r), _ptr(idx), _ptr(c2), _ptr(wstream6), _ptr(a), _ptr(logits), _ptr(pe),
+        n, kt.shape[0], k, d, _stream())))
+    return a, logits, pe
+
+
 def layernorm(x, gamma, beta, eps=1e-5, relu=False, out=None):
     x, ldx = _rows(_dev(x, name='x'), 'x')
     n, d = x.shape

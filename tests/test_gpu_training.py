@@ -536,6 +536,31 @@ def test_residual_block_node_and_shared_input_sum_match_the_separate_nodes():
     assert rel_err(a[0], ref.float()) < 2e-5
 
 
+@pytest.mark.parametrize('n,m,k', [(200, 90, 14), (37, 50, 5), (1, 3, 1), (300, 300, 14)])
+def test_split_precision_pair_tensors_match_the_fp32_kernel(n, m, k):
+    """occ4d_pt_pair_mlp_bf16x6_f32 (opt-in, fp32-class) against the fp32 pair-tensor kernel and an fp64 reference:
+    a / logits / pe at an fp32 GEMM's accuracy, ragged row counts (rows past n k are never written: canaries)."""
+    rng = np.random.default_rng(n + m + k)
+    Tc = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32)).cuda()   # noqa: E731
+    d = 416
+    aq, kt = Tc(rng.normal(size=(n, 2 * d))), Tc(rng.normal(size=(m, 2 * d)))
+    r = torch.relu(Tc(rng.normal(size=(n * k, 32))))
+    idx = torch.from_numpy(rng.integers(0, m, size=(n, k)).astype(np.int32)).cuda()
+    wp, w2 = Tc(0.1 * rng.normal(size=(2 * d, 32))), Tc(0.03 * rng.normal(size=(d, 2 * d)))
+    b2, p2, c2 = Tc(rng.normal(size=(d,))), Tc(0.1 * rng.normal(size=(d, 32))), Tc(rng.normal(size=(d,)))
+    a32, l32, p32 = pk.ops.pt_pair_mlp(aq, kt, r, idx, c2, pk.ops.pack_attn16p_stream(w2, b2, wp, p2, c2))
+    a6, l6, p6 = pk.ops.pt_pair_mlp_bf16x6(aq, kt, r, idx, c2, pk.ops.pack_attn_bf16x6_stream(w2, wp, p2))
+    ii = idx.long().reshape(-1)
+    q = torch.arange(n, device='cuda').repeat_interleave(k)
+    a64 = aq.double()[q] - kt.double()[ii] + r.double() @ wp.double().t()
+    l64 = torch.relu(a64) @ w2.double().t()
+    p64 = r.double() @ p2.double().t() + c2.double()
+    for got, ref32, ref in ((a6, a32, a64), (l6, l32, l64), (p6, p32, p64)):
+        e6 = float((got.double() - ref).abs().max())
+        e32 = float((ref32.double() - ref).abs().max())
+        assert e6 <= max(2.0 * e32, 1e-6 * float(ref.abs().max())), (e6, e32)
+
+
 def test_training_gemms_on_the_split_precision_kernels(monkeypatch):
     """OCC4D_TRAIN_PRECISION=bf16x6 (opt-in, fp32-class): forward Linears and data gradients with a 416-wide reduction on
     csrc/trunk_bf16x6.hip.  The same strict tests as the fp32 path -- residual-block node / shared-input sum, recompute
