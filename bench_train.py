@@ -111,7 +111,7 @@ def main():
     ap.add_argument('--no-checkpoint', action='store_true', help='store the attention pair tensors (merged form; OCC4D_STORED_ATTENTION_FORM=as_written for the round-1 path) instead of recomputing them in backward')
     ap.add_argument('--per-frame', action='store_true', help='decode the target frames one after the other (the reference\'s loop) instead of in one batched decoder call')
     ap.add_argument('--no-prefetch', action='store_true', help='do not prefetch the next step\'s FPS chain / kNNs under this step\'s backward')
-    ap.add_argument('--precision', choices=['f32', 'bf16x6'], default='f32', help='bf16x6 (opt-in, fp32-class): the 416-input Linear layers of the step (forward and data gradients) and the forward attention kernel on three-way split bf16 MFMAs, 6 partial products, fp32 accumulate; weight gradients and the recompute stay fp32')
+    ap.add_argument('--precision', choices=['f32', 'bf16x6'], default='f32', help='bf16x6 (opt-in, fp32-class): the 416-input Linear layers of the step (forward and data gradients) the forward attention kernel and the pair-tensor recompute on three-way split bf16 MFMAs, 6 partial products, fp32 accumulate; weight gradients stay fp32')
     ap.add_argument('--sampler', action='store_true',
                     help='draw the supervision points of every step with GuidedImplicitPointSampler (57344-point target '
                          'frames, bias low_moving_vehped_sembal) instead of fixed synthetic queries: the NEXT step\'s points '
@@ -298,7 +298,7 @@ def main():
             'metric': 'training step (BASELINE config 5: CARLA-4D, batch 1/GPU, n_points=28672, 4 x 17203 queries)',
             'value': world * args.steps / elapsed, 'unit': 'examples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'dtype': 'f32' if args.precision == 'f32' else 'f32 weight gradients / recompute; forward Linears, their data gradients and the forward attention kernel on bf16 x 3 pieces, 6 products, f32 accumulate (fp32-class)', 'precision': args.precision, 'data': 'synthetic', 'losses': losses, 'sampler_ms_per_step': sampler_ms, 'sampler': (None if not args.sampler else 'in front of the step (serial)' if args.sampler_serial else "next step's points drawn on a side stream beside this step (host time per step in sampler_ms_per_step)"), 'graph': False, 'loss_read': 'after the timed region', 'geometry_prefetch': bool(nxt), 'gradient_overlap': (('parameter gradients on a second stream beside the data-gradient chain, at most %.0f GB of operands held for it' % (pk.autograd.GRADIENT_OVERLAP_BYTES / 2 ** 30)) if pk.autograd.GRADIENT_OVERLAP else False), 'frames_batched': bool(step.batch_frames), 'attention_backward': ('stored pair tensors (%s form)' % pk.point_transformer_layer.STORED_ATTENTION_FORM) if args.no_checkpoint else 'recompute in backward (equal chunks of at most %d queries)' % pk.point_transformer_layer._CHECKPOINT_CHUNK,
+            'scaling': 'weak', 'dtype': 'f32' if args.precision == 'f32' else 'f32 weight gradients; forward Linears, their data gradients, the forward attention kernel and the pair-tensor recompute on bf16 x 3 pieces, 6 products, f32 accumulate (fp32-class)', 'precision': args.precision, 'data': 'synthetic', 'losses': losses, 'sampler_ms_per_step': sampler_ms, 'sampler': (None if not args.sampler else 'in front of the step (serial)' if args.sampler_serial else "next step's points drawn on a side stream beside this step (host time per step in sampler_ms_per_step)"), 'graph': False, 'loss_read': 'after the timed region', 'geometry_prefetch': bool(nxt), 'gradient_overlap': (('parameter gradients on a second stream beside the data-gradient chain, at most %.0f GB of operands held for it' % (pk.autograd.GRADIENT_OVERLAP_BYTES / 2 ** 30)) if pk.autograd.GRADIENT_OVERLAP else False), 'frames_batched': bool(step.batch_frames), 'attention_backward': ('stored pair tensors (%s form)' % pk.point_transformer_layer.STORED_ATTENTION_FORM) if args.no_checkpoint else 'recompute in backward (equal chunks of at most %d queries)' % pk.point_transformer_layer._CHECKPOINT_CHUNK,
             'peak_mem_gb': torch.cuda.max_memory_allocated() / 2 ** 30,
             'roofline': roof,
             'config': {'workload': 'CARLA-4D training step (BASELINE configs[4]): batch 1 per GPU, n_points=%d, %d x %d '
