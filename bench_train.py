@@ -293,6 +293,9 @@ def main():
                                      tflops=v['total_flops'] / max(v['total_ms'], 1e-9) / 1e9)
                              for k, v in sorted(summ.items(), key=lambda kv: -kv[1]['total_ms'])},
                     dominant=None if top is None else top[0])
+        if args.precision != 'f32':
+            roof['mixed_precision_note'] = ('part of the executed FLOP ran on bf16 MFMAs (six partial products each, not counted '
+                                            'six times): frac against the fp32 MFMA peak is informational for this mode')
     if rank == 0:
         print(json.dumps({
             'metric': 'training step (BASELINE config 5: CARLA-4D, batch 1/GPU, n_points=28672, 4 x 17203 queries)',
