@@ -16,3 +16,7 @@ run "OCC4D_KNN_GRID=0" "tests/test_gpu_parity.py tests/test_gpu_fullsize.py test
 run "OCC4D_KNN_GRID_MIN_PAIRS=1 OCC4D_KNN_GRID_MIN_DATA=1" "tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_training.py tests/test_gpu_sampler.py"
 run "OCC4D_KNN_GRID_MIN_PAIRS=1 OCC4D_KNN_GRID_MIN_DATA=1 OCC4D_KNN_GRID_ONE_THREAD_FROM=1" "tests/test_gpu_parity.py tests/test_gpu_fullsize.py"
 run "OCC4D_GRADIENT_OVERLAP=0" "tests/test_gpu_training.py tests/test_gpu_contracts.py"
+# (split-precision training: the strict tests against the ORACLE; the fp32-twin comparison of the fused / unfused pair chain is
+#  not in this list -- two fp32-class paths put a hidden unit of +-2.4e-7 on different sides of its ReLU there, the audited
+#  kink effect of DESIGN.md 7b, one entry of one gradient)
+echo "== OCC4D_TRAIN_PRECISION=bf16x6 OCC4D_LOGIT_PRECISION=bf16x6"; OCC4D_TRAIN_PRECISION=bf16x6 OCC4D_LOGIT_PRECISION=bf16x6 timeout 900 python -m pytest tests/test_gpu_training.py -x -q -k "split_precision or decoder_gradients or end_to_end or checkpointed or encoder_gradients or reduces" 2>&1 | tail -2

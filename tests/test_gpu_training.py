@@ -442,6 +442,7 @@ def test_parameter_gradients_beside_the_chain_change_nothing(monkeypatch):
     tgt = Tc(np.concatenate([rng.integers(0, 2, size=(2, 200, 1)), rng.uniform(size=(2, 200, 3)), np.zeros((2, 200, 1)),
                              rng.integers(-1, 13, size=(2, 200, 1))], -1))
     monkeypatch.setattr(pk.point_transformer_layer, '_CHECKPOINT_CHUNK', 128)      # 400 queries -> 4 chunks
+    monkeypatch.setattr(pk.autograd, 'GRADIENT_OVERLAP', True)                     # (whatever OCC4D_GRADIENT_OVERLAP says)
 
     def grads(overlap):
         enc = pk.model.PointCompletionNetV3(**pa).cuda().train()
