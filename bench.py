@@ -378,12 +378,10 @@ def main():
         # covers the other stream's kernels; this extra (untimed) step runs the same launches on ONE
         # stream so that the brackets are exclusive kernel durations.
         timer = pk.ops.KernelTimer(lambda name, **sh: name == 'cross_attn' and sh.get('d') == 416)
-        streams_saved = pk.inference.DECODE_STREAMS
-        pk.inference.DECODE_STREAMS = 1
         pk.ops.set_kernel_timer(timer)
-        step()
+        with pk.kernels(decode_streams=1):
+            step()
         pk.ops.set_kernel_timer(None)
-        pk.inference.DECODE_STREAMS = streams_saved
         psum = timer.summary().get('cross_attn', dict(launches=0, total_ms=0.0, total_flops=0.0))
         extra = not args.no_extra
         # Secondary grid (informational): the other strong-scaling curve's point for this N.
@@ -405,46 +403,57 @@ def main():
         # own roofline object: executed bf16 MFMA FLOP of the attention kernel / its HIP-event time / dense bf16 peak.
         # (The round-1 bf16x3 logit mode -- two pieces, NOT fp32-class -- is slower than this and no longer reported.)
         alt = None
+        alt_f16 = None
         if not args.no_alt and extra and world == 1:
-            ptl = pk.point_transformer_layer
-            ptl.LOGIT_PRECISION = 'bf16x6'
-            attn_elapsed, _, _ = timed(step, max(2, args.steps // 2), 1)
-            ptl.TRUNK_PRECISION = 'bf16x6'
-            alt_elapsed, _, (out_alt, _) = timed(step, args.steps, 1)
-            timer6 = pk.ops.KernelTimer(lambda name, **sh: name == 'cross_attn' and sh.get('d') == 416)
-            pk.inference.DECODE_STREAMS = 1
-            pk.ops.set_kernel_timer(timer6)
-            step()
-            pk.ops.set_kernel_timer(None)
-            pk.inference.DECODE_STREAMS = streams_saved
-            ps6 = timer6.summary().get('cross_attn', dict(launches=0, total_ms=0.0, total_flops=0.0))
-            ptl.LOGIT_PRECISION = ptl.TRUNK_PRECISION = 'f32'
-            # MFMAs the attention kernel executes per launch: workgroups (18 queries x 2 channel halves) x 8 waves x
-            # (26 stages x 180 + 14 epilogue pairs x 12) v_mfma_f32_16x16x32_bf16 of 2 * 16 * 16 * 32 FLOP
-            t6 = ps6['total_ms'] * 1e-3
-            bs6 = pk.inference.decode_chunk(BATCH)
-            batches6 = [min(bs6, hi - b) for b in range(lo, hi, bs6)]
-            wgs6 = sum(2 * (-(-c // 18)) for b in batches6 for c in pk.ops.path_row_chunks(b)) * ia['cross_attn_layers']
-            mfma6 = wgs6 * 8 * (26 * 180 + 14 * 12) * (2.0 * 16 * 16 * 32)
-            k_attn = max(2, args.steps // 2)
-            alt = dict(mode='bf16x6: the GEMMs of the cross-attention layers and of the trunk (residual blocks, query '
-                            'projection, layer3: 99 % of the decode FLOP) on 3-way split bf16 MFMAs, 6 partial products, fp32 '
-                            'accumulate (csrc/crossattn_bf16x6.hip, csrc/trunk_bf16x6.hip); encoder, lin_in / lin_out, tables fp32',
-                       dtype='bf16 x 3 pieces per operand, 6 of 9 products, f32 accumulate (fp32-class)',
-                       ms_per_step=1e3 * alt_elapsed / args.steps, value=n_total * args.steps / alt_elapsed,
-                       attention_only=dict(ms_per_step=1e3 * attn_elapsed / k_attn, value=n_total * k_attn / attn_elapsed),
-                       max_abs_diff_vs_f32=float((out_alt - out).abs().max()),
-                       regime_bound='every gate of the fp32 path: golden vectors at 1e-4 (measured <= 5e-6) and, with weights '
-                                    'x 4 / x 8, equal / dominant logits, far queries, |hip - ref64| <= max(1e-4, 2 |ref32 - '
-                                    'ref64|) (tests/test_gpu_regimes.py, variants "bf16x6", "bf16x6_trunk", "bf16x6_all")',
-                       roofline=dict(bound='mfma', unit='TFLOP/s', peak=2500.0,
-                                     achieved=mfma6 / t6 / 1e12 if t6 > 0 else None,
-                                     frac=mfma6 / t6 / 2.5e15 if t6 > 0 else None,
-                                     fp32_equivalent_tflops=ps6['total_flops'] / t6 / 1e12 if t6 > 0 else None,
-                                     launches=ps6['launches'], avg_launch_ms=ps6['total_ms'] / max(1, ps6['launches']),
-                                     kernel='cross_attn_bf16x6_kernel; achieved = executed v_mfma_f32_16x16x32_bf16 FLOP '
-                                            '(6 products, duplicated GEMM1 and dead rows included) / HIP-event time; '
-                                            'fp32_equivalent = the fp32 kernel\'s executed FLOP count / the same time'))
+            def split_leg(scheme):
+                """The whole decoder on one split scheme, selected for THIS thread's calls (`with pk.kernels(...)`: no
+                module global is assigned; the decoder keeps one prepared weight set per selection)."""
+                k_attn = max(2, args.steps // 2)
+                with pk.kernels(logit_precision=scheme):
+                    attn_elapsed, _, _ = timed(step, k_attn, 1)
+                with pk.kernels(precision=scheme):
+                    alt_elapsed, _, (out_alt, _) = timed(step, args.steps, 1)
+                    timer6 = pk.ops.KernelTimer(lambda name, **sh: name == 'cross_attn' and sh.get('d') == 416)
+                    pk.ops.set_kernel_timer(timer6)
+                    with pk.kernels(decode_streams=1):
+                        step()
+                    pk.ops.set_kernel_timer(None)
+                ps6 = timer6.summary().get('cross_attn', dict(launches=0, total_ms=0.0, total_flops=0.0))
+                # MFMAs the attention kernel executes per launch: workgroups (18 queries x 2 channel halves) x 8 waves x
+                # (26 stages x (2 x 2 GEMM1 + 13 x 2 GEMM2 tiles) + 14 epilogue tile pairs x 2) x products per tile
+                # (6 | 3) v_mfma_f32_16x16x32_{bf16 | f16} of 2 * 16 * 16 * 32 FLOP
+                prod = 6 if scheme == 'bf16x6' else 3
+                t6 = ps6['total_ms'] * 1e-3
+                bs6 = pk.inference.decode_chunk(BATCH)
+                batches6 = [min(bs6, hi - b) for b in range(lo, hi, bs6)]
+                wgs6 = sum(2 * (-(-c // 18)) for b in batches6 for c in pk.ops.path_row_chunks(b)) * ia['cross_attn_layers']
+                mfma6 = wgs6 * 8 * (26 * 30 + 14 * 2) * prod * (2.0 * 16 * 16 * 32)
+                traffic6, traffic6_source = pmc_traffic(args.kind + '_' + scheme)
+                what = ('bf16 x 3 pieces per operand, 6 of 9 products, f32 accumulate (fp32-class)' if scheme == 'bf16x6' else
+                        'fp16 x 2 pieces per operand (round to nearest), 3 of 4 products, f32 accumulate; weights packed * 2^8; '
+                        'inference forwards only, |w| < 255, |activation| < 65504')
+                return dict(
+                    mode='%s: the GEMMs of the cross-attention layers and of the trunk (residual blocks, query projection, '
+                         'layer3: 99 %% of the decode FLOP) on split-precision 16x16x32 MFMAs (csrc/crossattn_bf16x6.hip, '
+                         'csrc/trunk_bf16x6.hip, templates over the scheme); encoder, lin_in / lin_out, tables fp32' % scheme,
+                    dtype=what, ms_per_step=1e3 * alt_elapsed / args.steps, value=n_total * args.steps / alt_elapsed,
+                    attention_only=dict(ms_per_step=1e3 * attn_elapsed / k_attn, value=n_total * k_attn / attn_elapsed),
+                    max_abs_diff_vs_f32=float((out_alt - out).abs().max()),
+                    regime_bound='every gate of the fp32 path: golden vectors at 1e-4 and, with weights x 4 / x 8, equal / '
+                                 'dominant logits, far queries, |hip - ref64| <= max(1e-4, 2 |ref32 - ref64|) '
+                                 '(tests/test_gpu_regimes.py, variants "%s", "%s_trunk", "%s_all")' % (scheme, scheme, scheme),
+                    roofline=dict(bound='mfma', unit='TFLOP/s', peak=2500.0,
+                                  achieved=mfma6 / t6 / 1e12 if t6 > 0 else None,
+                                  frac=mfma6 / t6 / 2.5e15 if t6 > 0 else None,
+                                  fp32_equivalent_tflops=ps6['total_flops'] / t6 / 1e12 if t6 > 0 else None,
+                                  launches=ps6['launches'], avg_launch_ms=ps6['total_ms'] / max(1, ps6['launches']),
+                                  traffic=traffic6, traffic_source=traffic6_source,
+                                  kernel='cross_attn_split_kernel<%s>; achieved = executed v_mfma_f32_16x16x32 FLOP (%d '
+                                         'products, duplicated GEMM1 and dead rows included) / HIP-event time; fp32_equivalent '
+                                         '= the fp32 kernel\'s executed FLOP count / the same time'
+                                         % ('SplitBf16x6' if scheme == 'bf16x6' else 'SplitF16x3', prod)))
+            alt = split_leg('bf16x6')
+            alt_f16 = split_leg('f16x3')
         # Throughput mode (informational, never `value`): clips pipelined across steps -- the encode of step i + 1 is
         # issued on a side stream while step i decodes (distributed.ClipPipeline).  Every step still encodes and
         # decodes in full; K steps contain K encode launches and K decodes.
@@ -474,19 +483,31 @@ def main():
         # compress_air on the device, every result array copied back to host numpy (D2H over PCIe).
         host_boundary = None
         if extra and world == 1:
-            reps = 3
-            torch.cuda.synchronize()
-            th = time.perf_counter()
-            for _ in range(reps):
-                res = pk.inference.perform_inference(
+            # As the reference's eval loop calls it (eval/test.py:75) and keeps each result while the next call runs:
+            # two untimed calls first (the pinned host buffers of TWO result sets and the side streams' device pools
+            # exist after them; round 5 timed 3 calls from cold, two of which were allocating: 144 ms), then 5 timed.
+            def host_call():
+                return pk.inference.perform_inference(
                     pcl_cpu.clone(), None, None, [enc, dec], device, 'if', inf['min_z'], inf['cube_bounds'],
                     inf['color_mode'], 3, None, sample_implicit=True, num_sample=NUM_SAMPLE, point_sample_mode='grid',
                     batch_size=BATCH, predict_segmentation=inf['predict_segmentation'], track_mode='none',
                     semantic_classes=13, density_threshold=0.5, data_kind=inf['data_kind'], cube_mode=inf['cube_mode'],
                     compress_air=True)
-            t_host = (time.perf_counter() - th) / reps
+            reps = 5
+            res = host_call()
+            res = host_call()
+            torch.cuda.synchronize()
+            each = []
+            for _ in range(reps):
+                th = time.perf_counter()
+                res = host_call()
+                each.append(time.perf_counter() - th)
+            t_host = sum(each) / reps
             host_boundary = dict(ms_per_call=1e3 * t_host, value=res['points_query'].shape[0] / t_host,
-                                 what='perform_inference with host numpy inputs and outputs (PCIe inclusive)')
+                                 calls=reps, warmup_calls=2, ms_each=[round(1e3 * t, 2) for t in each],
+                                 what='perform_inference with host numpy inputs and outputs (PCIe inclusive), the '
+                                      'previous result held while the next call runs')
+            del res
         # the exchange step, measured on one more (untimed) step: HIP events around the encoder (rank 0) and around
         # the two broadcasts, per rank
         timing = {}
@@ -550,7 +571,7 @@ def main():
                        'rccl_info': rccl_log_excerpt(rccl_log) if rccl_log else None,
                        'ranks_share_one_gpu': share_gpu or None,
                        'per_rank_ms_per_step': [1e3 * t / args.steps for t in per_rank_s],
-                       'decode_streams': pk.inference.DECODE_STREAMS, 'decode_chunk': chunk},
+                       'decode_streams': pk.kernels.defaults().decode_streams, 'decode_chunk': chunk},
             'roofline': {
                 'bound': 'mfma', 'achieved': executed / 1e12, 'peak': FP32_MFMA_PEAK / 1e12, 'unit': 'TFLOP/s',
                 'frac': executed / FP32_MFMA_PEAK,
@@ -576,6 +597,8 @@ def main():
             line['config4_single_gpu' if world == 1 else 'strong_config2'] = other
         if alt is not None:
             line['alt_precision'] = alt
+        if alt_f16 is not None:
+            line['alt_precision_f16x3'] = alt_f16
         if pipelined is not None:
             line['pipelined'] = pipelined
         if host_boundary is not None:

@@ -153,10 +153,9 @@ def main():
         ones = torch.ones((), device=device)
         dist.all_reduce(ones)                   # the ranks RCCL really connected
         rccl_ranks = int(ones.item())
-    pk.point_transformer_layer.CHECKPOINT_ATTENTION = not args.no_checkpoint
+    selection = dict(checkpoint_attention=not args.no_checkpoint)     # kernels.Selection fields of this step (no globals)
     if args.precision == 'bf16x6':
-        pk.autograd.TRAIN_PRECISION = 'bf16x6'
-        pk.point_transformer_layer.LOGIT_PRECISION = 'bf16x6'      # (the fused forward kernel of the recompute path)
+        selection.update(train_precision='bf16x6', logit_precision='bf16x6')   # (logit: the recompute path's fused forward kernel)
     pa, ia, inf = pk.configs.model_args('carla', N_POINTS)
     esd, dsd = pk.configs.synthetic_weights(pa, ia, SEED)
     enc = pk.model.PointCompletionNetV3(**pa).to(device).train()
@@ -176,7 +175,7 @@ def main():
     # form without data-dependent shapes; it removes the 12 device->host reads (one per boolean index) that
     # stall the host between forward and backward.  OCC4D_BENCH_INDEXED_LOSS=1: the reference's indexing form.
     lkw = dict(density_lw=1.0, segmentation_lw=0.6, static_shapes=os.environ.get('OCC4D_BENCH_INDEXED_LOSS') != '1')
-    step = pk.training.TrainStep(enc, dec, lr=1e-3, grad_clip=0.2, loss_kwargs=lkw)
+    step = pk.training.TrainStep(enc, dec, lr=1e-3, grad_clip=0.2, loss_kwargs=lkw, kernel_selection=selection)
 
     def fence():
         torch.cuda.synchronize()
@@ -301,7 +300,7 @@ def main():
             'metric': 'training step (BASELINE config 5: CARLA-4D, batch 1/GPU, n_points=28672, 4 x 17203 queries)',
             'value': world * args.steps / elapsed, 'unit': 'examples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'dtype': 'f32' if args.precision == 'f32' else 'f32 weight gradients; forward Linears, their data gradients, the forward attention kernel and the pair-tensor recompute on bf16 x 3 pieces, 6 products, f32 accumulate (fp32-class)', 'precision': args.precision, 'data': 'synthetic', 'losses': losses, 'sampler_ms_per_step': sampler_ms, 'sampler': (None if not args.sampler else 'in front of the step (serial)' if args.sampler_serial else "next step's points drawn on a side stream beside this step (host time per step in sampler_ms_per_step)"), 'graph': False, 'loss_read': 'after the timed region', 'geometry_prefetch': bool(nxt), 'gradient_overlap': (('parameter gradients on a second stream beside the data-gradient chain, at most %.0f GB of operands held for it' % (pk.autograd.GRADIENT_OVERLAP_BYTES / 2 ** 30)) if pk.autograd.GRADIENT_OVERLAP else False), 'frames_batched': bool(step.batch_frames), 'attention_backward': ('stored pair tensors (%s form)' % pk.point_transformer_layer.STORED_ATTENTION_FORM) if args.no_checkpoint else 'recompute in backward (equal chunks of at most %d queries)' % pk.point_transformer_layer._CHECKPOINT_CHUNK,
+            'scaling': 'weak', 'dtype': 'f32' if args.precision == 'f32' else 'f32 weight gradients; forward Linears, their data gradients, the forward attention kernel and the pair-tensor recompute on bf16 x 3 pieces, 6 products, f32 accumulate (fp32-class)', 'precision': args.precision, 'data': 'synthetic', 'losses': losses, 'sampler_ms_per_step': sampler_ms, 'sampler': (None if not args.sampler else 'in front of the step (serial)' if args.sampler_serial else "next step's points drawn on a side stream beside this step (host time per step in sampler_ms_per_step)"), 'graph': False, 'loss_read': 'after the timed region', 'geometry_prefetch': bool(nxt), 'gradient_overlap': (('parameter gradients on a second stream beside the data-gradient chain, at most %.0f GB of operands held for it' % (pk.autograd.GRADIENT_OVERLAP_BYTES / 2 ** 30)) if pk.autograd.GRADIENT_OVERLAP else False), 'frames_batched': bool(step.batch_frames), 'attention_backward': ('stored pair tensors (%s form)' % pk.kernels.defaults().stored_attention_form) if args.no_checkpoint else 'recompute in backward (equal chunks of at most %d queries)' % pk.kernels.defaults().checkpoint_chunk,
             'peak_mem_gb': torch.cuda.max_memory_allocated() / 2 ** 30,
             'roofline': roof,
             'config': {'workload': 'CARLA-4D training step (BASELINE configs[4]): batch 1 per GPU, n_points=%d, %d x %d '

@@ -32,7 +32,7 @@ extern "C" {
 #define OCC4D_EINVAL (-1)   /* bad argument (maps to AssertionError / ValueError) */
 #define OCC4D_ELAUNCH (-2)  /* HIP launch failure */
 
-#define OCC4D_ABI_VERSION 3
+#define OCC4D_ABI_VERSION 4
 
 int occ4d_abi_version(void);
 const char* occ4d_last_error(void);
@@ -519,6 +519,8 @@ int occ4d_broadcast_rows_f32(const float* vec, float scale, int n, int d, float*
 #define OCC4D_PATH_BF16X6 64        /* opt-in, fp32-class: d = 416 attention GEMMs on 3-way split bf16 MFMAs, 6 partial products */
 #define OCC4D_PATH_BF16X6_TRUNK 128 /* opt-in, fp32-class: the decoder's 416-input Linear layers on the same split (csrc/trunk_bf16x6.hip) */
 #define OCC4D_PATH_FUSED_INTERP 32 /* A/B only (slower): lin_z table term of block i + 1 in block i's epilogue */
+#define OCC4D_PATH_SPLIT_F16 256    /* with OCC4D_PATH_BF16X6 / _TRUNK: the split is fp16 x 2 pieces, 3 partial products (round 6;
+                                     * half the matrix instructions; inference forwards only; |w| < 255, |activation| < 65504) */
 
 /* Stage packers as device kernels (layouts: occ4d_resblock_f32 / occ4d_resblock4_f32 / occ4d_pt_cross_attn16p_f32).
  * w: (n_out, 416) row-major with row stride ldw. */
@@ -584,6 +586,22 @@ int occ4d_rowlin_bf16x6_masked_f32(const float* x, int64_t ldx, float* y, int64_
                                    const float* b, int n_out, int relu_in, const float* res, int64_t ldr,
                                    int res_after_mask, const float* mask, int64_t ldm, int n, void* stream);
 int occ4d_debug_x6_stamps(unsigned long long* out, int n_words);   /* debug: phase time stamps (OCC4D_X6_STAMPS=1) */
+/* The same two kernels on v_mfma_f32_16x16x32_f16 with both operands split into TWO fp16 pieces, x = rn16(x) + rn16(x -
+ * rn16(x)) (+ <= 2^-23 |x|), three partial products a1 b1 + a1 b2 + a2 b1 accumulated in fp32 (csrc/bf16x6.hpp, round 6):
+ * half the matrix instructions of the bf16 scheme.  fp16's range is the contract: the packers store the pieces of w * 2^8
+ * (|w| < 255; weights below 2^-10 keep an absolute 2^-33), activations are split as they are (|x| < 65504; below 0.25 the
+ * second piece is an fp16 subnormal: absolute error <= 2^-25).  Inference forwards only (no masked / gradient variant).
+ * Same argument contracts as the _bf16x6 entry points; the packed streams are NOT interchangeable. */
+int64_t occ4d_pt_cross_attn_f16x3_stream_floats(void);
+int occ4d_pack_attn_f16x3_stream_f32(const float* w2, const float* wp, const float* p2, float* wstream, void* stream);
+int occ4d_pt_cross_attn_f16x3_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t q_stride, const float* apos,
+                                  int64_t a_stride, const int32_t* idx, const float* kt, int64_t ld_kt, const float* vtc,
+                                  int64_t ld_vt, const float* pos0_w, const float* pos0_b, const float* wstream, float* agg,
+                                  int64_t ld_agg, int n, int m, int k, int d, float divisor, void* stream);
+int64_t occ4d_rowlin_f16x3_packed_floats(int n_out);
+int occ4d_pack_rowlin_f16x3_f32(const float* w, int64_t ldw, int n_out, float* packed, void* stream);
+int occ4d_rowlin_f16x3_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed, const float* b,
+                           int n_out, int relu_in, const float* res, int64_t ldr, int n, void* stream);
 int occ4d_pt_cross_attn_bf16x6_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t q_stride, const float* apos,
                                    int64_t a_stride, const int32_t* idx, const float* kt, int64_t ld_kt, const float* vtc,
                                    int64_t ld_vt, const float* pos0_w, const float* pos0_b, const float* wstream, float* agg,

@@ -9,10 +9,11 @@ fallback.  ``configs`` is pure host code (named configurations, synthetic inputs
 """
 from . import configs  # noqa: F401
 from . import _lib  # noqa: F401
+from . import kernels  # noqa: F401   (`with occlusions4d_amd.kernels(precision='bf16x6'):` -- per-thread kernel selection)
 from . import ops  # noqa: F401
 from . import autograd  # noqa: F401
 from . import point_transformer_layer, modules, model, geometry, implicit, inference, distributed, training  # noqa: F401
 from . import evaluation  # noqa: F401
 
-__all__ = ['configs', 'ops', 'point_transformer_layer', 'modules', 'model', 'geometry', 'implicit',
+__all__ = ['configs', 'kernels', 'ops', 'point_transformer_layer', 'modules', 'model', 'geometry', 'implicit',
            'inference', 'distributed', 'autograd', 'training', 'evaluation']

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libocc4d.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OK, EINVAL, ELAUNCH = 0, -1, -2
 
@@ -31,6 +31,7 @@ class LinearArgs(C.Structure):
 
 # path-level entry points (include/occ4d.h, last section)
 PATH_DEFAULT, PATH_UNFUSED, PATH_FIRST_GEN, PATH_GENERIC_LINEAR, PATH_TRUNK4, PATH_FUSED_INTERP, PATH_BF16X6, PATH_BF16X6_TRUNK = 0, 1, 2, 8, 16, 32, 64, 128
+PATH_SPLIT_F16 = 256
 PROFILE_CROSS_ATTN, PROFILE_RESBLOCK, PROFILE_ROWLIN = 1, 2, 3
 MAX_BLOCKS, MAX_CROSS = 16, 4
 PROFILE_KINDS = {'cross_attn': PROFILE_CROSS_ATTN, 'resblock': PROFILE_RESBLOCK, 'rowlin': PROFILE_ROWLIN}
@@ -188,6 +189,13 @@ SIGNATURES = {
     'occ4d_pack_attn_bf16x6_stream_f32': (C.c_int, [_f, _f, _f, _f, _s]),
     'occ4d_pt_cross_attn_bf16x6_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, C.c_int64, _i, _f, C.c_int64, _f, C.c_int64,
                                                  _f, _f, _f, _f, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _s]),
+    'occ4d_pt_cross_attn_f16x3_stream_floats': (C.c_int64, []),
+    'occ4d_pack_attn_f16x3_stream_f32': (C.c_int, [_f, _f, _f, _f, _s]),
+    'occ4d_pt_cross_attn_f16x3_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, C.c_int64, _i, _f, C.c_int64, _f, C.c_int64,
+                                                _f, _f, _f, _f, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _s]),
+    'occ4d_rowlin_f16x3_packed_floats': (C.c_int64, [C.c_int]),
+    'occ4d_pack_rowlin_f16x3_f32': (C.c_int, [_f, C.c_int64, C.c_int, _f, _s]),
+    'occ4d_rowlin_f16x3_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, _f, C.c_int, C.c_int, _f, C.c_int64, C.c_int, _s]),
     'occ4d_pt_layer_prepared_floats': (C.c_int64, [_LW, C.c_int]),
     'occ4d_pt_layer_prepare_f32': (C.c_int, [_LW, _f, C.c_int, _s]),
     'occ4d_pt_layer_scene_floats': (C.c_int64, [_LW, C.c_int]),

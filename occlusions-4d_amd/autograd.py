@@ -12,6 +12,7 @@ import os
 import torch
 from torch.autograd import Function
 
+from . import kernels
 from . import ops
 
 # Training-path Linear layers with a 416-wide operand (the decoder trunk, the 416 -> 832 / 832 <- 416 layers of the
@@ -27,7 +28,14 @@ ROWLIN_HALF_CU = os.environ.get('OCC4D_TRAIN_ROWLIN_HALF_CU', '1') == '1'
 # Opt-in (round 5), fp32-class: the 416-input Linear layers of the training path -- forward, and the data gradients whose
 # reduction side is 416 wide -- on the split-precision row kernel (csrc/trunk_bf16x6.hip: bf16 x 3 pieces, 6 partial
 # products, fp32 accumulate).  Weight gradients stay on the fp32 MFMA kernels.  Same strict gradient tests.
-TRAIN_PRECISION = os.environ.get('OCC4D_TRAIN_PRECISION', 'f32')
+# Selected per call: kernels.Selection.train_precision (`with kernels.use(train_precision='bf16x6')`, default from
+# OCC4D_TRAIN_PRECISION); the Functions below carry the selection of their forward into their backward.
+
+
+def _x6():
+    return kernels.scope().train_precision == 'bf16x6'
+
+
 _PACKS = {}           # stage-packed copies of nn.Parameters only (small LRU); transient leaves are packed uncached
 _PACKS_MAX = 128
 _ZEROS = {}           # zero bias vectors, kept apart from the packs and created eagerly (never inside a capture)
@@ -223,7 +231,7 @@ def _linear_fwd(x, w, b, relu_in=False, relu_out=False, residual=None, transpose
     result is zeroed where mask <= 0 (the ReLU of a relu_in layer applied to its data gradient); `skip` is added AFTER the
     mask (the gradient of a skip connection around the layer: one launch on the half-CU row kernel)."""
     n_out, k = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
-    if (TRAIN_PRECISION == 'bf16x6' and k == ops.TRUNK_WIDTH and n_out in ops.X6_ROWLIN_WIDTHS and not relu_out
+    if (_x6() and k == ops.TRUNK_WIDTH and n_out in ops.X6_ROWLIN_WIDTHS and not relu_out
             and x.shape[0] >= 1024 and x.is_contiguous() and not (residual is not None and skip is not None)):
         res = residual if residual is not None else skip
         return ops.rowlin_bf16x6(x, None, b, relu_in=relu_in, res=res, packed=_packed(w, transposed, x6=True), mask=mask,
@@ -284,6 +292,7 @@ class FanOut:
         self.left, self.total = uses, None
 
 
+@kernels.carries_selection
 class LinearFn(Function):
     """y = [relu]( [relu](x) W^T + b ) + residual   (never relu_out together with residual)."""
 
@@ -333,6 +342,7 @@ def linear(x, lin, relu_in=False, relu_out=False, residual=None, fan=None):
     return LinearFn.apply(x, lin.weight, lin.bias, relu_in, relu_out, residual, fan)
 
 
+@kernels.carries_selection
 class ResBlockFn(Function):
     """y = x + W1 relu(W0 relu(x) + b0) + b1  (model/implicit.py:66-85 without shortcut, ReLU): the two Linear layers of a
     residual block as ONE autograd node, so that the skip connection's gradient is added in the epilogue of the last
@@ -452,6 +462,7 @@ def pair_mlp_fused_ok(aq, r, idx):
             and idx.numel() * 2 * d * 4 < 2 ** 32 and aq.shape[0] * aq.stride(0) * 4 < 2 ** 32)
 
 
+@kernels.carries_selection
 class PairMlpFn(Function):
     """(logits, pe) of the merged-form layer from ONE kernel (ops.pt_pair_mlp), for the chain
         a = aq_i - kt_j + Wp r;  logits = W2 relu(a) [+ b2];  pe = P2 r + c2
@@ -464,7 +475,7 @@ class PairMlpFn(Function):
 
     @staticmethod
     def _packed_stream(W2, b2, wp, P2, c2):
-        x6 = TRAIN_PRECISION == 'bf16x6'
+        x6 = _x6()
         hit = PairMlpFn._stream
         if (hit is not None and hit[0] is W2 and hit[1] is wp and hit[2] is P2
                 and hit[3] == (W2._version, wp._version, P2._version, x6)):
@@ -476,7 +487,7 @@ class PairMlpFn(Function):
     @staticmethod
     def forward(ctx, aq, kt, r, wp, W2, b2, P2, c2, idx):
         stream = PairMlpFn._packed_stream(W2, b2, wp, P2, c2)
-        if TRAIN_PRECISION == 'bf16x6':
+        if _x6():
             a, logits, pe = ops.pt_pair_mlp_bf16x6(aq, kt, r, idx, c2, stream)
         else:
             a, logits, pe = ops.pt_pair_mlp(aq, kt, r, idx, c2, stream)

@@ -103,4 +103,105 @@ __device__ __forceinline__ unsigned piece16(float x, int p) {
   const float r2 = r1 - __uint_as_float(u & 0xffff0000u);
   return __float_as_uint(r2) >> 16;
 }
+// ----------------------------------------------------------------------------------------------------------------
+// The two split schemes as types (csrc/crossattn_bf16x6.hip and csrc/trunk_bf16x6.hip are templates over them).
+//   NP            pieces per operand = weight fragments per (tile, stage)
+//   Op            the NP operand register sets of one 16 x 32 activation tile (p[0] = leading piece)
+//   split8        eight fp32 of a lane -> Op
+//   mm_x2 / _b    all kept partial products of two row tiles against one shared weight tile, small terms first, the
+//                 two accumulators alternately (shared operand on the B / on the A side)
+//   mm_1          the same for one row tile
+//   piece         packer side: piece p of x * WSCALE as 16 bits
+//   WSCALE        power of two the packers multiply every weight with (exact); the kernels multiply their accumulators
+//                 with INV_WSCALE where they leave the matrix pipe
+// ----------------------------------------------------------------------------------------------------------------
+struct SplitBf16x6 {
+  static constexpr int NP = 3;
+  static constexpr float WSCALE = 1.f, INV_WSCALE = 1.f;
+  struct Op { u32x4 p[3]; };
+  static __device__ __forceinline__ Op split8(const f32x4 a, const f32x4 b) {
+    const Split s = ::split8(a, b);
+    return Op{{s.h, s.m, s.l}};
+  }
+  static __device__ __forceinline__ void mm_x2(const Op& a0, const Op& a1, const u32x4 (&b)[3], f32x4& c0, f32x4& c1) {
+    mm6x2(Split{a0.p[0], a0.p[1], a0.p[2]}, Split{a1.p[0], a1.p[1], a1.p[2]}, b[0], b[1], b[2], c0, c1);
+  }
+  static __device__ __forceinline__ void mm_x2_b(const u32x4 (&a)[3], const Op& b0, const Op& b1, f32x4& c0, f32x4& c1) {
+    mm6x2_b(a[0], a[1], a[2], Split{b0.p[0], b0.p[1], b0.p[2]}, Split{b1.p[0], b1.p[1], b1.p[2]}, c0, c1);
+  }
+  static __device__ __forceinline__ f32x4 mm_1(const Op& a, const u32x4 (&b)[3], f32x4 e) {
+    e = mm(a.p[2], b[0], e);
+    e = mm(a.p[0], b[2], e);
+    e = mm(a.p[1], b[1], e);
+    e = mm(a.p[1], b[0], e);
+    e = mm(a.p[0], b[1], e);
+    e = mm(a.p[0], b[0], e);
+    return e;
+  }
+  static __device__ __forceinline__ unsigned piece(float x, int p) { return piece16(x, p); }
+};
+
+// fp16 x 2 pieces, 3 partial products (round 6):
+//     x = x1 + x2 + e,  x1 = rn_f16(x),  x2 = rn_f16(x - x1),  |e| <= 2^-23 |x|   (x - x1 is exact in fp32; 11 + 11 bits + the
+//         two round-to-nearest half bits; fp32 itself keeps 24)
+//     a b ~ a1 b1 + a1 b2 + a2 b1                                      (dropped: a2 b2 <= 2^-22 |a b|, typically 2^-25)
+// HALF the matrix instructions of the bf16 scheme (v_mfma_f32_16x16x32_f16 runs at the bf16 rate) and a third of its
+// split arithmetic (4 VALU per element pair: v_cvt_pk_f16_f32, 2 x v_fma_mix_f32, v_cvt_pk_f16_f32).  The price is
+// fp16's RANGE, which the bf16 pieces do not have to think about:
+//   * weights are packed as the pieces of w * 2^8 (exact), so that the second piece of a weight of ordinary size
+//     (>= 2^-10) is a normal fp16 number; smaller ones are kept to an absolute 2^-33; |w| must stay below 255.
+//   * activations are split as they are: |x| must stay below 65504, and below |x| = 0.25 the second piece is an
+//     fp16 subnormal (gfx950's matrix pipe does not flush them): absolute error <= 2^-25 instead of 2^-23 |x|.
+// Forward passes only -- gradient magnitudes do not live in that window.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mmh(const u32x4 a, const u32x4 b, const f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void split2h(float x0, float x1, unsigned& h, unsigned& l) {
+  const f32x2 x = {x0, x1};
+  const unsigned hu = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2));     // v_cvt_pk_f16_f32 (rn)
+  float r0, r1;      // x - f32(x1) in ONE instruction per element (the compiler's own form is 2 cvt + 1 packed add)
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hu), "v"(x0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hu), "v"(x1));
+  const f32x2 r = {r0, r1};
+  h = hu;
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+struct SplitF16x3 {
+  static constexpr int NP = 2;
+  static constexpr float WSCALE = 256.f, INV_WSCALE = 1.f / 256.f;
+  struct Op { u32x4 p[2]; };
+  static __device__ __forceinline__ Op split8(const f32x4 a, const f32x4 b) {
+    unsigned h[4], l[4];
+    split2h(a.x, a.y, h[0], l[0]);
+    split2h(a.z, a.w, h[1], l[1]);
+    split2h(b.x, b.y, h[2], l[2]);
+    split2h(b.z, b.w, h[3], l[3]);
+    return Op{{u32x4{h[0], h[1], h[2], h[3]}, u32x4{l[0], l[1], l[2], l[3]}}};
+  }
+  static __device__ __forceinline__ void mm_x2(const Op& a0, const Op& a1, const u32x4 (&b)[2], f32x4& c0, f32x4& c1) {
+    c0 = mmh(a0.p[1], b[0], c0); c1 = mmh(a1.p[1], b[0], c1);
+    c0 = mmh(a0.p[0], b[1], c0); c1 = mmh(a1.p[0], b[1], c1);
+    c0 = mmh(a0.p[0], b[0], c0); c1 = mmh(a1.p[0], b[0], c1);
+  }
+  static __device__ __forceinline__ void mm_x2_b(const u32x4 (&a)[2], const Op& b0, const Op& b1, f32x4& c0, f32x4& c1) {
+    c0 = mmh(a[1], b0.p[0], c0); c1 = mmh(a[1], b1.p[0], c1);
+    c0 = mmh(a[0], b0.p[1], c0); c1 = mmh(a[0], b1.p[1], c1);
+    c0 = mmh(a[0], b0.p[0], c0); c1 = mmh(a[0], b1.p[0], c1);
+  }
+  static __device__ __forceinline__ f32x4 mm_1(const Op& a, const u32x4 (&b)[2], f32x4 e) {
+    e = mmh(a.p[1], b[0], e);
+    e = mmh(a.p[0], b[1], e);
+    e = mmh(a.p[0], b[0], e);
+    return e;
+  }
+  static __device__ __forceinline__ unsigned piece(float x, int p) {
+    const float xs = x * WSCALE;
+    const _Float16 h = (_Float16)xs;
+    if (p == 0) return (unsigned)__builtin_bit_cast(unsigned short, h);
+    const _Float16 l = (_Float16)(xs - (float)h);
+    return (unsigned)__builtin_bit_cast(unsigned short, l);
+  }
+};
 }  // namespace

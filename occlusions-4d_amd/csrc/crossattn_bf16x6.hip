@@ -48,13 +48,20 @@ constexpr int XHALF = XD / 2;             // channels per workgroup
 constexpr int XT = XHALF / 16;            // 13 channel tiles
 constexpr int XS = XHID / 32;             // 26 hidden stages of 32
 constexpr int XFW = 256;                  // u32 words per fragment image (64 lanes x 16 B)
-constexpr int XW2F = 3 * XT;              // 39 W2 fragments of a stage
-constexpr int XSF = XW2F + 6;             // + 2 x 3 Wp fragments = 45
-constexpr int XSTAGE = XSF * XFW;         // 11520 words = 46080 B
 constexpr int XNSTAGE = XS + 1;           // + the P2 stage
 constexpr int XWAVES = 8;
 constexpr int XTILES = 2 * XWAVES;        // 16 row tiles per workgroup
 constexpr int XQPB = XTILES + 2;          // 18 queries per workgroup: one per row tile + two spread over the tiles' rows 14, 15
+constexpr int XPART = XTILES * 3 * XHALF; // floats of the extra queries' partial softmaxes [tile 16][3][XHALF]
+// stage geometry of a split scheme S (S::NP pieces per operand: csrc/bf16x6.hpp)
+template <typename S> struct XG {
+  static constexpr int W2F = S::NP * XT;          // W2 fragments of a stage: 39 (bf16 x 3) / 26 (fp16 x 2)
+  static constexpr int SF = W2F + 2 * S::NP;      // + the merged Wp fragments of GEMM1: 45 / 30
+  static constexpr int STAGE = SF * XFW;          // words: 46080 B / 30720 B
+  static constexpr int PARTS = (SF + XWAVES - 1) / XWAVES;   // fragments a wave fetches per stage: 6 / 4
+  static constexpr bool PART_IN_RING = STAGE >= XPART;       // the partial softmaxes fit the oldest stage buffer
+  static_assert(PARTS <= 6, "the DMA slots sit behind channel tiles 0-5 and 7-12");
+};
 
 struct AttnX6Args {
   const float* aq; int64_t ld_aq;
@@ -64,7 +71,7 @@ struct AttnX6Args {
   const float* kt; int64_t ld_kt;
   const float* vt; int64_t ld_vt;         // Wv f + c2
   const float* P1; const float* c1;
-  const unsigned* wstream;                // [half][XNSTAGE][XSF][64 lanes][4 words]
+  const unsigned* wstream;                // [half][XNSTAGE][SF][64 lanes][4 words]
   float* agg; int64_t ld_agg;
   int N, M, K;
   float divisor;
@@ -76,11 +83,16 @@ struct AttnX6Args {
 // debug (OCC4D_X6_STAMPS=1): s_memtime at the phase boundaries of waves 0 and 4 of the first 1024 workgroups
 __device__ unsigned long long g_x6_stamps[1024 * 2 * 6];
 
-__global__ __launch_bounds__(512, 2) void cross_attn_bf16x6_kernel(const AttnX6Args a) {
+template <typename S>
+__global__ __launch_bounds__(512, 2) void cross_attn_split_kernel(const AttnX6Args a) {
+  using G = XG<S>;
+  using Op = typename S::Op;
+  constexpr int NP = S::NP, XW2F = G::W2F, XSF = G::SF, XSTAGE = G::STAGE, PARTS = G::PARTS;
   // a ring of three stage buffers: stage s lives in buffer s % 3
   __shared__ __attribute__((aligned(16))) unsigned buf0[XSTAGE];
   __shared__ __attribute__((aligned(16))) unsigned buf1[XSTAGE];
   __shared__ __attribute__((aligned(16))) unsigned buf2[XSTAGE];
+  __shared__ __attribute__((aligned(16))) float s_part_own[G::PART_IN_RING ? 4 : XPART];
   __shared__ __attribute__((aligned(16))) float s_p1[32 * 4];   // (P1[m][0..2], c1[m])
   __shared__ int s_idx[XQPB * 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -108,13 +120,13 @@ __global__ __launch_bounds__(512, 2) void cross_attn_bf16x6_kernel(const AttnX6A
   const bool grp_b = a.skew == 2 ? (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) != 0
                                  : (a.skew == 1 && wave >= 4);
 
-  // this wave's i-th fragment of a stage (six per wave and stage; the tail repeats fragment 44: same bytes, same place)
+  // this wave's i-th fragment of a stage (PARTS per wave and stage; the tail repeats the last fragment: same bytes, same place)
   auto dma_part = [&](int stage_no, const unsigned* dst, int i) {
     const int f = min(wave + XWAVES * i, XSF - 1);                                  // wave-uniform
     dma_frag_x(wst + (int64_t)stage_no * XSTAGE + f * XFW, lds_addr_x(dst) + (unsigned)f * (XFW * 4), lane16);
   };
 #pragma unroll
-  for (int i = 0; i < 6; ++i) dma_part(0, buf0, i);
+  for (int i = 0; i < PARTS; ++i) dma_part(0, buf0, i);
   if (tid < XQPB * 16) {
     const int q = min(q0 + (tid >> 4), a.N - 1);
     const int s = min(tid & 15, a.K - 1);
@@ -130,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void cross_attn_bf16x6_kernel(const AttnX6A
 
   // ---- this lane's pair of each row tile: column c < 14 = neighbour slot c of the tile's own query; c = 14, 15 = slots
   // 2 (tile % 7) + c - 14 of extra query tile / 7 (tiles 14, 15: dead rows)
-  Split rs[2];                            // r = relu(P1 d + c1), hidden-pos units 8 g + j, three pieces
+  Op rs[2];                               // r = relu(P1 d + c1), hidden-pos units 8 g + j, NP pieces
   unsigned aq_off[2], kt_off[2];
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
@@ -150,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void cross_attn_bf16x6_kernel(const AttnX6A
       const float v = fmaf(dz, w.z, fmaf(dy, w.y, dx * w.x)) + w.w;
       rr[j] = my_valid ? fmaxf(v, 0.f) : 0.f;
     }
-    rs[rt] = split8(f32x4{rr[0], rr[1], rr[2], rr[3]}, f32x4{rr[4], rr[5], rr[6], rr[7]});
+    rs[rt] = S::split8(f32x4{rr[0], rr[1], rr[2], rr[3]}, f32x4{rr[4], rr[5], rr[6], rr[7]});
     aq_off[rt] = (unsigned)(my_q * (int)a.ld_aq + 4 * g) * 4u;
     kt_off[rt] = (unsigned)(my_j * (int)a.ld_kt + 4 * g) * 4u;
   }
@@ -177,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void cross_attn_bf16x6_kernel(const AttnX6A
   ts[2] = __builtin_amdgcn_s_memtime();
   if (grp_b) {                                        // (A issues its part of stage 1 inside stage 0, tile by tile)
 #pragma unroll
-    for (int i = 0; i < 6; ++i) dma_part(1, buf1, i);
+    for (int i = 0; i < PARTS; ++i) dma_part(1, buf1, i);
   }
 
   // stage s from `cur`; group A issues its fragments of stage s + 1 (-> dA) behind tiles 0-5, group B its fragments of
@@ -190,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void cross_attn_bf16x6_kernel(const AttnX6A
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int u = 0; u < 2; ++u)
-        h[rt][u] = ia[rt][u] - ik[rt][u];
+        h[rt][u] = S::WSCALE == 1.f ? ia[rt][u] - ik[rt][u] : (ia[rt][u] - ik[rt][u]) * S::WSCALE;   // (Wp is packed * WSCALE)
     // next stage's slices (consumed at its top)
     const int sn = s + 1 < XS ? s + 1 : s;
 #pragma unroll
@@ -202,33 +214,36 @@ __global__ __launch_bounds__(512, 2) void cross_attn_bf16x6_kernel(const AttnX6A
       }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const u32x4 wh = *reinterpret_cast<const u32x4*>(f + (XW2F + 3 * u + 0) * XFW);
-      const u32x4 wm = *reinterpret_cast<const u32x4*>(f + (XW2F + 3 * u + 1) * XFW);
-      const u32x4 wl = *reinterpret_cast<const u32x4*>(f + (XW2F + 3 * u + 2) * XFW);
-      mm6x2_b(wh, wm, wl, rs[0], rs[1], h[0][u], h[1][u]);
-    }
-    // ---- ReLU + three-way split: GEMM2's A operand of both row tiles
-    Split hs[2];
+      u32x4 wf[NP];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) hs[rt] = split8(relu4x(h[rt][0]), relu4x(h[rt][1]));
-    // ---- GEMM2: 13 channel tiles x (3 fragment reads, 12 MFMAs)
-    u32x4 bh = *reinterpret_cast<const u32x4*>(f);
-    u32x4 bm = *reinterpret_cast<const u32x4*>(f + XFW);
-    u32x4 bl = *reinterpret_cast<const u32x4*>(f + 2 * XFW);
+      for (int p = 0; p < NP; ++p) wf[p] = *reinterpret_cast<const u32x4*>(f + (XW2F + NP * u + p) * XFW);
+      S::mm_x2_b(wf, rs[0], rs[1], h[0][u], h[1][u]);
+    }
+    // ---- ReLU + split: GEMM2's A operand of both row tiles
+    Op hs[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+      hs[rt] = S::WSCALE == 1.f ? S::split8(relu4x(h[rt][0]), relu4x(h[rt][1]))
+                                : S::split8(relu4x(h[rt][0] * S::INV_WSCALE), relu4x(h[rt][1] * S::INV_WSCALE));
+    // ---- GEMM2: 13 channel tiles x (NP fragment reads, 2 x (6 | 3) MFMAs)
+    u32x4 bn[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) bn[p] = *reinterpret_cast<const u32x4*>(f + p * XFW);
 #pragma unroll
     for (int t = 0; t < XT; ++t) {
-      const u32x4 ch = bh, cm = bm, cl = bl;
+      u32x4 bc[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) bc[p] = bn[p];
       if (t + 1 < XT) {
-        bh = *reinterpret_cast<const u32x4*>(f + (3 * (t + 1)) * XFW);
-        bm = *reinterpret_cast<const u32x4*>(f + (3 * (t + 1) + 1) * XFW);
-        bl = *reinterpret_cast<const u32x4*>(f + (3 * (t + 1) + 2) * XFW);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) bn[p] = *reinterpret_cast<const u32x4*>(f + (NP * (t + 1) + p) * XFW);
       }
-      if (t < 6) {
+      if (t < PARTS) {
         if (!grp_b && s + 1 < XNSTAGE) dma_part(s + 1, dA, t);
-      } else if (t > 6) {
+      } else if (t > 6 && t - 7 < PARTS) {
         if (grp_b && s + 2 < XNSTAGE) dma_part(s + 2, dB, t - 7);
       }
-      mm6x2(hs[0], hs[1], ch, cm, cl, acc[0][t], acc[1][t]);
+      S::mm_x2(hs[0], hs[1], bc, acc[0][t], acc[1][t]);
       if (t == 6 && grp_b) {
         dma_wait_x();
         __builtin_amdgcn_s_barrier();
@@ -256,10 +271,10 @@ __global__ __launch_bounds__(512, 2) void cross_attn_bf16x6_kernel(const AttnX6A
   // log2 domain, denominator, numerator) goes to LDS.  The partials live in buf0: its last content was stage 24, which
   // every wave has left before barrier 26 (group B is in the second half of stage 25 at that barrier, group A done).
   constexpr float LOG2E = 1.44269504088896f;
-  const float sc = LOG2E / a.divisor;
+  const float sc = LOG2E / a.divisor * S::INV_WSCALE;        // (the logits left the matrix pipe * WSCALE)
   const float NINF = -__builtin_inff();
   const unsigned* fp = buf2 + lane * 4;
-  float* const s_part = reinterpret_cast<float*>(buf0);          // [tile 16][3][XHALF]
+  float* const s_part = G::PART_IN_RING ? reinterpret_cast<float*>(buf0) : s_part_own;          // [tile 16][3][XHALF]
   const bool g3 = g == 3;
   const float own23 = g3 ? 0.f : 1.f;
 #pragma unroll
@@ -295,17 +310,10 @@ __global__ __launch_bounds__(512, 2) void cross_attn_bf16x6_kernel(const AttnX6A
 #pragma unroll
       for (int x = 0; x < 2; ++x) {
         const int t = x ? tB : tA;
-        const u32x4 ph = *reinterpret_cast<const u32x4*>(fp + (3 * t) * XFW);
-        const u32x4 pm = *reinterpret_cast<const u32x4*>(fp + (3 * t + 1) * XFW);
-        const u32x4 pl = *reinterpret_cast<const u32x4*>(fp + (3 * t + 2) * XFW);
-        f32x4 e = {0.f, 0.f, 0.f, 0.f};
-        e = mm(rs[rt].l, ph, e);
-        e = mm(rs[rt].h, pl, e);
-        e = mm(rs[rt].m, pm, e);
-        e = mm(rs[rt].m, ph, e);
-        e = mm(rs[rt].h, pm, e);
-        e = mm(rs[rt].h, ph, e);
-        pe[x] = e;
+        u32x4 pf[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) pf[p] = *reinterpret_cast<const u32x4*>(fp + (NP * t + p) * XFW);
+        pe[x] = S::mm_1(rs[rt], pf, f32x4{0.f, 0.f, 0.f, 0.f});
       }
       float am[2][4], val[2][4], m23[2], lm[2];
 #pragma unroll
@@ -314,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void cross_attn_bf16x6_kernel(const AttnX6A
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           am[x][i] = act[i] ? av[i] : NINF;
-          val[x][i] = pe[x][i] + vq[x][i];
+          val[x][i] = S::WSCALE == 1.f ? pe[x][i] + vq[x][i] : fmaf(pe[x][i], S::INV_WSCALE, vq[x][i]);
         }
         m23[x] = fmaxf(am[x][2], am[x][3]);
         lm[x] = fmaxf(fmaxf(am[x][0], am[x][1]), g3 ? NINF : m23[x]);   // rows 14, 15 are not this query's
@@ -398,8 +406,10 @@ __global__ __launch_bounds__(512, 2) void cross_attn_bf16x6_kernel(const AttnX6A
 }
 
 // ---- packer: reference-layout matrices -> the kernel's fragment stream (three bf16 truncation pieces per weight)
-__global__ void pack_attn_bf16x6_kernel(const float* __restrict__ w2, const float* __restrict__ wp, const float* __restrict__ p2,
-                                        unsigned* __restrict__ out) {
+template <typename S>
+__global__ void pack_attn_split_kernel(const float* __restrict__ w2, const float* __restrict__ wp, const float* __restrict__ p2,
+                                       unsigned* __restrict__ out) {
+  constexpr int NP = S::NP, XW2F = XG<S>::W2F, XSF = XG<S>::SF, XSTAGE = XG<S>::STAGE;
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t total = (int64_t)2 * XNSTAGE * XSTAGE;
   if (e >= total) return;
@@ -413,40 +423,40 @@ __global__ void pack_attn_bf16x6_kernel(const float* __restrict__ w2, const floa
     float v = 0.f;
     int p = 0;
     if (frag < XW2F) {
-      const int t = frag / 3;
-      p = frag % 3;
+      const int t = frag / NP;
+      p = frag % NP;
       const int ch = XHALF * half + 16 * t + c;
       if (stage < XS) v = w2[(int64_t)ch * XHID + 32 * stage + 16 * (j >> 2) + 4 * g + (j & 3)];
       else v = p2[ch * 32 + 8 * g + j];
     } else if (stage < XS) {
-      const int u = (frag - XW2F) / 3;
-      p = (frag - XW2F) % 3;
+      const int u = (frag - XW2F) / NP;
+      p = (frag - XW2F) % NP;
       v = wp[(32 * stage + 16 * u + c) * 32 + 8 * g + j];      // A operand: row = lane & 15 = hidden unit
     }
-    res |= piece16(v, p) << (16 * q);
+    res |= S::piece(v, p) << (16 * q);
   }
   out[e] = res;
 }
 
 }  // namespace
 
-extern "C" int64_t occ4d_pt_cross_attn_bf16x6_stream_floats(void) { return (int64_t)2 * XNSTAGE * XSTAGE; }
+namespace {
+template <typename S> int64_t stream_floats() { return (int64_t)2 * XNSTAGE * XG<S>::STAGE; }
 
-extern "C" int occ4d_pack_attn_bf16x6_stream_f32(const float* w2, const float* wp, const float* p2, float* wstream,
-                                                 void* stream) {
-  OCC4D_REQUIRE(w2 && wp && p2 && wstream, "occ4d_pack_attn_bf16x6_stream_f32: null pointer");
-  const int64_t total = (int64_t)2 * XNSTAGE * XSTAGE;
-  pack_attn_bf16x6_kernel<<<occ4d::cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(w2, wp, p2,
+template <typename S>
+int pack_stream(const char* who, const float* w2, const float* wp, const float* p2, float* wstream, void* stream) {
+  OCC4D_REQUIRE(w2 && wp && p2 && wstream, "%s: null pointer", who);
+  const int64_t total = stream_floats<S>();
+  pack_attn_split_kernel<S><<<occ4d::cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(w2, wp, p2,
                                                                                       reinterpret_cast<unsigned*>(wstream));
-  return occ4d::check_launch("occ4d_pack_attn_bf16x6_stream_f32");
+  return occ4d::check_launch(who);
 }
 
-extern "C" int occ4d_pt_cross_attn_bf16x6_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t q_stride,
-                                              const float* apos, int64_t a_stride, const int32_t* idx, const float* kt,
-                                              int64_t ld_kt, const float* vtc, int64_t ld_vt, const float* pos0_w,
-                                              const float* pos0_b, const float* wstream, float* agg, int64_t ld_agg, int n,
-                                              int m, int k, int d, float divisor, void* stream) {
-  const char* who = "occ4d_pt_cross_attn_bf16x6_f32";
+template <typename S>
+int launch_attn(const char* who, const float* aq, int64_t ld_aq, const float* qpos, int64_t q_stride, const float* apos,
+                int64_t a_stride, const int32_t* idx, const float* kt, int64_t ld_kt, const float* vtc, int64_t ld_vt,
+                const float* pos0_w, const float* pos0_b, const float* wstream, float* agg, int64_t ld_agg, int n, int m,
+                int k, int d, float divisor, void* stream) {
   OCC4D_REQUIRE(d == XD, "%s: built for d = %d, got %d", who, XD, d);
   OCC4D_REQUIRE(k >= 1 && k <= 14 && m >= 1 && n >= 0, "%s: k = %d (1 .. 14), m = %d, n = %d", who, k, m, n);
   OCC4D_REQUIRE(aq && qpos && apos && idx && kt && vtc && pos0_w && pos0_b && wstream && agg, "%s: null pointer", who);
@@ -466,8 +476,38 @@ extern "C" int occ4d_pt_cross_attn_bf16x6_f32(const float* aq, int64_t ld_aq, co
   a.stamps = stamps;
   a.groups = (int)occ4d::cdiv(n, XQPB);
   a.per = (int)occ4d::cdiv(a.groups, 4);
-  cross_attn_bf16x6_kernel<<<8 * a.per, 512, 0, (hipStream_t)stream>>>(a);
+  cross_attn_split_kernel<S><<<8 * a.per, 512, 0, (hipStream_t)stream>>>(a);
   return occ4d::check_launch(who);
+}
+}  // namespace
+
+extern "C" int64_t occ4d_pt_cross_attn_bf16x6_stream_floats(void) { return stream_floats<SplitBf16x6>(); }
+extern "C" int64_t occ4d_pt_cross_attn_f16x3_stream_floats(void) { return stream_floats<SplitF16x3>(); }
+
+extern "C" int occ4d_pack_attn_bf16x6_stream_f32(const float* w2, const float* wp, const float* p2, float* wstream,
+                                                 void* stream) {
+  return pack_stream<SplitBf16x6>("occ4d_pack_attn_bf16x6_stream_f32", w2, wp, p2, wstream, stream);
+}
+extern "C" int occ4d_pack_attn_f16x3_stream_f32(const float* w2, const float* wp, const float* p2, float* wstream,
+                                                void* stream) {
+  return pack_stream<SplitF16x3>("occ4d_pack_attn_f16x3_stream_f32", w2, wp, p2, wstream, stream);
+}
+
+extern "C" int occ4d_pt_cross_attn_bf16x6_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t q_stride,
+                                              const float* apos, int64_t a_stride, const int32_t* idx, const float* kt,
+                                              int64_t ld_kt, const float* vtc, int64_t ld_vt, const float* pos0_w,
+                                              const float* pos0_b, const float* wstream, float* agg, int64_t ld_agg, int n,
+                                              int m, int k, int d, float divisor, void* stream) {
+  return launch_attn<SplitBf16x6>("occ4d_pt_cross_attn_bf16x6_f32", aq, ld_aq, qpos, q_stride, apos, a_stride, idx, kt, ld_kt,
+                                  vtc, ld_vt, pos0_w, pos0_b, wstream, agg, ld_agg, n, m, k, d, divisor, stream);
+}
+extern "C" int occ4d_pt_cross_attn_f16x3_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t q_stride,
+                                             const float* apos, int64_t a_stride, const int32_t* idx, const float* kt,
+                                             int64_t ld_kt, const float* vtc, int64_t ld_vt, const float* pos0_w,
+                                             const float* pos0_b, const float* wstream, float* agg, int64_t ld_agg, int n,
+                                             int m, int k, int d, float divisor, void* stream) {
+  return launch_attn<SplitF16x3>("occ4d_pt_cross_attn_f16x3_f32", aq, ld_aq, qpos, q_stride, apos, a_stride, idx, kt, ld_kt,
+                                 vtc, ld_vt, pos0_w, pos0_b, wstream, agg, ld_agg, n, m, k, d, divisor, stream);
 }
 
 // debug: the phase stamps of the last launch (OCC4D_X6_STAMPS=1): out[(workgroup * 2 + wave / 4) * 6 + i]

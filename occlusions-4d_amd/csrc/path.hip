@@ -187,12 +187,26 @@ int lin(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* b
 
 bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 
+// the split-precision row kernel in either scheme (csrc/trunk_bf16x6.hip): bf16 x 3 pieces / fp16 x 2 pieces
+int64_t split_packed_floats(bool f16, int n_out) {
+  return f16 ? occ4d_rowlin_f16x3_packed_floats(n_out) : occ4d_rowlin_bf16x6_packed_floats(n_out);
+}
+int split_pack_rowlin(bool f16, const float* w, int64_t ldw, int n_out, float* packed, hipStream_t st) {
+  return f16 ? occ4d_pack_rowlin_f16x3_f32(w, ldw, n_out, packed, st) : occ4d_pack_rowlin_bf16x6_f32(w, ldw, n_out, packed, st);
+}
+int split_rowlin(bool f16, const float* x, int64_t ldx, float* y, int64_t ldy, const float* wpk, const float* b, int n_out,
+                 int relu_in, const float* res, int64_t ldr, int n, hipStream_t st) {
+  return f16 ? occ4d_rowlin_f16x3_f32(x, ldx, y, ldy, wpk, b, n_out, relu_in, res, ldr, n, st)
+             : occ4d_rowlin_bf16x6_f32(x, ldx, y, ldy, wpk, b, n_out, relu_in, res, ldr, n, st);
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // one vector-attention layer (+ optional layer1 / layer3 of the PointTransformerBlock around it)
 // ----------------------------------------------------------------------------------------------------------------
 struct LayerLayout {
   int D, D2, h, Kq;                 // Kq: input width of the merged query projection (d_in when layer1 is folded in)
   bool fold_pre, fused16p, fused_first, fused_self16, bf16x6, wq_rows, w3_rows, trunk4, x6rows;
+  bool f16;                         // the split kernels' scheme: fp16 x 2 pieces instead of bf16 x 3 (OCC4D_PATH_SPLIT_F16)
   int64_t wq, bq, wk, wp, wq_packed, stream, stream6, w3_packed, wq_x6, w3_x6, scratch, total;
   int64_t s_A, s_B, s_C, s_C2, s_v, s_bq;      // doubles, inside the scratch region
 };
@@ -223,6 +237,7 @@ LayerLayout layer_layout(const occ4d_pt_layer_weights& w, int flags) {
   L.Kq = L.fold_pre ? w.d_in : L.D;
   const bool fusable = (L.D == 288 || L.D == 416) && L.h == 32 && !(flags & OCC4D_PATH_UNFUSED);
   L.bf16x6 = fusable && L.D == 416 && (flags & OCC4D_PATH_BF16X6) && !(flags & OCC4D_PATH_FIRST_GEN);
+  L.f16 = flags & OCC4D_PATH_SPLIT_F16;
   L.fused16p = fusable && L.D == 416 && !L.bf16x6 && !(flags & OCC4D_PATH_FIRST_GEN);
   L.fused_first = fusable && !L.fused16p && !L.bf16x6;
   L.fused_self16 = L.h == 32 && L.D % 4 == 0 && L.D <= 288 && !(flags & OCC4D_PATH_UNFUSED);   // (used when k == 16)
@@ -242,10 +257,10 @@ LayerLayout layer_layout(const occ4d_pt_layer_weights& w, int flags) {
   // split-precision trunk rows (csrc/trunk_bf16x6.hip): the merged query projection and layer3 of a d = 416 cross layer
   L.x6rows = (flags & OCC4D_PATH_BF16X6_TRUNK) && L.wq_rows && L.w3_rows && !L.trunk4;
   L.wq_packed = L.wq_rows ? take(packed(2 * L.D)) : -1;
-  L.wq_x6 = L.x6rows ? take(occ4d_rowlin_bf16x6_packed_floats(2 * L.D)) : -1;
-  L.w3_x6 = L.x6rows ? take(occ4d_rowlin_bf16x6_packed_floats(w.d_out)) : -1;
+  L.wq_x6 = L.x6rows ? take(split_packed_floats(L.f16, 2 * L.D)) : -1;
+  L.w3_x6 = L.x6rows ? take(split_packed_floats(L.f16, w.d_out)) : -1;
   L.stream = L.fused16p ? take(occ4d_pt_cross_attn16p_stream_floats()) : -1;
-  L.stream6 = L.bf16x6 ? take(occ4d_pt_cross_attn_bf16x6_stream_floats()) : -1;
+  L.stream6 = L.bf16x6 ? take(L.f16 ? occ4d_pt_cross_attn_f16x3_stream_floats() : occ4d_pt_cross_attn_bf16x6_stream_floats()) : -1;
   L.w3_packed = L.w3_rows ? take(packed(w.d_out)) : -1;
   // fp64 scratch (doubles): A = W1, B = right factor, C = W1 Wq, C2 = C L1, v / bq vectors
   int64_t d = 0;
@@ -295,11 +310,13 @@ int layer_prepare(const occ4d_pt_layer_weights& w, const LayerLayout& L, float* 
     else TRY(occ4d_pack_trunk_rows_f32(prep + L.wq, L.Kq, 2 * D, prep + L.wq_packed, st));
   }
   if (L.x6rows) {
-    TRY(occ4d_pack_rowlin_bf16x6_f32(prep + L.wq, L.Kq, 2 * D, prep + L.wq_x6, st));
-    TRY(occ4d_pack_rowlin_bf16x6_f32(w.post_w, D, w.d_out, prep + L.w3_x6, st));
+    TRY(split_pack_rowlin(L.f16, prep + L.wq, L.Kq, 2 * D, prep + L.wq_x6, st));
+    TRY(split_pack_rowlin(L.f16, w.post_w, D, w.d_out, prep + L.w3_x6, st));
   }
   if (L.fused16p) TRY(occ4d_pack_attn16p_stream_f32(w.attn2_w, prep + L.wp, w.pos2_w, prep + L.stream, st));
-  if (L.bf16x6) TRY(occ4d_pack_attn_bf16x6_stream_f32(w.attn2_w, prep + L.wp, w.pos2_w, prep + L.stream6, st));
+  if (L.bf16x6)
+    TRY(L.f16 ? occ4d_pack_attn_f16x3_stream_f32(w.attn2_w, prep + L.wp, w.pos2_w, prep + L.stream6, st)
+              : occ4d_pack_attn_bf16x6_stream_f32(w.attn2_w, prep + L.wp, w.pos2_w, prep + L.stream6, st));
   if (L.w3_rows) {
     if (L.trunk4) TRY(occ4d_pack_trunk4_rows_f32(w.post_w, D, w.d_out, prep + L.w3_packed, st));
     else TRY(occ4d_pack_trunk_rows_f32(w.post_w, D, w.d_out, prep + L.w3_packed, st));
@@ -337,10 +354,10 @@ int rowlin_any(bool trunk4, const float* x, int64_t ldx, float* y, int64_t ldy, 
   return rc;
 }
 
-int rowlin_x6(const float* x, int64_t ldx, float* y, int64_t ldy, const float* wpk, const float* b, int n_out, int relu_in,
-              const float* res, int64_t ldr, int n, const Events& E, hipStream_t st) {
+int rowlin_x6(bool f16, const float* x, int64_t ldx, float* y, int64_t ldy, const float* wpk, const float* b, int n_out,
+              int relu_in, const float* res, int64_t ldr, int n, const Events& E, hipStream_t st) {
   E.before(OCC4D_PROFILE_ROWLIN);
-  const int rc = occ4d_rowlin_bf16x6_f32(x, ldx, y, ldy, wpk, b, n_out, relu_in, res, ldr, n, st);
+  const int rc = split_rowlin(f16, x, ldx, y, ldy, wpk, b, n_out, relu_in, res, ldr, n, st);
   E.after(OCC4D_PROFILE_ROWLIN);
   return rc;
 }
@@ -410,7 +427,7 @@ int layer_forward(const occ4d_pt_layer_weights& w, const LayerLayout& L, const f
       float* ab = ws.take((int64_t)c * 2 * D);
       if (!dry) {
         if (L.x6rows)
-          TRY(rowlin_x6(x + (int64_t)lo * ldx, ldx, ab, 2 * D, prep + L.wq_x6, prep + L.bq, 2 * D, 0, nullptr, 0, c, E, st));
+          TRY(rowlin_x6(L.f16, x + (int64_t)lo * ldx, ldx, ab, 2 * D, prep + L.wq_x6, prep + L.bq, 2 * D, 0, nullptr, 0, c, E, st));
         else if (L.wq_rows)
           TRY(rowlin_any(L.trunk4, x + (int64_t)lo * ldx, ldx, ab, 2 * D, prep + L.wq_packed, prep + L.bq, 2 * D, 0, nullptr, 0,
                          c, E, st));
@@ -425,7 +442,10 @@ int layer_forward(const occ4d_pt_layer_weights& w, const LayerLayout& L, const f
       if (!dry) {
         E.before(OCC4D_PROFILE_CROSS_ATTN);
         int rc;
-        if (L.bf16x6)
+        if (L.bf16x6 && L.f16)
+          rc = occ4d_pt_cross_attn_f16x3_f32(aq, 2 * D, qp, ps, pos2, p2s, idx, kt, 2 * D, vtc, D, w.pos0_w, w.pos0_b,
+                                             prep + L.stream6, agg_c, ld_agg, c, m, k, D, divisor, st);
+        else if (L.bf16x6)
           rc = occ4d_pt_cross_attn_bf16x6_f32(aq, 2 * D, qp, ps, pos2, p2s, idx, kt, 2 * D, vtc, D, w.pos0_w, w.pos0_b,
                                               prep + L.stream6, agg_c, ld_agg, c, m, k, D, divisor, st);
         else if (L.fused16p)
@@ -465,7 +485,7 @@ int layer_forward(const occ4d_pt_layer_weights& w, const LayerLayout& L, const f
   }
   if (w.post_w && !dry) {
     if (L.x6rows)
-      TRY(rowlin_x6(agg, D, out, ldo, prep + L.w3_x6, w.post_b, w.d_out, 0, x, ldx, n, E, st));
+      TRY(rowlin_x6(L.f16, agg, D, out, ldo, prep + L.w3_x6, w.post_b, w.d_out, 0, x, ldx, n, E, st));
     else if (L.w3_rows)
       TRY(rowlin_any(L.trunk4, agg, D, out, ldo, prep + L.w3_packed, w.post_b, w.d_out, 0, x, ldx, n, E, st));
     else
@@ -482,6 +502,7 @@ struct DecoderLayout {
   int H, P, P4, dg, E, nB, nC;
   bool trunk, trunk4, resblock;              // row-resident Linear kernels usable / half-CU variant / fused residual block
   bool x6trunk;                              // residual blocks as two split-precision launches (csrc/trunk_bf16x6.hip)
+  bool f16;                                  // ... on the fp16 two-piece scheme (OCC4D_PATH_SPLIT_F16)
   int64_t w0p[OCC4D_MAX_BLOCKS], w1p[OCC4D_MAX_BLOCKS];
   int64_t w0x[OCC4D_MAX_BLOCKS], w1x[OCC4D_MAX_BLOCKS];
   int64_t cross[OCC4D_MAX_CROSS];
@@ -534,14 +555,15 @@ DecoderLayout decoder_layout(const occ4d_decoder_weights& w, int flags) {
   L.trunk4 = flags & OCC4D_PATH_TRUNK4;
   L.resblock = L.trunk && w.activation == 0;
   L.x6trunk = L.resblock && !L.trunk4 && (flags & OCC4D_PATH_BF16X6_TRUNK);
+  L.f16 = flags & OCC4D_PATH_SPLIT_F16;
   int64_t o = 0;
   auto take = [&](int64_t n) { const int64_t at = o; o += up(n); return at; };
   const int64_t pk = L.trunk4 ? occ4d_trunk4_packed_floats(TRUNK) : occ4d_trunk_packed_floats(TRUNK);
   for (int i = 0; i < L.nB; ++i) {
     L.w0p[i] = L.resblock ? take(pk) : -1;
     L.w1p[i] = L.resblock ? take(pk) : -1;
-    L.w0x[i] = L.x6trunk ? take(occ4d_rowlin_bf16x6_packed_floats(TRUNK)) : -1;
-    L.w1x[i] = L.x6trunk ? take(occ4d_rowlin_bf16x6_packed_floats(TRUNK)) : -1;
+    L.w0x[i] = L.x6trunk ? take(split_packed_floats(L.f16, TRUNK)) : -1;
+    L.w1x[i] = L.x6trunk ? take(split_packed_floats(L.f16, TRUNK)) : -1;
   }
   for (int j = 0; j < L.nC; ++j) {
     L.cl[j] = layer_layout(w.cross[j], flags);
@@ -639,8 +661,8 @@ int decoder_forward(const occ4d_decoder_weights& w, const DecoderLayout& L, cons
         if (L.x6trunk) {
           // h = fc_0(relu(x)); x = x + fc_1(relu(h)): two split-precision launches, h through the workspace
           E.before(OCC4D_PROFILE_RESBLOCK);
-          int rc = occ4d_rowlin_bf16x6_f32(x, ldx, hbuf, H, prep + L.w0x[i], w.fc0_b[i], H, 1, nullptr, 0, c, st);
-          if (!rc) rc = occ4d_rowlin_bf16x6_f32(hbuf, H, x, ldx, prep + L.w1x[i], w.fc1_b[i], H, 1, x, ldx, c, st);
+          int rc = split_rowlin(L.f16, x, ldx, hbuf, H, prep + L.w0x[i], w.fc0_b[i], H, 1, nullptr, 0, c, st);
+          if (!rc) rc = split_rowlin(L.f16, hbuf, H, x, ldx, prep + L.w1x[i], w.fc1_b[i], H, 1, x, ldx, c, st);
           E.after(OCC4D_PROFILE_RESBLOCK);
           TRY(rc);
         } else if (L.resblock) {
@@ -821,8 +843,8 @@ extern "C" int occ4d_decoder_prepare_f32(const occ4d_decoder_weights* w, float* 
     }
   }
   for (int i = 0; i < L.nB && L.x6trunk; ++i) {
-    TRY(occ4d_pack_rowlin_bf16x6_f32(w->fc0_w[i], TRUNK, TRUNK, prepared + L.w0x[i], st));
-    TRY(occ4d_pack_rowlin_bf16x6_f32(w->fc1_w[i], TRUNK, TRUNK, prepared + L.w1x[i], st));
+    TRY(split_pack_rowlin(L.f16, w->fc0_w[i], TRUNK, TRUNK, prepared + L.w0x[i], st));
+    TRY(split_pack_rowlin(L.f16, w->fc1_w[i], TRUNK, TRUNK, prepared + L.w1x[i], st));
   }
   for (int j = 0; j < L.nC; ++j) TRY(layer_prepare(w->cross[j], L.cl[j], prepared + L.cross[j], st));
   return OCC4D_OK;

@@ -22,15 +22,20 @@ constexpr int YKS = YK / 32;              // 13 stages
 constexpr int YCB = 208;                  // output channels per workgroup
 constexpr int YT = YCB / 16;              // 13 channel tiles
 constexpr int YFW = 256;                  // u32 words per fragment image
-constexpr int YSF = 3 * YT;               // 39 fragments per stage
-constexpr int YSTAGE = YSF * YFW;         // 9984 words = 39936 B
 constexpr int YWAVES = 8;
 constexpr int YROWS = 32 * YWAVES;        // 256 rows per workgroup
+// stage geometry of a split scheme S (csrc/bf16x6.hpp)
+template <typename S> struct YG {
+  static constexpr int SF = S::NP * YT;                       // fragments per stage: 39 (bf16 x 3) / 26 (fp16 x 2)
+  static constexpr int STAGE = SF * YFW;                      // words: 39936 B / 26624 B
+  static constexpr int PARTS = (SF + YWAVES - 1) / YWAVES;    // fragments a wave fetches per stage: 5 / 4
+  static_assert(PARTS <= 5, "the DMA slots sit behind channel tiles 0-4 and 7-11");
+};
 
 struct RowlinX6Args {
   const float* x; int64_t ldx;
   float* y; int64_t ldy;
-  const unsigned* wstream;                // [N / 208][13 stages][39][64 lanes][4 words]
+  const unsigned* wstream;                // [N / 208][13 stages][SF][64 lanes][4 words]
   const float* bias;
   const float* res; int64_t ldr;
   int n, nblk;                            // rows; channel blocks (N / 208)
@@ -39,8 +44,10 @@ struct RowlinX6Args {
   int res_post;                           // with a mask: res is added AFTER the mask (a skip connection's gradient)
 };
 
-template <bool RELU_IN>
-__global__ __launch_bounds__(512, 2) void rowlin_bf16x6_kernel(const RowlinX6Args a) {
+template <typename S, bool RELU_IN>
+__global__ __launch_bounds__(512, 2) void rowlin_split_kernel(const RowlinX6Args a) {
+  using Op = typename S::Op;
+  constexpr int NP = S::NP, YSF = YG<S>::SF, YSTAGE = YG<S>::STAGE, PARTS = YG<S>::PARTS;
   __shared__ __attribute__((aligned(16))) unsigned buf0[YSTAGE];
   __shared__ __attribute__((aligned(16))) unsigned buf1[YSTAGE];
   __shared__ __attribute__((aligned(16))) unsigned buf2[YSTAGE];
@@ -57,13 +64,13 @@ __global__ __launch_bounds__(512, 2) void rowlin_bf16x6_kernel(const RowlinX6Arg
   const unsigned lane16 = lane * 16;
   const bool grp_b = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) != 0;   // (see crossattn_bf16x6.hip)
 
-  // this wave's i-th fragment of a stage (five per wave and stage; the tail repeats fragment 38)
+  // this wave's i-th fragment of a stage (PARTS per wave and stage; the tail repeats the last fragment)
   auto dma_part = [&](int stage_no, const unsigned* dst, int i) {
     const int f = min(wave + YWAVES * i, YSF - 1);
     dma_frag_x(wst + (int64_t)stage_no * YSTAGE + f * YFW, lds_addr_x(dst) + (unsigned)f * (YFW * 4), lane16);
   };
 #pragma unroll
-  for (int i = 0; i < 5; ++i) dma_part(0, buf0, i);
+  for (int i = 0; i < PARTS; ++i) dma_part(0, buf0, i);
 
   // this lane's operand rows: row tile rt, row c; k = 32 ks + 8 g + j
   const float* xrow[2];
@@ -84,15 +91,15 @@ __global__ __launch_bounds__(512, 2) void rowlin_bf16x6_kernel(const RowlinX6Arg
   __builtin_amdgcn_s_barrier();                       // barrier 0: stage 0 is complete
   if (grp_b) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) dma_part(1, buf1, i);
+    for (int i = 0; i < PARTS; ++i) dma_part(1, buf1, i);
   }
 
   auto stage = [&](const int s, const unsigned* __restrict__ cur, const unsigned* dA, const unsigned* dB) {
     const unsigned* f = cur + lane * 4;
-    Split xs[2];
+    Op xs[2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
-      xs[rt] = RELU_IN ? split8(relu4x(xa[rt][0]), relu4x(xa[rt][1])) : split8(xa[rt][0], xa[rt][1]);
+      xs[rt] = RELU_IN ? S::split8(relu4x(xa[rt][0]), relu4x(xa[rt][1])) : S::split8(xa[rt][0], xa[rt][1]);
     const int sn = s + 1 < YKS ? s + 1 : s;           // next stage's inputs (consumed at its top)
 #ifndef OCC4D_X6T_ABL_NOX                              // (timing-only ablations: profiles/time_rowlin_x6.py)
 #pragma unroll
@@ -101,23 +108,24 @@ __global__ __launch_bounds__(512, 2) void rowlin_bf16x6_kernel(const RowlinX6Arg
       xa[rt][1] = *reinterpret_cast<const f32x4*>(xrow[rt] + 32 * sn + 4);
     }
 #endif
-    u32x4 bh = *reinterpret_cast<const u32x4*>(f);
-    u32x4 bm = *reinterpret_cast<const u32x4*>(f + YFW);
-    u32x4 bl = *reinterpret_cast<const u32x4*>(f + 2 * YFW);
+    u32x4 bn[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) bn[p] = *reinterpret_cast<const u32x4*>(f + p * YFW);
 #pragma unroll
     for (int t = 0; t < YT; ++t) {
-      const u32x4 ch = bh, cm = bm, cl = bl;
+      u32x4 bc[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) bc[p] = bn[p];
       if (t + 1 < YT) {
-        bh = *reinterpret_cast<const u32x4*>(f + (3 * (t + 1)) * YFW);
-        bm = *reinterpret_cast<const u32x4*>(f + (3 * (t + 1) + 1) * YFW);
-        bl = *reinterpret_cast<const u32x4*>(f + (3 * (t + 1) + 2) * YFW);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) bn[p] = *reinterpret_cast<const u32x4*>(f + (NP * (t + 1) + p) * YFW);
       }
-      if (t < 5) {
+      if (t < PARTS) {
         if (!grp_b && s + 1 < YKS) dma_part(s + 1, dA, t);
-      } else if (t > 6 && t < 12) {
+      } else if (t > 6 && t - 7 < PARTS) {
         if (grp_b && s + 2 < YKS) dma_part(s + 2, dB, t - 7);
       }
-      mm6x2_b(ch, cm, cl, xs[0], xs[1], acc[0][t], acc[1][t]);      // (weights on the A side: TRANSPOSED tiles)
+      S::mm_x2_b(bc, xs[0], xs[1], acc[0][t], acc[1][t]);           // (weights on the A side: TRANSPOSED tiles)
       if (t == 6 && grp_b) {
         dma_wait_x();
         __builtin_amdgcn_s_barrier();
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void rowlin_bf16x6_kernel(const RowlinX6Arg
       for (int t = 0; t < YT; ++t) mk[t] = *reinterpret_cast<const f32x4*>(a.mask + (int64_t)rowc * a.ldm + ch0 + 16 * t);
 #pragma unroll
       for (int t = 0; t < YT; ++t) {
-        f32x4 v = acc[rt][t];
+        f32x4 v = S::WSCALE == 1.f ? acc[rt][t] : acc[rt][t] * S::INV_WSCALE;
         if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + ch0 + 16 * t);
         if (a.res && !a.res_post) v += r[t];
         v.x = mk[t].x > 0.f ? v.x : 0.f; v.y = mk[t].y > 0.f ? v.y : 0.f;
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void rowlin_bf16x6_kernel(const RowlinX6Arg
     }
 #pragma unroll
     for (int t = 0; t < YT; ++t) {
-      f32x4 v = acc[rt][t];
+      f32x4 v = S::WSCALE == 1.f ? acc[rt][t] : acc[rt][t] * S::INV_WSCALE;
       if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + ch0 + 16 * t);
 #ifndef OCC4D_X6T_ABL_NORES
       if (a.res) v += r[t];
@@ -185,33 +193,38 @@ __global__ __launch_bounds__(512, 2) void rowlin_bf16x6_kernel(const RowlinX6Arg
   }
 }
 
-__global__ void pack_rowlin_bf16x6_kernel(const float* __restrict__ w, int64_t ldw, int n_out, unsigned* __restrict__ out) {
+template <typename S>
+__global__ void pack_rowlin_split_kernel(const float* __restrict__ w, int64_t ldw, int n_out, unsigned* __restrict__ out) {
+  constexpr int NP = S::NP, YSF = YG<S>::SF, YSTAGE = YG<S>::STAGE;
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t total = (int64_t)(n_out / YCB) * YKS * YSTAGE;
   if (e >= total) return;
   const int word = (int)(e & 3), lane = (int)((e >> 2) & 63);
   const int frag = (int)((e / YFW) % YSF), stage = (int)((e / YSTAGE) % YKS), cb = (int)(e / ((int64_t)YKS * YSTAGE));
-  const int c = lane & 15, g = lane >> 4, t = frag / 3, p = frag % 3;
+  const int c = lane & 15, g = lane >> 4, t = frag / NP, p = frag % NP;
   const float* row = w + (int64_t)(YCB * cb + 16 * t + c) * ldw + 32 * stage + 8 * g + 2 * word;
-  out[e] = piece16(row[0], p) | (piece16(row[1], p) << 16);
+  out[e] = S::piece(row[0], p) | (S::piece(row[1], p) << 16);
 }
 
 }  // namespace
 
-extern "C" int64_t occ4d_rowlin_bf16x6_packed_floats(int n_out) { return (int64_t)(n_out / YCB) * YKS * YSTAGE; }
+namespace {
+template <typename S> int64_t packed_floats(int n_out) { return (int64_t)(n_out / YCB) * YKS * YG<S>::STAGE; }
 
-extern "C" int occ4d_pack_rowlin_bf16x6_f32(const float* w, int64_t ldw, int n_out, float* packed, void* stream) {
+template <typename S>
+int pack_rowlin(const char* who, const float* w, int64_t ldw, int n_out, float* packed, void* stream) {
   OCC4D_REQUIRE(w && packed && n_out >= YCB && n_out % YCB == 0 && 8 % (n_out / YCB) == 0 && ldw >= YK,
-                "occ4d_pack_rowlin_bf16x6_f32: (%d, %d) weight with n_out in {208, 416, 832, 1664} expected", n_out, YK);
-  const int64_t total = occ4d_rowlin_bf16x6_packed_floats(n_out);
-  pack_rowlin_bf16x6_kernel<<<occ4d::cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(w, ldw, n_out,
-                                                                                      reinterpret_cast<unsigned*>(packed));
-  return occ4d::check_launch("occ4d_pack_rowlin_bf16x6_f32");
+                "%s: (%d, %d) weight with n_out in {208, 416, 832, 1664} expected", who, n_out, YK);
+  const int64_t total = packed_floats<S>(n_out);
+  pack_rowlin_split_kernel<S><<<occ4d::cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(w, ldw, n_out,
+                                                                                        reinterpret_cast<unsigned*>(packed));
+  return occ4d::check_launch(who);
 }
 
-static int rowlin_x6_launch(const char* who, const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed,
-                            const float* b, int n_out, int relu_in, const float* res, int64_t ldr, int res_post,
-                            const float* mask, int64_t ldm, int n, void* stream) {
+template <typename S>
+int rowlin_split_launch(const char* who, const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed,
+                        const float* b, int n_out, int relu_in, const float* res, int64_t ldr, int res_post,
+                        const float* mask, int64_t ldm, int n, void* stream) {
   if (n == 0) return OCC4D_OK;
   OCC4D_REQUIRE(x && y && w_packed && n > 0, "%s: null pointer", who);
   OCC4D_REQUIRE(n_out >= YCB && n_out % YCB == 0 && 8 % (n_out / YCB) == 0 && ldy >= n_out && ldx >= YK && ldx % 4 == 0 &&
@@ -225,16 +238,34 @@ static int rowlin_x6_launch(const char* who, const float* x, int64_t ldx, float*
   a.rowgroups = (int)occ4d::cdiv(n, YROWS);
   a.per = (int)occ4d::cdiv(a.rowgroups, 8 / a.nblk);
   hipStream_t st = (hipStream_t)stream;
-  if (relu_in) rowlin_bf16x6_kernel<true><<<8 * a.per, 512, 0, st>>>(a);
-  else rowlin_bf16x6_kernel<false><<<8 * a.per, 512, 0, st>>>(a);
+  if (relu_in) rowlin_split_kernel<S, true><<<8 * a.per, 512, 0, st>>>(a);
+  else rowlin_split_kernel<S, false><<<8 * a.per, 512, 0, st>>>(a);
   return occ4d::check_launch(who);
+}
+}  // namespace
+
+extern "C" int64_t occ4d_rowlin_bf16x6_packed_floats(int n_out) { return packed_floats<SplitBf16x6>(n_out); }
+extern "C" int64_t occ4d_rowlin_f16x3_packed_floats(int n_out) { return packed_floats<SplitF16x3>(n_out); }
+
+extern "C" int occ4d_pack_rowlin_bf16x6_f32(const float* w, int64_t ldw, int n_out, float* packed, void* stream) {
+  return pack_rowlin<SplitBf16x6>("occ4d_pack_rowlin_bf16x6_f32", w, ldw, n_out, packed, stream);
+}
+extern "C" int occ4d_pack_rowlin_f16x3_f32(const float* w, int64_t ldw, int n_out, float* packed, void* stream) {
+  return pack_rowlin<SplitF16x3>("occ4d_pack_rowlin_f16x3_f32", w, ldw, n_out, packed, stream);
 }
 
 extern "C" int occ4d_rowlin_bf16x6_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed,
                                        const float* b, int n_out, int relu_in, const float* res, int64_t ldr, int n,
                                        void* stream) {
-  return rowlin_x6_launch("occ4d_rowlin_bf16x6_f32", x, ldx, y, ldy, w_packed, b, n_out, relu_in, res, ldr, 0, nullptr, 0, n,
-                          stream);
+  return rowlin_split_launch<SplitBf16x6>("occ4d_rowlin_bf16x6_f32", x, ldx, y, ldy, w_packed, b, n_out, relu_in, res, ldr, 0,
+                                          nullptr, 0, n, stream);
+}
+// The fp16 two-piece scheme (csrc/bf16x6.hpp: forward passes only; |w| < 255, |x| < 65504)
+extern "C" int occ4d_rowlin_f16x3_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed,
+                                      const float* b, int n_out, int relu_in, const float* res, int64_t ldr, int n,
+                                      void* stream) {
+  return rowlin_split_launch<SplitF16x3>("occ4d_rowlin_f16x3_f32", x, ldx, y, ldy, w_packed, b, n_out, relu_in, res, ldr, 0,
+                                         nullptr, 0, n, stream);
 }
 
 // The same with the epilogue of a training data gradient: y = [mask > 0] ([relu](x) W^T + b [+ res]) [+ res], `res`
@@ -243,6 +274,6 @@ extern "C" int occ4d_rowlin_bf16x6_masked_f32(const float* x, int64_t ldx, float
                                               const float* b, int n_out, int relu_in, const float* res, int64_t ldr,
                                               int res_after_mask, const float* mask, int64_t ldm, int n, void* stream) {
   OCC4D_REQUIRE(mask, "occ4d_rowlin_bf16x6_masked_f32: null mask");
-  return rowlin_x6_launch("occ4d_rowlin_bf16x6_masked_f32", x, ldx, y, ldy, w_packed, b, n_out, relu_in, res, ldr,
-                          res_after_mask != 0, mask, ldm, n, stream);
+  return rowlin_split_launch<SplitBf16x6>("occ4d_rowlin_bf16x6_masked_f32", x, ldx, y, ldy, w_packed, b, n_out, relu_in, res,
+                                          ldr, res_after_mask != 0, mask, ldm, n, stream);
 }

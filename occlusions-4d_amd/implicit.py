@@ -15,6 +15,7 @@ tables are computed once per abstract cloud, not once per call.
 import torch
 
 from . import geometry  # noqa: F401  (same module graph as the reference)
+from . import kernels
 from . import modules
 from . import ops
 from . import autograd
@@ -44,11 +45,12 @@ def _trunk_pack(weight, kind):
     the library's packers), cached on the tensor object while (storage, version, weights epoch, variant) are unchanged."""
     if tuple(weight.shape) != (ops.TRUNK_WIDTH, ops.TRUNK_WIDTH) or not weight.is_cuda:
         return None
-    key = (weights_epoch(), weight.data_ptr(), weight._version, kind, ptl.USE_TRUNK4)
+    trunk4 = kernels.scope().trunk4
+    key = (weights_epoch(), weight.data_ptr(), weight._version, kind, trunk4)
     hit = getattr(weight, '_occ4d_trunk_pack', None)
     if hit is not None and hit[0] == key:
         return hit[1]
-    if ptl.USE_TRUNK4:
+    if trunk4:
         packed = ops.pack_trunk4_rows(weight) if kind == 'rows' else ops.pack_trunk4_cols(weight)
     else:
         packed = ops.pack_trunk_rows(weight) if kind == 'rows' else ops.pack_trunk_cols(weight)
@@ -84,7 +86,7 @@ class ResnetBlockFC(torch.nn.Module):
 
     def _run(self, x, inplace=False):
         act = ACTIVATIONS[self.activation]
-        if (self.shortcut is None and ptl.USE_TRUNK_KERNELS and self.d_in == self.d_hidden == self.d_out
+        if (self.shortcut is None and kernels.scope().trunk_kernels and self.d_in == self.d_hidden == self.d_out
                 and self.activation == 'relu'):
             # both layers in one kernel, the (n, d_hidden) intermediate never leaves the registers (csrc/trunk.hip)
             w0p, w1p = _trunk_pack(self.fc_0.weight, 'rows'), _trunk_pack(self.fc_1.weight, 'cols')
@@ -168,7 +170,7 @@ class ResnetFC(torch.nn.Module):
         return (output, penult)
 
 
-class LocalPclResnetFC(ResnetFC):
+class LocalPclResnetFC(ResnetFC, kernels.HasKernelSelection):
     """ResnetFC + local feature interpolation + query-to-abstract vector cross-attention."""
 
     def __init__(self, num_local_features=0, local_mode='attention', d_latent_local=64,
@@ -194,16 +196,17 @@ class LocalPclResnetFC(ResnetFC):
                 use_at.append(int((i + 1) * self.n_blocks / (cross_attn_layers + 1)))
             self.pt_blocks = torch.nn.ModuleList(blocks)
             self.use_pt_inds = {j: i for i, j in enumerate(use_at)}
-        self._scene = None
+        self._scene = {}              # per flag value: the last abstract cloud's tables
 
     # -- the library's view of this module ------------------------------------------------
     def path_weights(self):
         """occ4d_decoder_weights over this module's parameters in the reference's layout and the library's prepared
         buffer for them (occ4d_decoder_prepare_f32: stage-packed residual blocks, merged + packed cross-attention
         layers).  Cached while the parameters (storage, version, weights epoch) and the kernel flags are unchanged."""
-        flags = ptl.path_flags()
+        flags = ptl.path_flags(self)
         key = (flags, weights_epoch()) + tuple((p.data_ptr(), p._version) for p in self.parameters())
-        hit = getattr(self, '_path', None)
+        cache = self.__dict__.setdefault('_path', {})       # one entry per flag value (threads under different selections)
+        hit = cache.get(flags)
         if hit is not None and hit[0] == key:
             return hit[1], hit[2], flags
         L = ops._lib
@@ -235,14 +238,14 @@ class LocalPclResnetFC(ResnetFC):
         if self.local_mode == 'attention':
             after = sorted(self.use_pt_inds)
             for j, blk in enumerate(self.pt_blocks):
-                lw, _, _ = blk.layer2.path_weights(cross=True, pre=blk.layer1, post=blk.layer3)
+                lw, _, _ = blk.layer2.path_weights(cross=True, pre=blk.layer1, post=blk.layer3, flags=flags)
                 w.cross[j] = lw
                 keep.append(lw)
                 w.cross_after[j] = after[j]
                 assert self.use_pt_inds[after[j]] == j
         w._keep = keep
         prepared = ops.decoder_prepare(w, flags, self.lin_out.weight.device)
-        self._path = (key, w, prepared)
+        cache[flags] = (key, w, prepared)
         return w, prepared, flags
 
     def _library_path_ok(self):
@@ -260,7 +263,7 @@ class LocalPclResnetFC(ResnetFC):
         key = (id(points_abstract), points_abstract._version, id(features_global), features_global._version,
                id(features_abstract), None if features_abstract is None else features_abstract._version,
                id(prepared), flags)
-        sc = self._scene
+        sc = self._scene.get(flags)
         if sc is not None and sc['key'] == key and sc['owners'][0] is points_abstract \
                 and sc['owners'][1] is features_global and sc['owners'][2] is features_abstract:
             return sc
@@ -279,7 +282,7 @@ class LocalPclResnetFC(ResnetFC):
         assert fg.shape[-1] == self.d_latent - self.d_latent_local
         sc = dict(key=key, owners=(points_abstract, features_global, features_abstract), m=pa.shape[0], prepared=prepared,
                   scene=ops.decoder_prepare_scene(w, prepared, pa, fa, fg, flags))
-        self._scene = sc
+        self._scene[flags] = sc
         return sc
 
     # -- forward ----------------------------------------------------------------------
@@ -294,7 +297,13 @@ class LocalPclResnetFC(ResnetFC):
         geometry.my_knn_torch (model/implicit.py:328) and kNN_torch (model/point_transformer_layer.py:167) returned in
         the run to be reproduced.  The reference orders equidistant points with an unstable sort; CARLA's two-level
         abstract cloud holds every coarse point twice (model/model.py:202-228), so there its choice at the k-th rank is
-        implementation-defined and only the run's own lists pin it.  None = searched here, lowest index first."""
+        implementation-defined and only the run's own lists pin it.  None = searched here, lowest index first.
+        Kernel variants / precision: the calling thread's `kernels.use(...)` scope with this module's `kernel_selection`
+        on top (kernels.py); the nested layers run under the same selection."""
+        with kernels.use(kernels.current(self)):
+            return self._forward(points_query, points_abstract, features_global, features_abstract, knn_local, knn_cross)
+
+    def _forward(self, points_query, points_abstract, features_global, features_abstract, knn_local=None, knn_cross=None):
         if needs_grad(self, points_abstract, features_global, features_abstract):
             return self._forward_train(points_query, points_abstract, features_global, features_abstract,
                                        knn_local=knn_local, knn_cross=knn_cross)
@@ -330,10 +339,11 @@ class LocalPclResnetFC(ResnetFC):
         perform_inference discards (eval/inference.py:211), is not materialised for the caller."""
         assert not needs_grad(self, points_abstract, features_global, features_abstract)
         assert self.num_local_features > 0 and self._library_path_ok() and points_query.dim() == 2
-        sc = self.prepare_scene(points_abstract, features_global, features_abstract)
-        w, prepared, flags = self.path_weights()
-        ops.decoder_query_fwd(w, prepared, sc['scene'], sc['m'], points_query, flags, out=out, want_penult=False,
-                              knn_local=knn_local, knn_cross=knn_cross)
+        with kernels.use(kernels.current(self)):
+            sc = self.prepare_scene(points_abstract, features_global, features_abstract)
+            w, prepared, flags = self.path_weights()
+            ops.decoder_query_fwd(w, prepared, sc['scene'], sc['m'], points_query, flags, out=out, want_penult=False,
+                                  knn_local=knn_local, knn_cross=knn_cross)
         return out
 
     # -- training path (as-written op order, differentiable kernels) ------------------------

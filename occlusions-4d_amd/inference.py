@@ -15,6 +15,7 @@ import torch
 
 from . import geometry
 from . import implicit
+from . import kernels
 from . import model
 from . import ops
 
@@ -84,6 +85,23 @@ def squash_codes(d_out, color_mode, predict_segmentation, track_mode, semantic_c
 
 PINNED_HOST_IO = os.environ.get('OCC4D_PINNED_HOST_IO', '1') == '1'
 
+# Side streams live as long as the process, one set per device.  torch's caching allocator keeps a block pool PER STREAM:
+# with fresh `torch.cuda.Stream()` objects in every call the decode workspaces (465 MB at the BASELINE grid) and the
+# result buffers were allocated again by every perform_inference call until torch's 32-stream pool had gone round
+# (profiles/host_boundary_probe.py: +8 ms per call).
+_STREAMS = {}
+
+
+def side_streams(device, role, count=1):
+    """`count` persistent HIP streams of `device` for `role` ('decode' / 'copy')."""
+    device = torch.device(device)
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (index, role)
+    have = _STREAMS.setdefault(key, [])
+    while len(have) < count:
+        have.append(torch.cuda.Stream(device=torch.device('cuda', index)))
+    return have[:count]
+
 
 class _HostCopies:
     """Device -> host result copies of perform_inference: every array goes into a page-locked buffer from torch's caching
@@ -96,7 +114,7 @@ class _HostCopies:
     def __init__(self, device):
         self.device = torch.device(device)
         self.on = PINNED_HOST_IO and self.device.type == 'cuda'
-        self.stream = torch.cuda.Stream(device=self.device) if self.on else None
+        self.stream = side_streams(self.device, 'copy')[0] if self.on else None
         self.pending = []
 
     def fetch(self, t, dtype=None):
@@ -275,7 +293,7 @@ def infer_device(pcl_input, points_query, pcl_net, implicit_net, batch_size, col
     return dict(implicit_output=out, pcl_abstract=pcl_abstract, features_global=features_global)
 
 
-DECODE_STREAMS = int(os.environ.get('OCC4D_DECODE_STREAMS', '2'))   # 1 = the reference's strictly serial loop
+# decode streams: kernels.Selection.decode_streams (default 2, OCC4D_DECODE_STREAMS; 1 = the reference's strictly serial loop)
 # The fused attention kernel packs 9 queries per workgroup and one workgroup occupies a CU (129 KB LDS): a mini-batch
 # of 9 * 256 * r queries is exactly r full rounds of the 256 CUs.  The caller's batch_size (a memory knob in the
 # reference) is rounded DOWN to such a multiple (32768 -> 32256: 14 full rounds instead of 14.2 -> 15); every query
@@ -306,7 +324,7 @@ def decode_batches(implicit_net, points_query, lo, hi, batch_size, pcl_abstract,
                    lists=None):
     """Runs implicit_net on points_query[lo:hi] in mini-batches of `batch_size` (the reference's
     loop, eval/inference.py:204-246) and writes rows into out[out_offset:].  Mini-batches are
-    independent, so consecutive ones alternate between DECODE_STREAMS HIP streams: a 32768-query
+    independent, so consecutive ones alternate between `decode_streams` (kernels.Selection) HIP streams: a 32768-query
     batch is exactly one wave of 256 workgroups for the row-tiled kernels, and the next batch's
     kernels fill the tail of the previous one's instead of waiting behind it.  The first batch runs
     on the caller's stream so the per-scene tables are built (and cached) before the side streams
@@ -314,7 +332,8 @@ def decode_batches(implicit_net, points_query, lo, hi, batch_size, pcl_abstract,
     main = torch.cuda.current_stream()
     batch_size = decode_chunk(batch_size)
     starts = list(range(lo, hi, batch_size))
-    side = [torch.cuda.Stream() for _ in range(DECODE_STREAMS)] if DECODE_STREAMS > 1 and len(starts) > 2 else []
+    n_streams = kernels.scope().decode_streams
+    side = side_streams(points_query.device, 'decode', n_streams) if n_streams > 1 and len(starts) > 2 else []
     def rows(b, e):           # the caller's neighbour lists of these queries (rows are indexed like points_query)
         return None if lists is None else tuple(None if a is None else a[b:e] for a in lists)
 

@@ -11,13 +11,14 @@ import os
 import numpy as np
 import torch
 
+from . import kernels
 from . import ops
 from . import point_transformer_layer
 from . import autograd
 from .point_transformer_layer import needs_grad
 
 
-class PointTransformerBlock(torch.nn.Module):
+class PointTransformerBlock(torch.nn.Module, kernels.HasKernelSelection):
     """z = x + layer3(PointTransformerLayer(layer1(x), p[, x2, p2]))."""
 
     def __init__(self, d_in, d_hidden, d_out, num_neighbors=16, d_hidden_abstract=None):
@@ -35,6 +36,10 @@ class PointTransformerBlock(torch.nn.Module):
         `knn_idx` (extension, optional): (B,N,num_neighbors) int32 result of kNN_torch(p, p2) when the caller already
         has it.  Inference: the whole block -- layer1, the vector attention, layer3 + residual -- is ONE call of the
         library's path-level entry point per cloud (occ4d_pt_layer_fwd_f32)."""
+        with kernels.use(kernels.current(self)):
+            return self._forward(x, p, x2, p2, knn_idx)
+
+    def _forward(self, x, p, x2, p2, knn_idx):
         assert x.shape[:2] == p.shape[:2]
         if x2 is not None:
             assert x2.shape[:2] == p2.shape[:2]

@@ -370,26 +370,36 @@ FUSED_ATTN_MAX_K = 14
 X6_ROWLIN_WIDTHS = (208, 416, 832, 1664)
 
 
-def pack_rowlin_bf16x6(w):
-    """(n_out, 416) weight -> the stage-packed three-piece stream of occ4d_rowlin_bf16x6_f32."""
+SPLIT_SCHEMES = ('bf16x6', 'f16x3')      # bf16 x 3 pieces, 6 products / fp16 x 2 pieces, 3 products (csrc/bf16x6.hpp)
+
+
+def pack_rowlin_bf16x6(w, scheme='bf16x6'):
+    """(n_out, 416) weight -> the stage-packed piece stream of occ4d_rowlin_bf16x6_f32 (`scheme` 'f16x3':
+    occ4d_rowlin_f16x3_f32; the two streams are not interchangeable)."""
+    assert scheme in SPLIT_SCHEMES, scheme
     w, ldw = _rows(_dev(w, name='w'), 'w')
     n_out = w.shape[0]
     assert w.shape[1] == 416 and n_out in X6_ROWLIN_WIDTHS
     L = _lib.lib()
-    packed = torch.empty((int(L.occ4d_rowlin_bf16x6_packed_floats(n_out)),), dtype=torch.float32, device=w.device)
-    _lib.check(L.occ4d_pack_rowlin_bf16x6_f32(_ptr(w), ldw, n_out, _ptr(packed), _stream()))
+    size, pack = ((L.occ4d_rowlin_f16x3_packed_floats, L.occ4d_pack_rowlin_f16x3_f32) if scheme == 'f16x3' else
+                  (L.occ4d_rowlin_bf16x6_packed_floats, L.occ4d_pack_rowlin_bf16x6_f32))
+    packed = torch.empty((int(size(n_out)),), dtype=torch.float32, device=w.device)
+    _lib.check(pack(_ptr(w), ldw, n_out, _ptr(packed), _stream()))
     return packed
 
 
-def rowlin_bf16x6(x, w, b=None, relu_in=False, res=None, out=None, packed=None, mask=None, res_after_mask=False, n_out=None):
+def rowlin_bf16x6(x, w, b=None, relu_in=False, res=None, out=None, packed=None, mask=None, res_after_mask=False, n_out=None,
+                  scheme='bf16x6'):
     """y = [res +] w [relu](x) + b for a (n_out, 416) weight on the split-precision trunk kernel
     (occ4d_rowlin_bf16x6_f32; n_out in {208, 416, 832, 1664}).  `packed` (pack_rowlin_bf16x6) instead of `w` skips the
     per-call packing.  `mask` (n, n_out): the training data-gradient epilogue (occ4d_rowlin_bf16x6_masked_f32): zero where
-    mask <= 0, `res` added before (default) or after the mask."""
+    mask <= 0, `res` added before (default) or after the mask.  `scheme` 'f16x3': the fp16 two-piece kernel
+    (occ4d_rowlin_f16x3_f32: forward only, no mask)."""
+    assert scheme in SPLIT_SCHEMES and not (scheme == 'f16x3' and mask is not None), scheme
     x, ldx = _aligned_rows(_dev(x, name='x'), 'x')
     n = x.shape[0]
     if packed is None:
-        packed, n_out = pack_rowlin_bf16x6(w), w.shape[0]
+        packed, n_out = pack_rowlin_bf16x6(w, scheme), w.shape[0]
     assert x.shape[1] == 416 and n_out in X6_ROWLIN_WIDTHS
     L = _lib.lib()
     if out is None:
@@ -406,7 +416,8 @@ def rowlin_bf16x6(x, w, b=None, relu_in=False, res=None, out=None, packed=None, 
             _ptr(x), ldx, _ptr(out), out.stride(0), _ptr(packed), _ptr(bb), n_out, int(relu_in), _ptr(res), ldr,
             int(res_after_mask), _ptr(mm), ldm, n, _stream())))
         return out
-    _lib.check(_launch('rowlin', dict(n=n, n_out=n_out), flops, lambda: L.occ4d_rowlin_bf16x6_f32(
+    fn = L.occ4d_rowlin_f16x3_f32 if scheme == 'f16x3' else L.occ4d_rowlin_bf16x6_f32
+    _lib.check(_launch('rowlin', dict(n=n, n_out=n_out), flops, lambda: fn(
         _ptr(x), ldx, _ptr(out), out.stride(0), _ptr(packed), _ptr(bb), n_out, int(relu_in), _ptr(res), ldr, n, _stream())))
     return out
 

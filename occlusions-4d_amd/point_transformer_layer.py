@@ -21,47 +21,18 @@ import torch
 from torch import nn
 
 from . import autograd
+from . import kernels
 from . import ops
 
-USE_FUSED_ATTENTION = True   # tests flip this to cover the unfused kernel chain as well (OCC4D_PATH_UNFUSED)
-USE_ATTN16 = True            # d = 416: paired-workgroup 16x16x4 kernel (csrc/crossattn16p.hip); False = crossattn.hip
-USE_TRUNK_KERNELS = True     # row-resident fused trunk kernels (csrc/trunk*.hip) where the shapes allow; False = generic Linear
-# Opt-in variant, measured SLOWER end to end than the default (csrc/trunk.hip, one 8-wave workgroup per CU) and kept as a
-# tested alternative (bench.py, 20 steps, 2 decode streams: default 122.5-122.8 ms / step; OCC4D_TRUNK4=1 123.7; DESIGN.md
-# 6c): half-CU re-cut of the trunk kernels (csrc/trunk4.hip: 4-wave workgroups, two per CU)
-USE_TRUNK4 = os.environ.get('OCC4D_TRUNK4', '0') != '0'
-# 'f32' (default): every GEMM exact fp32.  'bf16x6' (round 5, opt-in): the d = 416 attention GEMMs on three-way split bf16
-# MFMAs, six partial products, fp32 accumulate (csrc/crossattn_bf16x6.hip): fp32-class.  (The two-piece 'bf16x3' logit mode
-# of rounds 1-4 -- not fp32-class, and slower than this one -- is gone.)
-LOGIT_PRECISION = os.environ.get('OCC4D_LOGIT_PRECISION', 'f32')
-# Opt-in (round 5): the decoder's 416-input Linear layers (residual blocks, merged query projection, layer3) on the same
-# three-way split bf16 MFMAs (csrc/trunk_bf16x6.hip); 'bf16x6' here + LOGIT_PRECISION 'bf16x6' = the whole decoder GEMM work
-TRUNK_PRECISION = os.environ.get('OCC4D_TRUNK_PRECISION', 'f32')
-# A/B only (measured slower): the lin_z table term of block i + 1 added in block i's epilogue
-FUSED_INTERP = os.environ.get('OCC4D_FUSED_INTERP', '0') != '0'
+# Which kernel variants / which arithmetic a call runs on is a per-module, per-call choice (kernels.py): process
+# defaults seeded from the OCC4D_* environment variables, a thread-local `with kernels.use(...)` scope, a module's own
+# `kernel_selection`.  There are no module-level switches to assign (round 6; rounds 1-5 had USE_*, LOGIT_PRECISION,
+# TRUNK_PRECISION, ... globals here, which `nn.DataParallel`'s one-thread-per-GPU forwards, train.py:305, would share).
 
 
-def path_flags():
-    """The OCC4D_PATH_* flags (include/occ4d.h) the switches above select for the library's path-level entry points."""
-    assert LOGIT_PRECISION in ('f32', 'bf16x6'), LOGIT_PRECISION
-    L = ops._lib
-    f = L.PATH_DEFAULT
-    if not USE_FUSED_ATTENTION:
-        f |= L.PATH_UNFUSED
-    if not USE_ATTN16:
-        f |= L.PATH_FIRST_GEN
-    if LOGIT_PRECISION == 'bf16x6':
-        f |= L.PATH_BF16X6
-    assert TRUNK_PRECISION in ('f32', 'bf16x6'), TRUNK_PRECISION
-    if TRUNK_PRECISION == 'bf16x6':
-        f |= L.PATH_BF16X6_TRUNK
-    if not USE_TRUNK_KERNELS:
-        f |= L.PATH_GENERIC_LINEAR
-    if USE_TRUNK4:
-        f |= L.PATH_TRUNK4
-    if FUSED_INTERP:
-        f |= L.PATH_FUSED_INTERP
-    return f
+def path_flags(module=None):
+    """The OCC4D_PATH_* flags (include/occ4d.h) of a call into `module` under the current thread's selection."""
+    return kernels.current(module).flags()
 
 
 # Derived-weight caches (merged matrices, per-scene tables, bf16 packs) are keyed on (data_ptr, _version) of the
@@ -80,15 +51,13 @@ def weights_epoch():
     return _WEIGHTS_EPOCH[0]
 
 
-CHECKPOINT_ATTENTION = True   # training: cross-attention layers recompute their pair tensors in backward (below)
-# training with CHECKPOINT_ATTENTION off: 'merged' stores the pair tensors of the MERGED form (forward_train_merged: the
-# per-pair first GEMM has K = 32), 'as_written' those of the reference's op order (forward_train)
-STORED_ATTENTION_FORM = os.environ.get('OCC4D_STORED_ATTENTION_FORM', 'merged')
-# queries per recompute chunk in backward: bounds the (chunk * K, 2D) workspace.  Measured on BASELINE config 5
-# (bench_train.py, ms per step eager / replayed, peak memory): 4096: 184 / 179, 4.4 GB; 8192: 173 / 170, 5.2 GB;
-# 16384: - / 161, 6.9 GB; 32768: 159 / 157, 10.2 GB (stored pair tensors: 167 / 163, 24.2 GB) -- small chunks run the
-# pair GEMMs at 57 K rows and repeat the accumulation of every weight gradient per chunk.
-_CHECKPOINT_CHUNK = int(os.environ.get('OCC4D_CHECKPOINT_CHUNK', '32768'))
+# Training switches (kernels.Selection): checkpoint_attention -- cross-attention layers recompute their pair tensors in
+# backward (below); stored_attention_form -- with the recompute off, 'merged' stores the pair tensors of the MERGED form
+# (forward_train_merged: the per-pair first GEMM has K = 32), 'as_written' those of the reference's op order
+# (forward_train); checkpoint_chunk -- queries per recompute chunk in backward: bounds the (chunk * K, 2D) workspace.
+# Measured on BASELINE config 5 (bench_train.py, ms per step eager / replayed, peak memory): 4096: 184 / 179, 4.4 GB;
+# 8192: 173 / 170, 5.2 GB; 16384: - / 161, 6.9 GB; 32768: 159 / 157, 10.2 GB (stored pair tensors: 167 / 163, 24.2 GB) --
+# small chunks run the pair GEMMs at 57 K rows and repeat the accumulation of every weight gradient per chunk.
 
 
 def _grad_or_none(outputs, inputs, grad_outputs):
@@ -126,6 +95,7 @@ def _merged_to_parameters(W1, b1, Wq, Wk, P2, c2, g_wq, g_bq, g_wk, g_wp):
     return (d_W1, d_b1, d_Wq, d_Wk, d_P2, d_c2)
 
 
+@kernels.carries_selection
 class _CheckpointedAttention(torch.autograd.Function):
     """Training-time vector attention without stored pair tensors ("recompute-in-backward to
     avoid storing (N_q, K, 832)").  forward = the fused inference kernel: nothing of size (N*K, .) is written.
@@ -180,10 +150,10 @@ class _CheckpointedAttention(torch.autograd.Function):
             x_all = x.detach().requires_grad_(True)
             aq_all = L(x_all, wq_l, bq_l, False, False, None, None)                                   # (n, 2D)
             g_aq = torch.empty_like(aq_all)
-            # chunks of EQUAL size, at most _CHECKPOINT_CHUNK queries each (a multiple of 64: whole 128-pair-row workgroups
+            # chunks of EQUAL size, at most `checkpoint_chunk` queries each (a multiple of 64: whole 128-pair-row workgroups
             # of the fused pair kernel): 68812 queries = 3 x 22976 instead of 2 x 32768 + 3276 -- the short chunk ran every
             # kernel of the backward at a fraction of its rate (94.8 -> 94.0 ms per step, 9.5 -> 7.7 GB peak)
-            n_chunks = max(1, -(-x.shape[0] // _CHECKPOINT_CHUNK))
+            n_chunks = max(1, -(-x.shape[0] // kernels.scope().checkpoint_chunk))
             step = -(-x.shape[0] // (64 * n_chunks)) * 64
             # The gradients of the leaves (merged matrices, tables, pos-MLP) are sums over the chunks that nothing reads
             # before the loop ends: they collect in sinks (autograd.gradient_sinks: added up on the parameter-gradient
@@ -264,7 +234,7 @@ def index_points(points, idx):
     return ops.stack_batch(out).reshape(*idx.shape, points.shape[-1])
 
 
-class PointTransformerLayer(nn.Module):
+class PointTransformerLayer(nn.Module, kernels.HasKernelSelection):
     def __init__(self, dim, pos_mlp_hidden_dim=32, attn_mlp_hidden_mult=2, num_neighbors=16, dim2=None):
         super().__init__()
         self.num_neighbors = num_neighbors
@@ -284,13 +254,16 @@ class PointTransformerLayer(nn.Module):
         ps = list(self.parameters()) + [p for m in extra if m is not None for p in (m.weight, m.bias)]
         return (weights_epoch(),) + tuple((p.data_ptr(), p._version) for p in ps)
 
-    def path_weights(self, cross, pre=None, post=None):
+    def path_weights(self, cross, pre=None, post=None, flags=None):
         """occ4d_pt_layer_weights over this layer's parameters in the reference's layout (+ `pre` = the block's layer1,
         `post` = its layer3), and the library's prepared buffer for them (merged matrices of refactoring (i), formed in
         fp64 and rounded once, and the stage-packed weight streams: occ4d_pt_layer_prepare_f32).  Cached while the
-        parameters (storage, version, weights epoch) and the kernel-selection flags are unchanged."""
-        flags = path_flags()
-        slot = (bool(cross), pre is not None, post is not None)
+        parameters (storage, version, weights epoch) and the kernel-selection flags are unchanged.  `flags`: the owning
+        module's selection (a decoder prepares its cross layers under ITS flags); None = this layer's own.  One cache
+        entry per flag value: two threads running this layer under different selections do not evict each other."""
+        if flags is None:
+            flags = path_flags(self)
+        slot = (bool(cross), pre is not None, post is not None, flags)
         key = (flags,) + self._params_key(pre, post)
         hit = self._path.get(slot)
         if hit is not None and hit[0] == key:
@@ -343,7 +316,8 @@ class PointTransformerLayer(nn.Module):
     # -- forward -----------------------------------------------------------------------
     def forward(self, x, pos, x2=None, pos2=None):
         """x (B,N,D), pos (B,N,3) [, x2 (B,M,D2), pos2 (B,M,3)] -> agg (B,N,D)."""
-        return self._forward(x, pos, x2, pos2, pre=None)
+        with kernels.use(kernels.current(self)):
+            return self._forward(x, pos, x2, pos2, pre=None)
 
     def _forward(self, x, pos, x2, pos2, pre, knn_idx=None, post=None):
         """`pre` / `post`: the Linear layers of the PointTransformerBlock around this layer (layer1, layer3 + residual).
@@ -353,14 +327,15 @@ class PointTransformerLayer(nn.Module):
             out = []
             for b in range(x.shape[0]):
                 y = x[b] if pre is None else autograd.linear(x[b], pre)
-                if (CHECKPOINT_ATTENTION and x2 is not None and self.dim in ops.FUSED_ATTN_DIMS
+                sel = kernels.current(self)
+                if (sel.checkpoint_attention and x2 is not None and self.dim in ops.FUSED_ATTN_DIMS
                         and self.num_neighbors <= ops.FUSED_ATTN_MAX_K and self.pos_mlp[0].out_features == 32):
                     idx = knn_idx[b] if knn_idx is not None else ops.knn(pos[b].detach(), pos2[b].detach(),
                                                                           self.num_neighbors, metric=0)
                     out.append(_CheckpointedAttention.apply(self, y, pos[b].detach(), x2[b], pos2[b].detach(), idx,
                                                             *self.parameters()))
                     continue
-                if (STORED_ATTENTION_FORM == 'merged' and x2 is not None and self.pos_mlp[0].out_features == 32
+                if (sel.stored_attention_form == 'merged' and x2 is not None and self.pos_mlp[0].out_features == 32
                         and self.attn_mlp[0].in_features == self.dim):
                     out.append(self.forward_train_merged(y, pos[b].detach(), x2[b], pos2[b].detach(),
                                                          idx=None if knn_idx is None else knn_idx[b]))

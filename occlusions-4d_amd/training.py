@@ -16,7 +16,7 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
-from . import autograd, ops
+from . import autograd, kernels, ops
 from .point_transformer_layer import invalidate_weight_caches
 
 
@@ -283,7 +283,12 @@ class TrainStep:
     """One optimisation step: forward (encoder + decoder per target frame), losses, backward,
     gradient all-reduce, clip (train.py:107-109, max norm 0.2), optimiser step."""
 
-    def __init__(self, pcl_net, implicit_net, lr=1e-3, weight_decay=1e-2, grad_clip=0.2, loss_kwargs=None):
+    def __init__(self, pcl_net, implicit_net, lr=1e-3, weight_decay=1e-2, grad_clip=0.2, loss_kwargs=None,
+                 kernel_selection=None):
+        """`kernel_selection`: dict of kernels.Selection fields this step's forward runs under (e.g.
+        dict(train_precision='bf16x6', logit_precision='bf16x6', checkpoint_attention=False)); the backward pass follows
+        it through the autograd Functions.  None = the calling thread's scope."""
+        self.kernel_selection = dict(kernel_selection or {})
         self.pcl_net, self.implicit_net = pcl_net, implicit_net
         self.params = list(pcl_net.parameters()) + list(implicit_net.parameters())
         self.optimizer = torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay)
@@ -299,6 +304,10 @@ class TrainStep:
         in the queries (the frame is their 4th coordinate), so batch_frames runs all T * Nq of them through ONE decoder
         call: same outputs, GEMMs of 68 812 instead of 17 203 rows (269 instead of 135 row tiles for 256 CUs) and a
         quarter of the launches."""
+        with kernels.use(**self.kernel_selection):
+            return self._forward_loss(pcl_input, points_query, implicit_target)
+
+    def _forward_loss(self, pcl_input, points_query, implicit_target):
         (pcl_abstract, features_global, _) = self.pcl_net(pcl_input, False)
         T_, Nq = points_query.shape[:2]
         if self.batch_frames:

@@ -349,3 +349,58 @@ def test_evaluate_clip_and_pickle_contract(tmp_path):
     back = pk.evaluation.load_clip(path)
     assert all(np.array_equal(x, y) for a, b in zip(shared, back) for x, y in zip(a, b))
     assert (tmp_path / 'test_unit' / 'metadata_s7.p').exists()
+
+
+# ------------------------------------------------------------------ re-entrancy (nn.DataParallel, train.py:305)
+def test_two_threads_decode_on_different_precisions_concurrently():
+    """One process, two Python threads (the reference's nn.DataParallel situation): one decodes on the fp32 kernels, the
+    other on a split-precision scheme -- once by a thread-local `with pk.kernels(...)` scope around the SAME module class,
+    once by the module's own `precision` attribute -- interleaved for many calls on their own streams.  Each must
+    reproduce, bit for bit, what it returns when it runs alone, and both stay at the golden vectors' bar: no selection
+    leaks across threads, no cache entry of one evicts the other's."""
+    import threading
+    case = gc.DEC_CASES[2]
+    q, abstract, fglob, ia, sd = gc.dec_inputs(case)
+    g = load_golden('g8_dec_' + case['name'])
+
+    def make(precision=None):
+        net = pk.implicit.LocalPclResnetFC(**ia).cuda().eval()
+        net.load_state_dict(sd)
+        net.precision = precision
+        return net
+    args = [T(a).cuda() for a in (q, abstract, fglob)]
+    shared = make()                       # ONE module called from both threads under different scopes
+    pinned = make('f16x3')                # a module that carries its own choice
+    with torch.no_grad():
+        alone = {'f32': shared(*args, None)[0].clone()}
+        with pk.kernels(precision='bf16x6'):
+            alone['bf16x6'] = shared(*args, None)[0].clone()
+        alone['f16x3'] = pinned(*args, None)[0].clone()
+    torch.cuda.synchronize()
+    assert not torch.equal(alone['f32'], alone['bf16x6']) and not torch.equal(alone['f32'], alone['f16x3'])
+    rounds, errors, start = 12, [], threading.Barrier(3)
+
+    def worker(name, net, scope):
+        try:
+            stream = torch.cuda.Stream()
+            start.wait()
+            with torch.no_grad(), torch.cuda.stream(stream), pk.kernels(**scope):
+                for i in range(rounds):
+                    out = net(*args, None)[0]
+                    stream.synchronize()
+                    if not torch.equal(out, alone[name]):
+                        errors.append('%s, call %d: differs from its solo run by %.3g'
+                                      % (name, i, float((out - alone[name]).abs().max())))
+        except Exception as e:            # noqa: BLE001  (reported by the main thread)
+            errors.append('%s: %r' % (name, e))
+    threads = [threading.Thread(target=worker, args=('f32', shared, {})),
+               threading.Thread(target=worker, args=('bf16x6', shared, dict(precision='bf16x6'))),
+               threading.Thread(target=worker, args=('f16x3', pinned, {}))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for name, out in alone.items():
+        assert np.abs(out.cpu().numpy() - g['output']).max() < 2e-5, name
+    assert pk.kernels.scope() is pk.kernels.defaults()

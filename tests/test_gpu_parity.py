@@ -201,13 +201,8 @@ def test_decoder_kernel_variants(pk, case, variant):
     points) against the same golden vectors (G8): half-CU trunk kernels (csrc/trunk4.hip), the generic Linear kernels in
     place of the row-resident ones, the first-generation attention kernel (csrc/crossattn.hip) and the unfused attention
     chain.  The library's launch-event hook tells which kernels really ran."""
-    ptl = pk.point_transformer_layer
-    old = (ptl.USE_TRUNK4, ptl.USE_TRUNK_KERNELS, ptl.USE_ATTN16, ptl.USE_FUSED_ATTENTION)
-    old_fi, ptl.FUSED_INTERP = ptl.FUSED_INTERP, variant == 'fused_interp'
-    ptl.USE_TRUNK4 = variant == 'trunk4'
-    ptl.USE_TRUNK_KERNELS = variant != 'generic_trunk'
-    ptl.USE_ATTN16 = variant != 'first_gen'
-    ptl.USE_FUSED_ATTENTION = variant != 'unfused'
+    selection = dict(trunk4=variant == 'trunk4', trunk_kernels=variant != 'generic_trunk', attn16=variant != 'first_gen',
+                     fused_attention=variant != 'unfused', fused_interp=variant == 'fused_interp')
     try:
         q, abstract, fglob, ia, sd = gc.dec_inputs(case)
         net = pk.implicit.LocalPclResnetFC(**ia).cuda().eval()
@@ -216,14 +211,12 @@ def test_decoder_kernel_variants(pk, case, variant):
         for fam in ('resblock', 'cross_attn'):
             timer = pk.ops.KernelTimer(lambda name, fam=fam, **shape: name == fam)
             pk.ops.set_kernel_timer(timer)
-            with torch.no_grad():
+            with torch.no_grad(), pk.kernels(**selection):
                 out, pen = net(dev(q), dev(abstract), dev(fglob), None)
             pk.ops.set_kernel_timer(None)
             counts[fam] = timer.summary().get(fam, dict(launches=0))['launches']
     finally:
         pk.ops.set_kernel_timer(None)
-        (ptl.USE_TRUNK4, ptl.USE_TRUNK_KERNELS, ptl.USE_ATTN16, ptl.USE_FUSED_ATTENTION) = old
-        ptl.FUSED_INTERP = old_fi
     g = load_golden('g8_dec_' + case['name'])
     close(out, g['output'])
     close(pen[:, ::8], g['penult'])
@@ -364,7 +357,7 @@ def test_decoder_two_level_cloud(pk, case):
                                           (1, 10, 416, 288), (14, 531, 288, 288), (5, 1, 416, 288),
                                           (14, 8, 416, 288), (14, 10, 416, 288), (14, 17, 416, 288), (14, 18, 416, 288),
                                           (14, 19, 416, 288), (11, 2, 416, 288), (2, 4000, 416, 288)])
-@pytest.mark.parametrize('generation', ['attn16p', 'first', 'bf16x6'])
+@pytest.mark.parametrize('generation', ['attn16p', 'first', 'bf16x6', 'f16x3'])
 def test_fused_attention_matches_unfused_chain(pk, k, n, dim, dim2, generation):
     """The fused kernels (9 queries x 14 rows packed per workgroup, masked slots for k < 14, ragged
     tail for n % 9 != 0) against the unfused kernel chain on the same inputs: the paired-workgroup 16 x 16
@@ -383,17 +376,11 @@ def test_fused_attention_matches_unfused_chain(pk, k, n, dim, dim2, generation):
     layer.load_state_dict(sd)
     args = (dev(x)[None], dev(pos)[None], dev(x2)[None], dev(pos2)[None])
     with torch.no_grad():
-        ptl.USE_ATTN16 = generation != 'first'
-        old_prec, ptl.LOGIT_PRECISION = ptl.LOGIT_PRECISION, 'bf16x6' if generation == 'bf16x6' else 'f32'
-        try:
+        with pk.kernels(attn16=generation != 'first',
+                        logit_precision=generation if generation in ('bf16x6', 'f16x3') else 'f32'):
             fused = layer(*args)[0]
-            ptl.USE_FUSED_ATTENTION = False
-            ptl.LOGIT_PRECISION = 'f32'
+        with pk.kernels(fused_attention=False, logit_precision='f32'):
             chain = layer(*args)[0]
-        finally:
-            ptl.USE_FUSED_ATTENTION = True
-            ptl.USE_ATTN16 = True
-            ptl.LOGIT_PRECISION = old_prec
     assert torch.isfinite(fused).all()
     close(fused, chain, 2e-5)
 
@@ -414,12 +401,9 @@ def test_fused_self_attention_matches_unfused_chain(pk, n, dim):
     layer.load_state_dict(pk.configs.fill_state_dict(layer, 77 + dim))
     args = (dev(x)[None], dev(pos)[None])
     with torch.no_grad():
-        try:
-            fused = layer(*args)[0]
-            ptl.USE_FUSED_ATTENTION = False
+        fused = layer(*args)[0]
+        with pk.kernels(fused_attention=False):
             chain = layer(*args)[0]
-        finally:
-            ptl.USE_FUSED_ATTENTION = True
     assert torch.isfinite(fused).all() and fused.shape == (n, dim)
     close(fused, chain, 2e-5)
 
@@ -456,21 +440,18 @@ def test_perform_inference_tracks_and_gt_labels(pk, case):
         assert res['gt_air'].shape[1] == 2
 
 
-# ------------------------------------------------------------------ opt-in split-precision (bf16 x 3 pieces) kernels
-@pytest.fixture
-def bf16x6_attention(pk):
-    ptl = pk.point_transformer_layer
-    old = ptl.LOGIT_PRECISION
-    ptl.LOGIT_PRECISION = 'bf16x6'
-    yield
-    ptl.LOGIT_PRECISION = old
+# ------------------------------------------------------------------ opt-in split-precision kernels: bf16 x 3 pieces
+# (6 products, round 5) and fp16 x 2 pieces (3 products, round 6), selected per call (`with pk.kernels(...)`)
+SPLIT_SCHEMES = ['bf16x6', 'f16x3']
 
 
 @pytest.mark.parametrize('n,n_out,relu_in,with_res', [(1000, 416, True, True), (257, 416, True, False), (32, 832, False, False),
                                                       (5, 208, False, True), (3000, 832, False, False), (256, 1664, True, True)])
-def test_split_precision_rowlin_against_fp64(pk, n, n_out, relu_in, with_res):
-    """csrc/trunk_bf16x6.hip alone: y = [res +] W [relu](x) + b, K = 416, three-way split bf16 operands, six partial
-    products, against fp64 -- at the accuracy of an fp32 GEMM (a few 2^-24 of sum |w||x|), ragged row counts included."""
+@pytest.mark.parametrize('scheme', SPLIT_SCHEMES)
+def test_split_precision_rowlin_against_fp64(pk, n, n_out, relu_in, with_res, scheme):
+    """csrc/trunk_bf16x6.hip alone: y = [res +] W [relu](x) + b, K = 416, split operands (bf16 x 3 pieces, six partial
+    products / fp16 x 2 pieces, three), against fp64 -- at the accuracy of an fp32 GEMM (a few 2^-24 of sum |w||x|), ragged
+    row counts included.  The SAME bound for both schemes."""
     rng = np.random.default_rng(n + n_out)
     x = (3.0 * rng.normal(size=(n, 416))).astype(np.float32)
     w = (rng.normal(size=(n_out, 416)) / np.sqrt(416)).astype(np.float32)
@@ -478,16 +459,16 @@ def test_split_precision_rowlin_against_fp64(pk, n, n_out, relu_in, with_res):
     r = rng.normal(size=(n, n_out)).astype(np.float32) if with_res else None
     xin = np.maximum(x, 0) if relu_in else x
     ref = xin.astype(np.float64) @ w.astype(np.float64).T + b + (r if with_res else 0.0)
-    got = pk.ops.rowlin_bf16x6(dev(x), dev(w), dev(b), relu_in=relu_in, res=None if r is None else dev(r))
+    got = pk.ops.rowlin_bf16x6(dev(x), dev(w), dev(b), relu_in=relu_in, res=None if r is None else dev(r), scheme=scheme)
     f32 = (T(xin) @ T(w).T + T(b) + (T(r) if with_res else 0.0)).numpy()
     e6, e32 = np.abs(got.cpu().numpy() - ref).max(), np.abs(f32 - ref).max()
     scale = (np.abs(xin).astype(np.float64) @ np.abs(w).astype(np.float64).T).max()
-    print('\n[rowlin x6 %d x %d] |x6 - f64| %.3g, |torch f32 - f64| %.3g, sum|w||x| %.3g' % (n, n_out, e6, e32, scale))
+    print('\n[rowlin %s %d x %d] |split - f64| %.3g, |torch f32 - f64| %.3g, sum|w||x| %.3g' % (scheme, n, n_out, e6, e32, scale))
     assert e6 <= 8 * 2.0 ** -24 * scale
     # in place over the residual rows (how the decoder calls it)
     if with_res:
         rr = dev(r).clone()
-        pk.ops.rowlin_bf16x6(dev(x), dev(w), dev(b), relu_in=relu_in, res=rr, out=rr)
+        pk.ops.rowlin_bf16x6(dev(x), dev(w), dev(b), relu_in=relu_in, res=rr, out=rr, scheme=scheme)
         assert torch.equal(rr, got)
 
 
@@ -512,32 +493,30 @@ def test_split_precision_rowlin_masked_epilogue(pk, n, n_out, after):
         assert (got[m <= 0] == r[m <= 0]).all()
 
 
+@pytest.mark.parametrize('scheme', SPLIT_SCHEMES)
 @pytest.mark.parametrize('case', gc.DEC_CASES + gc.DEC_TWOLEVEL_CASES, ids=lambda c: c['name'])
-def test_decoder_entirely_on_three_way_split_bf16(pk, bf16x6_attention, case):
+def test_decoder_entirely_on_split_precision(pk, scheme, case):
     """Attention AND trunk on the split-precision kernels (every GEMM of the decoder except lin_in / lin_out and the
-    per-scene tables): the golden vectors at the fp32 path's own bar."""
+    per-scene tables): the golden vectors at the fp32 path's own bar, in both split schemes."""
     two = case in gc.DEC_TWOLEVEL_CASES
     q, abstract, fglob, ia, sd = (gc.dec_twolevel_inputs if two else gc.dec_inputs)(case)
     net = pk.implicit.LocalPclResnetFC(**ia).cuda().eval()
     net.load_state_dict(sd)
     g = load_golden('g8_dec_' + case['name'])
     kw = dict(knn_local=dev(g['knn_local']), knn_cross=dev(g['knn_cross'])) if two else {}
-    ptl = pk.point_transformer_layer
-    old, ptl.TRUNK_PRECISION = ptl.TRUNK_PRECISION, 'bf16x6'
-    try:
-        with torch.no_grad():
-            out, pen = net(dev(q), dev(abstract), dev(fglob), None, **kw)
-    finally:
-        ptl.TRUNK_PRECISION = old
+    with torch.no_grad(), pk.kernels(precision=scheme):
+        out, pen = net(dev(q), dev(abstract), dev(fglob), None, **kw)
+    print('\n[%s all %s] |out - ref| %.3g' % (scheme, case['name'], float(np.abs(out.cpu().numpy() - g['output']).max())))
     close(out, g['output'], 2e-5)
     close(pen[:, ::8], g['penult'], 4e-5 if two else 2e-5)
 
 
+@pytest.mark.parametrize('scheme', SPLIT_SCHEMES)
 @pytest.mark.parametrize('case', gc.DEC_CASES + gc.DEC_TWOLEVEL_CASES, ids=lambda c: c['name'])
-def test_decoder_with_three_way_split_bf16_attention(pk, bf16x6_attention, case):
-    """Round 5 opt-in mode (csrc/crossattn_bf16x6.hip): every GEMM of the two cross-attention layers on bf16 MFMAs with
-    both operands split three ways (exact) and six partial products: the golden vectors at the fp32 path's own bar, and
-    the library must really have taken that kernel (its launches are counted)."""
+def test_decoder_with_split_precision_attention(pk, scheme, case):
+    """Opt-in modes of csrc/crossattn_bf16x6.hip: every GEMM of the two cross-attention layers on 16x16x32 MFMAs with
+    both operands split (bf16 x 3 pieces, six partial products / fp16 x 2 pieces, three): the golden vectors at the fp32
+    path's own bar, and the library must really have taken that kernel (the results differ from the fp32 kernel's)."""
     two = case in gc.DEC_TWOLEVEL_CASES
     q, abstract, fglob, ia, sd = (gc.dec_twolevel_inputs if two else gc.dec_inputs)(case)
     net = pk.implicit.LocalPclResnetFC(**ia).cuda().eval()
@@ -545,14 +524,14 @@ def test_decoder_with_three_way_split_bf16_attention(pk, bf16x6_attention, case)
     g = load_golden('g8_dec_' + case['name'])
     kw = dict(knn_local=dev(g['knn_local']), knn_cross=dev(g['knn_cross'])) if two else {}
     with torch.no_grad():
-        out, pen = net(dev(q), dev(abstract), dev(fglob), None, **kw)
-        pk.point_transformer_layer.LOGIT_PRECISION = 'f32'
+        with pk.kernels(logit_precision=scheme):
+            out, pen = net(dev(q), dev(abstract), dev(fglob), None, **kw)
         out32, pen32 = net(dev(q), dev(abstract), dev(fglob), None, **kw)
     close(out, g['output'], 2e-5)
     close(pen[:, ::8], g['penult'], 4e-5 if two else 2e-5)
     d = float((out - out32).abs().max())
-    print('\n[bf16x6 %s] |x6 - f32 path| %.3g, |x6 - ref| %.3g, |f32 path - ref| %.3g' % (
-        case['name'], d, float(np.abs(out.cpu().numpy() - g['output']).max()),
+    print('\n[%s %s] |split - f32 path| %.3g, |split - ref| %.3g, |f32 path - ref| %.3g' % (
+        scheme, case['name'], d, float(np.abs(out.cpu().numpy() - g['output']).max()),
         float(np.abs(out32.cpu().numpy() - g['output']).max())))
     assert 0.0 < d < 2e-5                 # a different kernel ran, and it agrees
 

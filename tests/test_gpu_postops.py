@@ -140,6 +140,64 @@ def test_perform_inference_results_own_their_buffers(pk, monkeypatch):
         assert np.array_equal(plain[k], frozen[k]) and plain[k].dtype == frozen[k].dtype, k
 
 
+def test_second_identical_perform_inference_call_prepares_and_allocates_nothing(pk, monkeypatch):
+    """Steady state of the reference's eval loop (eval/test.py:75: one perform_inference per output frame, same
+    networks): after the first calls a further identical call must not re-derive the decoder's weights
+    (ops.decoder_prepare), must not reserve more page-locked host memory, must not grow the device allocator's reserve
+    (the decode / copy side streams are persistent: torch keeps one block pool per stream) and must reuse the same side
+    streams.  (the bench's host_boundary leg had timed exactly these costs, 125.6 -> 144.4 ms.)"""
+    case = gc.INFER_CASES[0]
+    pcl, pa, ia, inf, esd, dsd = gc.infer_inputs(case)
+    enc = pk.model.PointCompletionNetV3(**pa).cuda().eval()
+    enc.load_state_dict(esd)
+    dec = pk.implicit.LocalPclResnetFC(**ia).cuda().eval()
+    dec.load_state_dict(dsd)
+    counts = dict(prepare=0, scene=0)
+    real_prepare, real_scene = pk.ops.decoder_prepare, pk.ops.decoder_prepare_scene
+
+    def counted_prepare(*a, **k):
+        counts['prepare'] += 1
+        return real_prepare(*a, **k)
+
+    def counted_scene(*a, **k):
+        counts['scene'] += 1
+        return real_scene(*a, **k)
+    monkeypatch.setattr(pk.ops, 'decoder_prepare', counted_prepare)
+    monkeypatch.setattr(pk.ops, 'decoder_prepare_scene', counted_scene)
+
+    def call():
+        with pk.kernels(decode_streams=2):
+            return _call()
+
+    def _call():
+        return pk.inference.perform_inference(
+            pcl.clone(), None, None, [enc, dec], torch.device('cuda'), 'if', inf['min_z'], inf['cube_bounds'],
+            inf['color_mode'], case['time_idx'], None, sample_implicit=True, num_sample=case['num_sample'],
+            point_sample_mode='grid', batch_size=1024, predict_segmentation=inf['predict_segmentation'],
+            track_mode='none', semantic_classes=13, density_threshold=0.5, data_kind=inf['data_kind'], cube_mode=4,
+            compress_air=True)
+
+    def pinned_reserved():
+        st = torch.cuda.host_memory_stats()
+        return st.get('reserved_bytes.current', st.get('allocated_bytes.current'))
+    held = [call(), call()]                     # as the eval loop: the previous result is alive while the next call runs
+    assert counts['prepare'] == 1, 'the first call derives the weights once'
+    torch.cuda.synchronize()
+    streams = {k: [s.cuda_stream for s in v] for k, v in pk.inference._STREAMS.items()}
+    assert any(role == 'decode' for (_, role) in streams) and any(role == 'copy' for (_, role) in streams)
+    base = dict(counts)
+    host0, dev0 = pinned_reserved(), torch.cuda.memory_reserved()
+    for _ in range(4):
+        held = [held[-1], call()]
+    torch.cuda.synchronize()
+    assert counts['prepare'] == base['prepare'], 'an identical call re-prepared the decoder weights'
+    assert counts['scene'] == base['scene'] + 4, 'one scene table per encoded cloud'
+    assert pinned_reserved() == host0, 'an identical call reserved more page-locked host memory'
+    assert torch.cuda.memory_reserved() == dev0, 'an identical call grew the device allocator (per-stream pools?)'
+    assert {k: [s.cuda_stream for s in v] for k, v in pk.inference._STREAMS.items()} == streams
+    assert np.array_equal(held[0]['implicit_output'], held[1]['implicit_output'])
+
+
 def test_clip_pipeline_matches_sequential_calls(pk):
     """Throughput mode: the encode of clip i + 1 issued while clip i decodes gives bit-identical outputs to
     sequential encode + decode calls, for a stream of DIFFERENT clips."""

@@ -43,24 +43,19 @@ def err(a, b):
     return float(np.abs(a.astype(np.float64) - np.asarray(b, dtype=np.float64)).max()) if a.size else 0.0
 
 
-ATTN_PATHS = ['attn16p', 'first', 'chain', 'bf16x6']
+ATTN_PATHS = ['attn16p', 'first', 'chain', 'bf16x6', 'f16x3']
+SPLIT = ('bf16x6', 'f16x3')
 
 
 @contextlib.contextmanager
 def attention_path(pk, which):
     """Selects the kernel generation the inference layer takes: 'attn16p' (default, csrc/crossattn16p.hip), 'first'
-    (crossattn.hip), 'chain' (unfused kernels), 'bf16x6' (round 5: every
-    attention GEMM on three-way split bf16 MFMAs, six partial products, csrc/crossattn_bf16x6.hip -- held to the fp32
-    paths' own bound, no relaxation: that is its claim)."""
-    ptl = pk.point_transformer_layer
-    old = (ptl.USE_ATTN16, ptl.USE_FUSED_ATTENTION, ptl.LOGIT_PRECISION)
-    ptl.USE_ATTN16 = which in ('attn16p', 'bf16x6')
-    ptl.USE_FUSED_ATTENTION = which != 'chain'
-    ptl.LOGIT_PRECISION = which if which == 'bf16x6' else 'f32'
-    try:
+    (crossattn.hip), 'chain' (unfused kernels), 'bf16x6' (round 5: every attention GEMM on three-way split bf16 MFMAs, six
+    partial products) / 'f16x3' (round 6: two fp16 pieces, three partial products), both csrc/crossattn_bf16x6.hip and
+    both held to the fp32 paths' own bound, no relaxation: that is their claim.  A thread-local scope (kernels.py)."""
+    with pk.kernels(attn16=which in ('attn16p',) + SPLIT, fused_attention=which != 'chain',
+                    logit_precision=which if which in SPLIT else 'f32'):
         yield
-    finally:
-        (ptl.USE_ATTN16, ptl.USE_FUSED_ATTENTION, ptl.LOGIT_PRECISION) = old
 
 
 # ------------------------------------------------------------------ G2r: one attention layer
@@ -69,7 +64,7 @@ def attention_path(pk, which):
 def test_pt_layer_regimes(pk, case, path):
     if case['dim'] not in pk.ops.FUSED_ATTN_DIMS and path != 'chain':
         pytest.skip('encoder widths run the unfused chain only')
-    if case['dim'] != 416 and path in ('attn16p', 'bf16x6'):
+    if case['dim'] != 416 and path in ('attn16p',) + SPLIT:
         pytest.skip('crossattn16p.hip / crossattn_bf16x6.hip are built for d = 416')
     x, pos, x2, pos2, sd = gc.ptl_inputs(case)
     layer = pk.point_transformer_layer.PointTransformerLayer(case['dim'], num_neighbors=case['k'],
@@ -124,24 +119,20 @@ def test_geometry_of_zero_padded_clouds_is_the_restated_torch_cluster(pk, case):
 
 
 # ------------------------------------------------------------------ G8r: decoder
-DEC_VARIANTS = ['default', 'trunk4', 'generic_trunk', 'first', 'chain', 'bf16x6', 'bf16x6_trunk', 'bf16x6_all']
+DEC_VARIANTS = ['default', 'trunk4', 'generic_trunk', 'first', 'chain', 'bf16x6', 'bf16x6_trunk', 'bf16x6_all',
+                'f16x3', 'f16x3_trunk', 'f16x3_all']
 
 
 @contextlib.contextmanager
 def decoder_variant(pk, variant):
-    ptl = pk.point_transformer_layer
-    old = (ptl.USE_TRUNK4, ptl.USE_TRUNK_KERNELS, ptl.TRUNK_PRECISION)
-    ptl.USE_TRUNK4 = variant == 'trunk4'
-    ptl.USE_TRUNK_KERNELS = variant != 'generic_trunk'
-    # round 5: the trunk's Linear layers (bf16x6_trunk) / the whole decoder (bf16x6_all) on three-way split bf16 MFMAs,
-    # held to the fp32 paths' own bound
-    ptl.TRUNK_PRECISION = 'bf16x6' if variant in ('bf16x6_trunk', 'bf16x6_all') else 'f32'
-    path = variant if variant in ('first', 'chain', 'bf16x6') else ('bf16x6' if variant == 'bf16x6_all' else 'attn16p')
-    try:
-        with attention_path(pk, path):
-            yield
-    finally:
-        (ptl.USE_TRUNK4, ptl.USE_TRUNK_KERNELS, ptl.TRUNK_PRECISION) = old
+    # the trunk's Linear layers (<scheme>_trunk) / the whole decoder (<scheme>_all) on the split-precision kernels, held to
+    # the fp32 paths' own bound
+    scheme = variant.split('_')[0] if variant.split('_')[0] in SPLIT else None
+    trunk = scheme if variant.endswith(('_trunk', '_all')) else 'f32'
+    path = variant if variant in ('first', 'chain') + SPLIT else (scheme if variant.endswith('_all') else 'attn16p')
+    with attention_path(pk, path), pk.kernels(trunk4=variant == 'trunk4', trunk_kernels=variant != 'generic_trunk',
+                                              trunk_precision=trunk):
+        yield
 
 
 @pytest.mark.parametrize('variant', DEC_VARIANTS)

@@ -171,15 +171,11 @@ def test_checkpointed_attention_gradients_strict(chunk):
     layer = ptl.PointTransformerLayer(case['dim'], num_neighbors=case['k'], dim2=case['dim2']).cuda()
     layer.load_state_dict(sd)
     xg, x2g = T(x).cuda().requires_grad_(True), T(x2).cuda().requires_grad_(True)
-    saved = ptl._CHECKPOINT_CHUNK
-    ptl._CHECKPOINT_CHUNK = chunk
-    try:
-        before = ptl._CheckpointedAttention.calls
+    with pk.kernels(checkpoint_chunk=chunk):       # (the backward below runs OUTSIDE the scope, on autograd's thread: the
+        before = ptl._CheckpointedAttention.calls   #  Function carries the selection of its forward)
         agg = layer(xg[None], T(pos).cuda()[None], x2g[None], T(pos2).cuda()[None])[0]
         assert ptl._CheckpointedAttention.calls == before + 1
-        (agg * go.cuda()).sum().backward()
-    finally:
-        ptl._CHECKPOINT_CHUNK = saved
+    (agg * go.cuda()).sum().backward()
     assert rel_err(agg, agg_r) < 1e-5
     assert rel_err(xg.grad, xr.grad) <= REL and rel_err(x2g.grad, x2r.grad) <= REL
     check_grads(layer, rsd)
@@ -202,8 +198,6 @@ def test_stored_attention_gradients_strict(form):
     layer = ptl.PointTransformerLayer(case['dim'], num_neighbors=case['k'], dim2=case['dim2']).cuda()
     layer.load_state_dict(sd)
     xg, x2g = T(x).cuda().requires_grad_(True), T(x2).cuda().requires_grad_(True)
-    saved = (ptl.CHECKPOINT_ATTENTION, ptl.STORED_ATTENTION_FORM)
-    ptl.CHECKPOINT_ATTENTION, ptl.STORED_ATTENTION_FORM = False, form
     calls = {'merged': 0}
     real = layer.forward_train_merged
 
@@ -211,13 +205,11 @@ def test_stored_attention_gradients_strict(form):
         calls['merged'] += 1
         return real(*a, **k)
     layer.forward_train_merged = counted
-    try:
+    with pk.kernels(checkpoint_attention=False, stored_attention_form=form):
         before = ptl._CheckpointedAttention.calls
         agg = layer(xg[None], T(pos).cuda()[None], x2g[None], T(pos2).cuda()[None])[0]
         assert ptl._CheckpointedAttention.calls == before and calls['merged'] == (1 if form == 'merged' else 0)
         (agg * go.cuda()).sum().backward()
-    finally:
-        ptl.CHECKPOINT_ATTENTION, ptl.STORED_ATTENTION_FORM = saved
     assert rel_err(agg, agg_r) < 1e-5
     assert rel_err(xg.grad, xr.grad) <= REL and rel_err(x2g.grad, x2r.grad) <= REL
     check_grads(layer, rsd)
@@ -441,7 +433,6 @@ def test_parameter_gradients_beside_the_chain_change_nothing(monkeypatch):
     q = Tc(np.concatenate([rng.uniform(-3, 3, size=(2, 200, 3)), np.zeros((2, 200, 1))], -1))
     tgt = Tc(np.concatenate([rng.integers(0, 2, size=(2, 200, 1)), rng.uniform(size=(2, 200, 3)), np.zeros((2, 200, 1)),
                              rng.integers(-1, 13, size=(2, 200, 1))], -1))
-    monkeypatch.setattr(pk.point_transformer_layer, '_CHECKPOINT_CHUNK', 128)      # 400 queries -> 4 chunks
     monkeypatch.setattr(pk.autograd, 'GRADIENT_OVERLAP', True)                     # (whatever OCC4D_GRADIENT_OVERLAP says)
 
     def grads(overlap):
@@ -451,7 +442,8 @@ def test_parameter_gradients_beside_the_chain_change_nothing(monkeypatch):
         dec.load_state_dict(dsd)
         dec.pt_blocks[0].layer2.to_v.weight.requires_grad_(False)
         step = pk.training.TrainStep(enc, dec, loss_kwargs=dict(density_lw=1.0, segmentation_lw=0.6))
-        loss = step.forward_loss(pcl, q, tgt)
+        with pk.kernels(checkpoint_chunk=128):                                     # 400 queries -> 4 chunks
+            loss = step.forward_loss(pcl, q, tgt)
         submitted = []
         if overlap:
             real = pk.autograd._deposit
@@ -573,12 +565,12 @@ def test_training_gemms_on_the_split_precision_kernels(monkeypatch):
         calls.append(k.get('mask') is not None)
         return real(*a, **k)
     monkeypatch.setattr(pk.ops, 'rowlin_bf16x6', spy)
-    monkeypatch.setattr(pk.autograd, 'TRAIN_PRECISION', 'bf16x6')
-    test_residual_block_node_and_shared_input_sum_match_the_separate_nodes()
-    n_block = len(calls)
-    assert n_block >= 8 and any(calls)                       # forward, masked data gradients, the shared-input chain
-    test_checkpointed_attention_gradients_strict(4096)
-    test_decoder_gradients(gc.DEC_CASES[2])
+    with pk.kernels(train_precision='bf16x6'):
+        test_residual_block_node_and_shared_input_sum_match_the_separate_nodes()
+        n_block = len(calls)
+        assert n_block >= 8 and any(calls)                       # forward, masked data gradients, the shared-input chain
+        test_checkpointed_attention_gradients_strict(4096)
+        test_decoder_gradients(gc.DEC_CASES[2])
     assert len(calls) > n_block
 
 
