@@ -240,6 +240,8 @@ def main():
 
     regimes(ref)
 
+    checkpoints(ref)
+
 
 @torch.no_grad()
 def g14(ref, cases):
@@ -292,6 +294,58 @@ def g14(ref, cases):
              terms=np.array([float(l_rgb), float(l_dens), float(l_segm), float(l_track)], dtype=np.float64),
              squashed=torch.stack(outs).detach().numpy()[:, :, ::16], grad=raw.grad.numpy())
 
+
+
+@torch.no_grad()
+def checkpoints(ref):
+    """G17: checkpoints in the reference's on-disk layout (train.py:339-350), written from the REFERENCE's modules'
+    state_dicts, and what the reference's own load_models + perform_inference (eval/inference.py:23-80, 83-325) return
+    for them.  torch >= 2.6 unpickles with weights_only=True by default, which rejects the argparse.Namespace the
+    reference stores under 'args': the reference's torch.load call is given weights_only=False for this run."""
+    import argparse
+    import collections
+    mdl, imp, inf = ref.model, ref.implicit, ref.inference
+    out_dir = os.path.join(OUT, gc.CKPT_DIR)
+    os.makedirs(out_dir, exist_ok=True)
+    pcl = pk.configs.synthetic_pcl(gc.CKPT_INFER['kind'], gc.CKPT_INFER['n'], gc.CKPT_INFER['video_len'],
+                                   gc.CKPT_INFER['seed'])
+    for case in gc.CKPT_CASES:
+        pa, ia, ia_inf = gc.ckpt_model_args(case)
+        enc, dec = mdl.PointCompletionNetV3(**pa), imp.LocalPclResnetFC(**ia)
+        enc.load_state_dict(pk.configs.fill_state_dict(enc, case['seed']))
+        dec.load_state_dict(pk.configs.fill_state_dict(dec, case['seed'] + 100))
+        dsd = dec.state_dict()
+        if case['legacy']:        # how checkpoints older than the pt_blocks ModuleList name the single cross layer
+            dsd = collections.OrderedDict(((('pt_block.' + k[len('pt_blocks.0.'):]) if k.startswith('pt_blocks.0.') else k), v)
+                                          for k, v in dsd.items())
+            assert any(k.startswith('pt_block.') for k in dsd) and not any(k.startswith('pt_blocks.') for k in dsd)
+        train_args = argparse.Namespace(name='g17_' + case['name'], data_path='synthetic', batch_size=1, learn_rate=1e-3,
+                                        n_points=gc.CKPT_INFER['n'], color_mode=ia_inf['color_mode'], seed=case['seed'])
+        ckpt = {'optimizer': {'state': {}, 'param_groups': []}, 'lr_scheduler': {}, 'scaler': {}, 'epoch': case['epoch'],
+                'args': train_args, 'pcl_args': dict(pa), 'dset_args': dict(n_points=gc.CKPT_INFER['n'], video_len=4,
+                                                                             data_kind=ia_inf['data_kind']),
+                'implicit_args': dict(ia), 'pcl_net': enc.state_dict(), 'implicit_net': dsd}
+        path = os.path.join(out_dir, case['file'])
+        torch.save(ckpt, path)
+        real_load = torch.load
+        torch.load = lambda *a, **k: real_load(*a, **dict(k, weights_only=False))
+        try:
+            (nets, targs, dargs, pargs, iargs, epoch) = inf.load_models(out_dir, torch.device('cpu'), epoch=case['epoch_arg'])
+        finally:
+            torch.load = real_load
+        assert epoch == case['epoch'] and pargs['fps_random_start'] is False and vars(targs) == vars(train_args)
+        for net in nets:
+            net.eval()
+        res = inf.perform_inference(
+            pcl.clone(), None, None, nets, torch.device('cpu'), 'if', ia_inf['min_z'], ia_inf['cube_bounds'],
+            ia_inf['color_mode'], gc.CKPT_INFER['time_idx'], None, sample_implicit=True,
+            num_sample=gc.CKPT_INFER['num_sample'], point_sample_mode='grid', batch_size=gc.CKPT_INFER['batch_size'],
+            predict_segmentation=False, track_mode='none', semantic_classes=13, density_threshold=0.5,
+            data_kind=ia_inf['data_kind'], cube_mode=4, compress_air=True)
+        save('g17_ckpt_' + case['name'], implicit_output=res['implicit_output'], pcl_abstract=res['pcl_abstract'],
+             features_global=res['features_global'], n_solid=np.array([res['output_solid'].shape[0]]),
+             decoder_keys=np.array(sorted(nets[1].state_dict().keys())), encoder_keys=np.array(sorted(nets[0].state_dict().keys())))
+        print('%-28s %8.1f KB' % (os.path.join(gc.CKPT_DIR, case['file']), os.path.getsize(path) / 1024))
 
 
 def _f64(sd):

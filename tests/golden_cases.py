@@ -531,3 +531,30 @@ def regime_bound(golden, key, floor=1e-4):
 
 def as_tensor(a):
     return torch.from_numpy(np.ascontiguousarray(a))
+
+
+# ---------------------------------------------------------------- G17: reference-format checkpoints (eval/inference.py:23-80)
+# Small-width networks saved by oracle/gen_golden.py with the REFERENCE's own modules and checkpoint layout
+# (train.py:339-350: optimizer / lr_scheduler / scaler / epoch / args / pcl_args / dset_args / implicit_args / pcl_net /
+# implicit_net) under tests/golden/<dir>/: `checkpoint.pth` with today's parameter names and `model_<epoch>.pth` of a
+# one-cross-layer decoder with the legacy `pt_block.` prefix (utils/utils.py:127-135), plus the reference's
+# load_models -> perform_inference outputs for both.
+CKPT_DIR = 'g17_ckpt_greater_small'
+CKPT_CASES = [
+    dict(name='current', file='checkpoint.pth', epoch_arg=-1, epoch=7, cross_attn_layers=2, legacy=False, seed=1850),
+    dict(name='legacy', file='model_3.pth', epoch_arg=3, epoch=3, cross_attn_layers=1, legacy=True, seed=1851),
+]
+CKPT_INFER = dict(kind='greater', n=768, video_len=4, num_sample=1024, batch_size=512, time_idx=2, seed=1852)
+
+
+def ckpt_model_args(case):
+    """Small-width constructor kwargs with the structure train.py:194-265 gives them (d_latent_local = d_feat * 2^blocks,
+    d_hidden = d_latent = global + local); fps_random_start is True in a training checkpoint (args.py default), which
+    load_models must override."""
+    pa, ia, inf = cfg.model_args('greater', CKPT_INFER['n'])
+    d_feat, g = 4, 16
+    pa.update(d_feat=d_feat, global_dim=g, fps_random_start=True)
+    d_local = d_feat * 2 ** pa['down_blocks']
+    ia.update(d_hidden=g + d_local, d_latent=g + d_local, d_latent_local=d_local,
+              cross_attn_layers=case['cross_attn_layers'], cr_attn_type='c' * case['cross_attn_layers'])
+    return pa, ia, inf

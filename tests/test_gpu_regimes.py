@@ -128,8 +128,8 @@ def decoder_variant(pk, variant):
     # the trunk's Linear layers (<scheme>_trunk) / the whole decoder (<scheme>_all) on the split-precision kernels, held to
     # the fp32 paths' own bound
     scheme = variant.split('_')[0] if variant.split('_')[0] in SPLIT else None
-    trunk = scheme if variant.endswith(('_trunk', '_all')) else 'f32'
-    path = variant if variant in ('first', 'chain') + SPLIT else (scheme if variant.endswith('_all') else 'attn16p')
+    trunk = scheme if scheme and variant.endswith(('_trunk', '_all')) else 'f32'
+    path = variant if variant in ('first', 'chain') + SPLIT else (scheme if scheme and variant.endswith('_all') else 'attn16p')
     with attention_path(pk, path), pk.kernels(trunk4=variant == 'trunk4', trunk_kernels=variant != 'generic_trunk',
                                               trunk_precision=trunk):
         yield
