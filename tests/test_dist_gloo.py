@@ -69,6 +69,36 @@ def _worker(rank, world, port, kind, ret):
                                                                squash=cpu_squash)
         assert torch.equal(full[lo:hi], local)
         assert calls == (['encode', 'encode'] if rank == 0 else []), calls   # only rank 0 encodes
+        # ONE packed broadcast per clip (round 6): the abstract cloud and the global embedding are views of one buffer
+        sent = []
+        real_broadcast = dist.broadcast
+
+        def counting_broadcast(tensor, src=0, **kw):
+            sent.append(tuple(tensor.shape))
+            return real_broadcast(tensor, src=src, **kw)
+        dist.broadcast = counting_broadcast
+        try:
+            shape = pk.distributed.abstract_shape(enc, case['n'])
+            ab, fg = pk.distributed.encode_and_share(pcl, enc, shape, enc.global_dim, torch.device('cpu'))
+        finally:
+            dist.broadcast = real_broadcast
+        off, total = pk.distributed.packed_layout(shape, enc.global_dim)
+        assert sent == [(total,)] and off % 4 == 0 and total == off + enc.global_dim
+        assert ab.untyped_storage().data_ptr() == fg.untyped_storage().data_ptr() and ab.is_contiguous()
+        ref_ab, ref_fg = op.encoder_forward(esd, pa, pcl)
+        assert torch.equal(ab, ref_ab[0]) and torch.equal(fg, ref_fg[0])
+        # the pipelined schedule (ClipPipeline: encode + broadcast of clip i + 1 issued before clip i decodes) over a
+        # stream of DIFFERENT clips = the sequential schedule, bit for bit, on every rank
+        clips = [pk.configs.synthetic_pcl(kind, case['n'], 4, 90 + i) for i in range(3)]
+        with torch.no_grad():
+            seq = [pk.distributed.sharded_inference(c, q, enc, dec, 128, inf['color_mode'], inf['predict_segmentation'],
+                                                    'none', 13, gather=True, squash=cpu_squash) for c in clips]
+            del calls[:]
+            pipe = pk.distributed.ClipPipeline(enc, dec, 128, inf['color_mode'], inf['predict_segmentation'], 'none', 13,
+                                               squash=cpu_squash)
+            piped = list(pipe.run(clips, q, gather=True))
+        assert len(piped) == 3 and all(torch.equal(a, b) for a, b in zip(seq, piped))
+        assert calls == (['encode'] * 3 if rank == 0 else []), calls
         if rank == 0:
             ret['full'] = full.numpy()
             ret['n'] = q.shape[0]
