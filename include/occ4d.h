@@ -36,6 +36,10 @@ extern "C" {
 
 int occ4d_abi_version(void);
 const char* occ4d_last_error(void);
+/* 0 in libocc4d.so.  1 in libocc4d_cpu.so, the g++ twin of the inference-path entry points (csrc_cpu/occ4d_twin.cpp:
+ * host pointers, `stream` ignored, plain as-written loops; SURVEY.md 8(b) "each with a CPU twin compiled by g++ for
+ * config 1").  The twin is loaded only on an explicit request (occlusions4d_amd.cpu_twin.enable()); it is not a fallback. */
+int occ4d_is_cpu_twin(void);
 
 /* ------------------------------------------------------------------------
  * K1 / K6 / K8  brute-force exact kNN, streaming top-k (k <= 16), never

@@ -14,6 +14,7 @@ from . import ops  # noqa: F401
 from . import autograd  # noqa: F401
 from . import point_transformer_layer, modules, model, geometry, implicit, inference, distributed, training  # noqa: F401
 from . import evaluation  # noqa: F401
+from . import cpu_twin  # noqa: F401   (explicit opt-in only: pk.cpu_twin.enable(); never a fallback)
 
 __all__ = ['configs', 'kernels', 'ops', 'point_transformer_layer', 'modules', 'model', 'geometry', 'implicit',
            'inference', 'distributed', 'autograd', 'training', 'evaluation']

@@ -65,6 +65,7 @@ _LW, _DW, _EV = C.POINTER(PtLayerWeights), C.POINTER(DecoderWeights), C.POINTER(
 # name -> (restype, argtypes): every symbol include/occ4d.h declares
 SIGNATURES = {
     'occ4d_abi_version': (C.c_int, []),
+    'occ4d_is_cpu_twin': (C.c_int, []),
     'occ4d_last_error': (C.c_char_p, []),
     'occ4d_knn_f32': (C.c_int, [_f, C.c_int64, C.c_int, _f, C.c_int64, C.c_int, C.c_int, C.c_int, _i, C.c_int,
                                 _f, _s]),
@@ -216,10 +217,54 @@ SIGNATURES = {
 }
 
 _lib = None
+_twin = False            # True only after an explicit load_cpu_twin(): host pointers, no streams (cpu_twin.py)
 
 
 class NativeLibraryError(RuntimeError):
     pass
+
+
+def is_twin():
+    return _twin
+
+
+def _missing(name):
+    def stub(*_a, **_k):
+        raise NotImplementedError('%s is not part of the CPU twin (libocc4d_cpu.so holds the inference path only)' % name)
+    return stub
+
+
+class _TwinHandle:
+    """The twin's exports with the argument types of SIGNATURES; an entry point the twin does not have raises
+    NotImplementedError when CALLED (the HIP library, in contrast, must export every symbol of the header)."""
+
+    def __init__(self, handle):
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError:
+                setattr(self, name, _missing(name))
+                continue
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, fn)
+
+
+def load_cpu_twin(path):
+    """Replaces the process's library handle by the g++ twin at `path`.  Only cpu_twin.enable() calls this; nothing in
+    the package does so on its own (no fallback: without this call a missing libocc4d.so raises NativeLibraryError)."""
+    global _lib, _twin
+    handle = C.CDLL(path)
+    twin = _TwinHandle(handle)
+    if twin.occ4d_abi_version() != ABI_VERSION or twin.occ4d_is_cpu_twin() != 1:
+        raise NativeLibraryError('%s is not the CPU twin of ABI version %d' % (path, ABI_VERSION))
+    _lib, _twin = twin, True
+    return twin
+
+
+def unload_cpu_twin():
+    global _lib, _twin
+    _lib, _twin = None, False
 
 
 def lib():

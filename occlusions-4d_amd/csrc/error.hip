@@ -13,4 +13,5 @@ void set_error(const char* fmt, ...) {
 }  // namespace occ4d
 
 extern "C" int occ4d_abi_version(void) { return OCC4D_ABI_VERSION; }
+extern "C" int occ4d_is_cpu_twin(void) { return 0; }
 extern "C" const char* occ4d_last_error(void) { return occ4d::g_err; }

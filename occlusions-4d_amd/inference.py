@@ -329,10 +329,10 @@ def decode_batches(implicit_net, points_query, lo, hi, batch_size, pcl_abstract,
     kernels fill the tail of the previous one's instead of waiting behind it.  The first batch runs
     on the caller's stream so the per-scene tables are built (and cached) before the side streams
     start."""
-    main = torch.cuda.current_stream()
     batch_size = decode_chunk(batch_size)
     starts = list(range(lo, hi, batch_size))
-    n_streams = kernels.scope().decode_streams
+    n_streams = kernels.scope().decode_streams if points_query.is_cuda else 1      # (host tensors: the explicit CPU twin)
+    main = torch.cuda.current_stream() if points_query.is_cuda else None
     side = side_streams(points_query.device, 'decode', n_streams) if n_streams > 1 and len(starts) > 2 else []
     def rows(b, e):           # the caller's neighbour lists of these queries (rows are indexed like points_query)
         return None if lists is None else tuple(None if a is None else a[b:e] for a in lists)

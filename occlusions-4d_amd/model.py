@@ -7,6 +7,8 @@ Interface mirror of the reference's model/model.py ``PointCompletionNetV3``
 Only the published inference configuration is built: enable_decoder=False,
 skip_connections=False (train.py:216-224); the UpTransition branch is out of scope.
 """
+import contextlib
+
 import torch
 
 from . import modules
@@ -65,30 +67,36 @@ class PointCompletionNetV3(torch.nn.Module):
                                 first level too when full=True (prefetch_geometry: nothing of it is left to forward()).
         `ready`: an event after which `pos` is complete; without it the side stream waits for everything queued on the
         current stream."""
-        main = torch.cuda.current_stream()
-        if self._geom_stream is None:
-            self._geom_stream = torch.cuda.Stream()
-        side = self._geom_stream
-        if ready is not None:
-            side.wait_event(ready)
-        else:
-            side.wait_stream(main)
+        on_device = pos.is_cuda                 # (host tensors: the explicit CPU twin -- the same chain, in line)
         out = {}
+        if on_device:
+            main = torch.cuda.current_stream()
+            if self._geom_stream is None:
+                self._geom_stream = torch.cuda.Stream()
+            side = self._geom_stream
+            if ready is not None:
+                side.wait_event(ready)
+            else:
+                side.wait_stream(main)
 
         def publish(i, payload, clouds):
+            if not on_device:
+                out[i] = (payload, clouds, None)
+                return
             for item in payload:                # produced on `side`, consumed on `main`
                 for t in (item if isinstance(item, tuple) else (item,)):
                     t.record_stream(main)
             ev = torch.cuda.Event()
             ev.record(side)
             out[i] = (payload, clouds, ev)
-        with torch.cuda.stream(side):
+        with (torch.cuda.stream(side) if on_device else contextlib.nullcontext()):
             cur = [ops.copy_rows(pos[b]) for b in range(pos.shape[0])]     # (the stride-8 xyz view, packed)
             nested = [modules.NestedFps() for _ in cur]      # (the levels' farthest-point subsets are prefixes of level 0's)
             for c in cur:
                 # allocated on the side stream, read by kernels on the main stream: without this the block could be
                 # recycled by a later side-stream allocation while such a kernel is still queued (ADVICE r2)
-                c.record_stream(main)
+                if on_device:
+                    c.record_stream(main)
             self_idx = None                     # self-kNN lists of `cur` when they were computed on this stream
             deferred = []                       # (block index, clouds) of the levels' self-kNNs: issued after ALL sampling
             for i, block in enumerate(self.blocks):

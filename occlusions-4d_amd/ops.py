@@ -70,13 +70,18 @@ def _stream():
     """The current HIP stream of the current device as a void pointer.  torch.cuda.current_stream() builds a Stream object
     through several Python layers (9 us; a decode mini-batch issues ~40 launches, a training step ~2000): the raw-handle
     accessor behind it is used when this torch build exposes it."""
+    if _lib.is_twin():
+        return C.c_void_p(0)             # (the CPU twin is synchronous)
     if _RAW_STREAM is not None:
         return C.c_void_p(_RAW_STREAM(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def _dev(t, dtype=torch.float32, name='tensor'):
-    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+    if _lib.is_twin():                   # explicit opt-in (cpu_twin.enable()): the g++ twin takes HOST tensors only
+        if not isinstance(t, torch.Tensor) or t.is_cuda:
+            raise RuntimeError('%s must be a CPU tensor while the CPU twin is loaded' % name)
+    elif not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise RuntimeError('%s must be a CUDA tensor: occlusions4d_amd runs only on the HIP library '
                            '(no CPU fallback)' % name)
     assert t.dtype == dtype, '%s must be %s, got %s' % (name, dtype, t.dtype)
@@ -105,7 +110,7 @@ def _aligned_rows(t, name, k_pad=None):
         ld = k_pad
     if t.data_ptr() % 16 or ld % 4:
         # (a library kernel, not .contiguous(): e.g. the abstract cloud's feature columns, a view 12 bytes into its rows)
-        t = copy_rows(t) if (t.is_cuda and t.dtype == torch.float32 and not t.requires_grad) else t.contiguous()
+        t = copy_rows(t) if ((t.is_cuda or _lib.is_twin()) and t.dtype == torch.float32 and not t.requires_grad) else t.contiguous()
         if t.shape[1] % 4:
             pad = 4 - t.shape[1] % 4
             t = torch.nn.functional.pad(t, (0, pad))
@@ -600,7 +605,8 @@ def fill_rows(out, value):
 def nested_fps_level(order, orig, m):
     """(positions (m) int32 ascending in the current cloud, their original indices (m) int32): the first m picks of the
     chain's selection order `order` located in the current cloud whose points have ascending original indices `orig`."""
-    assert order.dtype == torch.int32 and orig.dtype == torch.int32 and order.is_cuda and orig.is_cuda
+    assert order.dtype == torch.int32 and orig.dtype == torch.int32
+    _dev(order, torch.int32, 'order'), _dev(orig, torch.int32, 'orig')
     assert order.is_contiguous() and orig.is_contiguous() and order.numel() >= m
     pos = torch.empty((m,), dtype=torch.int32, device=orig.device)
     nxt = torch.empty((m,), dtype=torch.int32, device=orig.device)
@@ -923,7 +929,8 @@ def _neighbour_list(idx, n, k, name):
     """Caller-supplied neighbour list -> contiguous (n, k) int32 device tensor (any integer dtype comes in)."""
     if idx is None:
         return None
-    assert torch.is_tensor(idx) and idx.is_cuda and not idx.is_floating_point(), name + ' must be an integer CUDA tensor'
+    assert torch.is_tensor(idx) and (idx.is_cuda != _lib.is_twin()) and not idx.is_floating_point(), \
+        name + ' must be an integer CUDA tensor'
     assert tuple(idx.shape) == (n, k), '%s must have shape (%d, %d), got %s' % (name, n, k, tuple(idx.shape))
     return idx.to(torch.int32).contiguous()
 

@@ -13,12 +13,12 @@ import os
 import sys
 from collections import defaultdict
 
-WANT = ('cross_attn_bf16x6_kernel', 'cross_attn16p_kernel', 'cross_attn16_kernel', 'cross_attn_kernel', 'resblock_kernel', 'rowlin_kernel', 'linear_kernel<13', 'interp_add', 'knn_kernel')
+WANT = ('cross_attn_split_kernel', 'rowlin_split_kernel', 'cross_attn_bf16x6_kernel', 'cross_attn16p_kernel', 'cross_attn16_kernel', 'cross_attn_kernel', 'resblock_kernel', 'rowlin_kernel', 'linear_kernel<13', 'interp_add', 'knn_kernel')
 
 
 def short(name):
     name = name.replace('(anonymous namespace)::', '').replace('void ', '')
-    return name.split('(')[0]
+    return name.split('(')[0].replace(' ', '')
 
 
 def main():
@@ -65,8 +65,8 @@ def main():
         if os.path.exists(path):
             with open(path) as f:
                 rec = json.load(f)
-        ca = [k for k in out if ('cross_attn16' in k or 'cross_attn_kernel<13' in k) and '_hbm' in out[k]]
-        ca.sort(key=lambda k: (0 if 'cross_attn16p' in k else 1 if 'cross_attn16' in k else 2))
+        ca = [k for k in out if ('cross_attn16' in k or 'cross_attn_kernel<13' in k or 'cross_attn_split' in k) and '_hbm' in out[k]]
+        ca.sort(key=lambda k: (0 if 'cross_attn_split' in k else 1 if 'cross_attn16p' in k else 2 if 'cross_attn16' in k else 3))
         if ca:
             v = out[ca[0]]
             rec[kind] = dict(hbm_bytes_per_launch=v['_hbm'][0], fetch_size_kib=v['FETCH_SIZE'][0],
