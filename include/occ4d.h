@@ -494,6 +494,21 @@ int occ4d_pt_pos_hidden_bwd_det_workspace(int n, int k, int h, int64_t* floats);
 int occ4d_pt_pos_hidden_bwd_det_f32(const float* pos, int64_t ps, const float* pos2, int64_t p2s, const int32_t* idx,
                                     int n, int k, int h, const float* r, const float* gr, float* dP1, float* dc1,
                                     float* workspace, void* stream);
+/* Gradient clipping + AdamW for every parameter in three launches, no host read (train.py:107-109 clip_grad_norm_(0.2) + the
+ * optimiser step): params_flat / exp_avg / exp_avg_sq hold the parameters and both moments of ALL tensors back to back
+ * (tensor t at offsets[t], numels[t] elements); grad_ptrs[t] = device address of tensor t's gradient wherever the backward
+ * pass left it, 0 = no gradient this step (skipped entirely, as torch skips .grad is None); grad_ptrs holds 2 n_tensors
+ * words: behind the addresses, per tensor, the two floats (1 - beta1^k, sqrt(1 - beta2^k)) of its own update count k
+ * (torch counts steps per parameter).  chunk_tensor / chunk_start: one entry per chunk of occ4d_adamw_chunk() elements
+ * of a tensor.  All five tables are DEVICE arrays.
+ * total_norm = sqrt(sum g^2) over all gradients, coef = max_norm > 0 ? min(1, max_norm / (total_norm + 1e-6)) : 1;
+ * then torch.optim.AdamW's update with g * coef (amsgrad off).
+ * workspace: n_chunks + 2 floats; afterwards workspace[n_chunks] = total_norm, [n_chunks + 1] = coef. */
+int occ4d_adamw_chunk(void);
+int occ4d_adamw_clip_f32(float* params_flat, float* exp_avg, float* exp_avg_sq, const int64_t* grad_ptrs,
+                         const int64_t* offsets, const int64_t* numels, int n_tensors, const int32_t* chunk_tensor,
+                         const int32_t* chunk_start, int n_chunks, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, float max_norm, float* workspace, void* stream);
 int occ4d_axpby_f32(const float* a, int64_t lda, float alpha, const float* b, int64_t ldb, float beta, int n, int d,
                     float* out, int64_t ldo, void* stream);
 int occ4d_broadcast_rows_f32(const float* vec, float scale, int n, int d, float* out, int64_t ldo, void* stream);
@@ -602,6 +617,15 @@ int occ4d_pt_cross_attn_f16x3_f32(const float* aq, int64_t ld_aq, const float* q
                                   int64_t a_stride, const int32_t* idx, const float* kt, int64_t ld_kt, const float* vtc,
                                   int64_t ld_vt, const float* pos0_w, const float* pos0_b, const float* wstream, float* agg,
                                   int64_t ld_agg, int n, int m, int k, int d, float divisor, void* stream);
+/* ... with aq and kt already multiplied by occ4d_pt_cross_attn_f16x3_hidden_scale() (2^4: the scale the kernel keeps its
+ * hidden activations at; the path-level entry points scale the merged matrices behind Aq / Kt once per weight update, so no
+ * scaling instruction is left in the kernel's loop).  |hidden activation| < 65504 / 2^4. */
+float occ4d_pt_cross_attn_f16x3_hidden_scale(void);
+int occ4d_pt_cross_attn_f16x3_prescaled_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t q_stride,
+                                            const float* apos, int64_t a_stride, const int32_t* idx, const float* kt,
+                                            int64_t ld_kt, const float* vtc, int64_t ld_vt, const float* pos0_w,
+                                            const float* pos0_b, const float* wstream, float* agg, int64_t ld_agg, int n,
+                                            int m, int k, int d, float divisor, void* stream);
 int64_t occ4d_rowlin_f16x3_packed_floats(int n_out);
 int occ4d_pack_rowlin_f16x3_f32(const float* w, int64_t ldw, int n_out, float* packed, void* stream);
 int occ4d_rowlin_f16x3_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed, const float* b,

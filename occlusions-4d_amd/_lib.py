@@ -171,6 +171,8 @@ SIGNATURES = {
                                                   _f, _f, _f, _s]),
     'occ4d_axpby_f32': (C.c_int, [_f, C.c_int64, C.c_float, _f, C.c_int64, C.c_float, C.c_int, C.c_int, _f,
                                   C.c_int64, _s]),
+    'occ4d_adamw_chunk': (C.c_int, []),
+    'occ4d_adamw_clip_f32': (C.c_int, [_f, _f, _f, _i, _i, _i, C.c_int, _i, _i, C.c_int] + [C.c_float] * 6 + [_f, _s]),
     'occ4d_broadcast_rows_f32': (C.c_int, [_f, C.c_float, C.c_int, C.c_int, _f, C.c_int64, _s]),
     # packers + path-level entry points
     'occ4d_pack_trunk_rows_f32': (C.c_int, [_f, C.c_int64, C.c_int, _f, _s]),
@@ -194,6 +196,10 @@ SIGNATURES = {
     'occ4d_pack_attn_f16x3_stream_f32': (C.c_int, [_f, _f, _f, _f, _s]),
     'occ4d_pt_cross_attn_f16x3_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, C.c_int64, _i, _f, C.c_int64, _f, C.c_int64,
                                                 _f, _f, _f, _f, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _s]),
+    'occ4d_pt_cross_attn_f16x3_hidden_scale': (C.c_float, []),
+    'occ4d_pt_cross_attn_f16x3_prescaled_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, C.c_int64, _i, _f, C.c_int64, _f,
+                                                          C.c_int64, _f, _f, _f, _f, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                                          C.c_int, C.c_float, _s]),
     'occ4d_rowlin_f16x3_packed_floats': (C.c_int64, [C.c_int]),
     'occ4d_pack_rowlin_f16x3_f32': (C.c_int, [_f, C.c_int64, C.c_int, _f, _s]),
     'occ4d_rowlin_f16x3_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, _f, C.c_int, C.c_int, _f, C.c_int64, C.c_int, _s]),

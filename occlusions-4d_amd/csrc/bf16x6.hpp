@@ -117,7 +117,7 @@ __device__ __forceinline__ unsigned piece16(float x, int p) {
 // ----------------------------------------------------------------------------------------------------------------
 struct SplitBf16x6 {
   static constexpr int NP = 3;
-  static constexpr float WSCALE = 1.f, INV_WSCALE = 1.f;
+  static constexpr float WSCALE = 1.f, INV_WSCALE = 1.f, HSCALE = 1.f;
   struct Op { u32x4 p[3]; };
   static __device__ __forceinline__ Op split8(const f32x4 a, const f32x4 b) {
     const Split s = ::split8(a, b);
@@ -139,6 +139,7 @@ struct SplitBf16x6 {
     return e;
   }
   static __device__ __forceinline__ unsigned piece(float x, int p) { return piece16(x, p); }
+  static __device__ __forceinline__ unsigned piece_scaled(float x, int p, float) { return piece16(x, p); }
 };
 
 // fp16 x 2 pieces, 3 partial products (round 6):
@@ -150,6 +151,9 @@ struct SplitBf16x6 {
 // fp16's RANGE, which the bf16 pieces do not have to think about:
 //   * weights are packed as the pieces of w * 2^8 (exact), so that the second piece of a weight of ordinary size
 //     (>= 2^-10) is a normal fp16 number; smaller ones are kept to an absolute 2^-33; |w| must stay below 255.
+//     (The attention kernel's first GEMM packs its merged 832 x 32 matrix * 2^4 instead and keeps the hidden activations
+//     at 2^4 x their value up to the second GEMM -- no scaling instruction in the loop: |w| < 4094 there, entries below
+//     2^-6 kept to an absolute 2^-29, hidden activations below 4094.)
 //   * activations are split as they are: |x| must stay below 65504, and below |x| = 0.25 the second piece is an
 //     fp16 subnormal (gfx950's matrix pipe does not flush them): absolute error <= 2^-25 instead of 2^-23 |x|.
 // Forward passes only -- gradient magnitudes do not live in that window.
@@ -171,6 +175,9 @@ __device__ __forceinline__ void split2h(float x0, float x1, unsigned& h, unsigne
 struct SplitF16x3 {
   static constexpr int NP = 2;
   static constexpr float WSCALE = 256.f, INV_WSCALE = 1.f / 256.f;
+  // the attention kernel keeps its hidden activations at HSCALE x their value between GEMM1 and GEMM2 (GEMM1's weights are
+  // packed * HSCALE, its init term arrives * HSCALE, nothing is descaled in the loop): |hidden| < 65504 / 16 = 4094
+  static constexpr float HSCALE = 16.f;
   struct Op { u32x4 p[2]; };
   static __device__ __forceinline__ Op split8(const f32x4 a, const f32x4 b) {
     unsigned h[4], l[4];
@@ -196,8 +203,9 @@ struct SplitF16x3 {
     e = mmh(a.p[0], b[0], e);
     return e;
   }
-  static __device__ __forceinline__ unsigned piece(float x, int p) {
-    const float xs = x * WSCALE;
+  static __device__ __forceinline__ unsigned piece(float x, int p) { return piece_scaled(x, p, WSCALE); }
+  static __device__ __forceinline__ unsigned piece_scaled(float x, int p, float scale) {
+    const float xs = x * scale;
     const _Float16 h = (_Float16)xs;
     if (p == 0) return (unsigned)__builtin_bit_cast(unsigned short, h);
     const _Float16 l = (_Float16)(xs - (float)h);

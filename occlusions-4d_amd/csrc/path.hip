@@ -170,6 +170,14 @@ int add64(double* dst, const double* a, int64_t n, hipStream_t st) {
   add_f64_kernel<<<cdiv(n, 256), 256, 0, st>>>(dst, a, n);
   return occ4d::check_launch("merged weights: f64 add");
 }
+__global__ void scale_f32_kernel(float* __restrict__ x, int64_t n, float s) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) x[i] *= s;
+}
+int scale_f32(float* x, int64_t n, float s, hipStream_t st) {
+  scale_f32_kernel<<<cdiv(n, 256), 256, 0, st>>>(x, n, s);
+  return occ4d::check_launch("merged weights: scale");
+}
 int mm64(const double* a, const double* b, double* c, int m, int n, int k, hipStream_t st) {   // contiguous operands
   return occ4d_matmul_f64(a, k, 1, b, n, 1, c, m, n, k, st);
 }
@@ -305,6 +313,14 @@ int layer_prepare(const occ4d_pt_layer_weights& w, const LayerLayout& L, float* 
   TRY(to_f64(w.pos2_w, h, D, h, B, st));
   TRY(mm64(A, B, C2, 2 * D, h, D, st));
   TRY(to_f32(C2, (int64_t)2 * D * h, prep + L.wp, st));               // W1 P2
+  if (L.bf16x6 && L.f16) {
+    // the fp16 attention kernel keeps its hidden activations at HSCALE x their value: the matrices behind its init term
+    // (Aq = wq x + bq, Kt = wk f) are multiplied by that power of two here, once (exact), BEFORE they are packed
+    const float hs = occ4d_pt_cross_attn_f16x3_hidden_scale();
+    TRY(scale_f32(prep + L.wq, (int64_t)2 * D * L.Kq, hs, st));
+    TRY(scale_f32(prep + L.bq, 2 * D, hs, st));
+    TRY(scale_f32(prep + L.wk, (int64_t)2 * D * D2, hs, st));
+  }
   if (L.wq_rows) {
     if (L.trunk4) TRY(occ4d_pack_trunk4_rows_f32(prep + L.wq, L.Kq, 2 * D, prep + L.wq_packed, st));
     else TRY(occ4d_pack_trunk_rows_f32(prep + L.wq, L.Kq, 2 * D, prep + L.wq_packed, st));
@@ -403,6 +419,8 @@ int layer_forward(const occ4d_pt_layer_weights& w, const LayerLayout& L, const f
   int64_t ld_agg = ldo;
   if (w.post_w) { agg = ws.take((int64_t)n * D); ld_agg = D; }
   const bool fused = (L.fused16p || L.fused_first || L.bf16x6) && k <= 14;
+  OCC4D_REQUIRE(fused || !(L.bf16x6 && L.f16), "OCC4D_PATH_SPLIT_F16: the fp16 attention kernel takes k <= 14 neighbours (k = %d); "
+                "its prepared matrices are scaled for it", k);
   const float divisor = sqrtf((float)D);          // fp32(sqrt(d)), as torch.tensor(math.sqrt(d), float32)
   const int step = row_step(n);
   for (int lo = 0; lo < n; lo += step) {
@@ -443,8 +461,8 @@ int layer_forward(const occ4d_pt_layer_weights& w, const LayerLayout& L, const f
         E.before(OCC4D_PROFILE_CROSS_ATTN);
         int rc;
         if (L.bf16x6 && L.f16)
-          rc = occ4d_pt_cross_attn_f16x3_f32(aq, 2 * D, qp, ps, pos2, p2s, idx, kt, 2 * D, vtc, D, w.pos0_w, w.pos0_b,
-                                             prep + L.stream6, agg_c, ld_agg, c, m, k, D, divisor, st);
+          rc = occ4d_pt_cross_attn_f16x3_prescaled_f32(aq, 2 * D, qp, ps, pos2, p2s, idx, kt, 2 * D, vtc, D, w.pos0_w,
+                                                       w.pos0_b, prep + L.stream6, agg_c, ld_agg, c, m, k, D, divisor, st);
         else if (L.bf16x6)
           rc = occ4d_pt_cross_attn_bf16x6_f32(aq, 2 * D, qp, ps, pos2, p2s, idx, kt, 2 * D, vtc, D, w.pos0_w, w.pos0_b,
                                               prep + L.stream6, agg_c, ld_agg, c, m, k, D, divisor, st);

@@ -12,6 +12,9 @@ forward and backward kernel is libocc4d.so.  Query points and their targets are 
 the training-time point sampler that draws them (utils/geometry.py:578-1105, rank 2 of 8(f)) is
 geometry.GuidedImplicitPointSampler (bench_train.py --sampler runs it inside the step).
 """
+import math
+
+import numpy as np
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -279,19 +282,130 @@ class SideStreamSampler:
         return q, tgt
 
 
+class FusedClipAdamW:
+    """clip_grad_norm_(max_norm) + torch.optim.AdamW.step() for all parameters as ONE library call of three launches and no
+    host read (occ4d_adamw_clip_f32, csrc/optim.hip; train.py:107-109, 287-293).
+
+    The parameters become views of one flat fp32 buffer (`p.data` is re-pointed once, here; values unchanged) and the two
+    moment buffers are flat beside it; gradients stay wherever the backward pass left them -- a table of their addresses
+    (pinned host array -> one small asynchronous upload) is the only per-step host work: ~0.3 ms against ~15 ms for the
+    ~150-tensor foreach path of torch (profiles/r05_train_phases.txt).  A parameter whose .grad is None is skipped
+    entirely (no decay, no moment update), as torch does.  The gradients are NOT scaled in memory: the clip coefficient
+    is applied inside the update (`last_norm` / `last_coef` stay on the device for whoever wants to log them)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.params = [p for p in params]
+        assert self.params and all(p.is_cuda and p.dtype == torch.float32 for p in self.params), 'CUDA fp32 parameters'
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.steps = 0
+        self.counts = [0] * len(self.params)                                # updates per parameter (torch's state['step'])
+        dev = self.params[0].device
+        numels = [p.numel() for p in self.params]
+        offsets, total = [], 0
+        for n in numels:
+            offsets.append(total)
+            total += (n + 3) // 4 * 4                                   # (16-byte aligned views)
+        self.flat = torch.zeros((total,), dtype=torch.float32, device=dev)
+        for p, off, n in zip(self.params, offsets, numels):
+            view = self.flat[off:off + n].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        chunk = int(ops._lib.lib().occ4d_adamw_chunk())
+        ct, cs = [], []
+        for t, n in enumerate(numels):
+            for lo in range(0, n, chunk):
+                ct.append(t)
+                cs.append(lo)
+        i64 = lambda v: torch.tensor(v, dtype=torch.int64, device=dev)      # noqa: E731
+        i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)      # noqa: E731
+        self._offsets, self._numels, self._chunk_tensor, self._chunk_start = i64(offsets), i64(numels), i32(ct), i32(cs)
+        self._n_chunks = len(ct)
+        # the address table is uploaded asynchronously: a ring of pinned staging arrays, each reused only after the upload
+        # that read it has run (the host may be several steps ahead of the device)
+        self._staging = [[torch.zeros((2 * len(self.params),), dtype=torch.int64, pin_memory=True), None] for _ in range(4)]
+        self._grad_ptrs = torch.zeros((2 * len(self.params),), dtype=torch.int64, device=dev)
+        self._ws = torch.zeros((self._n_chunks + 2,), dtype=torch.float32, device=dev)
+
+    @property
+    def last_norm(self):
+        return self._ws[self._n_chunks]
+
+    @property
+    def last_coef(self):
+        return self._ws[self._n_chunks + 1]
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    def step(self, max_norm=None):
+        self.steps += 1
+        slot = self._staging[self.steps % len(self._staging)]
+        if slot[1] is not None:
+            slot[1].synchronize()
+        b1, b2 = self.betas
+        T = len(self.params)
+        table = slot[0].numpy()                                             # [0, T): addresses; [T, 2 T): (bias1, sqrt(bias2)) pairs
+        bias = table[T:].view(np.float32).reshape(T, 2)
+        keep = []                                                           # (non-contiguous gradients: packed copies, kept alive)
+        for i, p in enumerate(self.params):
+            g = p.grad
+            if g is None:
+                table[i] = 0
+                continue
+            if not g.is_contiguous():
+                g = g.contiguous()
+                keep.append(g)
+            assert g.dtype == torch.float32 and g.is_cuda
+            table[i] = g.data_ptr()
+            k = self.counts[i] = self.counts[i] + 1
+            bias[i, 0] = 1.0 - b1 ** k
+            bias[i, 1] = math.sqrt(1.0 - b2 ** k)
+        self._grad_ptrs.copy_(slot[0], non_blocking=True)
+        L = ops._lib
+        L.check(L.lib().occ4d_adamw_clip_f32(
+            ops._ptr(self.flat), ops._ptr(self.exp_avg), ops._ptr(self.exp_avg_sq), ops._ptr(self._grad_ptrs),
+            ops._ptr(self._offsets), ops._ptr(self._numels), len(self.params), ops._ptr(self._chunk_tensor),
+            ops._ptr(self._chunk_start), self._n_chunks, self.lr, b1, b2, self.eps, self.weight_decay,
+            float(max_norm) if max_norm else 0.0, ops._ptr(self._ws), ops._stream()))
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
+        del keep
+
+    def state_dict(self):
+        return dict(step=self.steps, counts=list(self.counts), exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(),
+                    lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay)
+
+    def load_state_dict(self, sd):
+        self.steps = int(sd['step'])
+        self.counts = list(sd.get('counts', [self.steps] * len(self.params)))
+        self.exp_avg.copy_(sd['exp_avg'])
+        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+
+
 class TrainStep:
     """One optimisation step: forward (encoder + decoder per target frame), losses, backward,
     gradient all-reduce, clip (train.py:107-109, max norm 0.2), optimiser step."""
 
     def __init__(self, pcl_net, implicit_net, lr=1e-3, weight_decay=1e-2, grad_clip=0.2, loss_kwargs=None,
-                 kernel_selection=None):
+                 kernel_selection=None, fused_optimizer=True):
         """`kernel_selection`: dict of kernels.Selection fields this step's forward runs under (e.g.
         dict(train_precision='bf16x6', logit_precision='bf16x6', checkpoint_attention=False)); the backward pass follows
         it through the autograd Functions.  None = the calling thread's scope."""
         self.kernel_selection = dict(kernel_selection or {})
         self.pcl_net, self.implicit_net = pcl_net, implicit_net
         self.params = list(pcl_net.parameters()) + list(implicit_net.parameters())
-        self.optimizer = torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay)
+        # clip + AdamW as one library call over flat buffers (round 6); fused_optimizer=False: torch's own two calls
+        self.fused = bool(fused_optimizer) and all(p.is_cuda for p in self.params)
+        if self.fused:
+            self.optimizer = FusedClipAdamW(self.params, lr=lr, weight_decay=weight_decay)
+        else:
+            self.optimizer = torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay)
         self.grad_clip = grad_clip
         self.loss_kwargs = loss_kwargs or {}
         self.participation = Participation()
@@ -330,8 +444,11 @@ class TrainStep:
         with autograd.gradient_overlap():      # parameter gradients beside the data-gradient chain, joined on exit
             loss.backward()
         allreduce_gradients(self.params, participation=self.participation)
-        if self.grad_clip:
-            torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
-        self.optimizer.step()
+        if self.fused:
+            self.optimizer.step(max_norm=self.grad_clip)
+        else:
+            if self.grad_clip:
+                torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
+            self.optimizer.step()
         invalidate_weight_caches()             # merged inference matrices / per-scene tables are stale now
         return loss.detach()

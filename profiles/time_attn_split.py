@@ -31,7 +31,18 @@ def variant(defs):
         defs = [x for x in defs if x != d]
         src = '/tmp/xa_src_%d.hip' % (abs(hash(d)) % 100000)
         with open(d[5:]) as fi, open(src, 'w') as fo:
-            fo.write(fi.read())
+            text = fi.read()
+            # an older revision of the file lacks entry points the rest of the library links against: stubs
+            if 'occ4d_pt_cross_attn_f16x3_hidden_scale' not in text:
+                text += '\nextern "C" float occ4d_pt_cross_attn_f16x3_hidden_scale(void) { return 1.f; }\n'
+            if 'occ4d_pt_cross_attn_f16x3_prescaled_f32' not in text:
+                text += ('extern "C" int occ4d_pt_cross_attn_f16x3_prescaled_f32(const float*, int64_t, const float*, int64_t, '
+                         'const float*, int64_t, const int32_t*, const float*, int64_t, const float*, int64_t, const float*, '
+                         'const float*, const float*, float*, int64_t, int, int, int, int, float, void*) { return -1; }\n')
+            if 'occ4d_pack_pair_mlp_bf16x6_stream_f32' not in text:
+                text += ('extern "C" int occ4d_pack_pair_mlp_bf16x6_stream_f32(const float*, const float*, const float*, float*, '
+                         'void*) { return -1; }\n')
+            fo.write(text)
     tag = '_'.join(d.replace('-DOCC4D_XA_ABL_', '') for d in defs) or os.path.basename(src)
     obj, so = '/tmp/xa_%s.o' % tag, '/tmp/xa_%s.so' % tag
     subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC',
@@ -41,8 +52,9 @@ def variant(defs):
                    [os.path.join(build, f) for f in sorted(os.listdir(build)) if f.endswith('.o') and f != 'crossattn_bf16x6.o'],
                    check=True)
     K = C.CDLL(so)
-    for name in ('occ4d_pt_cross_attn_bf16x6_f32', 'occ4d_pt_cross_attn_f16x3_f32'):
-        getattr(K, name).restype, getattr(K, name).argtypes = SIG[name]
+    for name in ('occ4d_pt_cross_attn_bf16x6_f32', 'occ4d_pt_cross_attn_f16x3_f32', 'occ4d_pt_cross_attn_f16x3_prescaled_f32'):
+        if hasattr(K, name):
+            getattr(K, name).restype, getattr(K, name).argtypes = SIG[name]
     return tag, K
 
 
@@ -73,12 +85,23 @@ def main():
                              'occ4d_pt_cross_attn_f16x3_f32') if scheme == 'f16x3' else
                             (L.occ4d_pt_cross_attn_bf16x6_stream_floats, L.occ4d_pack_attn_bf16x6_stream_f32,
                              'occ4d_pt_cross_attn_bf16x6_f32'))
-        ws = torch.empty((int(size()),), dtype=torch.float32, device='cuda')
-        ops._lib.check(pack(ops._ptr(w2), ops._ptr(wp), ops._ptr(p2), ops._ptr(ws), ops._stream()))
+        pack_name = 'occ4d_pack_attn_f16x3_stream_f32' if scheme == 'f16x3' else 'occ4d_pack_attn_bf16x6_stream_f32'
+        streams = {}
+        for tag, K in libs:                 # (every revision packs its own stream: the layouts differ)
+            fnp = getattr(K, pack_name)
+            fnp.restype, fnp.argtypes = SIG[pack_name]
+            ws = torch.empty((int(size()),), dtype=torch.float32, device='cuda')
+            ops._lib.check(fnp(ops._ptr(w2), ops._ptr(wp), ops._ptr(p2), ops._ptr(ws), ops._stream()))
+            streams[tag] = ws
         prod = 3 if scheme == 'f16x3' else 6
         flop = wgs * 8 * (26 * 30 + 28) * prod * 16384.0
-        for tag, K in libs:
-            fn = getattr(K, name)
+        entries = [(tag, K, name, tag) for tag, K in libs]
+        if scheme == 'f16x3':           # the path-level calls: init term pre-multiplied by the producers (timing: same data)
+            entries += [(tag + ' prescaled', K, 'occ4d_pt_cross_attn_f16x3_prescaled_f32', tag) for tag, K in libs
+                        if hasattr(K, 'occ4d_pt_cross_attn_f16x3_prescaled_f32') and not tag.startswith('xa_src')]
+        for tag, K, entry, stream_of in entries:
+            fn = getattr(K, entry)
+            ws = streams[stream_of]
 
             def run():
                 rc = fn(ops._ptr(aq), 2 * d, ops._ptr(qpos), 3, ops._ptr(apos), 3, ops._ptr(idx), ops._ptr(kt), 2 * d,

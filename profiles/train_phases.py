@@ -31,7 +31,8 @@ target = np.concatenate([rng.integers(0, 2, size=(FRAMES, QUERIES, 1)), rng.unif
 q = torch.from_numpy(q.astype(np.float32)).to(dev)
 target = torch.from_numpy(target.astype(np.float32)).to(dev)
 step = tr.TrainStep(enc, dec, lr=1e-3, grad_clip=0.2,
-                    loss_kwargs=dict(density_lw=1.0, segmentation_lw=0.6, static_shapes=True))
+                    loss_kwargs=dict(density_lw=1.0, segmentation_lw=0.6, static_shapes=True),
+                    fused_optimizer=os.environ.get('OCC4D_FUSED_OPTIMIZER', '1') == '1')
 NAMES = ['encoder', 'decoder', 'losses', 'prefetch issue', 'backward', 'clip + AdamW']
 
 
@@ -58,8 +59,11 @@ def one(record):
         loss.backward()
     mark(5)
     tr.allreduce_gradients(step.params, participation=step.participation)
-    torch.nn.utils.clip_grad_norm_(step.params, step.grad_clip)
-    step.optimizer.step()
+    if step.fused:
+        step.optimizer.step(max_norm=step.grad_clip)        # one library call: clip + AdamW over the flat buffers (round 6)
+    else:
+        torch.nn.utils.clip_grad_norm_(step.params, step.grad_clip)
+        step.optimizer.step()
     tr.invalidate_weight_caches()
     mark(6)
     if record is not None:

@@ -895,3 +895,45 @@ def test_batched_frames_equal_the_per_frame_loop():
     assert abs(res[0][0] - res[1][0]) <= 2e-6 * abs(res[0][0])
     for k, g in res[0][1].items():
         assert rel_err(res[1][1][k], g) <= 1e-4 or float(g.abs().max()) < 1e-7, k
+
+
+def test_fused_clip_adamw_matches_torch_over_several_steps():
+    """occ4d_adamw_clip_f32 (csrc/optim.hip) against torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW on the same
+    gradients for five steps: tensors of awkward sizes (1 element, not a multiple of 4, larger than one chunk), a
+    parameter without a gradient (skipped: no decay, no moments), a non-contiguous gradient, a step where the norm is
+    below max_norm (coefficient 1) -- parameters, both moments, the norm and the coefficient."""
+    torch.manual_seed(5)
+    shapes = [(1,), (3, 5), (416, 416), (7,), (832, 33), (10001,), (2, 2)]
+    mine = [torch.nn.Parameter(torch.randn(*s, device='cuda')) for s in shapes]
+    theirs = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    opt = pk.training.FusedClipAdamW(mine, lr=3e-3, weight_decay=1e-2)
+    ref = torch.optim.AdamW(theirs, lr=3e-3, weight_decay=1e-2)
+    assert all(p.data_ptr() >= opt.flat.data_ptr() and p.data_ptr() < opt.flat.data_ptr() + opt.flat.numel() * 4 for p in mine)
+    assert all(torch.equal(a, b) for a, b in zip(mine, theirs))              # re-pointing the parameters kept their values
+    for step in range(5):
+        scale = 1e-3 if step == 3 else 1.0                                    # (step 3: total norm < max_norm)
+        for i, (a, b) in enumerate(zip(mine, theirs)):
+            if i == 3 or (i == 6 and step < 2):                               # no gradient at all / only from step 2 on
+                a.grad = b.grad = None
+                continue
+            g = torch.randn(*a.shape, device='cuda') * scale
+            if i == 1:
+                g = (torch.randn(5, 3, device='cuda') * scale).t()            # non-contiguous
+            a.grad, b.grad = g, g.clone()
+        norm = torch.nn.utils.clip_grad_norm_(theirs, 0.2)
+        ref.step()
+        opt.step(max_norm=0.2)
+        assert abs(float(opt.last_norm) - float(norm)) <= 1e-5 * float(norm)
+        assert abs(float(opt.last_coef) - min(1.0, 0.2 / (float(norm) + 1e-6))) < 1e-6
+        for a, b in zip(mine, theirs):
+            assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max())), (step, tuple(a.shape))
+    assert torch.equal(mine[3], theirs[3])                                    # never had a gradient: untouched
+    for p, b in zip(mine, theirs):
+        st = ref.state.get(b)
+        if st:
+            off = (p.data_ptr() - opt.flat.data_ptr()) // 4
+            m = opt.exp_avg[off:off + p.numel()].view(p.shape)
+            v = opt.exp_avg_sq[off:off + p.numel()].view(p.shape)
+            assert float((m - st['exp_avg']).abs().max()) < 1e-6 and float((v - st['exp_avg_sq']).abs().max()) < 1e-6
+    opt.zero_grad()
+    assert all(p.grad is None for p in mine)
