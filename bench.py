@@ -38,9 +38,11 @@ Extra objects on the JSON line:
                 timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -221,7 +223,8 @@ def self_launch(n_gpus):
 def rccl_log_setup(rank):
     """N > 1 runs record RCCL's own initialisation log (NCCL_DEBUG=INFO into a per-process file) so that the bench line can
     carry which transport / ring RCCL really built: the first 8-GPU run is then diagnosable from its JSON tail."""
-    path = '/tmp/occ4d_rccl_rank%d_%d.log' % (rank, os.getpid())
+    fd, path = tempfile.mkstemp(prefix='occ4d_rccl_rank%d_' % rank, suffix='.log')      # (removed in main() once read)
+    os.close(fd)
     os.environ.setdefault('NCCL_DEBUG', 'INFO')
     os.environ.setdefault('NCCL_DEBUG_SUBSYS', 'INIT,GRAPH')
     os.environ['NCCL_DEBUG_FILE'] = path
@@ -620,6 +623,11 @@ def main():
             line['sequential' if schedule == 'pipelined' else 'pipelined'] = pipelined
         if host_boundary is not None:
             line['host_boundary'] = host_boundary
+        # The headline is complete here: a copy goes to STDERR now, so that a harness time limit that cuts the secondary
+        # legs or the CPU baseline below short still leaves the measured figure in the log (stdout keeps its ONE line)
+        print('bench.py headline (secondary legs follow): ' + json.dumps({k: line[k] for k in (
+            'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step')} | {'roofline_frac': line['roofline']['frac']}),
+            file=sys.stderr, flush=True)
         # BASELINE configs[2] and configs[4] on the same driver-timed line: each leg is its own
         # process on this GPU, K timed steps between fences exactly as above, its own `roofline` object.  (The CPU
         # baseline starts after them: beside them its 16 threads cost the host-bound eager training step 1.5 ms.)
@@ -645,6 +653,9 @@ def main():
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    if rccl_log:
+        with contextlib.suppress(OSError):
+            os.remove(rccl_log)
     return 0
 
 

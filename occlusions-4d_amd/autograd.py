@@ -67,6 +67,7 @@ GRADIENT_OVERLAP_BYTES = int(float(os.environ.get('OCC4D_GRADIENT_OVERLAP_GB', '
 
 class _Overlap:
     stream = None
+    device = None        # the device the side stream lives on (asserted: one device per process)
     depth = 0
     params = {}          # id(parameter) -> [parameter, sum]      (filled on the side stream)
     sinks = {}           # id(leaf) -> [leaf, sum or None]        (gradient_sinks)
@@ -106,7 +107,13 @@ def join_gradients():
 @contextlib.contextmanager
 def gradient_overlap():
     """Scope of one backward pass whose parameter gradients may run beside the data-gradient chain (see above).  On exit
-    the current stream waits for them and the collected sums are added to the parameters' .grad."""
+    the current stream waits for them and the collected sums are added to the parameters' .grad.
+    NOT compatible with hook-based reducers: inside the scope the Functions of this module report the
+    gradients of nn.Parameters to autograd as None and write .grad here, on exit -- AccumulateGrad never runs for them, so
+    parameter hooks / post-accumulate-grad hooks (DDP- or FSDP-style bucket reducers) do not fire and
+    torch.autograd.grad(loss, params) inside the scope returns None for them.  This package reduces gradients AFTER the
+    scope (training.allreduce_gradients).  The scope is process-wide state with one side stream on the device that was
+    current at its first use: one training thread, one device per process (the launch model of bench_train.py)."""
     _Overlap.depth += 1
     try:
         yield
@@ -177,6 +184,10 @@ def _deposit(targets, compute, *operands):
         return run()
     if _Overlap.stream is None:
         _Overlap.stream = torch.cuda.Stream()
+        _Overlap.device = torch.cuda.current_device()
+    assert torch.cuda.current_device() == _Overlap.device, \
+        'gradient_overlap(): one device per process (side stream on cuda:%d, called on cuda:%d)' % (
+            _Overlap.device, torch.cuda.current_device())
     ready = torch.cuda.Event()
     ready.record()
     _Overlap.stream.wait_event(ready)
@@ -286,10 +297,30 @@ class FanOut:
     """Shared by the `uses` LinearFn calls that consume the SAME input tensor (the decoder's per-query latent feeds one
     lin_z layer per block): each call's data gradient is a GEMM whose epilogue adds the running sum of the calls before it,
     and only the last one reports the total to autograd (the others report None) -- instead of `uses` separate gradients
-    that the engine adds up in `uses - 1` element-wise passes over an (n, K) tensor."""
+    that the engine adds up in `uses - 1` element-wise passes over an (n, K) tensor.
+    CONTRACT: every one of the `uses` nodes must run in the SAME backward pass, i.e. the whole decoder forward
+    is differentiated at once (what TrainStep and the tests do).  Differentiating a sub-graph that holds only some of them
+    (autograd.grad of an intermediate block output w.r.t. the shared latent) leaves the running sum unreported: the
+    object then says so -- `pending()` is True -- and the next pass through it raises instead of adding to a stale sum.
+    One object serves ONE forward pass (LocalPclResnetFC._forward_train builds a fresh one per call)."""
 
     def __init__(self, uses):
-        self.left, self.total = uses, None
+        self.uses, self.left, self.total = uses, uses, None
+
+    def pending(self):
+        """True between the first and the last of the sharing nodes' backward calls (a partial pass stays pending)."""
+        return 0 < self.left < self.uses
+
+    def take(self, dx):
+        """One sharing node's data gradient (already holding the running sum): returns the total for the last node, None
+        (not reported yet) for the others."""
+        assert self.left > 0, 'FanOut: more backward calls than the %d nodes that share the input' % self.uses
+        self.left -= 1
+        if self.left > 0:
+            self.total = dx
+            return None
+        self.total, self.left = None, self.uses          # complete: ready for a second pass over a retained graph
+        return dx
 
 
 @kernels.carries_selection
@@ -316,11 +347,8 @@ class LinearFn(Function):
         if ctx.needs_input_grad[0]:
             fan = ctx.fan
             if fan is not None and not relu_in:
-                dx = _linear_fwd(g, w, None, transposed=True, residual=fan.total)
-                fan.left -= 1
-                fan.total = dx if fan.left > 0 else None
-                if fan.left > 0:
-                    dx = None                      # (reported by the last of the calls that share the input)
+                dx = fan.take(_linear_fwd(g, w, None, transposed=True, residual=fan.total))   # (reported by the last of the
+                                                                                              #  calls that share the input)
             else:
                 dx = _linear_fwd(g, w, None, transposed=True, mask=x if relu_in else None)
         want_db = has_b and ctx.needs_input_grad[2]

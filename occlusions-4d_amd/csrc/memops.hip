@@ -68,6 +68,18 @@ __global__ __launch_bounds__(NEST_T) void nested_level_kernel(const int32_t* __r
     ++pos;
   }
   __syncthreads();
+  // picks that repeat (a cloud with fewer distinct points than samples): the entries behind the `distinct` compacted
+  // positions repeat the LAST of them -- out_pos stays ascending (non-decreasing), as the docstring of
+  // ops.nested_fps_level promises (the raw search results used to stay there, unsorted)
+  int distinct = 0;
+  for (int w = 0; w < NEST_T / 64; ++w) distinct += s_wave[w];
+  distinct = min(distinct, m);
+  if (distinct < m) {
+    const int last = out_pos[distinct - 1];
+    __syncthreads();
+    for (int i = distinct + t; i < m; i += NEST_T) out_pos[i] = last;
+    __syncthreads();
+  }
   for (int i = t; i < m; i += NEST_T) out_orig[i] = orig[out_pos[i]];
 }
 

@@ -367,8 +367,10 @@ class LocalPclResnetFC(ResnetFC, kernels.HasKernelSelection):
         fa = fa.contiguous()
         n = q.shape[0]
         dg = self.d_latent - self.d_latent_local
-        if knn_local is not None:
-            idx8 = (knn_local[0] if knn_local.dim() == 3 else knn_local).to(torch.int32).contiguous()
+        m_abs = pa.shape[0]
+        if knn_local is not None:            # (shape-checked and clamped into [0, m): the gathers below are unchecked -- ADVICE r5)
+            idx8 = ops._neighbour_list(knn_local[0] if knn_local.dim() == 3 else knn_local, n, self.num_local_features,
+                                       'knn_local', m=m_abs)
             dist = ops.knn_dists(q, pa, idx8, metric=1)
         else:
             idx8, dist = ops.knn(q, pa, self.num_local_features, metric=1, return_dist=True)
@@ -379,7 +381,8 @@ class LocalPclResnetFC(ResnetFC, kernels.HasKernelSelection):
         qxyz = q[:, :3].detach()
         idx_att = None
         if knn_cross is not None:
-            idx_att = (knn_cross[0] if knn_cross.dim() == 3 else knn_cross).to(torch.int32).contiguous()
+            idx_att = ops._neighbour_list(knn_cross[0] if knn_cross.dim() == 3 else knn_cross, n, self.cross_attn_neighbors,
+                                          'knn_cross', m=m_abs)
         fan = autograd.FanOut(self.n_blocks)       # f_query feeds one lin_z layer per block: one running gradient sum
         for i in range(self.n_blocks):
             x = autograd.linear(f_query, self.lin_z[i], residual=x, fan=fan)

@@ -604,7 +604,9 @@ def fill_rows(out, value):
 
 def nested_fps_level(order, orig, m):
     """(positions (m) int32 ascending in the current cloud, their original indices (m) int32): the first m picks of the
-    chain's selection order `order` located in the current cloud whose points have ascending original indices `orig`."""
+    chain's selection order `order` located in the current cloud whose points have ascending original indices `orig`.
+    When picks repeat (fewer distinct points than samples) the distinct positions come first, ascending, and the remaining
+    entries repeat the last of them."""
     assert order.dtype == torch.int32 and orig.dtype == torch.int32
     _dev(order, torch.int32, 'order'), _dev(orig, torch.int32, 'orig')
     assert order.is_contiguous() and orig.is_contiguous() and order.numel() >= m
@@ -925,14 +927,19 @@ def decoder_prepare_scene(w, prepared, xyz, feats, fglobal, flags):
     return scene
 
 
-def _neighbour_list(idx, n, k, name):
-    """Caller-supplied neighbour list -> contiguous (n, k) int32 device tensor (any integer dtype comes in)."""
+def _neighbour_list(idx, n, k, name, m=None):
+    """Caller-supplied neighbour list -> contiguous (n, k) int32 device tensor (any integer dtype comes in).  `m`: the
+    size of the cloud the entries index -- they are forced into [0, m) (the gathers behind them are unchecked; the
+    library's inference entry point does the same with its own clamp kernel)."""
     if idx is None:
         return None
     assert torch.is_tensor(idx) and (idx.is_cuda != _lib.is_twin()) and not idx.is_floating_point(), \
         name + ' must be an integer CUDA tensor'
     assert tuple(idx.shape) == (n, k), '%s must have shape (%d, %d), got %s' % (name, n, k, tuple(idx.shape))
-    return idx.to(torch.int32).contiguous()
+    idx = idx.to(torch.int32)
+    if m is not None:
+        idx = idx.clamp(0, m - 1)
+    return idx.contiguous()
 
 
 def decoder_query_fwd(w, prepared, scene, m, queries, flags=0, out=None, penult=None, want_penult=True,

@@ -25,6 +25,7 @@ step bench.json 'python bench.py --steps 20 --warmup 5 2> "$OUT/bench.err" | tai
 step bench_carla.json 'python bench.py --kind carla --steps 10 --warmup 3 --no-secondary 2>> "$OUT/bench.err" | tail -1 > "$OUT/bench_carla.json"'
 step bench_kernel_stats_streams1.csv 'OCC4D_DECODE_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof1" -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra 2>/dev/null | tail -1 > "$OUT/bench_streams1_under_rocprof.json"; cp "$(find "$OUT/prof1" -name "*kernel_stats.csv" | head -1)" "$OUT/bench_kernel_stats_streams1.csv"'
 step bench_kernel_stats.csv 'rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof2" -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra > /dev/null 2>&1; cp "$(find "$OUT/prof2" -name "*kernel_stats.csv" | head -1)" "$OUT/bench_kernel_stats.csv"'
+step bench_kernel_stats_f16x3_streams1.csv 'OCC4D_LOGIT_PRECISION=f16x3 OCC4D_TRUNK_PRECISION=f16x3 OCC4D_DECODE_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof7" -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra 2>/dev/null | tail -1 > "$OUT/bench_f16x3_streams1_under_rocprof.json"; cp "$(find "$OUT/prof7" -name "*kernel_stats.csv" | head -1)" "$OUT/bench_kernel_stats_f16x3_streams1.csv"'
 step bench_kernel_stats_bf16x6_streams1.csv 'OCC4D_LOGIT_PRECISION=bf16x6 OCC4D_TRUNK_PRECISION=bf16x6 OCC4D_DECODE_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof6" -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra 2>/dev/null | tail -1 > "$OUT/bench_bf16x6_streams1_under_rocprof.json"; cp "$(find "$OUT/prof6" -name "*kernel_stats.csv" | head -1)" "$OUT/bench_kernel_stats_bf16x6_streams1.csv"'
 : > "$OUT/bench_train.jsonl"
 for flags in "" "--no-checkpoint" "--precision bf16x6" "--precision bf16x6 --no-checkpoint"; do
@@ -45,8 +46,10 @@ step time_fps.txt 'python profiles/time_fps.py 2>/dev/null > "$OUT/time_fps.txt"
 step fps_stamps.txt 'python profiles/stamp_fps.py 14336 4779 2>/dev/null > "$OUT/fps_stamps.txt"; python profiles/stamp_fps.py 4779 1593 2>/dev/null >> "$OUT/fps_stamps.txt"'
 step x6_stamps.txt '(cd profiles && python stamp_x6.py 2>/dev/null | tail -2) > "$OUT/x6_stamps.txt"'
 step encode_timeline.txt 'rocprofv3 --kernel-trace --output-format csv -d "$OUT/enc" -- python profiles/probe.py encode 4 > /dev/null 2>&1; python profiles/encode_timeline.py "$(find "$OUT/enc" -name "*kernel_trace.csv" | head -1)" 6 > "$OUT/encode_timeline.txt"'
+step host_boundary_probe.txt 'python profiles/host_boundary_probe.py 6 2>/dev/null | grep -v amdgpu.ids > "$OUT/host_boundary_probe.txt"'
+step attn_split_ablations.txt 'python profiles/time_attn_split.py f16x3 bf16x6 -DOCC4D_XA_ABL_NOSPLIT -DOCC4D_XA_ABL_NOGEMM1 -DOCC4D_XA_ABL_NOINIT -DOCC4D_XA_ABL_NODMA -DOCC4D_XA_ABL_NOLDS -DOCC4D_XA_ABL_NODEP -DOCC4D_XA_ABL_NOLDS,-DOCC4D_XA_ABL_NODEP,-DOCC4D_XA_ABL_NOSPLIT,-DOCC4D_XA_ABL_NOINIT,-DOCC4D_XA_ABL_NODMA 2>/dev/null | grep -v amdgpu.ids > "$OUT/attn_split_ablations.txt"'
 step forced_dist_rccl.log '( OCC4D_FORCE_DIST=1 python bench.py --steps 10 --warmup 3 --no-extra --no-cpu-baseline; OCC4D_FORCE_DIST=1 NCCL_DEBUG=INFO python bench_train.py --steps 3 --warmup 1 ) > "$OUT/forced_dist_rccl.log" 2>&1'
-rm -rf "$OUT/prof1" "$OUT/prof2" "$OUT/prof3" "$OUT/prof6" "$OUT/enc"
+rm -rf "$OUT/prof1" "$OUT/prof2" "$OUT/prof3" "$OUT/prof6" "$OUT/prof7" "$OUT/enc"
 ls -la "$OUT"
 if [ -s "$OUT/FAILED.txt" ]; then echo "some steps FAILED:"; cat "$OUT/FAILED.txt"; exit 1; fi
 rm -f "$OUT/FAILED.txt"

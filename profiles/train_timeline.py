@@ -1,5 +1,5 @@
 """Where one training step's wall time goes, from a rocprofv3 --kernel-trace CSV of bench_train.py: the last step is cut
-at the optimizer's kernels (the multi-tensor AdamW launches end a step), then per queue: kernel time, idle time between
+at the optimizer's kernels (the library's adamw_kernel -- torch's multi-tensor AdamW launches before round 6 -- ends a step), then per queue: kernel time, idle time between
 consecutive kernels, and per kernel name its own time plus the idle time that follows it (what removing it would give
 back when the stream is serial).
 Usage: python profiles/train_timeline.py <kernel_trace.csv> [top] [sequence.txt | -: the step's launches in order] [back]
@@ -17,7 +17,9 @@ def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
-    opt = [i for i, r in enumerate(rows) if 'multi_tensor_apply' in r['Kernel_Name'] and 'Adam' in r['Kernel_Name']]
+    opt = [i for i, r in enumerate(rows) if 'adamw_kernel' in r['Kernel_Name']]      # (round 6: the library's fused clip + AdamW)
+    if not opt:
+        opt = [i for i, r in enumerate(rows) if 'multi_tensor_apply' in r['Kernel_Name'] and 'Adam' in r['Kernel_Name']]
     if not opt:
         opt = [i for i, r in enumerate(rows) if 'multi_tensor_apply' in r['Kernel_Name']]
     # runs of optimizer kernels: a step ends with the last kernel of a run

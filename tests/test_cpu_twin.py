@@ -140,3 +140,14 @@ def test_the_references_perform_inference_on_config1(twin):
     assert np.array_equal(res['pcl_abstract'][:, :3], g['pcl_abstract'][:, :3])
     assert np.abs(res['implicit_output'] - g['implicit_output']).max() < 1e-4
     assert res['output_solid'].shape[0] == int(g['n_solid'][0]) and res['output_air'].shape == (8640 - res['output_solid'].shape[0], 5)
+
+
+def test_twin_nested_level_rule_for_repeated_picks(twin):
+    """The rule the HIP kernel is tested against (tests/test_gpu_fps_pruned.py): distinct positions first, ascending, the
+    last one repeated behind them."""
+    orig = torch.tensor([2, 5, 7, 11, 13, 20, 21, 40], dtype=torch.int32)
+    order = torch.tensor([13, 2, 13, 40, 2, 2, 7, 13], dtype=torch.int32)
+    pos, nxt = pk.ops.nested_fps_level(order, orig, 6)
+    assert pos.tolist() == [0, 4, 7, 7, 7, 7] and nxt.tolist() == [2, 13, 40, 40, 40, 40]
+    pos, nxt = pk.ops.nested_fps_level(order, orig, 8)
+    assert pos.tolist() == [0, 2, 4, 7, 7, 7, 7, 7] and nxt.tolist() == [2, 7, 13, 40, 40, 40, 40, 40]

@@ -309,3 +309,18 @@ def test_inference_step_launches_library_kernels_only(pk, kind):
     names = [e.key for e in prof.key_averages() if e.device_type == torch.autograd.DeviceType.CUDA or 'kernel' in e.key.lower()]
     foreign = [k for k in names if 'at::native' in k or 'rocclr' in k or 'emcpy' in k or 'emset' in k]
     assert names and not foreign, foreign
+
+
+def test_nested_level_with_repeated_picks_is_ascending_and_repeats_the_last():
+    """a selection order that names a point more than once (a cloud with fewer distinct points than samples):
+    occ4d_nested_fps_level_i32 returns the distinct positions first, ascending, and repeats the last of them behind --
+    never the raw, unsorted search results.  The CPU twin's statement of the same rule is the reference here."""
+    import occlusions4d_amd as pk
+    orig = torch.tensor([2, 5, 7, 11, 13, 20, 21, 40], dtype=torch.int32)
+    order = torch.tensor([13, 2, 13, 40, 2, 2, 7, 13], dtype=torch.int32)      # 4 distinct picks among the first 6
+    pos, nxt = pk.ops.nested_fps_level(order.cuda(), orig.cuda(), 6)
+    assert pos.tolist() == [0, 4, 7, 7, 7, 7] and nxt.tolist() == [2, 13, 40, 40, 40, 40]
+    pos, nxt = pk.ops.nested_fps_level(order.cuda(), orig.cuda(), 8)           # + pick 7
+    assert pos.tolist() == [0, 2, 4, 7, 7, 7, 7, 7] and nxt.tolist() == [2, 7, 13, 40, 40, 40, 40, 40]
+    pos, _ = pk.ops.nested_fps_level(torch.tensor([5, 21, 2], dtype=torch.int32).cuda(), orig.cuda(), 3)   # no repeats
+    assert pos.tolist() == [0, 1, 6]
