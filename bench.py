@@ -613,6 +613,13 @@ def main():
                 'as_written_fp32_mfma_frac': fl / (ms_per_step * 1e-3) / FP32_MFMA_PEAK,
                 'encode_ms': 1e3 * t_encode},
         }
+        d0 = pk.kernels.defaults()
+        if (d0.logit_precision, d0.trunk_precision) != ('f32', 'f32'):
+            # a profiling run with OCC4D_LOGIT_PRECISION / OCC4D_TRUNK_PRECISION as the PROCESS default: say so on the line
+            line['dtype'] = 'NOT the fp32 figure: process default precision logits %s / trunk %s (OCC4D_*_PRECISION)' % (
+                d0.logit_precision, d0.trunk_precision)
+            line['roofline']['note'] = ('priced against the fp32 MFMA peak although a split-precision kernel ran: not a figure of '
+                                        'merit; the split modes\' rooflines are the alt_precision* objects of a default run')
         if other is not None:
             line['config4_single_gpu' if world == 1 else 'strong_config2'] = other
         if alt is not None:

@@ -626,6 +626,17 @@ int occ4d_pt_cross_attn_f16x3_prescaled_f32(const float* aq, int64_t ld_aq, cons
                                             int64_t ld_kt, const float* vtc, int64_t ld_vt, const float* pos0_w,
                                             const float* pos0_b, const float* wstream, float* agg, int64_t ld_agg, int n,
                                             int m, int k, int d, float divisor, void* stream);
+/* The fp16 scheme's attention layer on v_mfma_f32_32x32x16_f16 (csrc/crossattn_f16w.hip, round 6): one 32-row tile x all 416
+ * channels per wave, GEMM1 / split / init gathers once per pair row, Aq read once.  Contract of
+ * occ4d_pt_cross_attn_f16x3_prescaled_f32 (aq and kt * 2^4); its own packed stream (occ4d_pack_attn_f16w_stream_f32).  The
+ * path-level entry points take it for OCC4D_PATH_SPLIT_F16 only with OCC4D_F16W=1 in the environment (an A/B switch: measured
+ * slower than the 16 x 16 x 32 kernel). */
+int64_t occ4d_pt_cross_attn_f16w_stream_floats(void);
+int occ4d_pack_attn_f16w_stream_f32(const float* w2, const float* wp, const float* p2, float* wstream, void* stream);
+int occ4d_pt_cross_attn_f16w_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t q_stride, const float* apos,
+                                 int64_t a_stride, const int32_t* idx, const float* kt, int64_t ld_kt, const float* vtc,
+                                 int64_t ld_vt, const float* pos0_w, const float* pos0_b, const float* wstream, float* agg,
+                                 int64_t ld_agg, int n, int m, int k, int d, float divisor, void* stream);
 int64_t occ4d_rowlin_f16x3_packed_floats(int n_out);
 int occ4d_pack_rowlin_f16x3_f32(const float* w, int64_t ldw, int n_out, float* packed, void* stream);
 int occ4d_rowlin_f16x3_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed, const float* b,

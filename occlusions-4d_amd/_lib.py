@@ -200,6 +200,10 @@ SIGNATURES = {
     'occ4d_pt_cross_attn_f16x3_prescaled_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, C.c_int64, _i, _f, C.c_int64, _f,
                                                           C.c_int64, _f, _f, _f, _f, C.c_int64, C.c_int, C.c_int, C.c_int,
                                                           C.c_int, C.c_float, _s]),
+    'occ4d_pt_cross_attn_f16w_stream_floats': (C.c_int64, []),
+    'occ4d_pack_attn_f16w_stream_f32': (C.c_int, [_f, _f, _f, _f, _s]),
+    'occ4d_pt_cross_attn_f16w_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, C.c_int64, _i, _f, C.c_int64, _f, C.c_int64,
+                                               _f, _f, _f, _f, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _s]),
     'occ4d_rowlin_f16x3_packed_floats': (C.c_int64, [C.c_int]),
     'occ4d_pack_rowlin_f16x3_f32': (C.c_int, [_f, C.c_int64, C.c_int, _f, _s]),
     'occ4d_rowlin_f16x3_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, _f, C.c_int, C.c_int, _f, C.c_int64, C.c_int, _s]),

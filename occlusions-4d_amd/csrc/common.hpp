@@ -53,6 +53,9 @@ int copy_rows(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t n,
 // memops.hip: compute units of the current device (cached; 256 if the query fails)
 int cu_count();
 
+// path.hip: OCC4D_F16W=1 (default 0): the fp16 scheme's attention layers on csrc/crossattn_f16w.hip (A/B)
+bool f16w_enabled();
+
 // path.hip: phase offset of the paired attention workgroups (units of s_sleep(127); OCC4D_CA16P_SKEW, default 6)
 int attn16p_skew();
 

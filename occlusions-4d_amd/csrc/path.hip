@@ -215,6 +215,7 @@ struct LayerLayout {
   int D, D2, h, Kq;                 // Kq: input width of the merged query projection (d_in when layer1 is folded in)
   bool fold_pre, fused16p, fused_first, fused_self16, bf16x6, wq_rows, w3_rows, trunk4, x6rows;
   bool f16;                         // the split kernels' scheme: fp16 x 2 pieces instead of bf16 x 3 (OCC4D_PATH_SPLIT_F16)
+  bool f16w;                        // ... its attention kernel on 32 x 32 x 16 instructions (csrc/crossattn_f16w.hip)
   int64_t wq, bq, wk, wp, wq_packed, stream, stream6, w3_packed, wq_x6, w3_x6, scratch, total;
   int64_t s_A, s_B, s_C, s_C2, s_v, s_bq;      // doubles, inside the scratch region
 };
@@ -268,7 +269,9 @@ LayerLayout layer_layout(const occ4d_pt_layer_weights& w, int flags) {
   L.wq_x6 = L.x6rows ? take(split_packed_floats(L.f16, 2 * L.D)) : -1;
   L.w3_x6 = L.x6rows ? take(split_packed_floats(L.f16, w.d_out)) : -1;
   L.stream = L.fused16p ? take(occ4d_pt_cross_attn16p_stream_floats()) : -1;
-  L.stream6 = L.bf16x6 ? take(L.f16 ? occ4d_pt_cross_attn_f16x3_stream_floats() : occ4d_pt_cross_attn_bf16x6_stream_floats()) : -1;
+  L.f16w = L.bf16x6 && L.f16 && occ4d::f16w_enabled();
+  L.stream6 = L.bf16x6 ? take(L.f16w ? occ4d_pt_cross_attn_f16w_stream_floats()
+                                     : L.f16 ? occ4d_pt_cross_attn_f16x3_stream_floats() : occ4d_pt_cross_attn_bf16x6_stream_floats()) : -1;
   L.w3_packed = L.w3_rows ? take(packed(w.d_out)) : -1;
   // fp64 scratch (doubles): A = W1, B = right factor, C = W1 Wq, C2 = C L1, v / bq vectors
   int64_t d = 0;
@@ -331,8 +334,9 @@ int layer_prepare(const occ4d_pt_layer_weights& w, const LayerLayout& L, float* 
   }
   if (L.fused16p) TRY(occ4d_pack_attn16p_stream_f32(w.attn2_w, prep + L.wp, w.pos2_w, prep + L.stream, st));
   if (L.bf16x6)
-    TRY(L.f16 ? occ4d_pack_attn_f16x3_stream_f32(w.attn2_w, prep + L.wp, w.pos2_w, prep + L.stream6, st)
-              : occ4d_pack_attn_bf16x6_stream_f32(w.attn2_w, prep + L.wp, w.pos2_w, prep + L.stream6, st));
+    TRY(L.f16w ? occ4d_pack_attn_f16w_stream_f32(w.attn2_w, prep + L.wp, w.pos2_w, prep + L.stream6, st)
+        : L.f16 ? occ4d_pack_attn_f16x3_stream_f32(w.attn2_w, prep + L.wp, w.pos2_w, prep + L.stream6, st)
+                : occ4d_pack_attn_bf16x6_stream_f32(w.attn2_w, prep + L.wp, w.pos2_w, prep + L.stream6, st));
   if (L.w3_rows) {
     if (L.trunk4) TRY(occ4d_pack_trunk4_rows_f32(w.post_w, D, w.d_out, prep + L.w3_packed, st));
     else TRY(occ4d_pack_trunk_rows_f32(w.post_w, D, w.d_out, prep + L.w3_packed, st));
@@ -460,7 +464,10 @@ int layer_forward(const occ4d_pt_layer_weights& w, const LayerLayout& L, const f
       if (!dry) {
         E.before(OCC4D_PROFILE_CROSS_ATTN);
         int rc;
-        if (L.bf16x6 && L.f16)
+        if (L.f16w)
+          rc = occ4d_pt_cross_attn_f16w_f32(aq, 2 * D, qp, ps, pos2, p2s, idx, kt, 2 * D, vtc, D, w.pos0_w, w.pos0_b,
+                                            prep + L.stream6, agg_c, ld_agg, c, m, k, D, divisor, st);
+        else if (L.bf16x6 && L.f16)
           rc = occ4d_pt_cross_attn_f16x3_prescaled_f32(aq, 2 * D, qp, ps, pos2, p2s, idx, kt, 2 * D, vtc, D, w.pos0_w,
                                                        w.pos0_b, prep + L.stream6, agg_c, ld_agg, c, m, k, D, divisor, st);
         else if (L.bf16x6)
@@ -717,6 +724,15 @@ int decoder_forward(const occ4d_decoder_weights& w, const DecoderLayout& L, cons
 }  // namespace
 
 namespace occ4d {
+// fp16 scheme: OCC4D_F16W=1 selects the 32 x 32 x 16 attention kernel (csrc/crossattn_f16w.hip) for A/B runs; the default is
+// the 16 x 16 x 32 kernel of csrc/crossattn_bf16x6.hip
+bool f16w_enabled() {
+  static const bool v = [] {
+    const char* e = getenv("OCC4D_F16W");              // (opt-in: measured slower than the 16 x 16 x 32 kernel)
+    return e && atoi(e) != 0;
+  }();
+  return v;
+}
 // phase offset of the paired attention workgroups (units of s_sleep(127)); OCC4D_CA16P_SKEW overrides (performance only)
 int attn16p_skew() {
   static const int v = [] {

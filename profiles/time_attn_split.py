@@ -58,6 +58,20 @@ def variant(defs):
     return tag, K
 
 
+def variant_w(defs):
+    """A timing-only build of csrc/crossattn_f16w.hip (-DOCC4D_XW_ABL_...)."""
+    csrc, build = os.path.join(ROOT, 'occlusions-4d_amd', 'csrc'), os.path.join(ROOT, 'occlusions-4d_amd', 'build')
+    tag = '_'.join(d.replace('-DOCC4D_XW_ABL_', '') for d in defs)
+    obj, so = '/tmp/xw_%s.o' % tag, '/tmp/xw_%s.so' % tag
+    subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC',
+                    '-I' + os.path.join(ROOT, 'include'), '-I' + csrc, '-fno-honor-nans'] + defs +
+                   ['-c', os.path.join(csrc, 'crossattn_f16w.hip'), '-o', obj], check=True)
+    subprocess.run(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', so, obj] +
+                   [os.path.join(build, f) for f in sorted(os.listdir(build)) if f.endswith('.o') and f != 'crossattn_f16w.o'],
+                   check=True)
+    return tag, C.CDLL(so)
+
+
 def main():
     schemes = [a for a in sys.argv[1:] if not a.startswith('-')] or ['bf16x6', 'f16x3']
     variants = [[d for d in a.split(',')] for a in sys.argv[1:] if a.startswith('-')]
@@ -78,9 +92,34 @@ def main():
     wp, w2, p2 = T(0.1 * rng.normal(size=(2 * d, 32))), T(0.03 * rng.normal(size=(d, 2 * d))), T(0.1 * rng.normal(size=(d, 32)))
     out = torch.empty((n, d), device='cuda')
     L = ops._lib.lib()
-    libs = [('shipped', L)] + [variant(v) for v in variants]
+    libs = [('shipped', L)] + [variant(v) for v in variants if not any('XW_' in d for d in v)]
     wgs = 2 * -(-n // 18)
     for scheme in schemes:
+        if scheme == 'f16w':            # the fp16 scheme on 32 x 32 x 16 instructions (csrc/crossattn_f16w.hip)
+            ws = torch.empty((int(L.occ4d_pt_cross_attn_f16w_stream_floats()),), dtype=torch.float32, device='cuda')
+            ops._lib.check(L.occ4d_pack_attn_f16w_stream_f32(ops._ptr(w2), ops._ptr(wp), ops._ptr(p2), ops._ptr(ws), ops._stream()))
+            flop = -(-n // 9) * 4 * (26 * 84 + 78) * 32768.0
+            for tag, K in [('shipped', L)] + [variant_w(v) for v in variants if any('XW_' in d for d in v)]:
+              fn_w = K.occ4d_pt_cross_attn_f16w_f32
+              fn_w.restype, fn_w.argtypes = SIG['occ4d_pt_cross_attn_f16w_f32']
+
+              def run_w():
+                assert fn_w(
+                    ops._ptr(aq), 2 * d, ops._ptr(qpos), 3, ops._ptr(apos), 3, ops._ptr(idx), ops._ptr(kt), 2 * d, ops._ptr(vt), d,
+                    ops._ptr(P1), ops._ptr(c1), ops._ptr(ws), ops._ptr(out), d, n, m, k, d, float(np.sqrt(np.float32(d))),
+                    ops._stream()) == 0
+              for _ in range(3):
+                run_w()
+              e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+              e0.record()
+              for _ in range(20):
+                run_w()
+              e1.record()
+              torch.cuda.synchronize()
+              ms = e0.elapsed_time(e1) / 20
+              print('%-7s %-28s %7.3f ms   %5.0f TFLOP/s of executed 32x32x16 MFMA = %.3f of 2.5 PF (full kernel count)'
+                    % (scheme, tag, ms, flop / ms / 1e9, flop / ms / 1e9 / 2500.0), flush=True)
+            continue
         size, pack, name = ((L.occ4d_pt_cross_attn_f16x3_stream_floats, L.occ4d_pack_attn_f16x3_stream_f32,
                              'occ4d_pt_cross_attn_f16x3_f32') if scheme == 'f16x3' else
                             (L.occ4d_pt_cross_attn_bf16x6_stream_floats, L.occ4d_pack_attn_bf16x6_stream_f32,

@@ -385,6 +385,39 @@ def test_fused_attention_matches_unfused_chain(pk, k, n, dim, dim2, generation):
     close(fused, chain, 2e-5)
 
 
+@pytest.mark.parametrize('k,n,m', [(14, 1003, 76), (14, 9, 531), (14, 10, 20), (13, 100, 76), (8, 37, 76), (1, 10, 76),
+                                   (14, 4000, 531), (5, 1, 14)])
+def test_f16w_attention_kernel_matches_the_default_fp16_kernel(pk, k, n, m):
+    """csrc/crossattn_f16w.hip (32 x 32 x 16 instructions, 9 queries per workgroup, the 9th spread over the four waves) is
+    an A/B switch (OCC4D_F16W=1), so the path-level tests only reach it with that variable set: here its C entry point
+    is called directly, on the contract of occ4d_pt_cross_attn_f16x3_prescaled_f32 (aq, kt * hidden scale), against
+    that kernel: same scheme, same products, different accumulation order."""
+    from occlusions4d_amd import ops
+    L, d = ops._lib.lib(), 416
+    rng = np.random.default_rng(31 * k + n)
+    hs = float(L.occ4d_pt_cross_attn_f16x3_hidden_scale())
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()   # noqa: E731
+    aq, kt, vt = dev(hs * rng.normal(size=(n, 2 * d))), dev(hs * rng.normal(size=(m, 2 * d))), dev(rng.normal(size=(m, d)))
+    qpos, apos = dev(rng.uniform(-5, 5, size=(n, 3))), dev(rng.uniform(-5, 5, size=(m, 3)))
+    idx = ops.knn(qpos, apos, k, metric=0)
+    P1, c1 = dev(rng.normal(size=(32, 3))), dev(rng.normal(size=(32,)))
+    wp, w2, p2 = dev(0.1 * rng.normal(size=(2 * d, 32))), dev(0.03 * rng.normal(size=(d, 2 * d))), dev(0.1 * rng.normal(size=(d, 32)))
+    outs = []
+    for size, pack, run in ((L.occ4d_pt_cross_attn_f16x3_stream_floats, L.occ4d_pack_attn_f16x3_stream_f32,
+                             L.occ4d_pt_cross_attn_f16x3_prescaled_f32),
+                            (L.occ4d_pt_cross_attn_f16w_stream_floats, L.occ4d_pack_attn_f16w_stream_f32,
+                             L.occ4d_pt_cross_attn_f16w_f32)):
+        ws = torch.empty((int(size()),), dtype=torch.float32, device='cuda')
+        ops._lib.check(pack(ops._ptr(w2), ops._ptr(wp), ops._ptr(p2), ops._ptr(ws), ops._stream()))
+        out = torch.full((n, d), float('nan'), device='cuda')
+        ops._lib.check(run(ops._ptr(aq), 2 * d, ops._ptr(qpos), 3, ops._ptr(apos), 3, ops._ptr(idx), ops._ptr(kt), 2 * d,
+                           ops._ptr(vt), d, ops._ptr(P1), ops._ptr(c1), ops._ptr(ws), ops._ptr(out), d, n, m, k, d,
+                           float(np.sqrt(np.float32(d))), ops._stream()))
+        outs.append(out)
+    assert torch.isfinite(outs[1]).all()
+    close(outs[1], outs[0], 2e-5)
+
+
 @pytest.mark.parametrize('n,dim', [(14336, 36), (3584, 72), (896, 144), (224, 288), (16, 36), (21, 72), (1001, 20), (333, 100),
                                    (62, 260), (4099, 4)])
 def test_fused_self_attention_matches_unfused_chain(pk, n, dim):
