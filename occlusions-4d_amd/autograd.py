@@ -502,8 +502,8 @@ class PairMlpFn(Function):
                          # in chunks with the SAME weight tensors (identity + version: held here, so no address is recycled)
 
     @staticmethod
-    def _packed_stream(W2, b2, wp, P2, c2):
-        x6 = _x6()
+    def _packed_stream(W2, b2, wp, P2, c2, x6=None):
+        x6 = _x6() if x6 is None else x6
         hit = PairMlpFn._stream
         if (hit is not None and hit[0] is W2 and hit[1] is wp and hit[2] is P2
                 and hit[3] == (W2._version, wp._version, P2._version, x6)):
@@ -513,11 +513,18 @@ class PairMlpFn(Function):
         return stream
 
     @staticmethod
-    def forward(ctx, aq, kt, r, wp, W2, b2, P2, c2, idx):
-        stream = PairMlpFn._packed_stream(W2, b2, wp, P2, c2)
-        if _x6():
+    def forward(ctx, aq, kt, r, wp, W2, b2, P2, c2, idx, kept_logits=None):
+        """`kept_logits` (n k, 416): the logits the training forward's fused kernel stored for these rows -- the launch then
+        only recomputes a and pe (fp32 kernel, store-bound: the split scheme has nothing to gain there)."""
+        if kept_logits is not None:
+            stream = PairMlpFn._packed_stream(W2, b2, wp, P2, c2, x6=False)
+            a, logits, pe = ops.pt_pair_mlp(aq, kt, r, idx, c2, stream, logits=kept_logits)
+            logits = logits.detach()          # (a fresh tensor object on the same rows: an output, not the input itself)
+        elif _x6():
+            stream = PairMlpFn._packed_stream(W2, b2, wp, P2, c2)
             a, logits, pe = ops.pt_pair_mlp_bf16x6(aq, kt, r, idx, c2, stream)
         else:
+            stream = PairMlpFn._packed_stream(W2, b2, wp, P2, c2)
             a, logits, pe = ops.pt_pair_mlp(aq, kt, r, idx, c2, stream)
         ctx.save_for_backward(a, r, wp, W2, P2, idx)
         ctx.m = kt.shape[0]
@@ -555,7 +562,7 @@ class PairMlpFn(Function):
         if need[2]:
             dr = _linear_fwd(da, wp, None, transposed=True)
             dr += _linear_fwd(dpe, P2, None, transposed=True)
-        return daq, dkt, dr, dwp, dW2, db2, dP2, dc2, None
+        return daq, dkt, dr, dwp, dW2, db2, dP2, dc2, None, None
 
 
 class SoftmaxAggFn(Function):

@@ -61,6 +61,7 @@ struct Attn16pArgs {
   float divisor;
   int first_round;                        // workgroups of the first dispatch round (2 per CU)
   int skew;                               // s_sleep(127) repeats of the later-placed workgroup of a CU in that round
+  float* logits;                          // STORE only: (N * K, 416) pre-softmax logits W2 relu(a) (no attn_mlp[2].bias)
 };
 
 __device__ __forceinline__ unsigned lds_addr_p(const float* p) {
@@ -135,7 +136,9 @@ __device__ __forceinline__ Pair swap32(float x, float y) {
   return Pair{__uint_as_float(r[0]), __uint_as_float(r[1])};
 }
 
-template <bool K14>
+// STORE (training forward): the logits also go to HBM, row q K + slot, so that backward does not run GEMM2 again
+// (csrc: pair_mlp_kernel<false> recomputes only the hidden pre-activations and pe).
+template <bool K14, bool STORE = false>
 __global__ __launch_bounds__(256, 2) void cross_attn16p_kernel(const Attn16pArgs a) {
   __shared__ __attribute__((aligned(16))) float buf0[PSTAGE];
   __shared__ __attribute__((aligned(16))) float buf1[PSTAGE];
@@ -223,6 +226,7 @@ __global__ __launch_bounds__(256, 2) void cross_attn16p_kernel(const Attn16pArgs
     // rows 14, 15 (g = 3, i = 2, 3) = slots 8 ps + 2 wave, + 1 of the 9th query
     int voff[4];
     bool act[4];
+    float* lrow[4];                                      // STORE: this lane's element of the logits row of register i (or null)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = 4 * g + i;
@@ -230,6 +234,8 @@ __global__ __launch_bounds__(256, 2) void cross_attn16p_kernel(const Attn16pArgs
       const int slot = row < 14 ? row : 8 * ps + 2 * wave + row - 14;
       voff[i] = s_idx[ql * 16 + min(slot, 15)] * (int)a.ld_vt + c;
       act[i] = slot < a.K;
+      if (STORE)
+        lrow[i] = (slot < a.K && q0 + ql < a.N) ? a.logits + ((int64_t)(q0 + ql) * a.K + slot) * PD + c : nullptr;
     }
     const int qm = q0 + 4 * ps + wave;
     const float own23 = g3 ? 0.f : 1.f;
@@ -358,6 +364,11 @@ __global__ __launch_bounds__(256, 2) void cross_attn16p_kernel(const Attn16pArgs
           const f32x4 av = acc[tA + x];
           const f32x4 pv = pe[2 * pr + x];
           const float* vv = vq[2 * pr + x];
+          if (STORE) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (lrow[i]) lrow[i][16 * (tA + x)] = av[i];
+          }
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             am[x][i] = (K14 || act[i]) ? av[i] : NINF;     // (K = 14: every row a wave writes for is live)
@@ -505,13 +516,20 @@ struct PairMlpArgs {
   int first_round, skew;
 };
 
+// LOGITS = false (the training forward stored the logits, cross_attn16p_kernel<., true>): GEMM2 is skipped -- the stage
+// is GEMM1 + the store of `a`, only the two Wp fragments of a stage travel, and the epilogue is pe alone.
+template <bool LOGITS>
 __global__ __launch_bounds__(256, 2) void pair_mlp_kernel(const PairMlpArgs a) {
   __shared__ __attribute__((aligned(16))) float buf0[PSTAGE];
   __shared__ __attribute__((aligned(16))) float buf1[PSTAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
   const unsigned lane16 = lane * 16;
-  dma_stage_p(a.wstream, buf0, wave, lane16);
+  auto dma_first = [&]() {
+    if (LOGITS) dma_stage_p(a.wstream, buf0, wave, lane16);
+    else if (wave >= 2) dma_frag_p(a.wstream + (24 + wave) * PFRAG, lds_addr_p(buf0) + (unsigned)(24 + wave) * (PFRAG * 4), lane16);
+  };
+  dma_first();
   if (a.skew > 0 && (int)blockIdx.x < a.first_round) {      // phase skew of the two workgroups of a CU, as above
     const unsigned hw = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
     if (hw & 1)
@@ -556,18 +574,25 @@ __global__ __launch_bounds__(256, 2) void pair_mlp_kernel(const PairMlpArgs a) {
 #pragma unroll
       for (int gq = 0; gq < 14; ++gq) {
         const f32x4 ca = wa, cb = wb;
-        if (gq + 1 < 14) {
+        if (!LOGITS && gq > 1) break;
+        if (LOGITS && gq + 1 < 14) {
           wa = *reinterpret_cast<const f32x4*>(f + (2 * gq) * PFRAG);
           wb = *reinterpret_cast<const f32x4*>(f + (2 * gq + 1) * PFRAG);
         }
         if (gq == 0) ia = slice(a.aq + 16 * sn, aq_off);
         if (gq == 1) ik = slice(a.kt + 16 * sn, kt_off);
-        if (gq >= 2 && gq <= 8)
-          dma_frag_p(nsrc + (wave + 4 * (gq - 2)) * PFRAG, lds_addr_p(nxt) + (unsigned)(wave + 4 * (gq - 2)) * (PFRAG * 4), lane16);
+        if (LOGITS) {
+          if (gq >= 2 && gq <= 8)
+            dma_frag_p(nsrc + (wave + 4 * (gq - 2)) * PFRAG, lds_addr_p(nxt) + (unsigned)(wave + 4 * (gq - 2)) * (PFRAG * 4), lane16);
+        } else if (gq == 1) {
+          if (s + 1 == PHS) dma_stage_p(nsrc, nxt, wave, lane16);      // (the first P2 stage, whole: the epilogue's GEMM3)
+          else if (wave >= 2)                                           // fragments 26, 27 = Wp's K halves
+            dma_frag_p(nsrc + (24 + wave) * PFRAG, lds_addr_p(nxt) + (unsigned)(24 + wave) * (PFRAG * 4), lane16);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (gq == 0) {
           mm_g1_p(ca, cb, r_lo, r_hi, h);
-        } else {
+        } else if (LOGITS) {
           if (FIRST) acc[2 * (gq - 1)] = acc[2 * (gq - 1) + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
           mm_ba_p(h, ca, cb, acc[2 * (gq - 1)], acc[2 * (gq - 1) + 1]);
         }
@@ -602,12 +627,14 @@ __global__ __launch_bounds__(256, 2) void pair_mlp_kernel(const PairMlpArgs a) {
     // buf1 under it).  GEMM2 / GEMM3 ran with the fragments as the A operand (mm_ba_p): lane (g, c) holds channels
     // 16 t + 4 g .. + 3 of pair row c in every accumulator tile
     dma_stage_p(a.wstream + (int64_t)(PHS + 1) * PSTAGE, buf1, wave, lane16);
+    if (LOGITS) {
 #pragma unroll
-    for (int t = 0; t < PTD; ++t) {
+      for (int t = 0; t < PTD; ++t) {
 #ifdef OCC4D_PM_ABL_NOLOGITS
-      if (acc[t].x == 123.456f)                      // (ablation: keep the accumulators live, store nothing)
+        if (acc[t].x == 123.456f)                      // (ablation: keep the accumulators live, store nothing)
 #endif
-      put(a.logits + 16 * t, l_off, acc[t]);
+        put(a.logits + 16 * t, l_off, acc[t]);
+      }
     }
     auto pe_tiles = [&](auto T0c, auto NPc, const float* __restrict__ pbuf) {
       constexpr int T0 = decltype(T0c)::value, NP = decltype(NPc)::value;
@@ -633,7 +660,7 @@ __global__ __launch_bounds__(256, 2) void pair_mlp_kernel(const PairMlpArgs a) {
     pe_tiles(std::integral_constant<int, 0>{}, std::integral_constant<int, PTA / 2>{}, buf0);
     dma_wait_p();
     __syncthreads();
-    if (ps == 0) dma_stage_p(a.wstream, buf0, wave, lane16);   // pass B's first hidden stage
+    if (ps == 0) dma_first();                                  // pass B's first hidden stage
     pe_tiles(std::integral_constant<int, PTA>{}, std::integral_constant<int, PTB / 2>{}, buf1);
   }
 }
@@ -644,31 +671,55 @@ using occ4d::cu_count;
 
 extern "C" int64_t occ4d_pt_cross_attn16p_stream_floats(void) { return (int64_t)PNSTAGE * PSTAGE; }
 
+static int attn16p_launch(const char* who, const float* aq, int64_t ld_aq, const float* qpos, int64_t qs, const float* apos,
+                          int64_t as, const int32_t* idx, const float* kt, int64_t ld_kt, const float* vt, int64_t ld_vt,
+                          const float* P1, const float* c1, const float* wstream, float* agg, int64_t ld_agg, int n, int m,
+                          int k, int d, float divisor, int skew, float* logits, void* stream) {
+  OCC4D_REQUIRE(d == PD, "%s: built for d = %d, got %d", who, PD, d);
+  OCC4D_REQUIRE(k >= 1 && k <= PKMAX, "%s: k=%d outside [1,%d]", who, k, PKMAX);
+  OCC4D_REQUIRE(m >= 1 && n >= 0, "%s: bad n/m", who);
+  if (n == 0) return OCC4D_OK;
+  OCC4D_REQUIRE(aq && qpos && apos && idx && kt && vt && P1 && c1 && wstream && agg, "%s: null pointer", who);
+  OCC4D_REQUIRE(ld_aq >= 2 * d && ld_kt >= 2 * d && ld_vt >= d && ld_agg >= d && qs >= 3 && as >= 3,
+                "%s: leading dimension too small", who);
+  OCC4D_REQUIRE(ld_aq % 4 == 0 && ld_kt % 4 == 0 && ((uintptr_t)aq % 16) == 0 && ((uintptr_t)kt % 16) == 0 &&
+                    ((uintptr_t)wstream % 16) == 0,
+                "%s: aq / kt / wstream must be 16-byte aligned with ld %% 4 == 0", who);
+  OCC4D_REQUIRE((int64_t)m * ld_vt < (int64_t)1 << 31, "%s: vt too large for 32-bit row offsets", who);
+  OCC4D_REQUIRE(divisor > 0.f, "%s: divisor must be > 0", who);
+  OCC4D_REQUIRE(skew >= 0 && skew <= 64, "%s: skew=%d outside [0,64]", who, skew);
+  Attn16pArgs a{aq, ld_aq, qpos, qs, apos, as, idx, kt, ld_kt, vt, ld_vt, P1, c1, wstream, agg, ld_agg, n, m, k, divisor,
+                2 * cu_count(), skew, logits};
+  const int grid = occ4d::cdiv(n, PQPB);
+  hipStream_t st = (hipStream_t)stream;
+  if (logits) {
+    if (k == PKMAX) cross_attn16p_kernel<true, true><<<grid, 256, 0, st>>>(a);
+    else cross_attn16p_kernel<false, true><<<grid, 256, 0, st>>>(a);
+  } else {
+    if (k == PKMAX) cross_attn16p_kernel<true><<<grid, 256, 0, st>>>(a);
+    else cross_attn16p_kernel<false><<<grid, 256, 0, st>>>(a);
+  }
+  return occ4d::check_launch(who);
+}
+
 extern "C" int occ4d_pt_cross_attn16p_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t qs, const float* apos,
                                           int64_t as, const int32_t* idx, const float* kt, int64_t ld_kt, const float* vt,
                                           int64_t ld_vt, const float* P1, const float* c1, const float* wstream,
                                           float* agg, int64_t ld_agg, int n, int m, int k, int d, float divisor,
                                           int skew, void* stream) {
-  OCC4D_REQUIRE(d == PD, "occ4d_pt_cross_attn16p: built for d = %d, got %d", PD, d);
-  OCC4D_REQUIRE(k >= 1 && k <= PKMAX, "occ4d_pt_cross_attn16p: k=%d outside [1,%d]", k, PKMAX);
-  OCC4D_REQUIRE(m >= 1 && n >= 0, "occ4d_pt_cross_attn16p: bad n/m");
-  if (n == 0) return OCC4D_OK;
-  OCC4D_REQUIRE(aq && qpos && apos && idx && kt && vt && P1 && c1 && wstream && agg,
-                "occ4d_pt_cross_attn16p: null pointer");
-  OCC4D_REQUIRE(ld_aq >= 2 * d && ld_kt >= 2 * d && ld_vt >= d && ld_agg >= d && qs >= 3 && as >= 3,
-                "occ4d_pt_cross_attn16p: leading dimension too small");
-  OCC4D_REQUIRE(ld_aq % 4 == 0 && ld_kt % 4 == 0 && ((uintptr_t)aq % 16) == 0 && ((uintptr_t)kt % 16) == 0 &&
-                    ((uintptr_t)wstream % 16) == 0,
-                "occ4d_pt_cross_attn16p: aq / kt / wstream must be 16-byte aligned with ld %% 4 == 0");
-  OCC4D_REQUIRE((int64_t)m * ld_vt < (int64_t)1 << 31, "occ4d_pt_cross_attn16p: vt too large for 32-bit row offsets");
-  OCC4D_REQUIRE(divisor > 0.f, "occ4d_pt_cross_attn16p: divisor must be > 0");
-  OCC4D_REQUIRE(skew >= 0 && skew <= 64, "occ4d_pt_cross_attn16p: skew=%d outside [0,64]", skew);
-  Attn16pArgs a{aq, ld_aq, qpos, qs, apos, as, idx, kt, ld_kt, vt, ld_vt, P1, c1, wstream, agg, ld_agg, n, m, k, divisor,
-                2 * cu_count(), skew};
-  const int grid = occ4d::cdiv(n, PQPB);
-  if (k == PKMAX) cross_attn16p_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(a);
-  else cross_attn16p_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(a);
-  return occ4d::check_launch("occ4d_pt_cross_attn16p");
+  return attn16p_launch("occ4d_pt_cross_attn16p", aq, ld_aq, qpos, qs, apos, as, idx, kt, ld_kt, vt, ld_vt, P1, c1, wstream,
+                        agg, ld_agg, n, m, k, d, divisor, skew, nullptr, stream);
+}
+
+extern "C" int occ4d_pt_cross_attn16p_logits_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t qs,
+                                                 const float* apos, int64_t as, const int32_t* idx, const float* kt,
+                                                 int64_t ld_kt, const float* vt, int64_t ld_vt, const float* P1,
+                                                 const float* c1, const float* wstream, float* agg, int64_t ld_agg,
+                                                 float* logits, int n, int m, int k, int d, float divisor, int skew,
+                                                 void* stream) {
+  OCC4D_REQUIRE(logits, "occ4d_pt_cross_attn16p_logits: null logits buffer");
+  return attn16p_launch("occ4d_pt_cross_attn16p_logits", aq, ld_aq, qpos, qs, apos, as, idx, kt, ld_kt, vt, ld_vt, P1, c1,
+                        wstream, agg, ld_agg, n, m, k, d, divisor, skew, logits, stream);
 }
 
 extern "C" int occ4d_pt_pair_mlp_f32(const float* aq, int64_t ld_aq, const float* kt, int64_t ld_kt, const float* r,
@@ -677,11 +728,11 @@ extern "C" int occ4d_pt_pair_mlp_f32(const float* aq, int64_t ld_aq, const float
   OCC4D_REQUIRE(d == PD, "occ4d_pt_pair_mlp: built for d = %d, got %d", PD, d);
   OCC4D_REQUIRE(k >= 1 && m >= 1 && n >= 0, "occ4d_pt_pair_mlp: bad n/m/k");
   if (n == 0) return OCC4D_OK;
-  OCC4D_REQUIRE(aq && kt && r && idx && c2 && wstream && a_out && logits && pe, "occ4d_pt_pair_mlp: null pointer");
+  OCC4D_REQUIRE(aq && kt && r && idx && c2 && wstream && a_out && pe, "occ4d_pt_pair_mlp: null pointer");
   OCC4D_REQUIRE(ld_aq >= 2 * d && ld_kt >= 2 * d && ld_aq % 4 == 0 && ld_kt % 4 == 0,
                 "occ4d_pt_pair_mlp: aq / kt leading dimensions must be >= 832 and multiples of 4");
   auto al16 = [](const void* p) { return ((uintptr_t)p % 16) == 0; };
-  OCC4D_REQUIRE(al16(aq) && al16(kt) && al16(c2) && al16(wstream) && al16(a_out) && al16(logits) && al16(pe),
+  OCC4D_REQUIRE(al16(aq) && al16(kt) && al16(c2) && al16(wstream) && al16(a_out) && (!logits || al16(logits)) && al16(pe),
                 "occ4d_pt_pair_mlp: aq, kt, c2, wstream and the outputs must be 16-byte aligned");
   const int64_t pairs = (int64_t)n * k;
   OCC4D_REQUIRE(pairs * 2 * d * 4 < ((int64_t)1 << 32) && (int64_t)n * ld_aq * 4 < ((int64_t)1 << 32) &&
@@ -690,6 +741,8 @@ extern "C" int occ4d_pt_pair_mlp_f32(const float* aq, int64_t ld_aq, const float
                 "below 4 GiB (split the queries into chunks)");
   OCC4D_REQUIRE(skew >= 0 && skew <= 64, "occ4d_pt_pair_mlp: skew=%d outside [0,64]", skew);
   PairMlpArgs a{aq, ld_aq, kt, ld_kt, r, idx, c2, wstream, a_out, logits, pe, (int)pairs, k, 2 * cu_count(), skew};
-  pair_mlp_kernel<<<occ4d::cdiv(pairs, 128), 256, 0, (hipStream_t)stream>>>(a);
+  // logits == nullptr: the caller holds them already (occ4d_pt_cross_attn16p_logits_f32): a and pe only, no GEMM2
+  if (logits) pair_mlp_kernel<true><<<occ4d::cdiv(pairs, 128), 256, 0, (hipStream_t)stream>>>(a);
+  else pair_mlp_kernel<false><<<occ4d::cdiv(pairs, 128), 256, 0, (hipStream_t)stream>>>(a);
   return occ4d::check_launch("occ4d_pt_pair_mlp");
 }

@@ -78,6 +78,7 @@ struct AttnX6Args {
   int groups, per;                        // query groups of 16; groups per XCD slab
   int skew;                               // phase-skew grouping of the waves (see the kernel)
   int stamps;                             // debug: record phase time stamps
+  float* logits;                          // STORE only: (N * K, 416) pre-softmax logits W2 relu(a), unscaled
 };
 
 // debug (OCC4D_X6_STAMPS=1): s_memtime at the phase boundaries of waves 0 and 4 of the first 1024 workgroups
@@ -86,7 +87,8 @@ __device__ unsigned long long g_x6_stamps[1024 * 2 * 6];
 // PRESCALED (schemes with HSCALE != 1 only): aq and kt arrive multiplied by S::HSCALE (the path-level entry points scale
 // the merged matrices that produce them, csrc/path.hip: exact, a power of two); otherwise the kernel multiplies the init
 // term itself (8 packed multiplies per stage and wave)
-template <typename S, bool PRESCALED>
+// STORE (training forward): the logits also go to HBM, row q K + slot (csrc/crossattn16p.hip has the fp32 twin of this)
+template <typename S, bool PRESCALED, bool STORE = false>
 __global__ __launch_bounds__(512, 2) void cross_attn_split_kernel(const AttnX6Args a) {
   using G = XG<S>;
   using Op = typename S::Op;
@@ -308,6 +310,7 @@ __global__ __launch_bounds__(512, 2) void cross_attn_split_kernel(const AttnX6Ar
     const int tile = 2 * wave + rt;
     const int qm = q0 + tile;
     int voff[4];
+    int loff[4];                                           // STORE: float index of this lane's element of register i's row
     bool act[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -316,6 +319,7 @@ __global__ __launch_bounds__(512, 2) void cross_attn_split_kernel(const AttnX6Ar
       const int slot = row < 14 ? row : 2 * (tile % 7) + row - 14;
       voff[i] = s_idx[ql * 16 + slot] * (int)a.ld_vt + ch0 + c;
       act[i] = slot < a.K && (row < 14 || tile < 14);
+      if (STORE) loff[i] = (act[i] && q0 + ql < a.N) ? ((q0 + ql) * a.K + slot) * XD + ch0 + c : -1;
     }
     // output: lane groups 0 / 2 store the first / second channel tile of a pair for this tile's own query
     float* const orow = a.agg + (int64_t)min(qm, a.N - 1) * a.ld_agg + ch0 + 16 * (g >> 1) + c;
@@ -345,6 +349,11 @@ __global__ __launch_bounds__(512, 2) void cross_attn_split_kernel(const AttnX6Ar
 #pragma unroll
       for (int x = 0; x < 2; ++x) {
         const f32x4 av = acc[rt][x ? tB : tA];
+        if (STORE && !(x == 1 && single)) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (loff[i] >= 0) a.logits[loff[i] + 16 * (x ? tB : tA)] = av[i] * (S::INV_WSCALE / S::HSCALE);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           am[x][i] = act[i] ? av[i] : NINF;
@@ -479,12 +488,14 @@ int pack_stream(const char* who, const float* w2, const float* wp, const float* 
   return occ4d::check_launch(who);
 }
 
-template <typename S, bool PRESCALED>
+template <typename S, bool PRESCALED, bool STORE = false>
 int launch_attn(const char* who, const float* aq, int64_t ld_aq, const float* qpos, int64_t q_stride, const float* apos,
                 int64_t a_stride, const int32_t* idx, const float* kt, int64_t ld_kt, const float* vtc, int64_t ld_vt,
                 const float* pos0_w, const float* pos0_b, const float* wstream, float* agg, int64_t ld_agg, int n, int m,
-                int k, int d, float divisor, void* stream) {
+                int k, int d, float divisor, void* stream, float* logits = nullptr) {
   OCC4D_REQUIRE(d == XD, "%s: built for d = %d, got %d", who, XD, d);
+  OCC4D_REQUIRE(!STORE || (logits && ((uintptr_t)logits % 16) == 0 && (int64_t)n * k * XD < ((int64_t)1 << 31)),
+                "%s: logits buffer null, misaligned or beyond 2^31 floats (chunk the queries)", who);
   OCC4D_REQUIRE(k >= 1 && k <= 14 && m >= 1 && n >= 0, "%s: k = %d (1 .. 14), m = %d, n = %d", who, k, m, n);
   OCC4D_REQUIRE(aq && qpos && apos && idx && kt && vtc && pos0_w && pos0_b && wstream && agg, "%s: null pointer", who);
   OCC4D_REQUIRE(ld_aq % 4 == 0 && ld_kt % 4 == 0 && ((uintptr_t)aq % 16) == 0 && ((uintptr_t)kt % 16) == 0 &&
@@ -496,14 +507,14 @@ int launch_attn(const char* who, const float* aq, int64_t ld_aq, const float* qp
                 "%s: 32-bit row offsets: n * ld_aq and m * ld_kt must stay below 2^29 floats", who);
   if (n == 0) return OCC4D_OK;
   AttnX6Args a{aq, ld_aq, qpos, q_stride, apos, a_stride, idx, kt, ld_kt, vtc, ld_vt, pos0_w, pos0_b,
-               reinterpret_cast<const unsigned*>(wstream), agg, ld_agg, n, m, k, divisor, 0, 0, 0, 0};
+               reinterpret_cast<const unsigned*>(wstream), agg, ld_agg, n, m, k, divisor, 0, 0, 0, 0, logits};
   static const int skew = [] { const char* e = getenv("OCC4D_X6_SKEW"); return e ? atoi(e) : 2; }();   // read once
   static const int stamps = [] { const char* e = getenv("OCC4D_X6_STAMPS"); return e ? atoi(e) : 0; }();
   a.skew = skew;
   a.stamps = stamps;
   a.groups = (int)occ4d::cdiv(n, XQPB);
   a.per = (int)occ4d::cdiv(a.groups, 4);
-  cross_attn_split_kernel<S, PRESCALED><<<8 * a.per, 512, 0, (hipStream_t)stream>>>(a);
+  cross_attn_split_kernel<S, PRESCALED, STORE><<<8 * a.per, 512, 0, (hipStream_t)stream>>>(a);
   return occ4d::check_launch(who);
 }
 }  // namespace
@@ -527,6 +538,16 @@ extern "C" int occ4d_pt_cross_attn_bf16x6_f32(const float* aq, int64_t ld_aq, co
                                               int m, int k, int d, float divisor, void* stream) {
   return launch_attn<SplitBf16x6, false>("occ4d_pt_cross_attn_bf16x6_f32", aq, ld_aq, qpos, q_stride, apos, a_stride, idx, kt, ld_kt,
                                   vtc, ld_vt, pos0_w, pos0_b, wstream, agg, ld_agg, n, m, k, d, divisor, stream);
+}
+// ... that also leaves the pre-softmax logits in logits (n k, 416): the training forward of the split-precision step
+extern "C" int occ4d_pt_cross_attn_bf16x6_logits_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t q_stride,
+                                                     const float* apos, int64_t a_stride, const int32_t* idx, const float* kt,
+                                                     int64_t ld_kt, const float* vtc, int64_t ld_vt, const float* pos0_w,
+                                                     const float* pos0_b, const float* wstream, float* agg, int64_t ld_agg,
+                                                     float* logits, int n, int m, int k, int d, float divisor, void* stream) {
+  return launch_attn<SplitBf16x6, false, true>("occ4d_pt_cross_attn_bf16x6_logits_f32", aq, ld_aq, qpos, q_stride, apos, a_stride,
+                                               idx, kt, ld_kt, vtc, ld_vt, pos0_w, pos0_b, wstream, agg, ld_agg, n, m, k, d,
+                                               divisor, stream, logits);
 }
 extern "C" int occ4d_pt_cross_attn_f16x3_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t q_stride,
                                              const float* apos, int64_t a_stride, const int32_t* idx, const float* kt,

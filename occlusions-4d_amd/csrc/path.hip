@@ -386,7 +386,7 @@ int rowlin_x6(bool f16, const float* x, int64_t ldx, float* y, int64_t ldy, cons
 int layer_forward(const occ4d_pt_layer_weights& w, const LayerLayout& L, const float* prep, const float* x, int64_t ldx,
                   const float* pos, int64_t ps, int n, const float* x2, int64_t ldx2, const float* pos2, int64_t p2s, int m,
                   int k, const int32_t* knn_idx, const float* scene, float* out, int64_t ldo, Bump& ws,
-                  const Events& E, hipStream_t st, bool dry) {
+                  const Events& E, hipStream_t st, bool dry, float* logits_out = nullptr) {
   const int D = L.D, h = L.h;
   const int64_t mark = ws.mark();
   const float *kt, *vt, *vtc, *aq_all = nullptr, *yfeat = x;
@@ -470,9 +470,17 @@ int layer_forward(const occ4d_pt_layer_weights& w, const LayerLayout& L, const f
         else if (L.bf16x6 && L.f16)
           rc = occ4d_pt_cross_attn_f16x3_prescaled_f32(aq, 2 * D, qp, ps, pos2, p2s, idx, kt, 2 * D, vtc, D, w.pos0_w,
                                                        w.pos0_b, prep + L.stream6, agg_c, ld_agg, c, m, k, D, divisor, st);
+        else if (L.bf16x6 && logits_out)
+          rc = occ4d_pt_cross_attn_bf16x6_logits_f32(aq, 2 * D, qp, ps, pos2, p2s, idx, kt, 2 * D, vtc, D, w.pos0_w, w.pos0_b,
+                                                     prep + L.stream6, agg_c, ld_agg, logits_out + (int64_t)lo * k * D, c, m, k,
+                                                     D, divisor, st);
         else if (L.bf16x6)
           rc = occ4d_pt_cross_attn_bf16x6_f32(aq, 2 * D, qp, ps, pos2, p2s, idx, kt, 2 * D, vtc, D, w.pos0_w, w.pos0_b,
                                               prep + L.stream6, agg_c, ld_agg, c, m, k, D, divisor, st);
+        else if (L.fused16p && logits_out)          // training forward: the logits of rows lo k .. stay in HBM for backward
+          rc = occ4d_pt_cross_attn16p_logits_f32(aq, 2 * D, qp, ps, pos2, p2s, idx, kt, 2 * D, vtc, D, w.pos0_w, w.pos0_b,
+                                                 prep + L.stream, agg_c, ld_agg, logits_out + (int64_t)lo * k * D, c, m, k, D,
+                                                 divisor, occ4d::attn16p_skew(), st);
         else if (L.fused16p)
           rc = occ4d_pt_cross_attn16p_f32(aq, 2 * D, qp, ps, pos2, p2s, idx, kt, 2 * D, vtc, D, w.pos0_w, w.pos0_b,
                                           prep + L.stream, agg_c, ld_agg, c, m, k, D, divisor, occ4d::attn16p_skew(), st);
@@ -830,6 +838,33 @@ extern "C" int occ4d_pt_layer_fwd_f32(const occ4d_pt_layer_weights* w, const flo
   const Events E{ev, (hipStream_t)stream};
   return layer_forward(*w, layer_layout(*w, flags), prepared, x, ldx, pos, pos_stride, n, x2, ldx2, pos2, pos2_stride, m, k,
                        knn_idx, scene, out, ldo, ws, E, (hipStream_t)stream, false);
+}
+
+// ... and the pre-softmax logits W2 relu(a) of every (query, neighbour) pair into logits_out (n * k, dim): the training
+// forward (backward then recomputes only the hidden pre-activations: occ4d_pt_pair_mlp_f32 with logits = NULL).  Only the
+// layers the fp32 paired-workgroup kernel or the bf16 x 3 split kernel serves (dim = 416, k <= 14): OCC4D_ERR_INVALID otherwise.
+extern "C" int occ4d_pt_layer_fwd_logits_f32(const occ4d_pt_layer_weights* w, const float* prepared, const float* x, int64_t ldx,
+                                             const float* pos, int64_t pos_stride, int n, const float* x2, int64_t ldx2,
+                                             const float* pos2, int64_t pos2_stride, int m, int k, const int32_t* knn_idx,
+                                             const float* scene, float* out, int64_t ldo, float* logits_out, float* workspace,
+                                             int flags, void* stream) {
+  const char* who = "occ4d_pt_layer_fwd_logits_f32";
+  TRY(check_layer(w, who));
+  OCC4D_REQUIRE(n >= 0 && k >= 1 && k <= 14, "%s: n = %d, k = %d (1 .. 14)", who, n, k);
+  if (n == 0) return OCC4D_OK;
+  const LayerLayout L = layer_layout(*w, flags);
+  OCC4D_REQUIRE((L.fused16p || (L.bf16x6 && !L.f16)) && w->cross, "%s: only the cross-attention layers of the fp32 paired-workgroup "
+                "kernel or of the bf16 x 3 split kernel (dim = 416, fused) store their logits", who);
+  OCC4D_REQUIRE(prepared && x && pos && out && logits_out && workspace && al16(workspace) && al16(x) && al16(out) &&
+                    al16(logits_out) && ldx % 4 == 0 && ldo % 4 == 0,
+                "%s: null or misaligned buffer (x, out, logits_out, workspace 16-byte aligned; ldx, ldo multiples of 4)", who);
+  OCC4D_REQUIRE(pos2 && m >= k && (scene || (x2 && al16(x2) && ldx2 % 4 == 0)),
+                "%s: cross-attention needs pos2, m >= k and x2 (or the scene tables)", who);
+  OCC4D_REQUIRE(out != x || w->post_w, "%s: out may alias x only with layer3 (residual form)", who);
+  Bump ws(workspace);
+  const Events E{nullptr, (hipStream_t)stream};
+  return layer_forward(*w, L, prepared, x, ldx, pos, pos_stride, n, x2, ldx2, pos2, pos2_stride, m, k, knn_idx, scene, out, ldo,
+                       ws, E, (hipStream_t)stream, false, logits_out);
 }
 
 extern "C" int occ4d_down_pool_fwd_f32(const float* x, int64_t ldx, int n, int d_in, const float* w, const float* b,

@@ -48,6 +48,8 @@ class Selection:
     checkpoint_attention: bool = True     # training: cross-attention recomputes its pair tensors in backward
     stored_attention_form: str = 'merged'  # with checkpoint_attention off: 'merged' | 'as_written'
     checkpoint_chunk: int = 32768     # queries per recompute chunk in backward
+    store_logits: bool = True         # training: the checkpointed attention's forward keeps its logits (n k, 416) in HBM, backward
+                                      # skips GEMM2 of the recompute (fp32 forward kernel only; + 1.6 GB per layer at config 5)
     decode_streams: int = 2           # inference: HIP streams the decode mini-batches alternate between (1 = the reference's serial loop)
 
     def __post_init__(self):
@@ -106,6 +108,7 @@ def _from_environment():
         train_precision=os.environ.get('OCC4D_TRAIN_PRECISION', 'f32'),
         stored_attention_form=os.environ.get('OCC4D_STORED_ATTENTION_FORM', 'merged'),
         checkpoint_chunk=int(os.environ.get('OCC4D_CHECKPOINT_CHUNK', '32768')),
+        store_logits=_env_flag('OCC4D_STORE_LOGITS', '1'),
         decode_streams=int(os.environ.get('OCC4D_DECODE_STREAMS', '2')))
 
 

@@ -499,10 +499,12 @@ def pt_cross_attn16p(aq, qpos, apos, idx, kt, vt, P1, c1, wstream, out=None, ske
     return out
 
 
-def pt_pair_mlp(aq, kt, r, idx, c2, wstream, skew=None):
+def pt_pair_mlp(aq, kt, r, idx, c2, wstream, skew=None, logits=None):
     """Training: the pair tensors of the merged-form layer in one kernel (occ4d_pt_pair_mlp_f32):
     a (n k, 832) = aq_i - kt_j + Wp r before the ReLU, logits (n k, 416) = W2 relu(a) (attn_mlp[2].bias left out: it
-    cancels in the softmax), pe (n k, 416) = P2 r + c2.  wstream = pack_attn16p_stream(W2, ., Wp, P2, .)."""
+    cancels in the softmax), pe (n k, 416) = P2 r + c2.  wstream = pack_attn16p_stream(W2, ., Wp, P2, .).
+    `logits`: the (n k, 416) rows the training forward stored (pt_layer_fwd(..., logits_out=)): returned as they are,
+    the launch skips GEMM2 and only writes a and pe."""
     aq, ld_aq = _aligned_rows(_dev(aq, name='aq'), 'aq')
     kt, ld_kt = _aligned_rows(_dev(kt, name='kt'), 'kt')
     idx = _dev(idx, torch.int32, 'idx')
@@ -513,13 +515,19 @@ def pt_pair_mlp(aq, kt, r, idx, c2, wstream, skew=None):
     assert idx.is_contiguous() and r.is_contiguous() and r.shape == (n * k, 32) and aq.shape == (n, 2 * d)
     assert kt.shape[1] == 2 * d and c2.shape == (d,) and wstream.is_contiguous()
     a = torch.empty((n * k, 2 * d), dtype=torch.float32, device=aq.device)
-    logits = torch.empty((n * k, d), dtype=torch.float32, device=aq.device)
+    stored = logits is not None
+    if stored:
+        logits = _dev(logits, name='logits')
+        assert logits.is_contiguous() and tuple(logits.shape) == (n * k, d)
+    else:
+        logits = torch.empty((n * k, d), dtype=torch.float32, device=aq.device)
     pe = torch.empty((n * k, d), dtype=torch.float32, device=aq.device)
-    flops = 2.0 * n * k * (32 * 2 * d + 2 * d * d + 32 * d)
+    flops = 2.0 * n * k * (32 * 2 * d + (0 if stored else 2 * d * d) + 32 * d)
     sk = ATTN16P_SKEW if skew is None else int(skew)
-    _lib.check(_launch('pair_mlp', dict(n=n, k=k, d=d), flops, lambda: _lib.lib().occ4d_pt_pair_mlp_f32(
-        _ptr(aq), ld_aq, _ptr(kt), ld_kt, _ptr(r), _ptr(idx), _ptr(c2), _ptr(wstream), _ptr(a), _ptr(logits),
-        _ptr(pe), n, kt.shape[0], k, d, sk, _stream())))
+    _lib.check(_launch('pair_hidden' if stored else 'pair_mlp', dict(n=n, k=k, d=d), flops,
+                       lambda: _lib.lib().occ4d_pt_pair_mlp_f32(
+        _ptr(aq), ld_aq, _ptr(kt), ld_kt, _ptr(r), _ptr(idx), _ptr(c2), _ptr(wstream), _ptr(a),
+        None if stored else _ptr(logits), _ptr(pe), n, kt.shape[0], k, d, sk, _stream())))
     return a, logits, pe
 
 
@@ -846,9 +854,11 @@ def pt_layer_prepare(w, flags, device):
     return prep
 
 
-def pt_layer_fwd(w, prepared, x, pos, x2, pos2, k, flags=0, knn_idx=None, out=None):
+def pt_layer_fwd(w, prepared, x, pos, x2, pos2, k, flags=0, knn_idx=None, out=None, logits_out=None):
     """occ4d_pt_layer_fwd_f32: PointTransformerLayer / PointTransformerBlock forward of ONE cloud.  x (n, d_in), pos
-    (n, >= 3) [, x2 (m, dim2), pos2 (m, >= 3)] -> (n, d_out | dim)."""
+    (n, >= 3) [, x2 (m, dim2), pos2 (m, >= 3)] -> (n, d_out | dim).  `logits_out` (n k, 416): the training forward
+    (occ4d_pt_layer_fwd_logits_f32: the pre-softmax logits of every pair stay in HBM for backward; only the layers
+    logits_storable() names)."""
     x, ldx = _aligned_rows(_dev(x, name='x'), 'x')
     p, ps = _rows(_dev(pos, name='pos'), 'pos')
     n = x.shape[0]
@@ -877,11 +887,25 @@ def pt_layer_fwd(w, prepared, x, pos, x2, pos2, k, flags=0, knn_idx=None, out=No
     ev, finish = (None, lambda: None)
     if t is not None and chunks and t.want('cross_attn', n=chunks[0], k=k, d=w.dim):
         ev, finish = _path_timing('cross_attn', [_attn_flops(c, k, w.dim) for c in chunks])
+    if logits_out is not None:
+        lg = _dev(logits_out, name='logits_out')
+        assert lg.is_contiguous() and tuple(lg.shape) == (n * k, w.dim) and logits_storable(w, k, flags)
+        _lib.check(_lib.lib().occ4d_pt_layer_fwd_logits_f32(
+            C.byref(w), _ptr(prepared), _ptr(x), ldx, _ptr(p), ps, n, _ptr(x2p), ldx2, _ptr(p2), p2s, m, k, _ptr(knn_idx),
+            None, _ptr(o), ldo, _ptr(lg), _ptr(ws), flags, _stream()))
+        return out
     _lib.check(_lib.lib().occ4d_pt_layer_fwd_f32(
         C.byref(w), _ptr(prepared), _ptr(x), ldx, _ptr(p), ps, n, _ptr(x2p), ldx2, _ptr(p2), p2s, m, k, _ptr(knn_idx), None,
         _ptr(o), ldo, _ptr(ws), flags, C.byref(ev) if ev is not None else None, _stream()))
     finish()
     return out
+
+
+def logits_storable(w, k, flags):
+    """True for the layers whose forward kernel can leave its logits in HBM (occ4d_pt_layer_fwd_logits_f32): cross
+    attention on the fp32 paired-workgroup kernel or the bf16 x 3 split kernel -- dim 416, k <= 14, fused, not fp16."""
+    off = _lib.PATH_UNFUSED | _lib.PATH_SPLIT_F16 | _lib.PATH_FIRST_GEN
+    return bool(w.cross) and w.dim == TRUNK_WIDTH and k <= FUSED_ATTN_MAX_K and w.pos_hidden == 32 and not (flags & off)
 
 
 def down_pool_fwd(x, weight, bias, nn_idx, norm=0, gamma=None, beta=None, mean=None, var=None, eps=1e-5):

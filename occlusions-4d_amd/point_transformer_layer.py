@@ -111,8 +111,13 @@ class _CheckpointedAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, layer, x, pos, x2, pos2, idx, *params):
         _CheckpointedAttention.calls += 1
+        ctx.logits = None
         with torch.no_grad():
-            agg = layer._forward_one(x, pos, x2, pos2, None, None, knn_idx=idx)
+            if kernels.scope().store_logits and layer.logits_storable():
+                # the forward kernel leaves its logits in HBM (1664 B per pair): backward reads them instead of running
+                # the 832 -> 416 pair GEMM a second time (round 6: 2.3 -> 0.6 ms per recompute chunk)
+                ctx.logits = torch.empty((x.shape[0] * layer.num_neighbors, layer.dim), dtype=torch.float32, device=x.device)
+            agg = layer._forward_one(x, pos, x2, pos2, None, None, knn_idx=idx, logits_out=ctx.logits)
         ctx.layer = layer
         ctx.save_for_backward(x, pos, x2, pos2, idx)
         return agg
@@ -165,8 +170,11 @@ class _CheckpointedAttention(torch.autograd.Function):
                     aq = aq_all[lo:hi].detach().requires_grad_(True)                                # (c, 2D)
                     r = autograd.PosHiddenFn.apply(pos[lo:hi].contiguous(), pos2, ic, P1, c1)      # (c*K, 32)
                     if autograd.pair_mlp_fused_ok(aq, r, ic):
-                        # a = aq_i - kt_j + Wp r, logits = W2 relu(a), pe = P2 r + c2 from one kernel
-                        logits, pe = autograd.PairMlpFn.apply(aq, kt_l, r, wp_l, W2, b2, P2l, c2l, ic)
+                        # a = aq_i - kt_j + Wp r, logits = W2 relu(a), pe = P2 r + c2 from one kernel (the logits: the
+                        # forward's own, when it kept them)
+                        K = ic.shape[1]
+                        kept = None if ctx.logits is None else ctx.logits[lo * K:hi * K]
+                        logits, pe = autograd.PairMlpFn.apply(aq, kt_l, r, wp_l, W2, b2, P2l, c2l, ic, kept)
                     else:
                         a = autograd.AttnInLinearFn.apply(aq, kt_l, r, wp_l, ic)                     # aq_i - kt_j + Wp r
                         logits = L(a, W2, b2, True, False, None, None)                                    # W2 relu(.) + b2
@@ -350,12 +358,21 @@ class PointTransformerLayer(nn.Module, kernels.HasKernelSelection):
                                          pre, post, None if knn_idx is None else knn_idx[b]))
         return ops.stack_batch(out)
 
-    def _forward_one(self, x, pos, x2, pos2, pre=None, post=None, knn_idx=None):
-        """Inference forward of one cloud through the library's path-level entry point."""
+    def _forward_one(self, x, pos, x2, pos2, pre=None, post=None, knn_idx=None, logits_out=None):
+        """Inference forward of one cloud through the library's path-level entry point (`logits_out`: the training forward
+        of _CheckpointedAttention, ops.pt_layer_fwd)."""
         w, prepared, flags = self.path_weights(cross=x2 is not None, pre=pre, post=post)
         if knn_idx is not None and knn_idx.dtype != torch.int32:
             knn_idx = knn_idx.to(torch.int32)
-        return ops.pt_layer_fwd(w, prepared, x, pos, x2, pos2, self.num_neighbors, flags, knn_idx=knn_idx)
+        return ops.pt_layer_fwd(w, prepared, x, pos, x2, pos2, self.num_neighbors, flags, knn_idx=knn_idx,
+                                logits_out=logits_out)
+
+    def logits_storable(self):
+        """Can this layer's fused forward leave its logits in HBM (ops.logits_storable: cross attention, dim 416, k <= 14,
+        the fp32 or the bf16 x 3 kernel of the current selection)?"""
+        f, L = path_flags(self), ops._lib
+        off = L.PATH_UNFUSED | L.PATH_SPLIT_F16 | L.PATH_FIRST_GEN
+        return self.dim == ops.TRUNK_WIDTH and self.num_neighbors <= ops.FUSED_ATTN_MAX_K and not (f & off)
 
     def forward_train_merged(self, x, pos, x2, pos2, idx=None):
         """Differentiable cross-attention for one cloud in the MERGED form of DESIGN.md 4 (i): the query / key halves of

@@ -259,6 +259,67 @@ def test_fused_pair_tensors_match_the_unfused_chain(n, m, k):
     assert rel_err(a_f, a_u) < 2e-6
 
 
+@pytest.mark.parametrize('precision', ['f32', 'bf16x6'])
+@pytest.mark.parametrize('n,m,k', [(1003, 76, 14), (37, 50, 5), (9, 531, 14), (4000, 300, 13), (1, 14, 14)])
+def test_forward_keeps_its_logits_for_backward(n, m, k, precision):
+    """Round 6: the training forward's fused kernel leaves its logits in HBM (occ4d_pt_layer_fwd_logits_f32) and the
+    recompute skips GEMM2 (occ4d_pt_pair_mlp_f32 with logits = NULL).  (1) the layer output is bit-identical with and
+    without the store; (2) the stored rows are the logits of the pair kernel (same MFMA chain: different accumulation order
+    only); (3) the short launch's a and pe are the full launch's, bit for bit; (4) end to end, every gradient of the layer
+    with store_logits on equals the one with it off to rounding."""
+    ptl, ops, d, dim2 = pk.point_transformer_layer, pk.ops, 416, 288
+    rng = np.random.default_rng(77 * n + k)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()      # noqa: E731
+    x, x2 = dev(rng.normal(size=(n, d))), dev(rng.normal(size=(m, dim2)))
+    pos, pos2 = dev(rng.uniform(-5, 5, size=(n, 3))), dev(rng.uniform(-5, 5, size=(m, 3)))
+    layer = ptl.PointTransformerLayer(d, num_neighbors=k, dim2=dim2).cuda()
+    layer.load_state_dict(pk.configs.fill_state_dict(layer, 515 + k))
+    idx = ops.knn(pos, pos2, k, metric=0)
+    with pk.kernels(logit_precision=precision):
+        _keeps_logits_body(layer, x, pos, x2, pos2, idx, n, m, k, d, dim2, precision)
+
+
+def _keeps_logits_body(layer, x, pos, x2, pos2, idx, n, m, k, d, dim2, precision):
+    ptl, ops = pk.point_transformer_layer, pk.ops
+    assert layer.logits_storable()
+    with torch.no_grad():
+        kept = torch.full((n * k, d), float('nan'), device='cuda')
+        plain = layer._forward_one(x, pos, x2, pos2, knn_idx=idx)
+        stored = layer._forward_one(x, pos, x2, pos2, knn_idx=idx, logits_out=kept)
+        assert torch.equal(plain, stored) and torch.isfinite(kept).all()
+        # the pair kernel on the same merged matrices
+        f64 = torch.float64
+        W1, b1 = layer.attn_mlp[0].weight.to(f64), layer.attn_mlp[0].bias.to(f64)
+        P2, c2 = layer.pos_mlp[2].weight, layer.pos_mlp[2].bias
+        wq, bq = (W1 @ layer.to_q.weight.to(f64)).float(), (W1 @ c2.to(f64) + b1).float()
+        wk, wp = (W1 @ layer.to_k.weight.to(f64)).float(), (W1 @ P2.to(f64)).float()
+        aq, kt = ops.linear(x, wq, bq), ops.linear(x2, wk, None)
+        r = ops.pt_pos_hidden(pos, pos2, idx, layer.pos_mlp[0].weight, layer.pos_mlp[0].bias)
+        stream = ops.pack_attn16p_stream(layer.attn_mlp[2].weight, layer.attn_mlp[2].bias, wp, P2, c2)
+        a_full, l_full, pe_full = ops.pt_pair_mlp(aq, kt, r, idx, c2, stream)
+        a_short, l_short, pe_short = ops.pt_pair_mlp(aq, kt, r, idx, c2, stream, logits=kept)
+        assert l_short.data_ptr() == kept.data_ptr()
+        assert torch.equal(a_full, a_short) and torch.equal(pe_full, pe_short)
+        assert rel_err(kept, l_full) < (2e-6 if precision == 'f32' else 2e-5)
+
+    def grads(store):
+        lay = ptl.PointTransformerLayer(d, num_neighbors=k, dim2=dim2).cuda()
+        lay.load_state_dict(layer.state_dict())
+        xg, x2g = x.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+        with pk.kernels(store_logits=store, logit_precision=precision), ops.deterministic():
+            before = ptl._CheckpointedAttention.calls
+            out = lay(xg[None], pos[None], x2g[None], pos2[None])[0]
+            assert ptl._CheckpointedAttention.calls == before + 1
+            (out * torch.cos(out.detach())).sum().backward()
+        return [xg.grad, x2g.grad] + [p.grad for p in lay.parameters()]
+    for u, v in zip(grads(True), grads(False)):
+        assert u is not None and v is not None
+        if float(v.abs().max()) < 1e-5:       # (attn_mlp[2].bias: its gradient is zero up to rounding, the softmax cancels it)
+            assert float((u - v).abs().max()) < 1e-5
+        else:
+            assert rel_err(u, v) <= 2e-5, rel_err(u, v)
+
+
 def test_pair_tensor_paths_are_both_exercised(monkeypatch):
     """The strict layer-level tests above run the fused pair-tensor kernel (d = 416); with it switched off the unfused
     chain must satisfy the same criterion."""
