@@ -516,20 +516,13 @@ struct PairMlpArgs {
   int first_round, skew;
 };
 
-// LOGITS = false (the training forward stored the logits, cross_attn16p_kernel<., true>): GEMM2 is skipped -- the stage
-// is GEMM1 + the store of `a`, only the two Wp fragments of a stage travel, and the epilogue is pe alone.
-template <bool LOGITS>
 __global__ __launch_bounds__(256, 2) void pair_mlp_kernel(const PairMlpArgs a) {
   __shared__ __attribute__((aligned(16))) float buf0[PSTAGE];
   __shared__ __attribute__((aligned(16))) float buf1[PSTAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
   const unsigned lane16 = lane * 16;
-  auto dma_first = [&]() {
-    if (LOGITS) dma_stage_p(a.wstream, buf0, wave, lane16);
-    else if (wave >= 2) dma_frag_p(a.wstream + (24 + wave) * PFRAG, lds_addr_p(buf0) + (unsigned)(24 + wave) * (PFRAG * 4), lane16);
-  };
-  dma_first();
+  dma_stage_p(a.wstream, buf0, wave, lane16);
   if (a.skew > 0 && (int)blockIdx.x < a.first_round) {      // phase skew of the two workgroups of a CU, as above
     const unsigned hw = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
     if (hw & 1)
@@ -574,25 +567,18 @@ __global__ __launch_bounds__(256, 2) void pair_mlp_kernel(const PairMlpArgs a) {
 #pragma unroll
       for (int gq = 0; gq < 14; ++gq) {
         const f32x4 ca = wa, cb = wb;
-        if (!LOGITS && gq > 1) break;
-        if (LOGITS && gq + 1 < 14) {
+        if (gq + 1 < 14) {
           wa = *reinterpret_cast<const f32x4*>(f + (2 * gq) * PFRAG);
           wb = *reinterpret_cast<const f32x4*>(f + (2 * gq + 1) * PFRAG);
         }
         if (gq == 0) ia = slice(a.aq + 16 * sn, aq_off);
         if (gq == 1) ik = slice(a.kt + 16 * sn, kt_off);
-        if (LOGITS) {
-          if (gq >= 2 && gq <= 8)
-            dma_frag_p(nsrc + (wave + 4 * (gq - 2)) * PFRAG, lds_addr_p(nxt) + (unsigned)(wave + 4 * (gq - 2)) * (PFRAG * 4), lane16);
-        } else if (gq == 1) {
-          if (s + 1 == PHS) dma_stage_p(nsrc, nxt, wave, lane16);      // (the first P2 stage, whole: the epilogue's GEMM3)
-          else if (wave >= 2)                                           // fragments 26, 27 = Wp's K halves
-            dma_frag_p(nsrc + (24 + wave) * PFRAG, lds_addr_p(nxt) + (unsigned)(24 + wave) * (PFRAG * 4), lane16);
-        }
+        if (gq >= 2 && gq <= 8)
+          dma_frag_p(nsrc + (wave + 4 * (gq - 2)) * PFRAG, lds_addr_p(nxt) + (unsigned)(wave + 4 * (gq - 2)) * (PFRAG * 4), lane16);
         __builtin_amdgcn_sched_barrier(0);
         if (gq == 0) {
           mm_g1_p(ca, cb, r_lo, r_hi, h);
-        } else if (LOGITS) {
+        } else {
           if (FIRST) acc[2 * (gq - 1)] = acc[2 * (gq - 1) + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
           mm_ba_p(h, ca, cb, acc[2 * (gq - 1)], acc[2 * (gq - 1) + 1]);
         }
@@ -627,14 +613,12 @@ __global__ __launch_bounds__(256, 2) void pair_mlp_kernel(const PairMlpArgs a) {
     // buf1 under it).  GEMM2 / GEMM3 ran with the fragments as the A operand (mm_ba_p): lane (g, c) holds channels
     // 16 t + 4 g .. + 3 of pair row c in every accumulator tile
     dma_stage_p(a.wstream + (int64_t)(PHS + 1) * PSTAGE, buf1, wave, lane16);
-    if (LOGITS) {
 #pragma unroll
-      for (int t = 0; t < PTD; ++t) {
+    for (int t = 0; t < PTD; ++t) {
 #ifdef OCC4D_PM_ABL_NOLOGITS
-        if (acc[t].x == 123.456f)                      // (ablation: keep the accumulators live, store nothing)
+      if (acc[t].x == 123.456f)                      // (ablation: keep the accumulators live, store nothing)
 #endif
-        put(a.logits + 16 * t, l_off, acc[t]);
-      }
+      put(a.logits + 16 * t, l_off, acc[t]);
     }
     auto pe_tiles = [&](auto T0c, auto NPc, const float* __restrict__ pbuf) {
       constexpr int T0 = decltype(T0c)::value, NP = decltype(NPc)::value;
@@ -660,8 +644,73 @@ __global__ __launch_bounds__(256, 2) void pair_mlp_kernel(const PairMlpArgs a) {
     pe_tiles(std::integral_constant<int, 0>{}, std::integral_constant<int, PTA / 2>{}, buf0);
     dma_wait_p();
     __syncthreads();
-    if (ps == 0) dma_first();                                  // pass B's first hidden stage
+    if (ps == 0) dma_stage_p(a.wstream, buf0, wave, lane16);   // pass B's first hidden stage
     pe_tiles(std::integral_constant<int, PTA>{}, std::integral_constant<int, PTB / 2>{}, buf1);
+  }
+}
+
+// The same pair tensors WITHOUT the logits (the training forward kept them: cross_attn16p_kernel<., true>): a and pe only,
+// 4992 B of stores per pair row against 42 KFLOP -- memory-bound, so nothing is staged and nothing is shared: a wave reads
+// its Wp / P2 fragments (1 KB, coalesced, L2-resident: the packed stream of the kernels above) and its Aq / Kt slices
+// straight into registers two hidden stages ahead, and never meets a barrier.  Same MFMA chain and operand order per
+// stage as pair_mlp_kernel: a and pe are bit-identical to its.
+__global__ __launch_bounds__(256) void pair_hidden_kernel(const PairMlpArgs a) {
+  // a workgroup = 16 consecutive pair rows (53 KB of a, 26 KB of pe, contiguous); its four waves take a quarter of the hidden
+  // stages / of the channel tile pairs each.  Measured (profiles/time_pair_hidden.py, 22976 x 14 pairs, 1.61 GB stored):
+  // 0.78-0.89 ms against 5.0-5.5 ms for the full kernel on the same (random-neighbour) inputs and 0.23 ms for a fill of
+  // the same bytes; one wave per 16 rows over all stages measured the same -- per 1 KB stored a wave reads 4 KB (two
+  // fragments, the Aq and the Kt slice), so the L2 -> CU side, not the stores, is the bound.
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int p = min((int)blockIdx.x * 16 + c, a.P - 1);
+  const int q = p / a.K;
+  const int j = a.idx[p];
+  float rr[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) rr[s] = a.r[(int64_t)p * 32 + 4 * s + g];
+  const f32x4 r_lo = {rr[0], rr[1], rr[2], rr[3]}, r_hi = {rr[4], rr[5], rr[6], rr[7]};
+  const float* aq = a.aq + (int64_t)q * a.ld_aq + 4 * g;
+  const float* kt = a.kt + (int64_t)j * a.ld_kt + 4 * g;
+  float* ao = a.a_out + (int64_t)p * (2 * PD) + 4 * g;
+  float* po = a.pe + (int64_t)p * PD + 4 * g;
+  const float* ws = a.wstream + lane * 4;
+  auto ld = [](const float* q4) { return *reinterpret_cast<const f32x4*>(q4); };
+  constexpr int AHEAD = 2, PER = PHS / 4;                // stages in flight ahead of the one being computed; 13 per wave
+  const int s_begin = PER * wave, s_end = s_begin + PER;
+  f32x4 wa[AHEAD + 1], wb[AHEAD + 1], ia[AHEAD + 1], ik[AHEAD + 1];
+#pragma unroll
+  for (int u = 0; u < AHEAD; ++u) {
+    const int s = s_begin + u;
+    wa[u] = ld(ws + (int64_t)s * PSTAGE + 26 * PFRAG); wb[u] = ld(ws + (int64_t)s * PSTAGE + 27 * PFRAG);
+    ia[u] = ld(aq + 16 * s); ik[u] = ld(kt + 16 * s);
+  }
+#pragma unroll 1
+  for (int s0 = s_begin; s0 < s_end; s0 += AHEAD + 1) {  // (the slot index is a compile-time constant)
+#pragma unroll
+    for (int u = 0; u < AHEAD + 1; ++u) {
+      const int s = s0 + u;
+      if (s < s_end) {
+        const int sn = min(s + AHEAD, s_end - 1);
+        const int slot_n = (u + AHEAD) % (AHEAD + 1);
+        wa[slot_n] = ld(ws + (int64_t)sn * PSTAGE + 26 * PFRAG); wb[slot_n] = ld(ws + (int64_t)sn * PSTAGE + 27 * PFRAG);
+        ia[slot_n] = ld(aq + 16 * sn); ik[slot_n] = ld(kt + 16 * sn);
+        f32x4 h = ia[u] - ik[u];
+        mm_g1_p(wa[u], wb[u], r_lo, r_hi, h);
+        *reinterpret_cast<f32x4*>(ao + 16 * s) = h;      // units 16 s + 4 g .. + 3 of this lane's pair row, BEFORE the ReLU
+      }
+    }
+  }
+  // pe = P2 r + c2: the two P2 stages of the stream (channel tiles 0-13, 14-25), a tile pair at a time
+#pragma unroll 1
+  for (int pr = wave; pr < PTD / 2; pr += 4) {
+    const int t = 2 * pr;
+    const bool second = t >= PTA;
+    const float* fp = ws + (int64_t)(PHS + (second ? 1 : 0)) * PSTAGE + (int64_t)(4 * (second ? pr - PTA / 2 : pr)) * PFRAG;
+    f32x4 e0 = ld(a.c2 + 16 * t + 4 * g), e1 = ld(a.c2 + 16 * (t + 1) + 4 * g);
+    mm_ba_p(r_lo, ld(fp), ld(fp + 2 * PFRAG), e0, e1);
+    mm_ba_p(r_hi, ld(fp + PFRAG), ld(fp + 3 * PFRAG), e0, e1);
+    *reinterpret_cast<f32x4*>(po + 16 * t) = e0;
+    *reinterpret_cast<f32x4*>(po + 16 * (t + 1)) = e1;
   }
 }
 
@@ -742,7 +791,7 @@ extern "C" int occ4d_pt_pair_mlp_f32(const float* aq, int64_t ld_aq, const float
   OCC4D_REQUIRE(skew >= 0 && skew <= 64, "occ4d_pt_pair_mlp: skew=%d outside [0,64]", skew);
   PairMlpArgs a{aq, ld_aq, kt, ld_kt, r, idx, c2, wstream, a_out, logits, pe, (int)pairs, k, 2 * cu_count(), skew};
   // logits == nullptr: the caller holds them already (occ4d_pt_cross_attn16p_logits_f32): a and pe only, no GEMM2
-  if (logits) pair_mlp_kernel<true><<<occ4d::cdiv(pairs, 128), 256, 0, (hipStream_t)stream>>>(a);
-  else pair_mlp_kernel<false><<<occ4d::cdiv(pairs, 128), 256, 0, (hipStream_t)stream>>>(a);
+  if (logits) pair_mlp_kernel<<<occ4d::cdiv(pairs, 128), 256, 0, (hipStream_t)stream>>>(a);
+  else pair_hidden_kernel<<<occ4d::cdiv(pairs, 16), 256, 0, (hipStream_t)stream>>>(a);
   return occ4d::check_launch("occ4d_pt_pair_mlp");
 }
