@@ -270,12 +270,15 @@ int occ4d_pt_cross_attn16p_f32(const float* aq, int64_t ld_aq, const float* qpos
 
 /* occ4d_pt_cross_attn16p_f32 that also leaves the pre-softmax logits W2 relu(a) (attn_mlp[2].bias not added: it cancels
  * in the softmax) of pair p = i k + j in logits[p] (n k, 416), contiguous, 16-byte aligned: the training forward.  Backward
- * then needs no second GEMM2 (occ4d_pt_pair_mlp_f32 with logits = NULL).  Same results in agg, bit for bit. */
+ * then needs no second GEMM2 (occ4d_pt_pair_mlp_f32 with logits = NULL).  With a_out (n k, 832), pe_out (n k, 416) and
+ * c2 = pos_mlp[2].bias (all three or none) the hidden pre-activations a and pe = P2 r + c2 are left as well -- the three
+ * pair tensors of occ4d_pt_pair_mlp_f32 on the same operands -- and backward recomputes nothing.
+ * Same results in agg, bit for bit. */
 int occ4d_pt_cross_attn16p_logits_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t q_stride, const float* apos,
                                       int64_t a_stride, const int32_t* idx, const float* kt, int64_t ld_kt, const float* vt,
                                       int64_t ld_vt, const float* P1, const float* c1, const float* wstream, float* agg,
-                                      int64_t ld_agg, float* logits, int n, int m, int k, int d, float divisor, int skew,
-                                      void* stream);
+                                      int64_t ld_agg, float* logits, float* a_out, float* pe_out, const float* c2, int n,
+                                      int m, int k, int d, float divisor, int skew, void* stream);
 
 /* Training companion of occ4d_pt_cross_attn16p_f32 (same file, same weight stream and MFMA chain, no softmax): the
  * pair tensors of the layer in its merged form, which backward needs (the ops are
@@ -595,12 +598,15 @@ typedef struct occ4d_pt_layer_weights {
 int64_t occ4d_pt_cross_attn_bf16x6_stream_floats(void);
 int occ4d_pack_attn_bf16x6_stream_f32(const float* w2, const float* wp, const float* p2, float* wstream, void* stream);
 /* occ4d_pt_cross_attn_bf16x6_f32 that also leaves the pre-softmax logits of pair p = i k + j in logits[p] (n k, 416;
- * n k 416 < 2^31): the training forward of the split-precision step (cf. occ4d_pt_cross_attn16p_logits_f32). */
+ * n k 416 < 2^31) and, with a_out (n k, 832; n k 832 < 2^31), pe_out (n k, 416) and c2 = pos_mlp[2].bias (all three or
+ * none), the hidden pre-activations and pe: the training forward of the split-precision step (cf.
+ * occ4d_pt_cross_attn16p_logits_f32). */
 int occ4d_pt_cross_attn_bf16x6_logits_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t q_stride, const float* apos,
                                           int64_t a_stride, const int32_t* idx, const float* kt, int64_t ld_kt,
                                           const float* vtc, int64_t ld_vt, const float* pos0_w, const float* pos0_b,
-                                          const float* wstream, float* agg, int64_t ld_agg, float* logits, int n, int m, int k,
-                                          int d, float divisor, void* stream);
+                                          const float* wstream, float* agg, int64_t ld_agg, float* logits, float* a_out,
+                                          float* pe_out, const float* c2, int n, int m, int k, int d, float divisor,
+                                          void* stream);
 /* y[:, 0 .. n_out) = [res +] W [relu](x) + b, K = 416, on v_mfma_f32_16x16x32_bf16 with both operands split into three
  * bf16 pieces and six partial products (csrc/trunk_bf16x6.hip): occ4d_rowlin_f32's contract (no interpolation term),
  * fp32-class results.  n_out in {208, 416, 832, 1664}; y may alias res, never x.  w_packed: occ4d_pack_rowlin_bf16x6_f32
@@ -682,14 +688,16 @@ int occ4d_pt_layer_fwd_f32(const occ4d_pt_layer_weights* w, const float* prepare
                            occ4d_launch_events* ev, void* stream);
 
 /* occ4d_pt_layer_fwd_f32 of a cross-attention layer that the fp32 paired-workgroup kernel or the bf16 x 3 split kernel serves
- * (dim = 416, k <= 14, fused; not the fp16 scheme; OCC4D_ERR_INVALID otherwise), which also writes the pre-softmax logits of every (query, neighbour)
- * pair to logits_out (n k, 416) -- the training forward of the recompute-in-backward attention (round 6): backward reads them
- * instead of running GEMM2 a second time.  `out` is bit-identical to occ4d_pt_layer_fwd_f32's. */
+ * (dim = 416, k <= 14, fused; not the fp16 scheme; OCC4D_ERR_INVALID otherwise), which also writes the pre-softmax logits of
+ * every (query, neighbour) pair to logits_out (n k, 416) -- the training forward of the recompute-in-backward attention
+ * (round 6): backward reads them instead of running GEMM2 a second time.  a_out (n k, 832) and pe_out (n k, 416), both or
+ * neither: the other two pair tensors as well (nothing left to recompute).  `out` is bit-identical to
+ * occ4d_pt_layer_fwd_f32's. */
 int occ4d_pt_layer_fwd_logits_f32(const occ4d_pt_layer_weights* w, const float* prepared, const float* x, int64_t ldx,
                                   const float* pos, int64_t pos_stride, int n, const float* x2, int64_t ldx2,
                                   const float* pos2, int64_t pos2_stride, int m, int k, const int32_t* knn_idx,
-                                  const float* scene, float* out, int64_t ldo, float* logits_out, float* workspace, int flags,
-                                  void* stream);
+                                  const float* scene, float* out, int64_t ldo, float* logits_out, float* a_out, float* pe_out,
+                                  float* workspace, int flags, occ4d_launch_events* ev, void* stream);
 
 /* E6 feature half: DownTransition.forward after its FPS / kNN (model/modules.py:152-158): y = ReLU(norm(Linear(x))) on
  * ALL n points, z[i] = max_j y[nn_idx[i, j]].  norm 0 none, 1 LayerNorm(gamma, beta, eps), 2 BatchNorm1d in eval mode

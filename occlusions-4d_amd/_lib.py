@@ -96,11 +96,11 @@ SIGNATURES = {
                                              C.c_int64, _f, _f, _f, _f, C.c_int64, C.c_int, C.c_int, C.c_int,
                                              C.c_int, C.c_float, C.c_int, _s]),
     'occ4d_pt_cross_attn16p_logits_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, C.c_int64, _i, _f, C.c_int64, _f,
-                                                    C.c_int64, _f, _f, _f, _f, C.c_int64, _f, C.c_int, C.c_int, C.c_int,
-                                                    C.c_int, C.c_float, C.c_int, _s]),
+                                                    C.c_int64, _f, _f, _f, _f, C.c_int64, _f, _f, _f, _f, C.c_int, C.c_int,
+                                                    C.c_int, C.c_int, C.c_float, C.c_int, _s]),
     'occ4d_pt_cross_attn_bf16x6_logits_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, C.c_int64, _i, _f, C.c_int64, _f,
-                                                        C.c_int64, _f, _f, _f, _f, C.c_int64, _f, C.c_int, C.c_int, C.c_int,
-                                                        C.c_int, C.c_float, _s]),
+                                                        C.c_int64, _f, _f, _f, _f, C.c_int64, _f, _f, _f, _f, C.c_int, C.c_int,
+                                                        C.c_int, C.c_int, C.c_float, _s]),
     'occ4d_pt_pair_mlp_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, _i, _f, _f, _f, _f, _f, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, _s]),
     'occ4d_layernorm_f32': (C.c_int, [_f, C.c_int64, _f, _f, C.c_float, C.c_int, _f, C.c_int64, C.c_int, C.c_int,
@@ -221,7 +221,7 @@ SIGNATURES = {
     'occ4d_pt_layer_fwd_f32': (C.c_int, [_LW, _f, _f, C.c_int64, _f, C.c_int64, C.c_int, _f, C.c_int64, _f, C.c_int64,
                                          C.c_int, C.c_int, _i, _f, _f, C.c_int64, _f, C.c_int, _EV, _s]),
     'occ4d_pt_layer_fwd_logits_f32': (C.c_int, [_LW, _f, _f, C.c_int64, _f, C.c_int64, C.c_int, _f, C.c_int64, _f, C.c_int64,
-                                                C.c_int, C.c_int, _i, _f, _f, C.c_int64, _f, _f, C.c_int, _s]),
+                                                C.c_int, C.c_int, _i, _f, _f, C.c_int64, _f, _f, _f, _f, C.c_int, _EV, _s]),
     'occ4d_down_pool_fwd_f32': (C.c_int, [_f, C.c_int64, C.c_int, C.c_int, _f, _f, C.c_int, C.c_int, _f, _f, _f, _f,
                                           C.c_float, _i, C.c_int, C.c_int, _f, C.c_int64, _f, _s]),
     'occ4d_decoder_prepared_floats': (C.c_int64, [_DW, C.c_int]),

@@ -513,13 +513,16 @@ class PairMlpFn(Function):
         return stream
 
     @staticmethod
-    def forward(ctx, aq, kt, r, wp, W2, b2, P2, c2, idx, kept_logits=None):
-        """`kept_logits` (n k, 416): the logits the training forward's fused kernel stored for these rows -- the launch then
-        only recomputes a and pe (fp32 kernel, store-bound: the split scheme has nothing to gain there)."""
-        if kept_logits is not None:
+    def forward(ctx, aq, kt, r, wp, W2, b2, P2, c2, idx, kept=None):
+        """`kept` = (a | None, logits, pe | None): what the training forward's fused kernel stored for these rows
+        (Selection.store_pairs).  All three: no launch at all.  Logits only: the launch recomputes a and pe (fp32 kernel,
+        memory-bound: the split scheme has nothing to gain there)."""
+        if kept is not None and kept[0] is not None:
+            a, logits, pe = (t.detach() for t in kept)    # (fresh tensor objects on the same rows: outputs, not the inputs)
+        elif kept is not None:
             stream = PairMlpFn._packed_stream(W2, b2, wp, P2, c2, x6=False)
-            a, logits, pe = ops.pt_pair_mlp(aq, kt, r, idx, c2, stream, logits=kept_logits)
-            logits = logits.detach()          # (a fresh tensor object on the same rows: an output, not the input itself)
+            a, logits, pe = ops.pt_pair_mlp(aq, kt, r, idx, c2, stream, logits=kept[1])
+            logits = logits.detach()
         elif _x6():
             stream = PairMlpFn._packed_stream(W2, b2, wp, P2, c2)
             a, logits, pe = ops.pt_pair_mlp_bf16x6(aq, kt, r, idx, c2, stream)

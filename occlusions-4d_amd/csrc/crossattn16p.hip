@@ -61,7 +61,10 @@ struct Attn16pArgs {
   float divisor;
   int first_round;                        // workgroups of the first dispatch round (2 per CU)
   int skew;                               // s_sleep(127) repeats of the later-placed workgroup of a CU in that round
-  float* logits;                          // STORE only: (N * K, 416) pre-softmax logits W2 relu(a) (no attn_mlp[2].bias)
+  float* logits;                          // STORE >= 1: (N * K, 416) pre-softmax logits W2 relu(a) (no attn_mlp[2].bias)
+  float* a_out;                           // STORE == 2: (N * K, 832) hidden pre-activations a (before the ReLU)
+  float* pe_out;                          // STORE == 2: (N * K, 416) pe = P2 r + c2
+  const float* c2;                        // STORE == 2: pos_mlp[2].bias (the kernel's own GEMM3 starts from 0)
 };
 
 __device__ __forceinline__ unsigned lds_addr_p(const float* p) {
@@ -136,9 +139,10 @@ __device__ __forceinline__ Pair swap32(float x, float y) {
   return Pair{__uint_as_float(r[0]), __uint_as_float(r[1])};
 }
 
-// STORE (training forward): the logits also go to HBM, row q K + slot, so that backward does not run GEMM2 again
-// (csrc: pair_mlp_kernel<false> recomputes only the hidden pre-activations and pe).
-template <bool K14, bool STORE = false>
+// STORE (training forward): 1 = the logits also go to HBM, row q K + slot, so that backward does not run GEMM2 again
+// (pair_hidden_kernel recomputes only the hidden pre-activations and pe); 2 = a and pe as well: the three pair tensors
+// of pair_mlp_kernel, and backward recomputes nothing (6.4 GB per layer at BASELINE config 5).
+template <bool K14, int STORE = 0>
 __global__ __launch_bounds__(256, 2) void cross_attn16p_kernel(const Attn16pArgs a) {
   __shared__ __attribute__((aligned(16))) float buf0[PSTAGE];
   __shared__ __attribute__((aligned(16))) float buf1[PSTAGE];
@@ -219,6 +223,9 @@ __global__ __launch_bounds__(256, 2) void cross_attn16p_kernel(const Attn16pArgs
     auto slice = [](const float* base, unsigned off) {
       return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + off);
     };
+    // STORE == 2: this lane's four hidden units per stage of ITS pair row (operand layout: pair row = lane & 15)
+    float* const my_a = (STORE == 2 && my_valid && q0 + my_ql < a.N)
+                            ? a.a_out + ((int64_t)(q0 + my_ql) * a.K + my_slot) * (2 * PD) + 4 * g : nullptr;
     // GEMM1 accumulator init of stage 0 (later stages: fetched one stage ahead)
     f32x4 ia = slice(a.aq, aq_off);
     f32x4 ik = slice(a.kt, kt_off);
@@ -227,6 +234,7 @@ __global__ __launch_bounds__(256, 2) void cross_attn16p_kernel(const Attn16pArgs
     int voff[4];
     bool act[4];
     float* lrow[4];                                      // STORE: this lane's element of the logits row of register i (or null)
+    float* prow[4];                                      // STORE == 2: the same of the pe row
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = 4 * g + i;
@@ -234,8 +242,12 @@ __global__ __launch_bounds__(256, 2) void cross_attn16p_kernel(const Attn16pArgs
       const int slot = row < 14 ? row : 8 * ps + 2 * wave + row - 14;
       voff[i] = s_idx[ql * 16 + min(slot, 15)] * (int)a.ld_vt + c;
       act[i] = slot < a.K;
-      if (STORE)
-        lrow[i] = (slot < a.K && q0 + ql < a.N) ? a.logits + ((int64_t)(q0 + ql) * a.K + slot) * PD + c : nullptr;
+      if (STORE) {
+        const bool live = slot < a.K && q0 + ql < a.N;
+        const int64_t e = ((int64_t)(q0 + ql) * a.K + slot) * PD + c;
+        lrow[i] = live ? a.logits + e : nullptr;
+        if (STORE == 2) prow[i] = live ? a.pe_out + e : nullptr;
+      }
     }
     const int qm = q0 + 4 * ps + wave;
     const float own23 = g3 ? 0.f : 1.f;
@@ -289,6 +301,10 @@ __global__ __launch_bounds__(256, 2) void cross_attn16p_kernel(const Attn16pArgs
         }
         __builtin_amdgcn_sched_barrier(0);
         if (gq == 0) {
+          if (STORE == 2) {
+            if (my_a) *reinterpret_cast<f32x4*>(my_a + 16 * s) = h;        // (before the ReLU)
+            __builtin_amdgcn_sched_barrier(0);
+          }
           h.x = fmaxf(h.x, 0.f); h.y = fmaxf(h.y, 0.f); h.z = fmaxf(h.z, 0.f); h.w = fmaxf(h.w, 0.f);
         }
       }
@@ -368,6 +384,12 @@ __global__ __launch_bounds__(256, 2) void cross_attn16p_kernel(const Attn16pArgs
 #pragma unroll
             for (int i = 0; i < 4; ++i)
               if (lrow[i]) lrow[i][16 * (tA + x)] = av[i];
+          }
+          if (STORE == 2) {                              // pe = P2 r + c2 (GEMM3 started from 0: c2 sits in the value table)
+            const float c2v = a.c2[16 * (tA + x) + c];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (prow[i]) prow[i][16 * (tA + x)] = pv[i] + c2v;
           }
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -723,7 +745,8 @@ extern "C" int64_t occ4d_pt_cross_attn16p_stream_floats(void) { return (int64_t)
 static int attn16p_launch(const char* who, const float* aq, int64_t ld_aq, const float* qpos, int64_t qs, const float* apos,
                           int64_t as, const int32_t* idx, const float* kt, int64_t ld_kt, const float* vt, int64_t ld_vt,
                           const float* P1, const float* c1, const float* wstream, float* agg, int64_t ld_agg, int n, int m,
-                          int k, int d, float divisor, int skew, float* logits, void* stream) {
+                          int k, int d, float divisor, int skew, float* logits, float* a_out, float* pe_out, const float* c2,
+                          void* stream) {
   OCC4D_REQUIRE(d == PD, "%s: built for d = %d, got %d", who, PD, d);
   OCC4D_REQUIRE(k >= 1 && k <= PKMAX, "%s: k=%d outside [1,%d]", who, k, PKMAX);
   OCC4D_REQUIRE(m >= 1 && n >= 0, "%s: bad n/m", who);
@@ -738,12 +761,15 @@ static int attn16p_launch(const char* who, const float* aq, int64_t ld_aq, const
   OCC4D_REQUIRE(divisor > 0.f, "%s: divisor must be > 0", who);
   OCC4D_REQUIRE(skew >= 0 && skew <= 64, "%s: skew=%d outside [0,64]", who, skew);
   Attn16pArgs a{aq, ld_aq, qpos, qs, apos, as, idx, kt, ld_kt, vt, ld_vt, P1, c1, wstream, agg, ld_agg, n, m, k, divisor,
-                2 * cu_count(), skew, logits};
+                2 * cu_count(), skew, logits, a_out, pe_out, c2};
   const int grid = occ4d::cdiv(n, PQPB);
   hipStream_t st = (hipStream_t)stream;
-  if (logits) {
-    if (k == PKMAX) cross_attn16p_kernel<true, true><<<grid, 256, 0, st>>>(a);
-    else cross_attn16p_kernel<false, true><<<grid, 256, 0, st>>>(a);
+  if (logits && a_out) {
+    if (k == PKMAX) cross_attn16p_kernel<true, 2><<<grid, 256, 0, st>>>(a);
+    else cross_attn16p_kernel<false, 2><<<grid, 256, 0, st>>>(a);
+  } else if (logits) {
+    if (k == PKMAX) cross_attn16p_kernel<true, 1><<<grid, 256, 0, st>>>(a);
+    else cross_attn16p_kernel<false, 1><<<grid, 256, 0, st>>>(a);
   } else {
     if (k == PKMAX) cross_attn16p_kernel<true><<<grid, 256, 0, st>>>(a);
     else cross_attn16p_kernel<false><<<grid, 256, 0, st>>>(a);
@@ -757,18 +783,22 @@ extern "C" int occ4d_pt_cross_attn16p_f32(const float* aq, int64_t ld_aq, const 
                                           float* agg, int64_t ld_agg, int n, int m, int k, int d, float divisor,
                                           int skew, void* stream) {
   return attn16p_launch("occ4d_pt_cross_attn16p", aq, ld_aq, qpos, qs, apos, as, idx, kt, ld_kt, vt, ld_vt, P1, c1, wstream,
-                        agg, ld_agg, n, m, k, d, divisor, skew, nullptr, stream);
+                        agg, ld_agg, n, m, k, d, divisor, skew, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int occ4d_pt_cross_attn16p_logits_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t qs,
                                                  const float* apos, int64_t as, const int32_t* idx, const float* kt,
                                                  int64_t ld_kt, const float* vt, int64_t ld_vt, const float* P1,
                                                  const float* c1, const float* wstream, float* agg, int64_t ld_agg,
-                                                 float* logits, int n, int m, int k, int d, float divisor, int skew,
-                                                 void* stream) {
-  OCC4D_REQUIRE(logits, "occ4d_pt_cross_attn16p_logits: null logits buffer");
-  return attn16p_launch("occ4d_pt_cross_attn16p_logits", aq, ld_aq, qpos, qs, apos, as, idx, kt, ld_kt, vt, ld_vt, P1, c1,
-                        wstream, agg, ld_agg, n, m, k, d, divisor, skew, logits, stream);
+                                                 float* logits, float* a_out, float* pe_out, const float* c2, int n, int m,
+                                                 int k, int d, float divisor, int skew, void* stream) {
+  const char* who = "occ4d_pt_cross_attn16p_logits";
+  OCC4D_REQUIRE(logits && ((uintptr_t)logits % 16) == 0, "%s: null or misaligned logits buffer", who);
+  OCC4D_REQUIRE((a_out != nullptr) == (pe_out != nullptr) && (a_out != nullptr) == (c2 != nullptr),
+                "%s: a_out, pe_out and c2 come together (all three pair tensors) or not at all", who);
+  OCC4D_REQUIRE(!a_out || (((uintptr_t)a_out | (uintptr_t)pe_out) % 16) == 0, "%s: misaligned a_out / pe_out", who);
+  return attn16p_launch(who, aq, ld_aq, qpos, qs, apos, as, idx, kt, ld_kt, vt, ld_vt, P1, c1, wstream, agg, ld_agg, n, m, k, d,
+                        divisor, skew, logits, a_out, pe_out, c2, stream);
 }
 
 extern "C" int occ4d_pt_pair_mlp_f32(const float* aq, int64_t ld_aq, const float* kt, int64_t ld_kt, const float* r,

@@ -78,7 +78,10 @@ struct AttnX6Args {
   int groups, per;                        // query groups of 16; groups per XCD slab
   int skew;                               // phase-skew grouping of the waves (see the kernel)
   int stamps;                             // debug: record phase time stamps
-  float* logits;                          // STORE only: (N * K, 416) pre-softmax logits W2 relu(a), unscaled
+  float* logits;                          // STORE >= 1: (N * K, 416) pre-softmax logits W2 relu(a), unscaled
+  float* a_out;                           // STORE == 2: (N * K, 832) hidden pre-activations a (before the ReLU), unscaled
+  float* pe_out;                          // STORE == 2: (N * K, 416) pe = P2 r + c2
+  const float* c2;                        // STORE == 2: pos_mlp[2].bias (the kernel's GEMM3 starts from 0)
 };
 
 // debug (OCC4D_X6_STAMPS=1): s_memtime at the phase boundaries of waves 0 and 4 of the first 1024 workgroups
@@ -87,8 +90,9 @@ __device__ unsigned long long g_x6_stamps[1024 * 2 * 6];
 // PRESCALED (schemes with HSCALE != 1 only): aq and kt arrive multiplied by S::HSCALE (the path-level entry points scale
 // the merged matrices that produce them, csrc/path.hip: exact, a power of two); otherwise the kernel multiplies the init
 // term itself (8 packed multiplies per stage and wave)
-// STORE (training forward): the logits also go to HBM, row q K + slot (csrc/crossattn16p.hip has the fp32 twin of this)
-template <typename S, bool PRESCALED, bool STORE = false>
+// STORE (training forward): 1 = the logits also go to HBM, row q K + slot; 2 = a and pe as well (csrc/crossattn16p.hip has the
+// fp32 twin of this; a by the workgroups of channel half 0 only: both halves compute the same hidden units)
+template <typename S, bool PRESCALED, int STORE = 0>
 __global__ __launch_bounds__(512, 2) void cross_attn_split_kernel(const AttnX6Args a) {
   using G = XG<S>;
   using Op = typename S::Op;
@@ -149,6 +153,7 @@ __global__ __launch_bounds__(512, 2) void cross_attn_split_kernel(const AttnX6Ar
   // 2 (tile % 7) + c - 14 of extra query tile / 7 (tiles 14, 15: dead rows)
   Op rs[2];                               // r = relu(P1 d + c1), hidden-pos units 8 g + j, NP pieces
   unsigned aq_off[2], kt_off[2];
+  int a_idx[2];                           // STORE == 2: float index of this lane's four hidden units of stage 0, per row tile
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
     const int tile = 2 * wave + rt;
@@ -168,6 +173,8 @@ __global__ __launch_bounds__(512, 2) void cross_attn_split_kernel(const AttnX6Ar
       rr[j] = my_valid ? fmaxf(v, 0.f) : 0.f;
     }
     rs[rt] = S::split8(f32x4{rr[0], rr[1], rr[2], rr[3]}, f32x4{rr[4], rr[5], rr[6], rr[7]});
+    if (STORE == 2)
+      a_idx[rt] = (half == 0 && my_valid && q0 + ql < a.N) ? ((q0 + ql) * a.K + slot) * XHID + 4 * g : -1;
     aq_off[rt] = (unsigned)(my_q * (int)a.ld_aq + 4 * g) * 4u;
     kt_off[rt] = (unsigned)(my_j * (int)a.ld_kt + 4 * g) * 4u;
   }
@@ -227,6 +234,12 @@ __global__ __launch_bounds__(512, 2) void cross_attn_split_kernel(const AttnX6Ar
 #ifndef OCC4D_XA_ABL_NOGEMM1
       S::mm_x2_b(wf, rs[0], rs[1], h[0][u], h[1][u]);
 #endif
+      if (STORE == 2) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+          if (a_idx[rt] >= 0)
+            *reinterpret_cast<f32x4*>(a.a_out + a_idx[rt] + 32 * s + 16 * u) = h[rt][u] * (1.f / S::HSCALE);
+      }
     }
     // ---- ReLU + split: GEMM2's A operand of both row tiles
     Op hs[2];
@@ -353,6 +366,12 @@ __global__ __launch_bounds__(512, 2) void cross_attn_split_kernel(const AttnX6Ar
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             if (loff[i] >= 0) a.logits[loff[i] + 16 * (x ? tB : tA)] = av[i] * (S::INV_WSCALE / S::HSCALE);
+          if (STORE == 2) {
+            const float c2v = a.c2[ch0 + 16 * (x ? tB : tA) + c];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (loff[i] >= 0) a.pe_out[loff[i] + 16 * (x ? tB : tA)] = fmaf(pe[x][i], S::INV_WSCALE, c2v);
+          }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -488,14 +507,18 @@ int pack_stream(const char* who, const float* w2, const float* wp, const float* 
   return occ4d::check_launch(who);
 }
 
-template <typename S, bool PRESCALED, bool STORE = false>
+template <typename S, bool PRESCALED, int STORE = 0>
 int launch_attn(const char* who, const float* aq, int64_t ld_aq, const float* qpos, int64_t q_stride, const float* apos,
                 int64_t a_stride, const int32_t* idx, const float* kt, int64_t ld_kt, const float* vtc, int64_t ld_vt,
                 const float* pos0_w, const float* pos0_b, const float* wstream, float* agg, int64_t ld_agg, int n, int m,
-                int k, int d, float divisor, void* stream, float* logits = nullptr) {
+                int k, int d, float divisor, void* stream, float* logits = nullptr, float* a_out = nullptr,
+                float* pe_out = nullptr, const float* c2 = nullptr) {
   OCC4D_REQUIRE(d == XD, "%s: built for d = %d, got %d", who, XD, d);
   OCC4D_REQUIRE(!STORE || (logits && ((uintptr_t)logits % 16) == 0 && (int64_t)n * k * XD < ((int64_t)1 << 31)),
                 "%s: logits buffer null, misaligned or beyond 2^31 floats (chunk the queries)", who);
+  OCC4D_REQUIRE(STORE != 2 || (a_out && pe_out && c2 && (((uintptr_t)a_out | (uintptr_t)pe_out) % 16) == 0 &&
+                               (int64_t)n * k * XHID < ((int64_t)1 << 31)),
+                "%s: a_out / pe_out / c2 null, misaligned or beyond 2^31 floats (chunk the queries)", who);
   OCC4D_REQUIRE(k >= 1 && k <= 14 && m >= 1 && n >= 0, "%s: k = %d (1 .. 14), m = %d, n = %d", who, k, m, n);
   OCC4D_REQUIRE(aq && qpos && apos && idx && kt && vtc && pos0_w && pos0_b && wstream && agg, "%s: null pointer", who);
   OCC4D_REQUIRE(ld_aq % 4 == 0 && ld_kt % 4 == 0 && ((uintptr_t)aq % 16) == 0 && ((uintptr_t)kt % 16) == 0 &&
@@ -507,7 +530,7 @@ int launch_attn(const char* who, const float* aq, int64_t ld_aq, const float* qp
                 "%s: 32-bit row offsets: n * ld_aq and m * ld_kt must stay below 2^29 floats", who);
   if (n == 0) return OCC4D_OK;
   AttnX6Args a{aq, ld_aq, qpos, q_stride, apos, a_stride, idx, kt, ld_kt, vtc, ld_vt, pos0_w, pos0_b,
-               reinterpret_cast<const unsigned*>(wstream), agg, ld_agg, n, m, k, divisor, 0, 0, 0, 0, logits};
+               reinterpret_cast<const unsigned*>(wstream), agg, ld_agg, n, m, k, divisor, 0, 0, 0, 0, logits, a_out, pe_out, c2};
   static const int skew = [] { const char* e = getenv("OCC4D_X6_SKEW"); return e ? atoi(e) : 2; }();   // read once
   static const int stamps = [] { const char* e = getenv("OCC4D_X6_STAMPS"); return e ? atoi(e) : 0; }();
   a.skew = skew;
@@ -544,10 +567,16 @@ extern "C" int occ4d_pt_cross_attn_bf16x6_logits_f32(const float* aq, int64_t ld
                                                      const float* apos, int64_t a_stride, const int32_t* idx, const float* kt,
                                                      int64_t ld_kt, const float* vtc, int64_t ld_vt, const float* pos0_w,
                                                      const float* pos0_b, const float* wstream, float* agg, int64_t ld_agg,
-                                                     float* logits, int n, int m, int k, int d, float divisor, void* stream) {
-  return launch_attn<SplitBf16x6, false, true>("occ4d_pt_cross_attn_bf16x6_logits_f32", aq, ld_aq, qpos, q_stride, apos, a_stride,
-                                               idx, kt, ld_kt, vtc, ld_vt, pos0_w, pos0_b, wstream, agg, ld_agg, n, m, k, d,
-                                               divisor, stream, logits);
+                                                     float* logits, float* a_out, float* pe_out, const float* c2, int n, int m,
+                                                     int k, int d, float divisor, void* stream) {
+  const char* who = "occ4d_pt_cross_attn_bf16x6_logits_f32";
+  OCC4D_REQUIRE((a_out != nullptr) == (pe_out != nullptr) && (a_out != nullptr) == (c2 != nullptr),
+                "%s: a_out, pe_out and c2 come together (all three pair tensors) or not at all", who);
+  if (a_out)
+    return launch_attn<SplitBf16x6, false, 2>(who, aq, ld_aq, qpos, q_stride, apos, a_stride, idx, kt, ld_kt, vtc, ld_vt, pos0_w,
+                                              pos0_b, wstream, agg, ld_agg, n, m, k, d, divisor, stream, logits, a_out, pe_out, c2);
+  return launch_attn<SplitBf16x6, false, 1>(who, aq, ld_aq, qpos, q_stride, apos, a_stride, idx, kt, ld_kt, vtc, ld_vt, pos0_w,
+                                            pos0_b, wstream, agg, ld_agg, n, m, k, d, divisor, stream, logits);
 }
 extern "C" int occ4d_pt_cross_attn_f16x3_f32(const float* aq, int64_t ld_aq, const float* qpos, int64_t q_stride,
                                              const float* apos, int64_t a_stride, const int32_t* idx, const float* kt,

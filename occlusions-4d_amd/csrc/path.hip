@@ -386,7 +386,8 @@ int rowlin_x6(bool f16, const float* x, int64_t ldx, float* y, int64_t ldy, cons
 int layer_forward(const occ4d_pt_layer_weights& w, const LayerLayout& L, const float* prep, const float* x, int64_t ldx,
                   const float* pos, int64_t ps, int n, const float* x2, int64_t ldx2, const float* pos2, int64_t p2s, int m,
                   int k, const int32_t* knn_idx, const float* scene, float* out, int64_t ldo, Bump& ws,
-                  const Events& E, hipStream_t st, bool dry, float* logits_out = nullptr) {
+                  const Events& E, hipStream_t st, bool dry, float* logits_out = nullptr, float* a_out = nullptr,
+                  float* pe_out = nullptr) {
   const int D = L.D, h = L.h;
   const int64_t mark = ws.mark();
   const float *kt, *vt, *vtc, *aq_all = nullptr, *yfeat = x;
@@ -472,15 +473,19 @@ int layer_forward(const occ4d_pt_layer_weights& w, const LayerLayout& L, const f
                                                        w.pos0_b, prep + L.stream6, agg_c, ld_agg, c, m, k, D, divisor, st);
         else if (L.bf16x6 && logits_out)
           rc = occ4d_pt_cross_attn_bf16x6_logits_f32(aq, 2 * D, qp, ps, pos2, p2s, idx, kt, 2 * D, vtc, D, w.pos0_w, w.pos0_b,
-                                                     prep + L.stream6, agg_c, ld_agg, logits_out + (int64_t)lo * k * D, c, m, k,
-                                                     D, divisor, st);
+                                                     prep + L.stream6, agg_c, ld_agg, logits_out + (int64_t)lo * k * D,
+                                                     a_out ? a_out + (int64_t)lo * k * 2 * D : nullptr,
+                                                     pe_out ? pe_out + (int64_t)lo * k * D : nullptr, a_out ? w.pos2_b : nullptr,
+                                                     c, m, k, D, divisor, st);
         else if (L.bf16x6)
           rc = occ4d_pt_cross_attn_bf16x6_f32(aq, 2 * D, qp, ps, pos2, p2s, idx, kt, 2 * D, vtc, D, w.pos0_w, w.pos0_b,
                                               prep + L.stream6, agg_c, ld_agg, c, m, k, D, divisor, st);
         else if (L.fused16p && logits_out)          // training forward: the logits of rows lo k .. stay in HBM for backward
           rc = occ4d_pt_cross_attn16p_logits_f32(aq, 2 * D, qp, ps, pos2, p2s, idx, kt, 2 * D, vtc, D, w.pos0_w, w.pos0_b,
-                                                 prep + L.stream, agg_c, ld_agg, logits_out + (int64_t)lo * k * D, c, m, k, D,
-                                                 divisor, occ4d::attn16p_skew(), st);
+                                                 prep + L.stream, agg_c, ld_agg, logits_out + (int64_t)lo * k * D,
+                                                 a_out ? a_out + (int64_t)lo * k * 2 * D : nullptr,
+                                                 pe_out ? pe_out + (int64_t)lo * k * D : nullptr, a_out ? w.pos2_b : nullptr, c, m,
+                                                 k, D, divisor, occ4d::attn16p_skew(), st);
         else if (L.fused16p)
           rc = occ4d_pt_cross_attn16p_f32(aq, 2 * D, qp, ps, pos2, p2s, idx, kt, 2 * D, vtc, D, w.pos0_w, w.pos0_b,
                                           prep + L.stream, agg_c, ld_agg, c, m, k, D, divisor, occ4d::attn16p_skew(), st);
@@ -846,10 +851,12 @@ extern "C" int occ4d_pt_layer_fwd_f32(const occ4d_pt_layer_weights* w, const flo
 extern "C" int occ4d_pt_layer_fwd_logits_f32(const occ4d_pt_layer_weights* w, const float* prepared, const float* x, int64_t ldx,
                                              const float* pos, int64_t pos_stride, int n, const float* x2, int64_t ldx2,
                                              const float* pos2, int64_t pos2_stride, int m, int k, const int32_t* knn_idx,
-                                             const float* scene, float* out, int64_t ldo, float* logits_out, float* workspace,
-                                             int flags, void* stream) {
+                                             const float* scene, float* out, int64_t ldo, float* logits_out, float* a_out,
+                                             float* pe_out, float* workspace, int flags, occ4d_launch_events* ev,
+                                             void* stream) {
   const char* who = "occ4d_pt_layer_fwd_logits_f32";
   TRY(check_layer(w, who));
+  if (ev) ev->used = 0;
   OCC4D_REQUIRE(n >= 0 && k >= 1 && k <= 14, "%s: n = %d, k = %d (1 .. 14)", who, n, k);
   if (n == 0) return OCC4D_OK;
   const LayerLayout L = layer_layout(*w, flags);
@@ -861,10 +868,12 @@ extern "C" int occ4d_pt_layer_fwd_logits_f32(const occ4d_pt_layer_weights* w, co
   OCC4D_REQUIRE(pos2 && m >= k && (scene || (x2 && al16(x2) && ldx2 % 4 == 0)),
                 "%s: cross-attention needs pos2, m >= k and x2 (or the scene tables)", who);
   OCC4D_REQUIRE(out != x || w->post_w, "%s: out may alias x only with layer3 (residual form)", who);
+  OCC4D_REQUIRE((a_out != nullptr) == (pe_out != nullptr) && (!a_out || (al16(a_out) && al16(pe_out))),
+                "%s: a_out and pe_out come together, 16-byte aligned", who);
   Bump ws(workspace);
-  const Events E{nullptr, (hipStream_t)stream};
+  const Events E{ev, (hipStream_t)stream};
   return layer_forward(*w, L, prepared, x, ldx, pos, pos_stride, n, x2, ldx2, pos2, pos2_stride, m, k, knn_idx, scene, out, ldo,
-                       ws, E, (hipStream_t)stream, false, logits_out);
+                       ws, E, (hipStream_t)stream, false, logits_out, a_out, pe_out);
 }
 
 extern "C" int occ4d_down_pool_fwd_f32(const float* x, int64_t ldx, int n, int d_in, const float* w, const float* b,

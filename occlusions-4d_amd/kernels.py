@@ -48,8 +48,9 @@ class Selection:
     checkpoint_attention: bool = True     # training: cross-attention recomputes its pair tensors in backward
     stored_attention_form: str = 'merged'  # with checkpoint_attention off: 'merged' | 'as_written'
     checkpoint_chunk: int = 32768     # queries per recompute chunk in backward
-    store_logits: bool = True         # training: the checkpointed attention's forward keeps its logits (n k, 416) in HBM, backward
-                                      # skips GEMM2 of the recompute (fp32 forward kernel only; + 1.6 GB per layer at config 5)
+    store_pairs: str = 'all'          # training, checkpointed attention: what the fused forward kernel leaves in HBM for backward --
+                                      # 'none' (backward recomputes a, logits, pe), 'logits' (backward skips GEMM2; + 1.6 GB per
+                                      # layer at config 5), 'all' (nothing recomputed; + 6.4 GB per layer)
     decode_streams: int = 2           # inference: HIP streams the decode mini-batches alternate between (1 = the reference's serial loop)
 
     def __post_init__(self):
@@ -57,6 +58,7 @@ class Selection:
         assert self.trunk_precision in PRECISIONS, self.trunk_precision
         assert self.train_precision in ('f32', 'bf16x6'), self.train_precision
         assert self.stored_attention_form in ('merged', 'as_written'), self.stored_attention_form
+        assert self.store_pairs in ('none', 'logits', 'all'), self.store_pairs
         split = {p for p in (self.logit_precision, self.trunk_precision) if p != 'f32'}
         assert len(split) <= 1, 'one split scheme per module: logit %s, trunk %s' % (self.logit_precision, self.trunk_precision)
 
@@ -108,7 +110,7 @@ def _from_environment():
         train_precision=os.environ.get('OCC4D_TRAIN_PRECISION', 'f32'),
         stored_attention_form=os.environ.get('OCC4D_STORED_ATTENTION_FORM', 'merged'),
         checkpoint_chunk=int(os.environ.get('OCC4D_CHECKPOINT_CHUNK', '32768')),
-        store_logits=_env_flag('OCC4D_STORE_LOGITS', '1'),
+        store_pairs=os.environ.get('OCC4D_STORE_PAIRS', 'all'),
         decode_streams=int(os.environ.get('OCC4D_DECODE_STREAMS', '2')))
 
 

@@ -854,11 +854,12 @@ def pt_layer_prepare(w, flags, device):
     return prep
 
 
-def pt_layer_fwd(w, prepared, x, pos, x2, pos2, k, flags=0, knn_idx=None, out=None, logits_out=None):
+def pt_layer_fwd(w, prepared, x, pos, x2, pos2, k, flags=0, knn_idx=None, out=None, logits_out=None, pair_out=None):
     """occ4d_pt_layer_fwd_f32: PointTransformerLayer / PointTransformerBlock forward of ONE cloud.  x (n, d_in), pos
     (n, >= 3) [, x2 (m, dim2), pos2 (m, >= 3)] -> (n, d_out | dim).  `logits_out` (n k, 416): the training forward
     (occ4d_pt_layer_fwd_logits_f32: the pre-softmax logits of every pair stay in HBM for backward; only the layers
-    logits_storable() names)."""
+    logits_storable() names).  `pair_out` = (a (n k, 832), pe (n k, 416)) beside logits_out: the other two pair tensors
+    too."""
     x, ldx = _aligned_rows(_dev(x, name='x'), 'x')
     p, ps = _rows(_dev(pos, name='pos'), 'pos')
     n = x.shape[0]
@@ -890,9 +891,15 @@ def pt_layer_fwd(w, prepared, x, pos, x2, pos2, k, flags=0, knn_idx=None, out=No
     if logits_out is not None:
         lg = _dev(logits_out, name='logits_out')
         assert lg.is_contiguous() and tuple(lg.shape) == (n * k, w.dim) and logits_storable(w, k, flags)
+        pa = pp = None
+        if pair_out is not None:
+            pa, pp = (_dev(t, name='pair_out') for t in pair_out)
+            assert pa.is_contiguous() and pp.is_contiguous() and tuple(pa.shape) == (n * k, 2 * w.dim) and pp.shape == lg.shape
         _lib.check(_lib.lib().occ4d_pt_layer_fwd_logits_f32(
             C.byref(w), _ptr(prepared), _ptr(x), ldx, _ptr(p), ps, n, _ptr(x2p), ldx2, _ptr(p2), p2s, m, k, _ptr(knn_idx),
-            None, _ptr(o), ldo, _ptr(lg), _ptr(ws), flags, _stream()))
+            None, _ptr(o), ldo, _ptr(lg), _ptr(pa), _ptr(pp), _ptr(ws), flags, C.byref(ev) if ev is not None else None,
+            _stream()))
+        finish()
         return out
     _lib.check(_lib.lib().occ4d_pt_layer_fwd_f32(
         C.byref(w), _ptr(prepared), _ptr(x), ldx, _ptr(p), ps, n, _ptr(x2p), ldx2, _ptr(p2), p2s, m, k, _ptr(knn_idx), None,

@@ -111,13 +111,20 @@ class _CheckpointedAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, layer, x, pos, x2, pos2, idx, *params):
         _CheckpointedAttention.calls += 1
-        ctx.logits = None
+        ctx.kept = None
         with torch.no_grad():
-            if kernels.scope().store_logits and layer.logits_storable():
+            mode = kernels.scope().store_pairs
+            logits = pair = None
+            if mode != 'none' and layer.logits_storable():
                 # the forward kernel leaves its logits in HBM (1664 B per pair): backward reads them instead of running
-                # the 832 -> 416 pair GEMM a second time (round 6: 2.3 -> 0.6 ms per recompute chunk)
-                ctx.logits = torch.empty((x.shape[0] * layer.num_neighbors, layer.dim), dtype=torch.float32, device=x.device)
-            agg = layer._forward_one(x, pos, x2, pos2, None, None, knn_idx=idx, logits_out=ctx.logits)
+                # the 832 -> 416 pair GEMM a second time; 'all': a and pe as well, nothing is recomputed
+                pairs = x.shape[0] * layer.num_neighbors
+                new = lambda width: torch.empty((pairs, width), dtype=torch.float32, device=x.device)   # noqa: E731
+                logits = new(layer.dim)
+                if mode == 'all':
+                    pair = (new(2 * layer.dim), new(layer.dim))
+                ctx.kept = (logits, pair)
+            agg = layer._forward_one(x, pos, x2, pos2, None, None, knn_idx=idx, logits_out=logits, pair_out=pair)
         ctx.layer = layer
         ctx.save_for_backward(x, pos, x2, pos2, idx)
         return agg
@@ -173,7 +180,10 @@ class _CheckpointedAttention(torch.autograd.Function):
                         # a = aq_i - kt_j + Wp r, logits = W2 relu(a), pe = P2 r + c2 from one kernel (the logits: the
                         # forward's own, when it kept them)
                         K = ic.shape[1]
-                        kept = None if ctx.logits is None else ctx.logits[lo * K:hi * K]
+                        kept = None
+                        if ctx.kept is not None:
+                            (kl, pair), rows = ctx.kept, slice(lo * K, hi * K)
+                            kept = (None if pair is None else pair[0][rows], kl[rows], None if pair is None else pair[1][rows])
                         logits, pe = autograd.PairMlpFn.apply(aq, kt_l, r, wp_l, W2, b2, P2l, c2l, ic, kept)
                     else:
                         a = autograd.AttnInLinearFn.apply(aq, kt_l, r, wp_l, ic)                     # aq_i - kt_j + Wp r
@@ -358,14 +368,14 @@ class PointTransformerLayer(nn.Module, kernels.HasKernelSelection):
                                          pre, post, None if knn_idx is None else knn_idx[b]))
         return ops.stack_batch(out)
 
-    def _forward_one(self, x, pos, x2, pos2, pre=None, post=None, knn_idx=None, logits_out=None):
+    def _forward_one(self, x, pos, x2, pos2, pre=None, post=None, knn_idx=None, logits_out=None, pair_out=None):
         """Inference forward of one cloud through the library's path-level entry point (`logits_out`: the training forward
         of _CheckpointedAttention, ops.pt_layer_fwd)."""
         w, prepared, flags = self.path_weights(cross=x2 is not None, pre=pre, post=post)
         if knn_idx is not None and knn_idx.dtype != torch.int32:
             knn_idx = knn_idx.to(torch.int32)
         return ops.pt_layer_fwd(w, prepared, x, pos, x2, pos2, self.num_neighbors, flags, knn_idx=knn_idx,
-                                logits_out=logits_out)
+                                logits_out=logits_out, pair_out=pair_out)
 
     def logits_storable(self):
         """Can this layer's fused forward leave its logits in HBM (ops.logits_storable: cross attention, dim 416, k <= 14,
