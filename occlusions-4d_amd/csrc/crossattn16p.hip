@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256, 2) void pair_mlp_kernel(const PairMlpArgs a) {
 __global__ __launch_bounds__(256) void pair_hidden_kernel(const PairMlpArgs a) {
   // a workgroup = 16 consecutive pair rows (53 KB of a, 26 KB of pe, contiguous); its four waves take a quarter of the hidden
   // stages / of the channel tile pairs each.  Measured (profiles/time_pair_hidden.py, 22976 x 14 pairs, 1.61 GB stored):
-  // 0.78-0.89 ms against 5.0-5.5 ms for the full kernel on the same (random-neighbour) inputs and 0.23 ms for a fill of
+  // 0.78-0.89 ms against 2.0 ms for the full kernel on the same (random-neighbour) inputs and 0.23 ms for a fill of
   // the same bytes; one wave per 16 rows over all stages measured the same -- per 1 KB stored a wave reads 4 KB (two
   // fragments, the Aq and the Kt slice), so the L2 -> CU side, not the stores, is the bound.
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
