@@ -339,6 +339,32 @@ def _keeps_logits_body(layer, x, pos, x2, pos2, idx, n, m, k, d, dim2, precision
                 assert float((u - v).norm() / v.norm()) <= 2e-3 and rel_err(u, v) <= 5e-2, (mode, rel_err(u, v))
 
 
+@pytest.mark.parametrize('precision', ['f32', 'bf16x6'])
+def test_kept_pair_tensors_across_the_path_level_row_chunks(precision):
+    """The path-level entry point walks more than 32768 queries in balanced chunks (csrc/path.hip row_step): the kept pair
+    tensors of a 70 001-query forward (BASELINE config 5 has 68 812), row for row, against a forward of 200 of those queries
+    alone taken from inside the LAST chunk -- and no row of the three tensors left unwritten."""
+    ptl, ops, d, dim2, n, m, k = pk.point_transformer_layer, pk.ops, 416, 288, 70001, 531, 14
+    rng = np.random.default_rng(5)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()      # noqa: E731
+    x, x2 = dev(rng.normal(size=(n, d))), dev(rng.normal(size=(m, dim2)))
+    pos, pos2 = dev(rng.uniform(-5, 5, size=(n, 3))), dev(rng.uniform(-5, 5, size=(m, 3)))
+    layer = ptl.PointTransformerLayer(d, num_neighbors=k, dim2=dim2).cuda()
+    layer.load_state_dict(pk.configs.fill_state_dict(layer, 99))
+    idx = ops.knn(pos, pos2, k, metric=0)
+    lo, hi = 69000, 69200
+    with torch.no_grad(), pk.kernels(logit_precision=precision):
+        big = [torch.full((n * k, w_), float('nan'), device='cuda') for w_ in (2 * d, d, d)]
+        out = layer._forward_one(x, pos, x2, pos2, knn_idx=idx, logits_out=big[1], pair_out=(big[0], big[2]))
+        assert all(bool(torch.isfinite(t).all()) for t in big)
+        small = [torch.empty(((hi - lo) * k, w_), device='cuda') for w_ in (2 * d, d, d)]
+        part = layer._forward_one(x[lo:hi].contiguous(), pos[lo:hi].contiguous(), x2, pos2, knn_idx=idx[lo:hi].contiguous(),
+                                  logits_out=small[1], pair_out=(small[0], small[2]))
+        assert rel_err(out[lo:hi], part) < 1e-6
+        for b_, s_ in zip(big, small):
+            assert rel_err(b_[lo * k:hi * k], s_) < 1e-6
+
+
 def test_pair_tensor_paths_are_both_exercised(monkeypatch):
     """The strict layer-level tests above run the fused pair-tensor kernel (d = 416); with it switched off the unfused
     chain must satisfy the same criterion."""
