@@ -661,6 +661,16 @@ int occ4d_pt_cross_attn_f16w_f32(const float* aq, int64_t ld_aq, const float* qp
                                  int64_t a_stride, const int32_t* idx, const float* kt, int64_t ld_kt, const float* vtc,
                                  int64_t ld_vt, const float* pos0_w, const float* pos0_b, const float* wstream, float* agg,
                                  int64_t ld_agg, int n, int m, int k, int d, float divisor, void* stream);
+/* ResnetBlockFC (model/implicit.py:92-101), width 416, relu, as ONE launch in the fp16 two-piece scheme (csrc/resblock_f16x3.hip,
+ * round 6): y = x + W1 relu(W0 relu(x) + b0) + b1 with the hidden activation in registers (the two-launch form moves it through
+ * HBM twice).  y may alias x (a workgroup owns whole rows).  w_packed: occ4d_pack_resblock_f16x3_f32 of fc_0.weight, fc_1.weight
+ * (416, 416; row strides ld0, ld1) -> occ4d_resblock_f16x3_packed_floats() floats.  Range contract of the scheme:
+ * |weight| < 255, |x|, |hidden| < 65504.  The path-level decoder entry points use it for OCC4D_PATH_BF16X6_TRUNK |
+ * OCC4D_PATH_SPLIT_F16 unless OCC4D_F16_RESBLOCK=0 is in the environment (A/B: two occ4d_rowlin_f16x3_f32 launches). */
+int64_t occ4d_resblock_f16x3_packed_floats(void);
+int occ4d_pack_resblock_f16x3_f32(const float* w0, int64_t ld0, const float* w1, int64_t ld1, float* packed, void* stream);
+int occ4d_resblock_f16x3_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed, const float* b0,
+                             const float* b1, int n, void* stream);
 int64_t occ4d_rowlin_f16x3_packed_floats(int n_out);
 int occ4d_pack_rowlin_f16x3_f32(const float* w, int64_t ldw, int n_out, float* packed, void* stream);
 int occ4d_rowlin_f16x3_f32(const float* x, int64_t ldx, float* y, int64_t ldy, const float* w_packed, const float* b,

@@ -24,7 +24,7 @@ FLAGS += os.environ.get('OCC4D_HIPCC_EXTRA', '').split()      # experiments only
 # in front of every maximum, and in these kernels every VALU instruction costs matrix time (profiles/micro/
 # valu_beside_mfma.hip).  The kernels' masking uses infinities (still honoured), never NaNs.
 FILE_FLAGS = {f: ['-fno-honor-nans'] for f in ('crossattn16p.hip', 'trunk4.hip', 'trunk.hip', 'wgrad16.hip',
-                                                'crossattn_bf16x6.hip', 'trunk_bf16x6.hip', 'pairmlp_bf16x6.hip', 'crossattn_f16w.hip')}
+                                                'crossattn_bf16x6.hip', 'trunk_bf16x6.hip', 'pairmlp_bf16x6.hip', 'crossattn_f16w.hip', 'resblock_f16x3.hip')}
 FILE_FLAGS['wgrad16.hip'] += ['-fno-slp-vectorize']    # (packed fp32 adds come with register shuffles: VALU = matrix time)
 
 

@@ -55,6 +55,9 @@ int cu_count();
 
 // path.hip: OCC4D_F16W=1 (default 0): the fp16 scheme's attention layers on csrc/crossattn_f16w.hip (A/B)
 bool f16w_enabled();
+// path.hip: OCC4D_F16_RESBLOCK=0 (default 1): the fp16 scheme's residual blocks as two row-kernel launches instead of the fused
+// block of csrc/resblock_f16x3.hip (A/B)
+bool f16_resblock_enabled();
 
 // path.hip: phase offset of the paired attention workgroups (units of s_sleep(127); OCC4D_CA16P_SKEW, default 6)
 int attn16p_skew();

@@ -541,6 +541,7 @@ struct DecoderLayout {
   bool trunk, trunk4, resblock;              // row-resident Linear kernels usable / half-CU variant / fused residual block
   bool x6trunk;                              // residual blocks as two split-precision launches (csrc/trunk_bf16x6.hip)
   bool f16;                                  // ... on the fp16 two-piece scheme (OCC4D_PATH_SPLIT_F16)
+  bool f16block;                             // ... as ONE launch per block (csrc/resblock_f16x3.hip): w0x holds both weights
   int64_t w0p[OCC4D_MAX_BLOCKS], w1p[OCC4D_MAX_BLOCKS];
   int64_t w0x[OCC4D_MAX_BLOCKS], w1x[OCC4D_MAX_BLOCKS];
   int64_t cross[OCC4D_MAX_CROSS];
@@ -594,14 +595,15 @@ DecoderLayout decoder_layout(const occ4d_decoder_weights& w, int flags) {
   L.resblock = L.trunk && w.activation == 0;
   L.x6trunk = L.resblock && !L.trunk4 && (flags & OCC4D_PATH_BF16X6_TRUNK);
   L.f16 = flags & OCC4D_PATH_SPLIT_F16;
+  L.f16block = L.x6trunk && L.f16 && occ4d::f16_resblock_enabled();
   int64_t o = 0;
   auto take = [&](int64_t n) { const int64_t at = o; o += up(n); return at; };
   const int64_t pk = L.trunk4 ? occ4d_trunk4_packed_floats(TRUNK) : occ4d_trunk_packed_floats(TRUNK);
   for (int i = 0; i < L.nB; ++i) {
     L.w0p[i] = L.resblock ? take(pk) : -1;
     L.w1p[i] = L.resblock ? take(pk) : -1;
-    L.w0x[i] = L.x6trunk ? take(split_packed_floats(L.f16, TRUNK)) : -1;
-    L.w1x[i] = L.x6trunk ? take(split_packed_floats(L.f16, TRUNK)) : -1;
+    L.w0x[i] = L.f16block ? take(occ4d_resblock_f16x3_packed_floats()) : L.x6trunk ? take(split_packed_floats(L.f16, TRUNK)) : -1;
+    L.w1x[i] = L.x6trunk && !L.f16block ? take(split_packed_floats(L.f16, TRUNK)) : -1;
   }
   for (int j = 0; j < L.nC; ++j) {
     L.cl[j] = layer_layout(w.cross[j], flags);
@@ -654,7 +656,7 @@ int decoder_forward(const occ4d_decoder_weights& w, const DecoderLayout& L, cons
     float* w8 = ws.take((int64_t)c * w.k_local);
     int32_t* idx_att = L.nC ? reinterpret_cast<int32_t*>(ws.take((int64_t)c * w.k_cross)) : nullptr;
     float* pe = ws.take((int64_t)c * L.P4);
-    float* hbuf = (L.resblock && !L.x6trunk) ? nullptr : ws.take((int64_t)c * H);
+    float* hbuf = (L.resblock && (!L.x6trunk || L.f16block)) ? nullptr : ws.take((int64_t)c * H);
     if (!dry) {
       // D2 + D3 (model/implicit.py:328-342): 8 nearest abstract points by Euclidean norm, inverse-distance weights
       // (caller-supplied lists: the reference's own tie order; distances recomputed with the search's expression)
@@ -696,7 +698,13 @@ int decoder_forward(const occ4d_decoder_weights& w, const DecoderLayout& L, cons
         if (!had_it)
           TRY(occ4d_interp_add_f32(x, ldx, scene + S.zconst + (int64_t)i * H, scene + S.ztab + (int64_t)i * H,
                                    (int64_t)L.nB * H, idx8, w8, c, w.k_local, H, st));
-        if (L.x6trunk) {
+        if (L.f16block) {
+          // x = x + fc_1(relu(fc_0(relu(x)))) in place, one launch, h in registers
+          E.before(OCC4D_PROFILE_RESBLOCK);
+          const int rc = occ4d_resblock_f16x3_f32(x, ldx, x, ldx, prep + L.w0x[i], w.fc0_b[i], w.fc1_b[i], c, st);
+          E.after(OCC4D_PROFILE_RESBLOCK);
+          TRY(rc);
+        } else if (L.x6trunk) {
           // h = fc_0(relu(x)); x = x + fc_1(relu(h)): two split-precision launches, h through the workspace
           E.before(OCC4D_PROFILE_RESBLOCK);
           int rc = split_rowlin(L.f16, x, ldx, hbuf, H, prep + L.w0x[i], w.fc0_b[i], H, 1, nullptr, 0, c, st);
@@ -739,6 +747,13 @@ int decoder_forward(const occ4d_decoder_weights& w, const DecoderLayout& L, cons
 namespace occ4d {
 // fp16 scheme: OCC4D_F16W=1 selects the 32 x 32 x 16 attention kernel (csrc/crossattn_f16w.hip) for A/B runs; the default is
 // the 16 x 16 x 32 kernel of csrc/crossattn_bf16x6.hip
+bool f16_resblock_enabled() {
+  static const bool v = [] {
+    const char* e = getenv("OCC4D_F16_RESBLOCK");
+    return !e || atoi(e) != 0;
+  }();
+  return v;
+}
 bool f16w_enabled() {
   static const bool v = [] {
     const char* e = getenv("OCC4D_F16W");              // (opt-in: measured slower than the 16 x 16 x 32 kernel)
@@ -920,7 +935,9 @@ extern "C" int occ4d_decoder_prepare_f32(const occ4d_decoder_weights* w, float* 
       TRY(occ4d_pack_trunk_cols_f32(w->fc1_w[i], TRUNK, prepared + L.w1p[i], st));
     }
   }
-  for (int i = 0; i < L.nB && L.x6trunk; ++i) {
+  for (int i = 0; i < L.nB && L.f16block; ++i)
+    TRY(occ4d_pack_resblock_f16x3_f32(w->fc0_w[i], TRUNK, w->fc1_w[i], TRUNK, prepared + L.w0x[i], st));
+  for (int i = 0; i < L.nB && L.x6trunk && !L.f16block; ++i) {
     TRY(split_pack_rowlin(L.f16, w->fc0_w[i], TRUNK, TRUNK, prepared + L.w0x[i], st));
     TRY(split_pack_rowlin(L.f16, w->fc1_w[i], TRUNK, TRUNK, prepared + L.w1x[i], st));
   }

@@ -427,6 +427,30 @@ def rowlin_bf16x6(x, w, b=None, relu_in=False, res=None, out=None, packed=None, 
     return out
 
 
+def resblock_f16x3(x, w0, b0, w1, b1, out=None, packed=None):
+    """ResnetBlockFC of width 416 (relu) as one launch in the fp16 two-piece split scheme (occ4d_resblock_f16x3_f32):
+    y = x + W1 relu(W0 relu(x) + b0) + b1, the hidden activation in registers.  `out` may be x itself.  `packed`
+    (occ4d_pack_resblock_f16x3_f32 of the two weights) instead of w0 / w1 skips the per-call packing."""
+    L = _lib.lib()
+    x, ldx = _aligned_rows(_dev(x, name='x'), 'x')
+    n, d = x.shape
+    assert d == TRUNK_WIDTH
+    if packed is None:
+        w0, w1 = (_cont(t.detach(), 'w') for t in (w0, w1))
+        assert tuple(w0.shape) == (d, d) and tuple(w1.shape) == (d, d)
+        packed = torch.empty((int(L.occ4d_resblock_f16x3_packed_floats()),), dtype=torch.float32, device=x.device)
+        _lib.check(L.occ4d_pack_resblock_f16x3_f32(_ptr(w0), d, _ptr(w1), d, _ptr(packed), _stream()))
+    b0, b1 = (_cont(t.detach(), 'b') for t in (b0, b1))
+    if out is None:
+        out = torch.empty((n, d), dtype=torch.float32, device=x.device)
+    o, ldo = _aligned_rows(_dev(out, name='out'), 'out')
+    assert o is out and tuple(o.shape) == (n, d)
+    flops = 2.0 * 2.0 * n * d * d
+    _lib.check(_launch('resblock', dict(n=n), flops, lambda: L.occ4d_resblock_f16x3_f32(
+        _ptr(x), ldx, _ptr(o), ldo, _ptr(packed), _ptr(b0), _ptr(b1), n, _stream())))
+    return out
+
+
 def pt_cross_attn(aq, qpos, apos, idx, kt, vt, P1, c1, wp, w2, b2, p2, c2, out=None):
     """Fused vector attention (occ4d_pt_cross_attn_f32): agg (n,d)."""
     aq, ld_aq = _aligned_rows(_dev(aq, name='aq'), 'aq')

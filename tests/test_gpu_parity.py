@@ -505,6 +505,34 @@ def test_split_precision_rowlin_against_fp64(pk, n, n_out, relu_in, with_res, sc
         assert torch.equal(rr, got)
 
 
+@pytest.mark.parametrize('n', [32256, 1500, 129, 128, 127, 17, 1])
+def test_fused_fp16_residual_block_against_fp64(pk, n):
+    """csrc/resblock_f16x3.hip: y = x + W1 relu(W0 relu(x) + b0) + b1 in ONE launch (fp16 x 2 pieces, three products, the
+    hidden activation in registers) against fp64 at the accuracy of two chained fp32 GEMMs, against the two-launch form of
+    csrc/trunk_bf16x6.hip (same products: equal to rounding), ragged row counts, and in place (how the decoder calls it)."""
+    rng = np.random.default_rng(n)
+    x = (2.0 * rng.normal(size=(n, 416))).astype(np.float32)
+    w0, w1 = ((rng.normal(size=(416, 416)) / np.sqrt(416)).astype(np.float32) for _ in range(2))
+    b0, b1 = (rng.normal(size=(416,)).astype(np.float32) for _ in range(2))
+    x64, w064, w164 = x.astype(np.float64), w0.astype(np.float64), w1.astype(np.float64)
+    h64 = np.maximum(x64, 0) @ w064.T + b0
+    ref = x64 + np.maximum(h64, 0) @ w164.T + b1
+    got = pk.ops.resblock_f16x3(dev(x), dev(w0), dev(b0), dev(w1), dev(b1))
+    scale1 = (np.abs(np.maximum(x64, 0)) @ np.abs(w064).T).max()
+    scale2 = (np.abs(np.maximum(h64, 0)) @ np.abs(w164).T).max()
+    # layer 2 sees layer 1's error through |W1| (row sums ~ 416 / sqrt(416) * E|w|): bound both terms generously
+    bound = 8 * 2.0 ** -24 * (scale2 + scale1 * np.abs(w164).sum(axis=1).max())
+    err = np.abs(got.cpu().numpy() - ref).max()
+    print('\n[resblock f16x3 %d rows] |fused - f64| %.3g (bound %.3g)' % (n, err, bound))
+    assert torch.isfinite(got).all() and err <= bound
+    h = pk.ops.rowlin_bf16x6(dev(x), dev(w0), dev(b0), relu_in=True, scheme='f16x3')
+    two = pk.ops.rowlin_bf16x6(h, dev(w1), dev(b1), relu_in=True, res=dev(x), scheme='f16x3')
+    assert np.abs((got - two).cpu().numpy()).max() <= bound       # (h is rounded independently in the two forms)
+    xin = dev(x).clone()
+    pk.ops.resblock_f16x3(xin, dev(w0), dev(b0), dev(w1), dev(b1), out=xin)
+    assert torch.equal(xin, got)
+
+
 @pytest.mark.parametrize('n,n_out,after', [(1500, 416, False), (1500, 416, True), (700, 832, False), (257, 208, True)])
 def test_split_precision_rowlin_masked_epilogue(pk, n, n_out, after):
     """occ4d_rowlin_bf16x6_masked_f32 (training data gradients): y = [mask > 0] (x W^T [+ res]) [+ res] -- the residual
