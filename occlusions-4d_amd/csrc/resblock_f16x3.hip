@@ -68,6 +68,9 @@ __global__ __launch_bounds__(512, 2) void resblock_f16x3_kernel(const ResblockX3
   const unsigned lane16 = lane * 16;
   // this wave's i-th fragment of a stage (the tail repeats the last fragment: same bytes, same place)
   auto dma_stage = [&](int stage_no, const unsigned* dst) {
+#ifdef OCC4D_RB_ABL_NODMA                              // (timing-only ablations: profiles/time_resblock_f16x3.py -D...)
+    if (stage_no > 0) return;
+#endif
 #pragma unroll
     for (int i = 0; i < RPARTS; ++i) {
       const int f = min(wave + RWAVES * i, RSF - 1);
@@ -89,22 +92,28 @@ __global__ __launch_bounds__(512, 2) void resblock_f16x3_kernel(const ResblockX3
     dma_stage(ks + 1, nxt);                                           // (stage 13 = layer 2's first: the stream goes on)
     const S::Op xs = S::split8(relu4x(xa0), relu4x(xa1));
     const int kn = ks + 1 < RKS ? ks + 1 : ks;
+#ifndef OCC4D_RB_ABL_NOX
     xa0 = *reinterpret_cast<const f32x4*>(xrow + 32 * kn);
     xa1 = *reinterpret_cast<const f32x4*>(xrow + 32 * kn + 4);
+#endif
     u32x4 wn[2][2] = {{frag(cur, 0), frag(cur, 1)}, {frag(cur, 2), frag(cur, 3)}};
 #pragma unroll
     for (int tp = 0; tp < RT / 2; ++tp) {                             // tile pairs (2 tp, 2 tp + 1)
       const u32x4 w0[2] = {wn[0][0], wn[0][1]}, w1[2] = {wn[1][0], wn[1][1]};
+#ifndef OCC4D_RB_ABL_NOLDS
       if (tp + 1 < RT / 2) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
           for (int p = 0; p < 2; ++p) wn[q][p] = frag(cur, 2 * (2 * (tp + 1) + q) + p);
       }
+#endif
       mm3_t2(w0, w1, xs, h[2 * tp], h[2 * tp + 1]);
     }
     dma_wait_x();
+#ifndef OCC4D_RB_ABL_NOBAR
     __builtin_amdgcn_s_barrier();
+#endif
   };
 #pragma clang loop unroll(disable)
   for (int ks = 0; ks < RKS - 1; ks += 2) {
@@ -145,18 +154,22 @@ __global__ __launch_bounds__(512, 2) void resblock_f16x3_kernel(const ResblockX3
 #pragma unroll
         for (int tp = 0; tp < RT / 4; ++tp) {                         // 6 tile pairs + the 13th tile
           const u32x4 w0[2] = {wn[0][0], wn[0][1]}, w1[2] = {wn[1][0], wn[1][1]};
+#ifndef OCC4D_RB_ABL_NOLDS
 #pragma unroll
           for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int p = 0; p < 2; ++p)
               if (2 * (tp + 1) + q < RT / 2) wn[q][p] = frag(fb, 2 * (2 * (tp + 1) + q) + p);
+#endif
           mm3_t2(w0, w1, hs[T], acc[2 * tp], acc[2 * tp + 1]);
         }
         const u32x4 wl[2] = {wn[0][0], wn[0][1]};                     // (tile 12: loaded by the last prefetch above)
         acc[RT / 2 - 1] = mm3_t(wl, hs[T], acc[RT / 2 - 1]);
       }
       dma_wait_x();
+#ifndef OCC4D_RB_ABL_NOBAR
       __builtin_amdgcn_s_barrier();
+#endif
     }
     // epilogue of the half: y = x + acc / WSCALE + b1, float4 per tile and row
     const int ch0 = 16 * (RT / 2) * half;
@@ -165,6 +178,9 @@ __global__ __launch_bounds__(512, 2) void resblock_f16x3_kernel(const ResblockX3
       const f32x4 r = *reinterpret_cast<const f32x4*>(xres + ch0 + 16 * t);
       const f32x4 b = *reinterpret_cast<const f32x4*>(a.b1 + ch0 + 16 * t + 4 * g);
       const f32x4 v = acc[t] * S::INV_WSCALE + b + r;
+#ifdef OCC4D_RB_ABL_NOSTORE
+      if (v.x == 123.456f)
+#endif
       if (row < a.n) *reinterpret_cast<f32x4*>(yrow + ch0 + 16 * t) = v;
     }
   }

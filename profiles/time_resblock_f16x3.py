@@ -1,5 +1,10 @@
 """The fused fp16 residual block (csrc/resblock_f16x3.hip) beside the two-launch form (csrc/trunk_bf16x6.hip) on one decode
-chunk, stand-alone.   python profiles/time_resblock_f16x3.py [rows]"""
+chunk, stand-alone.   python profiles/time_resblock_f16x3.py [rows] [-DOCC4D_RB_ABL_...[,-D...]] ...
+Every -D argument rebuilds csrc/resblock_f16x3.hip with those timing-only macros into /tmp and times it beside the shipped kernel
+(results of an ablated kernel are garbage): NODMA (no weight stream after stage 0), NOLDS (a stage's first four fragments serve
+every tile), NOX (no operand-row loads after stage 0), NOBAR (no stage barrier), NOSTORE."""
+import ctypes as C
+import subprocess
 import os
 import sys
 
@@ -10,7 +15,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import occlusions4d_amd as pk  # noqa: E402
 from occlusions4d_amd import ops  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 32256
+args = [a for a in sys.argv[1:] if not a.startswith('-')]
+variants = [a.split(',') for a in sys.argv[1:] if a.startswith('-')]
+n = int(args[0]) if args else 32256
 g = torch.Generator().manual_seed(0)
 rnd = lambda *s: torch.randn(*s, generator=g).cuda()       # noqa: E731
 x, w0, w1, b0, b1 = rnd(n, 416), rnd(416, 416) / 20, rnd(416, 416) / 20, rnd(416), rnd(416)
@@ -43,3 +50,24 @@ for name, fn in (('fused block', lambda: ops.resblock_f16x3(x, None, b0, None, b
     us = t(fn)
     print('%-14s %7.1f us per block of %d rows   %5.0f TFLOP/s of executed 16x16x32 MFMA = %.2f of 2.5 PF'
           % (name, us, n, flop / us / 1e6, flop / us / 1e6 / 2500))
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for defs in variants:
+    csrc, build = os.path.join(ROOT, 'occlusions-4d_amd', 'csrc'), os.path.join(ROOT, 'occlusions-4d_amd', 'build')
+    tag = '_'.join(d.replace('-DOCC4D_RB_ABL_', '') for d in defs)
+    obj, so = '/tmp/rb_%s.o' % tag, '/tmp/rb_%s.so' % tag
+    subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC',
+                    '-I' + os.path.join(ROOT, 'include'), '-I' + csrc, '-fno-honor-nans'] + defs +
+                   ['-c', os.path.join(csrc, 'resblock_f16x3.hip'), '-o', obj], check=True)
+    subprocess.run(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', so, obj] +
+                   [os.path.join(build, f) for f in sorted(os.listdir(build)) if f.endswith('.o') and f != 'resblock_f16x3.o'],
+                   check=True)
+    K = C.CDLL(so)
+    fn = K.occ4d_resblock_f16x3_f32
+    fn.restype, fn.argtypes = ops._lib.SIGNATURES['occ4d_resblock_f16x3_f32']
+
+    def run():
+        assert fn(ops._ptr(x), 416, ops._ptr(y), 416, ops._ptr(packed), ops._ptr(b0), ops._ptr(b1), n, ops._stream()) == 0
+    us = t(run)
+    print('%-28s %7.1f us per block of %d rows   %5.0f TFLOP/s = %.2f of 2.5 PF' % (tag, us, n, flop / us / 1e6, flop / us / 1e6 / 2500))
