@@ -300,7 +300,7 @@ def main():
             'metric': 'training step (BASELINE config 5: CARLA-4D, batch 1/GPU, n_points=28672, 4 x 17203 queries)',
             'value': world * args.steps / elapsed, 'unit': 'examples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'dtype': 'f32' if args.precision == 'f32' else 'f32 weight gradients; forward Linears, their data gradients, the forward attention kernel and the pair-tensor recompute on bf16 x 3 pieces, 6 products, f32 accumulate (fp32-class)', 'precision': args.precision, 'data': 'synthetic', 'losses': losses, 'sampler_ms_per_step': sampler_ms, 'sampler': (None if not args.sampler else 'in front of the step (serial)' if args.sampler_serial else "next step's points drawn on a side stream beside this step (host time per step in sampler_ms_per_step)"), 'graph': False, 'loss_read': 'after the timed region', 'geometry_prefetch': bool(nxt), 'gradient_overlap': (('parameter gradients on a second stream beside the data-gradient chain, at most %.0f GB of operands held for it' % (pk.autograd.GRADIENT_OVERLAP_BYTES / 2 ** 30)) if pk.autograd.GRADIENT_OVERLAP else False), 'frames_batched': bool(step.batch_frames), 'attention_backward': ('stored pair tensors (%s form)' % pk.kernels.defaults().stored_attention_form) if args.no_checkpoint else 'recompute in backward (equal chunks of at most %d queries)' % pk.kernels.defaults().checkpoint_chunk,
+            'scaling': 'weak', 'dtype': 'f32' if args.precision == 'f32' else 'f32 weight gradients; forward Linears, their data gradients, the forward attention kernel (and any pair-tensor recompute) on bf16 x 3 pieces, 6 products, f32 accumulate (fp32-class)', 'precision': args.precision, 'data': 'synthetic', 'losses': losses, 'sampler_ms_per_step': sampler_ms, 'sampler': (None if not args.sampler else 'in front of the step (serial)' if args.sampler_serial else "next step's points drawn on a side stream beside this step (host time per step in sampler_ms_per_step)"), 'graph': False, 'loss_read': 'after the timed region', 'geometry_prefetch': bool(nxt), 'gradient_overlap': (('parameter gradients on a second stream beside the data-gradient chain, at most %.0f GB of operands held for it' % (pk.autograd.GRADIENT_OVERLAP_BYTES / 2 ** 30)) if pk.autograd.GRADIENT_OVERLAP else False), 'frames_batched': bool(step.batch_frames), 'attention_backward': ('stored pair tensors (%s form)' % pk.kernels.defaults().stored_attention_form) if args.no_checkpoint else {'all': 'fused forward kernel keeps a, logits and pe; backward walks them in equal chunks of at most %d queries, nothing recomputed', 'logits': 'fused forward kernel keeps its logits; a and pe recomputed in backward in equal chunks of at most %d queries', 'none': 'recompute in backward (equal chunks of at most %d queries)'}[pk.kernels.defaults().store_pairs] % pk.kernels.defaults().checkpoint_chunk,
             'peak_mem_gb': torch.cuda.max_memory_allocated() / 2 ** 30,
             'roofline': roof,
             'config': {'workload': 'CARLA-4D training step (BASELINE configs[4]): batch 1 per GPU, n_points=%d, %d x %d '

@@ -36,6 +36,17 @@ def test_flags_map_to_the_header_bits():
         s.trunk4 = True                                                # frozen
 
 
+def test_store_pairs_modes_are_validated():
+    """Selection.store_pairs (training: what the fused forward attention kernel keeps for backward) takes three values."""
+    from occlusions4d_amd import kernels
+    assert kernels.defaults().store_pairs in ('none', 'logits', 'all')
+    for mode in ('none', 'logits', 'all'):
+        with kernels.use(store_pairs=mode):
+            assert kernels.scope().store_pairs == mode
+    with pytest.raises(AssertionError):
+        kernels.defaults().replace(store_pairs='everything')
+
+
 def test_scopes_nest_and_unwind():
     base = K.scope()
     with pk.kernels(precision='bf16x6') as a:
