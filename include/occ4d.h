@@ -661,6 +661,18 @@ int occ4d_pt_cross_attn_f16w_f32(const float* aq, int64_t ld_aq, const float* qp
                                  int64_t a_stride, const int32_t* idx, const float* kt, int64_t ld_kt, const float* vtc,
                                  int64_t ld_vt, const float* pos0_w, const float* pos0_b, const float* wstream, float* agg,
                                  int64_t ld_agg, int n, int m, int k, int d, float divisor, void* stream);
+/* Training loss of the published configurations and its gradient in two launches (csrc/loss.hip, round 6; loss.py:50-64,
+ * 156-173, 243-250, 276-277): out (cells, n, g) raw decoder outputs (row stride ldo), target (cells, n, > label_col) with the
+ * density target in column 0 and the semantic label (float, < 0 = unlabelled) in column label_col;
+ *   loss[0] = sum_cells [ density_lw mean_i BCEwithLogits(out[i, 0], target[i, 0])
+ *                         + segmentation_lw mean_{label_i >= 0} CE(out[i, g - semantic_classes :], label_i) ] / cells
+ * grad (cells, n, g) (row stride ldg) or NULL: d loss / d out.  workspace: occ4d_implicit_loss_workspace_floats(cells) floats.
+ * Deterministic (fixed-order partial sums).  Colour / tracking terms are not covered (weights 0 in the published configs). */
+int64_t occ4d_implicit_loss_workspace_floats(int cells);
+int occ4d_implicit_loss_f32(const float* out, int64_t ldo, const float* target, int64_t ldt, int cells, int n, int g, int label_col,
+                            int semantic_classes, float density_lw, float segmentation_lw, float* workspace, float* loss,
+                            float* grad, int64_t ldg, void* stream);
+
 /* ResnetBlockFC (model/implicit.py:92-101), width 416, relu, as ONE launch in the fp16 two-piece scheme (csrc/resblock_f16x3.hip,
  * round 6): y = x + W1 relu(W0 relu(x) + b0) + b1 with the hidden activation in registers (the two-launch form moves it through
  * HBM twice).  y may alias x (a workgroup owns whole rows).  w_packed: occ4d_pack_resblock_f16x3_f32 of fc_0.weight, fc_1.weight

@@ -101,6 +101,9 @@ SIGNATURES = {
     'occ4d_pt_cross_attn_bf16x6_logits_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, C.c_int64, _i, _f, C.c_int64, _f,
                                                         C.c_int64, _f, _f, _f, _f, C.c_int64, _f, _f, _f, _f, C.c_int, C.c_int,
                                                         C.c_int, C.c_int, C.c_float, _s]),
+    'occ4d_implicit_loss_workspace_floats': (C.c_int64, [C.c_int]),
+    'occ4d_implicit_loss_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                          C.c_float, _f, _f, _f, C.c_int64, _s]),
     'occ4d_resblock_f16x3_packed_floats': (C.c_int64, []),
     'occ4d_pack_resblock_f16x3_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, _s]),
     'occ4d_resblock_f16x3_f32': (C.c_int, [_f, C.c_int64, _f, C.c_int64, _f, _f, _f, C.c_int, _s]),

@@ -416,6 +416,23 @@ def resblock(x, fc_0, fc_1):
     return ResBlockFn.apply(x, fc_0.weight, fc_0.bias, fc_1.weight, fc_1.bias)
 
 
+class ImplicitLossFn(Function):
+    """training.implicit_loss's density + segmentation terms as one library call (ops.implicit_loss_fused): the gradient
+    is formed with the value and scaled by the incoming scalar in backward."""
+
+    @staticmethod
+    def forward(ctx, out, target, semantic_classes, density_lw, segmentation_lw):
+        loss, grad = ops.implicit_loss_fused(out, target, semantic_classes, density_lw, segmentation_lw,
+                                             want_grad=out.requires_grad)
+        ctx.save_for_backward(grad)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None, None
+
+
 class PosHiddenFn(Function):
     """r = relu(P1 (pos_i - pos2_j) + c1); gradients to P1, c1 only (coordinates are data)."""
 

@@ -427,6 +427,24 @@ def rowlin_bf16x6(x, w, b=None, relu_in=False, res=None, out=None, packed=None, 
     return out
 
 
+def implicit_loss_fused(out, target, semantic_classes, density_lw, segmentation_lw, want_grad=True):
+    """occ4d_implicit_loss_f32: density BCE-with-logits + masked segmentation cross entropy over (cells, n, g) raw decoder
+    outputs (training.implicit_loss's terms with non-zero weight in the published configurations) -> (loss (1,), d loss / d out
+    or None), two launches."""
+    out, target = _dev(out, name='out'), _dev(target, name='target')
+    assert out.dim() == 3 and target.dim() == 3 and out.is_contiguous() and target.is_contiguous()
+    cells, n, g = out.shape
+    assert tuple(target.shape[:2]) == (cells, n) and target.shape[2] >= 2
+    L = _lib.lib()
+    ws = torch.empty((int(L.occ4d_implicit_loss_workspace_floats(cells)),), dtype=torch.float32, device=out.device)
+    loss = torch.empty((1,), dtype=torch.float32, device=out.device)
+    grad = torch.empty_like(out) if want_grad else None
+    _lib.check(L.occ4d_implicit_loss_f32(_ptr(out), g, _ptr(target), target.shape[2], cells, n, g, target.shape[2] - 1,
+                                         int(semantic_classes), float(density_lw), float(segmentation_lw), _ptr(ws), _ptr(loss),
+                                         _ptr(grad), g, _stream()))
+    return loss, grad
+
+
 def resblock_f16x3(x, w0, b0, w1, b1, out=None, packed=None):
     """ResnetBlockFC of width 416 (relu) as one launch in the fp16 two-piece split scheme (occ4d_resblock_f16x3_f32):
     y = x + W1 relu(W0 relu(x) + b0) + b1, the hidden activation in registers.  `out` may be x itself.  `packed`

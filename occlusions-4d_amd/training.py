@@ -13,6 +13,7 @@ the training-time point sampler that draws them (utils/geometry.py:578-1105, ran
 geometry.GuidedImplicitPointSampler (bench_train.py --sampler runs it inside the step).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -21,6 +22,9 @@ import torch.nn.functional as F
 
 from . import autograd, kernels, ops
 from .point_transformer_layer import invalidate_weight_caches
+
+
+FUSED_LOSS = os.environ.get('OCC4D_FUSED_LOSS', '1') == '1'      # density + segmentation terms as one library call (csrc/loss.hip)
 
 
 def _masked_mean(values, mask):
@@ -127,6 +131,15 @@ def implicit_loss(implicit_output, implicit_target, density_lw=1.0, color_lw=0.0
     if color_mode not in TRACK_IDX:
         raise ValueError('Unknown color_mode: ' + str(color_mode))
     track_idx = TRACK_IDX[color_mode]    # the tracking logit sits behind the colour channels (utils.get_track_idx)
+    if (FUSED_LOSS and implicit_output.is_cuda and color_lw == 0.0 and tracking_lw == 0.0 and not ops._lib.is_twin()
+            and implicit_output.dtype == torch.float32 and implicit_target.dtype == torch.float32
+            and semantic_classes < implicit_output.shape[-1]):
+        # the two terms the published configurations weight, value and gradient, as one library call (csrc/loss.hip, round 6:
+        # ~60 element-wise launches and 6.6 ms of host time per step otherwise); same means over the same points
+        (nf, nb, n, g) = implicit_output.shape
+        return autograd.ImplicitLossFn.apply(implicit_output.reshape(nf * nb, n, g).contiguous(),
+                                             implicit_target.reshape(nf * nb, n, -1).contiguous(), int(semantic_classes),
+                                             float(density_lw), float(segmentation_lw))
     total = implicit_output.new_zeros(())
     (nf, nb) = implicit_output.shape[:2]
     cells = nf * nb

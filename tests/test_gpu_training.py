@@ -365,6 +365,34 @@ def test_kept_pair_tensors_across_the_path_level_row_chunks(precision):
             assert rel_err(b_[lo * k:hi * k], s_) < 1e-6
 
 
+@pytest.mark.parametrize('frames,n,g,seg', [(4, 17203, 18, 0.6), (1, 1000, 18, 0.6), (3, 257, 5, 0.0), (2, 64, 18, 0.6)])
+def test_fused_loss_matches_the_torch_glue(monkeypatch, frames, n, g, seg):
+    """csrc/loss.hip (density BCE + masked segmentation cross entropy, value and gradient in two launches) against
+    training.implicit_loss's torch path on the same tensors: value to 1e-6 relative, gradient to 1e-6 of its largest entry;
+    a frame without any labelled point gives NaN in both."""
+    tr = pk.training
+    rng = np.random.default_rng(frames * n)
+    out = torch.from_numpy(rng.normal(size=(frames, n, g)).astype(np.float32) * 3).cuda()
+    tgt = np.concatenate([rng.integers(0, 2, size=(frames, n, 1)), rng.uniform(size=(frames, n, 3)), np.zeros((frames, n, 1)),
+                          rng.integers(-1, 13, size=(frames, n, 1))], -1).astype(np.float32)
+    tgt = torch.from_numpy(tgt).cuda()
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(tr, 'FUSED_LOSS', fused)
+        o = out.clone().requires_grad_(True)
+        loss = tr.implicit_loss(o, tgt, density_lw=1.0, segmentation_lw=seg, static_shapes=True)
+        (2.5 * loss).backward()
+        res.append((float(loss), o.grad.clone()))
+    (lf, gf), (lt, gt) = res
+    assert abs(lf - lt) <= 1e-6 * abs(lt), (lf, lt)
+    assert rel_err(gf, gt) <= 2e-6
+    if seg > 0:
+        monkeypatch.setattr(tr, 'FUSED_LOSS', True)
+        none = tgt.clone()
+        none[0, :, -1] = -1.0                          # no labelled point in frame 0
+        assert not np.isfinite(float(tr.implicit_loss(out, none, density_lw=1.0, segmentation_lw=seg, static_shapes=True)))
+
+
 def test_pair_tensor_paths_are_both_exercised(monkeypatch):
     """The strict layer-level tests above run the fused pair-tensor kernel (d = 416); with it switched off the unfused
     chain must satisfy the same criterion."""
